@@ -1,0 +1,133 @@
+"""oracle/nets_oracle.py - TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Functional torch-CPU restatement of the reference networks' forward pass, driven directly by a
+state_dict (no nn.Module tree).  The arithmetic is the reference's own third-party arithmetic
+(PyTorch ATen / oneDNN fp32 kernels behind torch.nn.functional - SURVEY.md section 8c), so on
+identical weights it reproduces the reference up to oneDNN's blocking choices (checked against
+the committed golden heat maps in tests/test_oracle_golden.py).
+
+  resnet_dconv_forward  <- nets/pose_resnet_dconv.py:251-265 (_forward_impl), Bottleneck.forward :112-133,
+                            _make_layer :201-228, _make_deconv_layer :230-249, final_layer :173-178
+  resnet_duc_forward    <- nets/pose_resnet_duc.py (_forward_impl), _make_duc_layer :227-232, nets/commons.py:21-43
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+RESNET50_BLOCKS = (3, 4, 6, 3)
+BN_EPS = 1e-5
+
+
+def _bn(x, sd, prefix, training=False):
+    # nn.BatchNorm2d(eps=1e-5, momentum=0.1); eval mode uses running stats
+    if training:
+        return F.batch_norm(x, None, None, sd[prefix + ".weight"], sd[prefix + ".bias"], True, 0.1, BN_EPS)
+    return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"],
+                        sd[prefix + ".weight"], sd[prefix + ".bias"], False, 0.1, BN_EPS)
+
+
+def _se(x, sd, prefix):
+    # nets/commons.py:4-18 (reduction=1: C -> C -> C)
+    y = F.adaptive_avg_pool2d(x, 1)
+    y = F.relu(F.conv2d(y, sd[prefix + ".fc.0.weight"], sd[prefix + ".fc.0.bias"]))
+    y = torch.sigmoid(F.conv2d(y, sd[prefix + ".fc.2.weight"], sd[prefix + ".fc.2.bias"]))
+    return x * y
+
+
+def _bottleneck(x, sd, p, stride, training=False):
+    # nets/pose_resnet_dconv.py:112-133 (stride sits on conv2: "ResNet v1.5", :84-88)
+    out = F.relu(_bn(F.conv2d(x, sd[p + ".conv1.weight"]), sd, p + ".bn1", training))
+    out = F.relu(_bn(F.conv2d(out, sd[p + ".conv2.weight"], stride=stride, padding=1), sd, p + ".bn2", training))
+    out = _bn(F.conv2d(out, sd[p + ".conv3.weight"]), sd, p + ".bn3", training)
+    if (p + ".se.fc.0.weight") in sd:
+        out = _se(out, sd, p + ".se")
+    if (p + ".downsample.0.weight") in sd:
+        x = _bn(F.conv2d(x, sd[p + ".downsample.0.weight"], stride=stride), sd, p + ".downsample.1", training)
+    return F.relu(out + x)
+
+
+def resnet_trunk(sd: Dict[str, torch.Tensor], x: torch.Tensor, training=False,
+                 tap: Optional[Callable[[str, torch.Tensor], None]] = None, blocks=RESNET50_BLOCKS):
+    x = F.relu(_bn(F.conv2d(x, sd["conv1.weight"], stride=2, padding=3), sd, "bn1", training))
+    x = F.max_pool2d(x, 3, 2, 1)
+    if tap:
+        tap("maxpool", x)
+    for li, n in enumerate(blocks, start=1):
+        for bi in range(n):
+            x = _bottleneck(x, sd, f"layer{li}.{bi}", 2 if (bi == 0 and li > 1) else 1, training)
+        if tap:
+            tap(f"layer{li}", x)
+    return x
+
+
+def resnet_dconv_forward(sd, x, training=False, tap=None):
+    x = resnet_trunk(sd, x, training, tap)
+    for n, idx in enumerate((0, 3, 6)):  # Sequential indices: deconv, bn, relu triples
+        x = F.conv_transpose2d(x, sd[f"deconv_layers.{idx}.weight"], stride=2, padding=1, output_padding=0)
+        x = F.relu(_bn(x, sd, f"deconv_layers.{idx + 1}", training))
+        if tap:
+            tap(f"deconv{n}", x)
+    return F.conv2d(x, sd["final_layer.weight"], sd["final_layer.bias"])
+
+
+def resnet_duc_forward(sd, x, training=False, tap=None):
+    x = resnet_trunk(sd, x, training, tap)
+    x = F.pixel_shuffle(x, 2)
+    for n, idx in enumerate((1, 2)):
+        x = F.conv2d(x, sd[f"duc_layers.{idx}.conv.weight"], padding=1)
+        x = F.pixel_shuffle(F.relu(_bn(x, sd, f"duc_layers.{idx}.bn", training)), 2)
+        if tap:
+            tap(f"duc{n}", x)
+    return F.conv2d(x, sd["final_layer.weight"], sd["final_layer.bias"], padding=1)
+
+
+FORWARDS = {"resnet50_dconv": resnet_dconv_forward, "resnet50_duc": resnet_duc_forward}
+
+
+def state_dict_shapes_resnet50(head: str, num_joints: int = 17, se: bool = False):
+    """(key, shape, dtype) list of the reference's resnet50 state_dict without
+    instantiating anything: lets the GPU box regenerate the synthetic weights with no reference."""
+    out = []
+
+    def conv(k, o, i, kh, kw):
+        out.append((k + ".weight", (o, i, kh, kw), "torch.float32"))
+
+    def bn(k, c):
+        for leaf in ("weight", "bias", "running_mean", "running_var"):
+            out.append((f"{k}.{leaf}", (c,), "torch.float32"))
+        out.append((f"{k}.num_batches_tracked", (), "torch.int64"))
+
+    conv("conv1", 64, 3, 7, 7)
+    bn("bn1", 64)
+    inpl = 64
+    for li, (planes, n) in enumerate(zip((64, 128, 256, 512), RESNET50_BLOCKS), start=1):
+        for bi in range(n):
+            p = f"layer{li}.{bi}"
+            conv(p + ".conv1", planes, inpl, 1, 1); bn(p + ".bn1", planes)
+            conv(p + ".conv2", planes, planes, 3, 3); bn(p + ".bn2", planes)
+            conv(p + ".conv3", planes * 4, planes, 1, 1); bn(p + ".bn3", planes * 4)
+            if bi == 0:
+                conv(p + ".downsample.0", planes * 4, inpl, 1, 1); bn(p + ".downsample.1", planes * 4)
+                if se:
+                    for f in ("0", "2"):
+                        out.append((f"{p}.se.fc.{f}.weight", (planes * 4, planes * 4, 1, 1), "torch.float32"))
+                        out.append((f"{p}.se.fc.{f}.bias", (planes * 4,), "torch.float32"))
+            inpl = planes * 4
+    if head == "dconv":
+        cin = 2048
+        for idx in (0, 3, 6):
+            out.append((f"deconv_layers.{idx}.weight", (cin, 256, 4, 4), "torch.float32"))
+            bn(f"deconv_layers.{idx + 1}", 256)
+            cin = 256
+        conv("final_layer", num_joints, 256, 1, 1)
+    elif head == "duc":
+        conv("duc_layers.1.conv", 1024, 512, 3, 3); bn("duc_layers.1.bn", 1024)
+        conv("duc_layers.2.conv", 512, 256, 3, 3); bn("duc_layers.2.bn", 512)
+        conv("final_layer", num_joints, 128, 3, 3)
+    else:
+        raise ValueError(head)
+    out.append(("final_layer.bias", (num_joints,), "torch.float32"))
+    return out

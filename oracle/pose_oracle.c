@@ -1,0 +1,237 @@
+/*
+ * oracle/pose_oracle.c - TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Scalar C restatement of the reference's heat-map encoder / decoders / loss, used only by
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg as the checker for the
+ * HIP kernels.  Nothing in simple_pose_amd/ may call into this file.
+ *
+ * Every function cites the reference lines it restates (paths relative to the upstream
+ * repo liangheming/simple_pose).  Arithmetic follows the reference operation by operation
+ * in fp32 (each op rounded separately: build with -ffp-contract=off), with three stated
+ * deviations where the reference calls third-party numerics we cannot replay bit for bit:
+ *   - torch.log  (SLEEF, <=1 ulp)          -> correctly rounded log (double log, then float)
+ *   - Tensor.inverse (MKL LU) + bmm        -> closed-form 2x2 solve in double, rounded once
+ *   - einsum("bcd,bad->bca") (MKL sgemm)   -> double dot product, rounded once
+ * The 11x11 blur IS bit-exact: oneDNN's depthwise conv accumulates a (ky,kx)-ordered fmaf
+ * chain per output pixel, which blur_dense() replays (verified bitwise against
+ * torch.nn.functional.conv2d on 208,896 pixels; see DESIGN.md "oracle pinning").
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define SP_MAX_KS 31
+
+/* cv2.getGaussianKernel(ks, 0) closed form (metrics/pose_metrics.py:57): sigma = 0.3*((ks-1)*0.5-1)+0.8,
+ * exp(-x^2/(2 sigma^2)) normalised to sum 1 in float64; k2d = g g^T in float64 then .float() (:60). */
+void sp_oracle_blur_kernel(int ks, float* k2d /* [ks*ks] */) {
+    double g[SP_MAX_KS];
+    double sigma = 0.3 * ((ks - 1) * 0.5 - 1.0) + 0.8;
+    double sum = 0.0;
+    for (int i = 0; i < ks; ++i) {
+        double x = i - (ks - 1) * 0.5;
+        g[i] = exp(-(x * x) / (2.0 * sigma * sigma));
+        sum += g[i];
+    }
+    for (int i = 0; i < ks; ++i) g[i] /= sum;
+    for (int i = 0; i < ks; ++i)
+        for (int j = 0; j < ks; ++j) k2d[i * ks + j] = (float)(g[i] * g[j]);
+}
+
+/* torch.max(dim) semantics on CPU (metrics/pose_metrics.py:18): first index of the maximum, NaN wins. */
+static void argmax_first(const float* h, int n, int* idx_out, float* max_out) {
+    int idx = 0;
+    float m = h[0];
+    for (int i = 1; i < n; ++i) {
+        float v = h[i];
+        if ((v > m) || (isnan(v) && !isnan(m))) { m = v; idx = i; }
+    }
+    *idx_out = idx;
+    *max_out = m;
+}
+
+/* BasicKeyPointDecoder.heat_map_to_axis, metrics/pose_metrics.py:11-24.
+ * coords[b,j,:] = (idx % W, floor(idx / W)) * (max > 0); max_val[b,j] = raw max. */
+void sp_oracle_heat_map_to_axis(const float* heat, int B, int J, int H, int W, float* coords, float* max_val) {
+    for (int m = 0; m < B * J; ++m) {
+        int idx; float mx;
+        argmax_first(heat + (size_t)m * H * W, H * W, &idx, &mx);
+        float keep = (mx > 0.f) ? 1.f : 0.f;
+        coords[2 * m + 0] = (float)(idx % W) * keep;
+        coords[2 * m + 1] = (float)(idx / W) * keep;
+        max_val[m] = mx;
+    }
+}
+
+/* F.conv2d(heat, k2d, padding=ks/2, groups=J) for one map, metrics/pose_metrics.py:68-69:
+ * zero padding, cross-correlation, one fmaf chain per pixel in (ky,kx) order. */
+static void blur_dense(const float* h, const float* k2d, int ks, int H, int W, float* out) {
+    int p = ks / 2;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            float acc = 0.f;
+            for (int ky = 0; ky < ks; ++ky) {
+                int iy = y + ky - p;
+                if (iy < 0 || iy >= H) continue;
+                for (int kx = 0; kx < ks; ++kx) {
+                    int ix = x + kx - p;
+                    if (ix < 0 || ix >= W) continue;
+                    acc = fmaf(h[iy * W + ix], k2d[ky * ks + kx], acc);
+                }
+            }
+            out[y * W + x] = acc;
+        }
+}
+
+static inline float log_cr(float v) { return (float)log((double)v); }
+
+/* einsum("bcd,bad->bca", [x,y,1], trans_inv[b]) : metrics/pose_metrics.py:50-51,105-106 */
+static inline void affine_out(const float* t /* [2,3] */, float x, float y, float* out2) {
+    out2[0] = (float)((double)x * t[0] + (double)y * t[1] + (double)t[2]);
+    out2[1] = (float)((double)x * t[3] + (double)y * t[4] + (double)t[5]);
+}
+
+/* GaussTaylorKeyPointDecoder.__call__, metrics/pose_metrics.py:62-107. */
+void sp_oracle_decode_gauss_taylor(const float* heat, const float* trans_inv, int B, int J, int H, int W, int ks,
+                                   float* kps /* [B,J,2] */, float* max_val /* [B,J] */) {
+    float k2d[SP_MAX_KS * SP_MAX_KS];
+    sp_oracle_blur_kernel(ks, k2d);
+    float* hb = (float*)malloc(sizeof(float) * (size_t)H * W);
+    for (int m = 0; m < B * J; ++m) {
+        const float* h = heat + (size_t)m * H * W;
+        int idx; float mx;
+        argmax_first(h, H * W, &idx, &mx);                      /* :64  (heat_map_to_axis :18) */
+        float keep = (mx > 0.f) ? 1.f : 0.f;
+        float cx = (float)(idx % W) * keep, cy = (float)(idx / W) * keep; /* :20-23 */
+        max_val[m] = mx;
+        blur_dense(h, k2d, ks, H, W, hb);                      /* :68-69 */
+        int bidx; float bmax;
+        argmax_first(hb, H * W, &bidx, &bmax);                 /* :72 */
+        int xi = (int)cx, yi = (int)cy;                        /* :76 .long() */
+        if (xi > 1 && xi < W - 2 && yi > 1 && yi < H - 2) {    /* :78 */
+            /* L(y,x) = log(clamp(hb*ori_max/blur_max, 1e-10))     :73 */
+#define L_(yy, xx) log_cr(fmaxf((hb[(yy) * W + (xx)] * mx) / bmax, 1e-10f))
+            float c = L_(yi, xi);
+            float dx = 0.5f * (L_(yi, xi + 1) - L_(yi, xi - 1));                         /* :80-81 */
+            float dy = 0.5f * (L_(yi + 1, xi) - L_(yi - 1, xi));                         /* :82-83 */
+            float dxx = 0.25f * ((L_(yi, xi + 2) - 2.f * c) + L_(yi, xi - 2));           /* :84-86 */
+            float dxy = 0.25f * (((L_(yi + 1, xi + 1) - L_(yi - 1, xi + 1)) - L_(yi + 1, xi - 1)) +
+                                 L_(yi - 1, xi - 1));                                     /* :87-90 */
+            float dyy = 0.25f * ((L_(yi + 2, xi) - 2.f * c) + L_(yi - 2, xi));           /* :91-93 */
+#undef L_
+            float p1 = dxx * dyy, p2 = dxy * dxy;
+            float det32 = p1 - p2;                                                       /* :94 */
+            if (det32 != 0.f) {
+                double det = (double)dxx * dyy - (double)dxy * dxy;
+                float ox = (float)(-((double)dyy * dx - (double)dxy * dy) / det);        /* :95-100 */
+                float oy = (float)(-((double)dxx * dy - (double)dxy * dx) / det);
+                cx = fmaxf(cx + ox, 0.f);                                                /* :103 */
+                cy = fmaxf(cy + oy, 0.f);
+                if (isnan(ox)) cx = ox;  /* torch.clamp propagates NaN */
+                if (isnan(oy)) cy = oy;
+            }
+        }
+        affine_out(trans_inv + (size_t)(m / J) * 6, cx, cy, kps + 2 * (size_t)m);        /* :105-106 */
+    }
+    free(hb);
+}
+
+static inline float signf_(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : v /* 0 or NaN */); }
+
+/* BasicKeyPointDecoder.__call__, metrics/pose_metrics.py:26-52 */
+void sp_oracle_decode_basic(const float* heat, const float* trans_inv, int B, int J, int H, int W,
+                            float* kps, float* max_val) {
+    for (int m = 0; m < B * J; ++m) {
+        const float* h = heat + (size_t)m * H * W;
+        int idx; float mx;
+        argmax_first(h, H * W, &idx, &mx);
+        float keep = (mx > 0.f) ? 1.f : 0.f;
+        float cx = (float)(idx % W) * keep, cy = (float)(idx / W) * keep;
+        max_val[m] = mx;
+        int xi = (int)cx, yi = (int)cy;
+        if (xi > 1 && xi < W - 1 && yi > 1 && yi < H - 1) {                              /* :40 */
+            float ddx = signf_(h[yi * W + xi + 1] - h[yi * W + xi - 1]);                 /* :41-43 */
+            float ddy = signf_(h[(yi + 1) * W + xi] - h[(yi - 1) * W + xi]);             /* :44-46 */
+            cx = cx + ddx * 0.25f;                                                       /* :49 */
+            cy = cy + ddy * 0.25f;
+        }
+        affine_out(trans_inv + (size_t)(m / J) * 6, cx, cy, kps + 2 * (size_t)m);
+    }
+}
+
+/* RefineSimpleTransform.get_heat_map, commons/transforms.py:167-191, batched.
+ * joints [B,J,3] (x,y,vis) in heat-map px; targets [B,J,H,W]; weights [B,J].  Bounds arithmetic is fp32
+ * (numpy >= 2 / NEP 50: np.float32 scalar +- python float stays float32), int() truncates toward zero. */
+void sp_oracle_encode_refine(const float* joints, int B, int J, int H, int W, float sigma,
+                             float* targets, float* weights) {
+    float tmp = sigma * 3.f;                                                             /* :177 */
+    double two_s2 = 2.0 * (double)sigma * (double)sigma;                                 /* :189 2*sigma**2 */
+    for (int m = 0; m < B * J; ++m) {
+        float mux = joints[3 * m + 0], muy = joints[3 * m + 1], vis = joints[3 * m + 2];
+        float* t = targets + (size_t)m * H * W;
+        memset(t, 0, sizeof(float) * (size_t)H * W);
+        weights[m] = vis;                                                                /* :175 */
+        int ulx = (int)(mux - tmp), uly = (int)(muy - tmp);                              /* :181 */
+        int brx = (int)((mux + tmp) + 1.f), bry = (int)((muy + tmp) + 1.f);              /* :182 */
+        if (ulx >= W || uly >= H || brx < 0 || bry < 0) { weights[m] = 0.f; continue; }  /* :183-185 */
+        if (vis > 0.5f) {                                                                /* :187 */
+            for (int y = 0; y < H; ++y)
+                for (int x = 0; x < W; ++x) {
+                    double dx = (double)x - (double)mux, dy = (double)y - (double)muy;  /* int64 - f32 -> f64 */
+                    double s = dx * dx + dy * dy;
+                    t[y * W + x] = (float)exp(-s / two_s2);                              /* :190 */
+                }
+        }
+    }
+}
+
+/* BasicSimpleTransform.get_heat_map, commons/transforms.py:80-116: joints in INPUT px, quantised centre,
+ * (6 sigma + 1)^2 fp32 patch pasted with clipping. */
+void sp_oracle_encode_basic(const float* joints, int B, int J, int H, int W, float sigma, int stride,
+                            float* targets, float* weights) {
+    float tmpf = sigma * 3.f;                                                            /* :91 */
+    int size = (int)(2.f * tmpf + 1.f);                                                  /* :103 */
+    float x0 = (float)(size / 2);                                                        /* :106 size // 2 */
+    float two_s2 = 2.f * (sigma * sigma);
+    for (int m = 0; m < B * J; ++m) {
+        float jx = joints[3 * m + 0], jy = joints[3 * m + 1], vis = joints[3 * m + 2];
+        float* t = targets + (size_t)m * H * W;
+        memset(t, 0, sizeof(float) * (size_t)H * W);
+        weights[m] = vis;
+        int mux = (int)(jx / (float)stride + 0.5f), muy = (int)(jy / (float)stride + 0.5f); /* :95-96 */
+        int ulx = (int)((double)mux - tmpf), uly = (int)((double)muy - tmpf);            /* :98 */
+        int brx = (int)((double)mux + tmpf + 1.0), bry = (int)((double)muy + tmpf + 1.0); /* :99 */
+        if (ulx >= W || uly >= H || brx < 0 || bry < 0) { weights[m] = 0.f; continue; }  /* :100-102 */
+        int gx0 = ulx < 0 ? -ulx : 0, gx1 = (brx < W ? brx : W) - ulx;                   /* :108 */
+        int gy0 = uly < 0 ? -uly : 0, gy1 = (bry < H ? bry : H) - uly;                   /* :109 */
+        int ix0 = ulx > 0 ? ulx : 0, iy0 = uly > 0 ? uly : 0;                            /* :111-112 */
+        if (vis > 0.5f) {                                                                /* :114 */
+            for (int gy = gy0; gy < gy1; ++gy)
+                for (int gx = gx0; gx < gx1; ++gx) {
+                    float ddx = (float)gx - x0, ddy = (float)gy - x0;
+                    float s = ddx * ddx + ddy * ddy;
+                    float e = -s / two_s2;
+                    t[(iy0 + gy - gy0) * W + (ix0 + gx - gx0)] = (float)exp((double)e);  /* :107 fp32 exp */
+                }
+        }
+    }
+}
+
+/* loss = 0.5 * MSELoss(pred * mask[...,None,None], target * mask[...,None,None]),
+ * processors/ddp_pose_resnet_solver.py:94,117: mean over ALL B*J*H*W elements.  Also d loss / d pred. */
+double sp_oracle_masked_mse(const float* pred, const float* target, const float* mask, int B, int J, int HW,
+                            float* grad /* may be NULL; [B,J,HW] */) {
+    double acc = 0.0;
+    double n = (double)B * J * HW;
+    for (int m = 0; m < B * J; ++m) {
+        float w = mask[m];
+        for (int i = 0; i < HW; ++i) {
+            size_t o = (size_t)m * HW + i;
+            float d = pred[o] * w - target[o] * w;
+            acc += (double)d * d;
+            if (grad) grad[o] = (float)((double)d * w / n); /* 0.5 * 2 * d * w / n */
+        }
+    }
+    return 0.5 * acc / n;
+}

@@ -1,0 +1,107 @@
+"""oracle/pose_oracle.py - TEST INFRASTRUCTURE.  ctypes front-end of oracle/pose_oracle.c (numpy in/out)."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libpose_oracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "pose_oracle.c")
+    if force or not os.path.isfile(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.run(["make", "-s", "-C", _HERE, "-f", os.path.join(_HERE, "Makefile")] + (["-B"] if force else []),
+                       check=True)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(_SO):
+            build()
+        _lib = ctypes.CDLL(_SO)
+        _lib.sp_oracle_masked_mse.restype = ctypes.c_double
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def blur_kernel(ks: int = 11) -> np.ndarray:
+    k = np.empty((ks, ks), np.float32)
+    lib().sp_oracle_blur_kernel(ctypes.c_int(ks), _p(k))
+    return k
+
+
+def heat_map_to_axis(heat):
+    heat = _f32(heat)
+    B, J, H, W = heat.shape
+    coords = np.empty((B, J, 2), np.float32)
+    mv = np.empty((B, J, 1), np.float32)
+    lib().sp_oracle_heat_map_to_axis(_p(heat), B, J, H, W, _p(coords), _p(mv))
+    return coords, mv
+
+
+def decode_gauss_taylor(heat, trans_inv, kernel_size: int = 11):
+    heat, trans_inv = _f32(heat), _f32(trans_inv)
+    B, J, H, W = heat.shape
+    assert trans_inv.shape == (B, 2, 3)
+    kps = np.empty((B, J, 2), np.float32)
+    mv = np.empty((B, J, 1), np.float32)
+    lib().sp_oracle_decode_gauss_taylor(_p(heat), _p(trans_inv), B, J, H, W, kernel_size, _p(kps), _p(mv))
+    return kps, mv
+
+
+def decode_basic(heat, trans_inv):
+    heat, trans_inv = _f32(heat), _f32(trans_inv)
+    B, J, H, W = heat.shape
+    kps = np.empty((B, J, 2), np.float32)
+    mv = np.empty((B, J, 1), np.float32)
+    lib().sp_oracle_decode_basic(_p(heat), _p(trans_inv), B, J, H, W, _p(kps), _p(mv))
+    return kps, mv
+
+
+def encode_refine(joints, sigma: float = 2.0, shape=(48, 64)):
+    """joints [B,J,3] or [J,3]; shape=(W,H) as in the reference; returns targets [.., J,H,W], weights [.., J]."""
+    joints = _f32(joints)
+    single = joints.ndim == 2
+    if single:
+        joints = joints[None]
+    B, J, _ = joints.shape
+    W, H = shape
+    t = np.empty((B, J, H, W), np.float32)
+    w = np.empty((B, J), np.float32)
+    lib().sp_oracle_encode_refine(_p(joints), B, J, H, W, ctypes.c_float(sigma), _p(t), _p(w))
+    return (t[0], w[0]) if single else (t, w)
+
+
+def encode_basic(joints, sigma: float = 2.0, shape=(48, 64), stride: int = 4):
+    joints = _f32(joints)
+    single = joints.ndim == 2
+    if single:
+        joints = joints[None]
+    B, J, _ = joints.shape
+    W, H = shape
+    t = np.empty((B, J, H, W), np.float32)
+    w = np.empty((B, J), np.float32)
+    lib().sp_oracle_encode_basic(_p(joints), B, J, H, W, ctypes.c_float(sigma), int(stride), _p(t), _p(w))
+    return (t[0], w[0]) if single else (t, w)
+
+
+def masked_mse(pred, target, mask, want_grad: bool = False):
+    pred, target, mask = _f32(pred), _f32(target), _f32(mask)
+    B, J, H, W = pred.shape
+    g = np.empty_like(pred) if want_grad else None
+    loss = lib().sp_oracle_masked_mse(_p(pred), _p(target), _p(mask), B, J, H * W, _p(g) if want_grad else None)
+    return (np.float32(loss), g) if want_grad else np.float32(loss)
