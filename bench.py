@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py - images/sec of forward + GaussTaylor decode, ResNet50-DConv 256x192, bs=128 per GPU, fp32.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 128] [--arch dconv|duc] [--no-cpu-baseline]
+
+One "step" = one pass of the hot path (network forward + key-point decode) over one batch of synthetic images that
+are already resident in HBM.  N > 1: launched by torch.distributed.run, one process per GPU; the path shards by image
+(independent replicas, no data-path collective) -> weak scaling; barrier + device sync on both sides of the timed
+region, MAX over ranks, rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 FLOP/clk/CU x 256 CU x 2.4 GHz
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=128, help="images per GPU per step")
+    ap.add_argument("--arch", default="dconv", choices=["dconv", "duc"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (roofline object)")
+    return ap.parse_args()
+
+
+def cpu_baseline(arch: str):
+    """Oracle ("port" of the reference's CPU path: torch-CPU forward + C GaussTaylor decode) on the host cores,
+    BASELINE configs[0]: bs=4, fp32, eval; ~10 s of CPU work."""
+    import numpy as np
+    import torch
+
+    from oracle import nets_oracle, pose_oracle
+    from simple_pose_amd import synth
+
+    head = arch
+    sd = {k: torch.from_numpy(v) for k, v in
+          synth.conditioned_state_dict(nets_oracle.state_dict_shapes_resnet50(head), 0).items()}
+    x = torch.from_numpy(synth.input_images(4, 0))
+    tinv = synth.trans_inv_batch(4)
+    fwd = nets_oracle.FORWARDS["resnet50_" + head]
+    threads = torch.get_num_threads()
+
+    def one():
+        with torch.no_grad():
+            hm = fwd(sd, x)
+        pose_oracle.decode_gauss_taylor(hm.numpy(), tinv)
+
+    for _ in range(2):
+        one()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or n >= 40:
+            break
+    return {"value": round(4 * n / el, 2), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"{n} iterations of bs=4 ResNet50-{head} 256x192 fp32 forward (torch-CPU oracle) + C GaussTaylor decode, "
+                      f"{threads} threads of {os.cpu_count()} logical CPUs"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    elif args.gpus > 1:
+        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from oracle import nets_oracle  # only for the reference state_dict LAYOUT (names/shapes) of the synthetic weights
+    from simple_pose_amd import _lib, synth
+    from simple_pose_amd.metrics import GaussTaylorKeyPointDecoder
+    from simple_pose_amd.nets import pose_resnet_dconv, pose_resnet_duc
+
+    _lib.lib()  # fail loudly if the HIP library is missing
+    mod = {"dconv": pose_resnet_dconv, "duc": pose_resnet_duc}[args.arch]
+    model = mod.resnet50(pretrained=False, num_classes=17)
+    sd = synth.conditioned_state_dict(nets_oracle.state_dict_shapes_resnet50(args.arch), seed=0)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model = model.to(dev).eval()
+    decoder = GaussTaylorKeyPointDecoder(kernel_size=11, num_joints=17)
+
+    B = args.batch
+    import numpy as np
+    base = synth.input_images(8, seed=100 + rank)  # 8 distinct random images per rank, tiled to the batch
+    x = torch.from_numpy(np.concatenate([base] * ((B + 7) // 8), 0)[:B]).to(dev)
+    tinv = torch.from_numpy(synth.trans_inv_batch(B)).to(dev)
+    prog = model.hip_program(x)
+
+    def step():
+        hm = prog.run(x)
+        return decoder(hm, tinv)
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = step()
+    torch.cuda.synchronize()
+
+    # ---- timed region -------------------------------------------------------------------------------
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for _ in range(args.steps):
+            out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(out[0]).all()
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * B * args.steps / elapsed
+
+    # ---- per-kernel roofline: HIP events around every conv launch, on the launch stream, same inputs ----
+    roofline = None
+    if rank == 0 and not args.no_kernel_events:
+        roofline = kernel_roofline(prog, x, steps=max(3, min(args.steps, 10)))
+
+    if rank == 0:
+        line = {
+            "metric": "images/sec fwd+decode, ResNet50-%s 256x192 bs=%d" % ("DConv" if args.arch == "dconv" else "DUC", B),
+            "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"ResNet50-{'DConv' if args.arch == 'dconv' else 'DUC'} 256x192 bs={B} per GPU, fp32 forward "
+                                   "(NCHW in -> heat maps) + GaussTaylor decode, eval-mode BN, conditioned random weights",
+                       "images_per_gpu": B, "global_batch": B * world, "parallelism": f"replicas x{world} (no collective)"},
+            "gflop_per_image": round(prog.flops_per_image / 1e9, 4),
+            "network_tflops": round(value * prog.flops_per_image / 1e12, 2),
+            "network_frac_of_fp32_matrix_peak": round(value * prog.flops_per_image / 1e12 / (FP32_MATRIX_PEAK_TFLOPS * world), 4),
+            "roofline": roofline,
+            "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(args.arch),
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def kernel_roofline(prog, x, steps: int):
+    """Average duration of the dominant kernel (the fp32 implicit-GEMM conv family) measured with HIP events recorded on
+    the launch stream around each of its launches, and its achieved algorithmic TFLOP/s against the fp32 matrix peak."""
+    import torch
+
+    from simple_pose_amd import _lib
+
+    lib = _lib.lib()
+    B = x.shape[0]
+    bufs = dict(prog._alloc(B, x.device))
+    bufs["input"] = x
+    bufs[prog.out_name] = torch.empty((B,) + tuple(prog.out_shape), dtype=torch.float32, device=x.device)
+    P = _lib.ptr
+    conv_ops = [op for op in prog.ops if op.kind == "conv"]
+    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in conv_ops]
+          for _ in range(steps)]
+    stream = _lib.current_stream()
+    for s in range(steps):
+        ci = 0
+        for op in prog.ops:
+            if op.kind == "conv":
+                op.desc.batch = B
+                ev[s][ci][0].record()
+                _lib.check(lib.sp_conv2d_fwd(op.desc, P(bufs[op.src]), P(op.w), P(op.scale), P(op.shift),
+                                             P(bufs[op.res]) if op.res else None, P(bufs[op.dst]), stream), op.name)
+                ev[s][ci][1].record()
+                ci += 1
+            elif op.kind == "maxpool":
+                h, w, c = op.args
+                lib.sp_maxpool3x3s2_nhwc(P(bufs[op.src]), P(bufs[op.dst]), B, h, w, c, stream)
+            elif op.kind == "to_nhwc4":
+                c, h, w = op.args
+                lib.sp_nchw_to_nhwc4(P(bufs[op.src]), P(bufs[op.dst]), B, c, h, w, stream)
+            elif op.kind == "pixel_shuffle":
+                h, w, c = op.args
+                lib.sp_pixel_shuffle2_nhwc(P(bufs[op.src]), P(bufs[op.dst]), B, h, w, c, stream)
+    torch.cuda.synchronize()
+    per_layer = []
+    for ci, op in enumerate(conv_ops):
+        ms = sorted(ev[s][ci][0].elapsed_time(ev[s][ci][1]) for s in range(steps))[steps // 2]
+        per_layer.append((op.name, ms, op.flops * B))
+    tot_ms = sum(m for _, m, _ in per_layer)
+    tot_flop = sum(f for _, _, f in per_layer)
+    achieved = tot_flop / (tot_ms * 1e-3) / 1e12
+    worst = sorted(per_layer, key=lambda t: -t[1])[:8]
+    return {"bound": "mfma", "kernel": "conv_igemm_kernel (fp32 MFMA implicit GEMM, all %d launches of a step)" % len(per_layer),
+            "achieved": round(achieved, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
+            "launches_per_step": len(per_layer), "avg_launch_us": round(1e3 * tot_ms / len(per_layer), 2),
+            "conv_ms_per_step": round(tot_ms, 3),
+            "slowest_layers": [{"layer": n, "us": round(1e3 * m, 1), "tflops": round(f / (m * 1e-3) / 1e12, 1)} for n, m, f in worst]}
+
+
+if __name__ == "__main__":
+    main()

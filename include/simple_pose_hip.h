@@ -1,0 +1,123 @@
+/*
+ * simple_pose_hip.h - C ABI of libsimple_pose_hip.so (MI355X / gfx950 only).
+ *
+ * The upstream reference (liangheming/simple_pose) has no native code and no FFI: its hot path is
+ * reached through Python objects that call torch.nn.functional.  This header is the boundary a
+ * maintainer would bind instead (ctypes stubs in INTEGRATION.md); every entry point names the
+ * reference lines it replaces.  Conventions:
+ *
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
+ *     (the library never allocates, frees or retains pointers past the call);
+ *   - asynchronous on the caller's `hipStream_t` passed as `void* stream`; no implicit device sync;
+ *   - returns SP_OK (0) or a negative SP_E* code; sp_last_error() gives the message of the last
+ *     failure on the calling thread; nothing throws or aborts across the boundary;
+ *   - activations are fp32 NHWC inside the network (channels % 4 == 0); the public tensors keep
+ *     the reference's NCHW fp32 layout (input [B,3,H,W], heat maps [B,J,H,W]).
+ */
+#ifndef SIMPLE_POSE_HIP_H
+#define SIMPLE_POSE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SP_OK 0
+#define SP_EINVAL (-1)   /* bad argument / unsupported shape (message in sp_last_error) */
+#define SP_ELAUNCH (-2)  /* HIP launch or runtime failure */
+
+#define SP_ABI_VERSION 1
+
+/* epilogue / layout flags of sp_conv_desc.flags */
+#define SP_CONV_RELU 0x1u          /* y = max(y, 0) after scale/shift (+ residual) */
+#define SP_CONV_OUT_NCHW 0x2u      /* store y as NCHW [B, N, out_h, out_w] (final_layer -> heat maps) */
+#define SP_CONV_PIXEL_SHUFFLE 0x4u /* fused nn.PixelShuffle(2): weights packed with sp_pack order, see below */
+
+/*
+ * One launch of the fp32 implicit-GEMM convolution family:
+ *   rows    M = batch * grid_h * grid_w      (output pixels of one phase)
+ *   columns N = c_out
+ *   depth   K = taps_h * taps_w * c_in       (zero taps allowed through k_pad)
+ *   x[b, iy, ix, c] with iy = gy * stride + dy0 + ty * dy_step  (same for x), zero outside the image
+ *   y[b, gy * oy_mul + oy_add, gx * ox_mul + ox_add, n] = act(acc * scale[n] + shift[n] + res[...])
+ * A stride-s conv with padding p is (dy0 = -p, dy_step = +1, oy_mul = 1, oy_add = 0); output phase
+ * (py,px) of ConvTranspose2d(k=4, s=2, p=1) is a 2x2-tap launch with (stride = 1, dy0 = py,
+ * dy_step = -1, oy_mul = 2, oy_add = py).  `w` is packed [phases][n_pad][k_pad] fp32, K contiguous,
+ * K ordered (ty, tx, c) - see sp_conv_weight_index().
+ */
+typedef struct sp_conv_desc {
+    int32_t batch, in_h, in_w, c_in; /* x: NHWC [batch, in_h, in_w, c_in], c_in % 4 == 0 */
+    int32_t grid_h, grid_w;          /* logical output grid per phase */
+    int32_t c_out;                   /* N (real) */
+    int32_t n_pad;                   /* packed rows per phase: multiple of 32, >= c_out (extra rows are zero) */
+    int32_t taps_h, taps_w;          /* taps as stored in the packed weights (taps_w may exceed the real kw) */
+    int32_t k_pad;                   /* packed K per row: multiple of 32, >= taps_h*taps_w*c_in */
+    int32_t stride;
+    int32_t dy0, dy_step, dx0, dx_step;
+    int32_t out_h, out_w, out_c;     /* y: NHWC [batch, out_h, out_w, out_c] (or NCHW with SP_CONV_OUT_NCHW) */
+    int32_t oy_mul, oy_add, ox_mul, ox_add;
+    int32_t phases_y, phases_x;      /* 1,1 for conv; 2,2 for the k4s2p1 transposed conv (dy0/oy_add become per-phase) */
+    uint32_t flags;
+} sp_conv_desc;
+
+/* ---- library ---------------------------------------------------------------------------------- */
+int sp_abi_version(void);
+const char* sp_last_error(void);
+
+/* ---- network ops: replace torch.nn.functional calls inside nets/pose_resnet_dconv.py:251-265,
+ *      nets/pose_resnet_duc.py (_forward_impl), nets/pose_hrnet.py:419-454 ------------------------ */
+
+/* input [B,C,H,W] fp32 NCHW (C<=4) -> NHWC4 [B,H,W,4] (channel C..3 = 0); feeds conv1 (pose_resnet_dconv.py:158) */
+int sp_nchw_to_nhwc4(const float* x_nchw, float* y_nhwc4, int batch, int channels, int h, int w, void* stream);
+
+/* nn.Conv2d / nn.ConvTranspose2d(4,2,1) + folded eval-mode nn.BatchNorm2d (scale/shift) or bias (shift)
+ * + residual add + nn.ReLU + nn.PixelShuffle(2), one kernel.  Replaces: conv1/bn1/relu (:252-254),
+ * Bottleneck.forward (:112-133), deconv_layers (:230-249), final_layer (:173-178), DUC (nets/commons.py:36-41).
+ * scale/shift: [c_out] or NULL (scale NULL -> 1, shift NULL -> 0); residual: same layout as y or NULL. */
+int sp_conv2d_fwd(const sp_conv_desc* desc, const float* x, const float* w_packed, const float* scale,
+                  const float* shift, const float* residual, float* y, void* stream);
+
+/* nn.MaxPool2d(3, 2, 1) on NHWC fp32 (pose_resnet_dconv.py:162,255) */
+int sp_maxpool3x3s2_nhwc(const float* x, float* y, int batch, int h, int w, int c, void* stream);
+
+/* nn.PixelShuffle(2) on NHWC fp32: x [B,h,w,c] -> y [B,2h,2w,c/4], y[b,2Y+i,2X+j,k] = x[b,Y,X,4k+2i+j]
+ * (the bare shuffle that opens the DUC head, nets/pose_resnet_duc.py:228; the two DUC blocks fuse theirs into the conv) */
+int sp_pixel_shuffle2_nhwc(const float* x, float* y, int batch, int h, int w, int c, void* stream);
+
+/* nearest-neighbour upsample by `factor` of NHWC `x` [B,h,w,c] added into NHWC `y` [B,h*f,w*f,c]
+ * (+ optional ReLU): HighResolutionModule fuse sum, nets/pose_hrnet.py:192-202,250-257 */
+int sp_upsample_add_nhwc(const float* x, float* y, int batch, int h, int w, int c, int factor, int relu, void* stream);
+
+/* ---- decoders: metrics/pose_metrics.py --------------------------------------------------------- */
+
+/* BasicKeyPointDecoder.heat_map_to_axis (:11-24): coords [B,J,2], max_val [B,J] */
+int sp_heat_map_to_axis(const float* heat_nchw, int batch, int joints, int h, int w, float* coords, float* max_val,
+                        void* stream);
+/* GaussTaylorKeyPointDecoder.__call__ (:62-107), kernel_size odd <= 15; trans_inv [B,2,3]; kps [B,J,2]; max_val [B,J] */
+int sp_decode_gauss_taylor(const float* heat_nchw, const float* trans_inv, int batch, int joints, int h, int w,
+                           int kernel_size, float* kps, float* max_val, void* stream);
+/* BasicKeyPointDecoder.__call__ (:26-52) */
+int sp_decode_basic(const float* heat_nchw, const float* trans_inv, int batch, int joints, int h, int w, float* kps,
+                    float* max_val, void* stream);
+
+/* ---- encoders: commons/transforms.py ----------------------------------------------------------- */
+
+/* RefineSimpleTransform.get_heat_map (:167-191), batched: joints [B,J,3] (x,y,vis in heat-map px) ->
+ * targets [B,J,h,w], weights [B,J] */
+int sp_encode_gauss_refine(const float* joints, int batch, int joints_n, int h, int w, float sigma, float* targets,
+                           float* weights, void* stream);
+/* BasicSimpleTransform.get_heat_map (:80-116): joints in INPUT px, quantised centre, truncated patch */
+int sp_encode_gauss_basic(const float* joints, int batch, int joints_n, int h, int w, float sigma, int stride,
+                          float* targets, float* weights, void* stream);
+
+/* ---- loss: processors/ddp_pose_resnet_solver.py:94,117 ------------------------------------------
+ * loss = 0.5 * mean((pred*m - target*m)^2) over all B*J*h*w elements; grad (may be NULL) = d loss / d pred.
+ * `loss_out` is one device float, written by the kernel (no host sync). `workspace`: >= 4096 bytes, zeroed by the call. */
+int sp_masked_mse(const float* pred, const float* target, const float* mask, int batch, int joints, int hw,
+                  float* loss_out, float* grad, void* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIMPLE_POSE_HIP_H */

@@ -1,0 +1,97 @@
+"""ctypes binding of libsimple_pose_hip.so (C ABI: include/simple_pose_hip.h).
+
+There is NO fallback: if the HIP library is missing or a call fails, this module raises.  The product path never
+routes through torch ops or the oracle.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int32, c_uint32, c_void_p
+
+from .build import LIB_PATH
+
+SP_CONV_RELU = 0x1
+SP_CONV_OUT_NCHW = 0x2
+SP_CONV_PIXEL_SHUFFLE = 0x4
+ABI_VERSION = 1
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+class ConvDesc(ctypes.Structure):
+    """Mirror of `sp_conv_desc` (field order is ABI)."""
+    _fields_ = [(n, c_int32) for n in (
+        "batch", "in_h", "in_w", "c_in", "grid_h", "grid_w", "c_out", "n_pad", "taps_h", "taps_w", "k_pad", "stride",
+        "dy0", "dy_step", "dx0", "dx_step", "out_h", "out_w", "out_c", "oy_mul", "oy_add", "ox_mul", "ox_add",
+        "phases_y", "phases_x")] + [("flags", c_uint32)]
+
+
+# every symbol include/simple_pose_hip.h declares: name -> (restype, argtypes)
+_P = c_void_p
+SYMBOLS = {
+    "sp_abi_version": (c_int, []),
+    "sp_last_error": (ctypes.c_char_p, []),
+    "sp_nchw_to_nhwc4": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "sp_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
+    "sp_maxpool3x3s2_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "sp_pixel_shuffle2_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "sp_upsample_add_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "sp_heat_map_to_axis": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "sp_decode_gauss_taylor": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "sp_decode_basic": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "sp_encode_gauss_refine": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P]),
+    "sp_encode_gauss_basic": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, c_int, _P, _P, _P]),
+    "sp_masked_mse": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the library (once).  Raises HipLibraryError if it has not been built - no silent fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise HipLibraryError(
+                f"{LIB_PATH} is missing: build it with `python -m simple_pose_amd.build` (hipcc, gfx950). "
+                "simple_pose_amd has no CPU/torch fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        if handle.sp_abi_version() != ABI_VERSION:
+            raise HipLibraryError(f"ABI mismatch: library {handle.sp_abi_version()} vs binding {ABI_VERSION}")
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().sp_last_error().decode("utf-8", "replace")
+        raise HipLibraryError(f"{what or 'libsimple_pose_hip'} failed (code {rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda_f32(t, name: str):
+    import torch
+
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise HipLibraryError(f"{name}: tensor is on {t.device}; simple_pose_amd runs on the MI355X only (no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    return t.contiguous()

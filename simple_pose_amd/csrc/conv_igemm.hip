@@ -1,0 +1,333 @@
+// conv_igemm.hip - fp32 implicit-GEMM convolution family on the gfx950 matrix cores.
+//
+// One kernel template covers every conv / transposed-conv of the reference networks
+// (nets/pose_resnet_dconv.py:99-103,158,210,236-244,173-178; nets/commons.py:31-32; nets/pose_hrnet.py):
+//
+//   D[m][n] = sum_k A[m][k] * Wp[n][k]
+//   m = (b, gy, gx)   output pixel of this phase            (rows)
+//   n = output channel                                      (columns)
+//   k = (ty, tx, c)   filter tap x input channel            (depth, c fastest = NHWC contiguous)
+//
+// A is never materialised: each 16-byte chunk (4 channels of one tap of one pixel) is gathered straight
+// from the NHWC activation with zero fill outside the image.  The transposed conv k4 s2 p1 is launched as
+// its 4 output phases (blockIdx.y), each a dense 2x2-tap conv, so no multiply is wasted on the zeros a
+// naive "dilate the input" formulation inserts.
+//
+// Math: v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate) - 256 FLOP/clk/CU, the fp32
+// matrix peak of the chip (157 TFLOP/s).  Block tile BM x BN x 32, 4 waves, each wave (BM/WR)x(BN/WC).
+//
+// LDS image: [rows][32 floats] (128-B rows), 16-B chunk index XOR ((row>>1)&7): the ds_read_b128 of a
+// 32x32x2 operand (lane = row, lane>>5 picks the chunk parity) is then conflict-free in every 16-lane
+// group, and so is the 8-lanes-per-row ds_write_b128 of the staging pass.
+//
+// Pipeline: register-staged double buffer (issue global loads of tile t+1, run the 64 MFMAs of tile t,
+// then ds_write t+1, one barrier per tile).  A tile's MFMA work is >= 2048 cycles per wave, so HBM/L2
+// latency hides behind it at 2 workgroups per CU.
+#include "sp_common.h"
+
+namespace {
+
+struct ConvArgs {
+    const float* x;
+    const float* w;
+    const float* scale;
+    const float* shift;
+    const float* res;
+    float* y;
+    int M;  // batch * grid_h * grid_w
+    int in_h, in_w, c_in;
+    int grid_h, grid_w;
+    int c_out, n_pad, k_pad;
+    int taps_h, taps_w;
+    int stride, dy0, dy_step, dx0, dx_step;
+    int out_h, out_w, out_c;
+    int oy_mul, oy_add, ox_mul, ox_add;
+    int phases_x;  // 1 or 2
+    unsigned flags;
+    int tiles_m, tiles_n;
+};
+
+constexpr int BK = 32;  // floats per K tile (8 chunks of 16 B)
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * BK + ((chunk ^ ((row >> 1) & 7)) << 2); }
+
+template <int BM, int BN, int WR, int WC, bool UNIFORM_TAP>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
+    static_assert(WR * WC == 4, "4 waves per workgroup");
+    constexpr int WM = BM / WR, WN = BN / WC;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int A_CH = BM / 32, B_CH = BN / 32;  // 16-B chunks each thread stages per tile
+    static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                    // [2][BM][32]
+    float* Bs = smem + 2 * BM * BK;      // [2][BN][32]
+    int* rowtab = reinterpret_cast<int*>(smem + 2 * (BM + BN) * BK);  // [BM][4]: in_base, iy0, ix0, out_off
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WC, wc = wave % WC;
+
+    // ---- tile id: XCD-aware remap (blocks b and b+8 share an XCD's L2), n fastest inside an XCD chunk ----
+    const int nwg = p.tiles_m * p.tiles_n;
+    int t;
+    {
+        const int orig = blockIdx.x;
+        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int tn = t % p.tiles_n, tm = t / p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- phase (transposed conv) ----
+    const int phase = blockIdx.y;
+    const int py = phase / p.phases_x, px = phase % p.phases_x;
+    const int dy0 = p.dy0 + py, dx0 = p.dx0 + px;
+    const int oy_add = p.oy_add + py, ox_add = p.ox_add + px;
+    const float* __restrict__ wp = p.w + (size_t)phase * p.n_pad * p.k_pad;
+
+    // ---- per-row table: one decode per row per workgroup ----
+    if (tid < BM) {
+        const int m = m0 + tid;
+        int4 e;
+        if (m < p.M) {
+            const int gw = p.grid_w, ghw = p.grid_h * gw;
+            const int b = m / ghw, rem = m - b * ghw;
+            const int gy = rem / gw, gx = rem - gy * gw;
+            e.x = b * p.in_h * p.in_w;
+            e.y = gy * p.stride + dy0;
+            e.z = gx * p.stride + dx0;
+            const int oy = gy * p.oy_mul + oy_add, ox = gx * p.ox_mul + ox_add;
+            e.w = (p.flags & SP_CONV_OUT_NCHW) ? (b * p.out_c * p.out_h + oy) * p.out_w + ox
+                                               : ((b * p.out_h + oy) * p.out_w + ox) * p.out_c;
+        } else {
+            e.x = 0; e.y = -(1 << 28); e.z = -(1 << 28); e.w = -1;
+        }
+        reinterpret_cast<int4*>(rowtab)[tid] = e;
+    }
+    __syncthreads();
+
+    // ---- staging assignment: thread -> (row = tid/8 + 32 i, chunk = tid%8) ----
+    const int kc = tid & 7;
+    const int srow = tid >> 3;
+    int a_base[A_CH], a_iy[A_CH], a_ix[A_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        const int4 e = reinterpret_cast<const int4*>(rowtab)[srow + 32 * i];
+        a_base[i] = e.x; a_iy[i] = e.y; a_ix[i] = e.z;
+    }
+    const float* __restrict__ bsrc = wp + (size_t)(n0 + srow) * p.k_pad + kc * 4;
+
+    f32x4 sa[A_CH], sb[B_CH];
+    const int cin_chunks = p.c_in >> 2;
+
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK;
+        int ty, tx, c_off;
+        bool tap_ok = true;
+        if (UNIFORM_TAP) {  // c_in % 32 == 0: the whole K tile sits inside one tap (scalar math)
+            const int tap = k0 / p.c_in;
+            c_off = k0 - tap * p.c_in + kc * 4;
+            ty = tap / p.taps_w; tx = tap - ty * p.taps_w;
+        } else {            // small c_in (stem: NHWC4): every 16-B chunk may be a different tap
+            const int q = (k0 >> 2) + kc;
+            const int tap = q / cin_chunks;
+            c_off = (q - tap * cin_chunks) << 2;
+            ty = tap / p.taps_w; tx = tap - ty * p.taps_w;
+            tap_ok = ty < p.taps_h;
+        }
+        const int ddy = ty * p.dy_step, ddx = tx * p.dx_step;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+            const int iy = a_iy[i] + ddy, ix = a_ix[i] + ddx;
+            const bool ok = tap_ok && (unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *reinterpret_cast<const f32x4*>(p.x + ((size_t)(a_base[i] + iy * p.in_w + ix) * p.c_in + c_off));
+            sa[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) sb[i] = *reinterpret_cast<const f32x4*>(bsrc + (size_t)(32 * i) * p.k_pad + k0);
+    };
+    auto store_tile = [&](int buf) {
+        float* a = As + buf * BM * BK;
+        float* b = Bs + buf * BN * BK;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) *reinterpret_cast<f32x4*>(a + swz(srow + 32 * i, kc)) = sa[i];
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) *reinterpret_cast<f32x4*>(b + swz(srow + 32 * i, kc)) = sb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.f;
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const int nk = p.k_pad / BK;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const float* a = As + cur * BM * BK + (wr * WM) * BK;
+        const float* b = Bs + cur * BN * BK + (wc * WN) * BK;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(a + swz(i * 32 + fr, 2 * j + fh));
+#pragma unroll
+            for (int n = 0; n < TN; ++n) bf[n] = *reinterpret_cast<const f32x4*>(b + swz(n * 32 + fr, 2 * j + fh));
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[n][s], acc[i][n], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: y = act(acc * scale + shift (+ residual)); C/D map: col = lane&31, row = (r&3)+8(r>>2)+4(lane>>5)
+    const bool nchw = p.flags & SP_CONV_OUT_NCHW;
+    const bool pshuf = p.flags & SP_CONV_PIXEL_SHUFFLE;
+    const bool relu = p.flags & SP_CONV_RELU;
+    const int hw_out = p.out_h * p.out_w;
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+        const int col = n0 + wc * WN + n * 32 + fr;
+        const bool col_ok = col < p.c_out;
+        float sc = 1.f, sh = 0.f;
+        if (col_ok) {
+            if (p.scale) sc = p.scale[col];
+            if (p.shift) sh = p.shift[col];
+        }
+        int col_off;
+        if (nchw) col_off = col * hw_out;
+        else if (pshuf) {
+            const int sub = col / p.out_c, c = col - sub * p.out_c;  // packed column order: sub-pixel major
+            col_off = ((sub >> 1) * p.out_w + (sub & 1)) * p.out_c + c;
+        } else col_off = col;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int row = wr * WM + i * 32 + 8 * g + 4 * fh;
+                const int4 ro = make_int4(rowtab[(row + 0) * 4 + 3], rowtab[(row + 1) * 4 + 3],
+                                          rowtab[(row + 2) * 4 + 3], rowtab[(row + 3) * 4 + 3]);
+                const int roff[4] = {ro.x, ro.y, ro.z, ro.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (col_ok && roff[e] >= 0) {
+                        const size_t o = (size_t)roff[e] + col_off;
+                        float v = acc[i][n][4 * g + e] * sc + sh;
+                        if (p.res) v += p.res[o];
+                        if (relu) v = v > 0.f ? v : 0.f;
+                        p.y[o] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WR, int WC>
+int launch(const ConvArgs& a, int phases, bool uniform, hipStream_t stream) {
+    ConvArgs p = a;
+    p.tiles_m = (a.M + BM - 1) / BM;
+    p.tiles_n = a.n_pad / BN;
+    const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float) + (size_t)BM * 4 * sizeof(int);
+    dim3 grid(p.tiles_m * p.tiles_n, phases, 1), block(256, 1, 1);
+    // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel instantiation
+    static const hipError_t attr_u = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, true>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static const hipError_t attr_c = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, false>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr_u != hipSuccess || attr_c != hipSuccess) {
+        sp_set_error("conv_igemm: hipFuncSetAttribute(max dynamic LDS = %zu) failed", lds);
+        return SP_ELAUNCH;
+    }
+    if (uniform)
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, true>), grid, block, lds, stream, p);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, false>), grid, block, lds, stream, p);
+    return sp_check_launch("conv_igemm_kernel");
+}
+
+}  // namespace
+
+extern "C" int sp_conv2d_fwd(const sp_conv_desc* d, const float* x, const float* w_packed, const float* scale,
+                             const float* shift, const float* residual, float* y, void* stream) {
+    SP_REQUIRE(d && x && w_packed && y, "sp_conv2d_fwd: null pointer");
+    SP_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->grid_h > 0 && d->grid_w > 0 && d->c_out > 0,
+               "sp_conv2d_fwd: non-positive dimension");
+    SP_REQUIRE(d->c_in > 0 && d->c_in % 4 == 0, "sp_conv2d_fwd: c_in=%d must be a positive multiple of 4", d->c_in);
+    SP_REQUIRE(d->taps_h > 0 && d->taps_w > 0 && d->stride > 0, "sp_conv2d_fwd: bad taps/stride");
+    SP_REQUIRE(d->k_pad % 32 == 0 && d->k_pad >= d->taps_h * d->taps_w * d->c_in,
+               "sp_conv2d_fwd: k_pad=%d must be a multiple of 32 and >= taps*c_in=%d", d->k_pad,
+               d->taps_h * d->taps_w * d->c_in);
+    SP_REQUIRE(d->n_pad % 32 == 0 && d->n_pad >= d->c_out, "sp_conv2d_fwd: n_pad=%d must be a multiple of 32 >= c_out=%d",
+               d->n_pad, d->c_out);
+    const bool uniform = (d->c_in % 32 == 0);
+    if (uniform) SP_REQUIRE(d->k_pad == d->taps_h * d->taps_w * d->c_in, "sp_conv2d_fwd: k_pad must equal taps*c_in when c_in%%32==0");
+    SP_REQUIRE((d->phases_y == 1 || d->phases_y == 2) && (d->phases_x == 1 || d->phases_x == 2), "sp_conv2d_fwd: phases must be 1 or 2");
+    const unsigned known = SP_CONV_RELU | SP_CONV_OUT_NCHW | SP_CONV_PIXEL_SHUFFLE;
+    SP_REQUIRE((d->flags & ~known) == 0, "sp_conv2d_fwd: unknown flag bits 0x%x", d->flags);
+    SP_REQUIRE(!((d->flags & SP_CONV_OUT_NCHW) && (d->flags & SP_CONV_PIXEL_SHUFFLE)), "sp_conv2d_fwd: NCHW output and pixel shuffle are exclusive");
+    SP_REQUIRE(!((d->flags & SP_CONV_OUT_NCHW) && residual), "sp_conv2d_fwd: residual needs NHWC output");
+    // output footprint of the launch must lie inside y
+    int max_oy = (d->grid_h - 1) * d->oy_mul + d->oy_add + (d->phases_y - 1);
+    int max_ox = (d->grid_w - 1) * d->ox_mul + d->ox_add + (d->phases_x - 1);
+    int min_oy = d->oy_add, min_ox = d->ox_add;
+    if (d->flags & SP_CONV_PIXEL_SHUFFLE) {
+        SP_REQUIRE(d->c_out % 4 == 0 && d->out_c * 4 == d->c_out && d->oy_mul == 2 && d->ox_mul == 2 && d->n_pad == d->c_out,
+                   "sp_conv2d_fwd: pixel shuffle needs out_c == c_out/4 == n_pad/4, oy_mul == ox_mul == 2");
+        max_oy += 1; max_ox += 1;
+    } else {
+        SP_REQUIRE(d->out_c == d->c_out, "sp_conv2d_fwd: out_c=%d != c_out=%d", d->out_c, d->c_out);
+    }
+    SP_REQUIRE(d->oy_mul > 0 && d->ox_mul > 0 && min_oy >= 0 && min_ox >= 0 && max_oy < d->out_h && max_ox < d->out_w,
+               "sp_conv2d_fwd: output mapping leaves the output tensor (max oy %d / out_h %d, max ox %d / out_w %d)", max_oy,
+               d->out_h, max_ox, d->out_w);
+    const long long M = (long long)d->batch * d->grid_h * d->grid_w;
+    const long long in_elems = (long long)d->batch * d->in_h * d->in_w * d->c_in;
+    const long long out_elems = (long long)d->batch * d->out_h * d->out_w * d->out_c;
+    SP_REQUIRE(M < (1ll << 31) && in_elems < (1ll << 31) && out_elems < (1ll << 31), "sp_conv2d_fwd: tensor too large for 32-bit indexing");
+
+    ConvArgs a;
+    a.x = x; a.w = w_packed; a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
+    a.M = (int)M;
+    a.in_h = d->in_h; a.in_w = d->in_w; a.c_in = d->c_in;
+    a.grid_h = d->grid_h; a.grid_w = d->grid_w;
+    a.c_out = d->c_out; a.n_pad = d->n_pad; a.k_pad = d->k_pad;
+    a.taps_h = d->taps_h; a.taps_w = d->taps_w;
+    a.stride = d->stride; a.dy0 = d->dy0; a.dy_step = d->dy_step; a.dx0 = d->dx0; a.dx_step = d->dx_step;
+    a.out_h = d->out_h; a.out_w = d->out_w; a.out_c = d->out_c;
+    a.oy_mul = d->oy_mul; a.oy_add = d->oy_add; a.ox_mul = d->ox_mul; a.ox_add = d->ox_add;
+    a.phases_x = d->phases_x; a.flags = d->flags; a.tiles_m = a.tiles_n = 0;
+    const int phases = d->phases_y * d->phases_x;
+    hipStream_t s = (hipStream_t)stream;
+
+    // tile choice: widest N tile that divides n_pad; halve BM when the launch would not fill the 256 CUs twice
+    const int np = d->n_pad;
+    if (np % 128 == 0) {
+        const long long wgs = ((M + 127) / 128) * (np / 128) * phases;
+        if (wgs >= 512) return launch<128, 128, 2, 2>(a, phases, uniform, s);
+        return launch<64, 128, 2, 2>(a, phases, uniform, s);
+    }
+    if (np % 64 == 0) {
+        const long long wgs = ((M + 127) / 128) * (np / 64) * phases;
+        if (wgs >= 512) return launch<128, 64, 2, 2>(a, phases, uniform, s);
+        return launch<64, 64, 2, 2>(a, phases, uniform, s);
+    }
+    return launch<128, 32, 4, 1>(a, phases, uniform, s);
+}

@@ -1,0 +1,173 @@
+// pointwise.hip - HBM-bound layout / pooling / fuse / loss kernels (NHWC fp32, 16 B per lane).
+#include "sp_common.h"
+
+namespace {
+
+// [B,C,H,W] (C <= 4) -> [B,H,W,4], zero-filled tail channels.  Reads are coalesced along W per plane.
+__global__ void nchw_to_nhwc4_kernel(const float* __restrict__ x, f32x4* __restrict__ y, int C, int hw, long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / hw;
+        const int pix = (int)(i - b * hw);
+        const float* src = x + b * C * hw + pix;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        v[0] = src[0];
+        if (C > 1) v[1] = src[hw];
+        if (C > 2) v[2] = src[2 * (long long)hw];
+        if (C > 3) v[3] = src[3 * (long long)hw];
+        y[i] = v;
+    }
+}
+
+__device__ __forceinline__ float pmax(float m, float v) { return (v > m || v != v) ? v : m; }  // NaN propagates like torch
+
+// nn.MaxPool2d(3,2,1), NHWC, one lane = 4 channels of one output pixel
+__global__ void maxpool3x3s2_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y, int H, int W, int C4, int Ho, int Wo,
+                                    long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long long r = i / C4;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho);
+        const long long b = r / Ho;
+        const float ninf = -__builtin_inff();
+        f32x4 m = {ninf, ninf, ninf, ninf};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * 2 - 1 + ky;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * 2 - 1 + kx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const f32x4 v = x[((b * H + iy) * W + ix) * C4 + c];
+                m[0] = pmax(m[0], v[0]); m[1] = pmax(m[1], v[1]); m[2] = pmax(m[2], v[2]); m[3] = pmax(m[3], v[3]);
+            }
+        }
+        y[i] = m;
+    }
+}
+
+// y[b, Y, X, :] (+)= x[b, Y/f, X/f, :]  (nearest upsample + add [+ relu])
+__global__ void upsample_add_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y, int h, int w, int C4, int f, int relu,
+                                    long long total) {
+    const int W = w * f, H = h * f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long long r = i / C4;
+        const int X = (int)(r % W); r /= W;
+        const int Y = (int)(r % H);
+        const long long b = r / H;
+        const f32x4 a = x[((b * h + Y / f) * w + X / f) * C4 + c];
+        f32x4 v = y[i];
+        v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3];
+        if (relu) {
+            v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f;
+            v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f;
+        }
+        y[i] = v;
+    }
+}
+
+// nn.PixelShuffle(2): one lane gathers 4 output channels (stride 4 in the source pixel) and stores 16 B
+__global__ void pixel_shuffle2_kernel(const float* __restrict__ x, f32x4* __restrict__ y, int h, int w, int C, long long total) {
+    const int Co = C >> 2, Co4 = Co >> 2, W2 = 2 * w, H2 = 2 * h;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int k4 = (int)(i % Co4);
+        long long r = i / Co4;
+        const int X = (int)(r % W2); r /= W2;
+        const int Y = (int)(r % H2);
+        const long long b = r / H2;
+        const int sub = ((Y & 1) << 1) | (X & 1);
+        const float* src = x + ((b * h + (Y >> 1)) * w + (X >> 1)) * C + (k4 << 4) + sub;
+        f32x4 v = {src[0], src[4], src[8], src[12]};
+        y[i] = v;
+    }
+}
+
+// masked MSE: per-block double partial sums (deterministic), then one block folds them.
+__global__ void mse_partial_kernel(const float* __restrict__ pred, const float* __restrict__ tgt, const float* __restrict__ mask,
+                                   float* __restrict__ grad, int hw, long long total, double inv_n, double* __restrict__ part) {
+    double acc = 0.0;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const float w = mask[i / hw];
+        const float d = pred[i] * w - tgt[i] * w;
+        acc += (double)d * (double)d;
+        if (grad) grad[i] = (float)((double)d * (double)w * inv_n);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, SP_WAVE);
+    __shared__ double wsum[4];
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+__global__ void mse_final_kernel(const double* __restrict__ part, int n, double inv_n, float* __restrict__ loss) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) acc += part[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, SP_WAVE);
+    if (threadIdx.x == 0) *loss = (float)(0.5 * acc * inv_n);
+}
+
+inline int grid_for(long long total, int block) {
+    long long g = (total + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));  // cap + grid-stride (guide, Guideline 11)
+}
+
+}  // namespace
+
+extern "C" int sp_nchw_to_nhwc4(const float* x, float* y, int batch, int channels, int h, int w, void* stream) {
+    SP_REQUIRE(x && y, "sp_nchw_to_nhwc4: null pointer");
+    SP_REQUIRE(batch > 0 && h > 0 && w > 0 && channels >= 1 && channels <= 4, "sp_nchw_to_nhwc4: bad shape B=%d C=%d H=%d W=%d", batch, channels, h, w);
+    const long long total = (long long)batch * h * w;
+    SP_REQUIRE(total * 4 < (1ll << 31), "sp_nchw_to_nhwc4: tensor too large");
+    hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       reinterpret_cast<f32x4*>(y), channels, h * w, total);
+    return sp_check_launch("nchw_to_nhwc4_kernel");
+}
+
+extern "C" int sp_maxpool3x3s2_nhwc(const float* x, float* y, int batch, int h, int w, int c, void* stream) {
+    SP_REQUIRE(x && y, "sp_maxpool3x3s2_nhwc: null pointer");
+    SP_REQUIRE(batch > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "sp_maxpool3x3s2_nhwc: bad shape (c %% 4 != 0?)");
+    const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+    const long long total = (long long)batch * ho * wo * (c / 4);
+    SP_REQUIRE((long long)batch * h * w * c < (1ll << 31), "sp_maxpool3x3s2_nhwc: tensor too large");
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const f32x4*>(x), reinterpret_cast<f32x4*>(y), h, w, c / 4, ho, wo, total);
+    return sp_check_launch("maxpool3x3s2_kernel");
+}
+
+extern "C" int sp_pixel_shuffle2_nhwc(const float* x, float* y, int batch, int h, int w, int c, void* stream) {
+    SP_REQUIRE(x && y, "sp_pixel_shuffle2_nhwc: null pointer");
+    SP_REQUIRE(batch > 0 && h > 0 && w > 0 && c > 0 && c % 16 == 0, "sp_pixel_shuffle2_nhwc: c=%d must be a multiple of 16", c);
+    const long long total = (long long)batch * h * w * c / 4;
+    SP_REQUIRE(total * 4 < (1ll << 31), "sp_pixel_shuffle2_nhwc: tensor too large");
+    hipLaunchKernelGGL(pixel_shuffle2_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       reinterpret_cast<f32x4*>(y), h, w, c, total);
+    return sp_check_launch("pixel_shuffle2_kernel");
+}
+
+extern "C" int sp_upsample_add_nhwc(const float* x, float* y, int batch, int h, int w, int c, int factor, int relu, void* stream) {
+    SP_REQUIRE(x && y, "sp_upsample_add_nhwc: null pointer");
+    SP_REQUIRE(batch > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0 && factor >= 1, "sp_upsample_add_nhwc: bad shape");
+    const long long total = (long long)batch * h * factor * w * factor * (c / 4);
+    SP_REQUIRE(total * 4 < (1ll << 31), "sp_upsample_add_nhwc: tensor too large");
+    hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const f32x4*>(x), reinterpret_cast<f32x4*>(y), h, w, c / 4, factor, relu, total);
+    return sp_check_launch("upsample_add_kernel");
+}
+
+extern "C" int sp_masked_mse(const float* pred, const float* target, const float* mask, int batch, int joints, int hw,
+                             float* loss_out, float* grad, void* workspace, void* stream) {
+    SP_REQUIRE(pred && target && mask && loss_out && workspace, "sp_masked_mse: null pointer");
+    SP_REQUIRE(batch > 0 && joints > 0 && hw > 0, "sp_masked_mse: bad shape");
+    const long long total = (long long)batch * joints * hw;
+    int g = grid_for(total, 256);
+    if (g > 512) g = 512;  // workspace holds 512 doubles
+    const double inv_n = 1.0 / (double)total;
+    hipLaunchKernelGGL(mse_partial_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, pred, target, mask, grad, hw, total, inv_n,
+                       reinterpret_cast<double*>(workspace));
+    hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<const double*>(workspace), g, inv_n, loss_out);
+    return sp_check_launch("mse kernels");
+}

@@ -1,0 +1,341 @@
+"""Host-side lowering of the reference networks onto libsimple_pose_hip.so.
+
+A network is compiled once into a `Program`: a flat list of launches (sp_conv2d_fwd, sp_maxpool3x3s2_nhwc, ...)
+over named NHWC fp32 activation buffers, with weights pre-packed into the kernel's [n_pad][k_pad] layout and
+eval-mode BatchNorm folded into a per-channel (scale, shift) epilogue.  Python/PyTorch is glue only: it owns the
+device memory and the stream; every FLOP runs in the HIP library.
+
+Reference behaviour being lowered (file:line relative to liangheming/simple_pose):
+  nets/pose_resnet_dconv.py:251-265  ResNet._forward_impl        -> resnet_program(head="dconv")
+  nets/pose_resnet_dconv.py:112-133  Bottleneck.forward          -> _bottleneck()
+  nets/pose_resnet_dconv.py:230-249  _make_deconv_layer          -> deconv_k4s2p1 launches (4 output phases)
+  nets/pose_resnet_duc.py:227-232, nets/commons.py:21-43  DUC    -> conv3x3 with fused PixelShuffle epilogue
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, SP_CONV_OUT_NCHW, SP_CONV_PIXEL_SHUFFLE, SP_CONV_RELU
+
+BN_EPS = 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# weight packing (pure torch; runs on whatever device the weights live on; unit-tested on CPU)
+# ------------------------------------------------------------------------------------------------
+def _round_up(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+def n_pad_for(c_out: int) -> int:
+    """Packed row count: the kernel's N tile must divide it (128 / 64 / 32 wide tiles)."""
+    if c_out >= 128:
+        return _round_up(c_out, 128)
+    if c_out > 32:
+        return _round_up(c_out, 64)
+    return 32
+
+
+def fold_bn(weight, bias, running_mean, running_var, eps: float = BN_EPS):
+    """Eval-mode BatchNorm2d as y = x*scale + shift (same factoring as ATen's CPU kernel: alpha = w/sqrt(var+eps),
+    beta = b - mean*alpha)."""
+    invstd = 1.0 / torch.sqrt(running_var.float() + eps)
+    scale = weight.float() * invstd
+    shift = bias.float() - running_mean.float() * scale
+    return scale.contiguous(), shift.contiguous()
+
+
+def pack_conv(w: torch.Tensor, c_in_pad: Optional[int] = None, taps_w_pad: Optional[int] = None,
+              row_perm: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, int, int, int, int]:
+    """Conv2d weight [O,I,kh,kw] -> packed [n_pad, k_pad] with K ordered (ky, kx, c), c fastest.
+    Returns (packed, taps_h, taps_w, c_in_packed, k_pad)."""
+    O, I, kh, kw = w.shape
+    ci = c_in_pad or I
+    tw = taps_w_pad or kw
+    assert ci >= I and ci % 4 == 0 and tw >= kw
+    p = torch.zeros((O, kh, tw, ci), dtype=torch.float32, device=w.device)
+    p[:, :, :kw, :I] = w.float().permute(0, 2, 3, 1)
+    p = p.reshape(O, kh * tw * ci)
+    if row_perm is not None:
+        p = p[row_perm]
+    k = kh * tw * ci
+    k_pad = _round_up(k, 32)
+    n_pad = n_pad_for(O)
+    out = torch.zeros((n_pad, k_pad), dtype=torch.float32, device=w.device)
+    out[:O, :k] = p
+    return out.contiguous(), kh, tw, ci, k_pad
+
+
+def pack_deconv_k4s2p1(w: torch.Tensor) -> Tuple[torch.Tensor, int]:
+    """ConvTranspose2d(k=4, s=2, p=1) weight [I,O,4,4] -> [4 phases, n_pad, 4*I].
+    Output pixel (2y+py, 2x+px) = sum over 2x2 taps (ty,tx) of x[y+py-ty, x+px-tx] * W[:, :, 2ty+1-py, 2tx+1-px]."""
+    I, O, kh, kw = w.shape
+    assert (kh, kw) == (4, 4) and I % 32 == 0
+    n_pad = n_pad_for(O)
+    out = torch.zeros((4, n_pad, 4 * I), dtype=torch.float32, device=w.device)
+    wf = w.float()
+    for py in range(2):
+        for px in range(2):
+            for ty in range(2):
+                for tx in range(2):
+                    ky, kx = 2 * ty + 1 - py, 2 * tx + 1 - px
+                    t = ty * 2 + tx
+                    out[py * 2 + px, :O, t * I:(t + 1) * I] = wf[:, :, ky, kx].t()
+    return out.contiguous(), n_pad
+
+
+def pixel_shuffle_row_perm(c_out: int, device) -> torch.Tensor:
+    """Packed column n' = sub*(C/4) + c holds original channel c*4 + sub (sub = i*2 + j of nn.PixelShuffle(2)),
+    so that a wave's 32 consecutive columns store 32 consecutive output channels of one pixel."""
+    c4 = c_out // 4
+    n = torch.arange(c_out, device=device)
+    return (n % c4) * 4 + (n // c4)
+
+
+# ------------------------------------------------------------------------------------------------
+# program
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class Op:
+    kind: str                    # "conv" | "maxpool" | "to_nhwc4" | "upsample_add"
+    src: str
+    dst: str
+    res: Optional[str] = None
+    desc: Optional[ConvDesc] = None
+    w: Optional[torch.Tensor] = None
+    scale: Optional[torch.Tensor] = None
+    shift: Optional[torch.Tensor] = None
+    args: tuple = ()
+    flops: int = 0               # algorithmic FLOPs per image (2*MACs, real taps/channels only)
+    name: str = ""
+
+
+@dataclass
+class Program:
+    ops: List[Op] = field(default_factory=list)
+    shapes: Dict[str, Tuple[int, int, int]] = field(default_factory=dict)  # buffer -> (H, W, C) NHWC per image
+    out_name: str = "heat"
+    out_shape: Tuple[int, int, int] = (17, 64, 48)                          # NCHW per image
+    _pools: Dict[int, Dict[str, torch.Tensor]] = field(default_factory=dict)
+
+    # -- buffer planning: greedy reuse of dead activations (keeps the working set small for L2 / MALL) --
+    def _alloc(self, batch: int, device) -> Dict[str, torch.Tensor]:
+        key = (batch, str(device))
+        if key in self._pools:
+            return self._pools[key]
+        last_use: Dict[str, int] = {}
+        for i, op in enumerate(self.ops):
+            for nm in (op.src, op.res, op.dst):
+                if nm:
+                    last_use[nm] = i
+        free: Dict[int, List[torch.Tensor]] = {}
+        bufs: Dict[str, torch.Tensor] = {}
+        for i, op in enumerate(self.ops):
+            if op.dst not in bufs and op.dst != self.out_name and op.kind != "upsample_add":
+                h, w, c = self.shapes[op.dst]
+                n = batch * h * w * c
+                pool = free.get(n)
+                bufs[op.dst] = pool.pop() if pool else torch.empty(n, dtype=torch.float32, device=device)
+            for nm in (op.src, op.res):
+                if nm and nm in bufs and last_use[nm] == i and nm != "input":
+                    free.setdefault(bufs[nm].numel(), []).append(bufs[nm])
+        self._pools[key] = bufs
+        return bufs
+
+    def run(self, x: torch.Tensor) -> torch.Tensor:
+        """x: fp32 NCHW [B,3,H,W] on the GPU -> heat maps fp32 NCHW [B,J,H/4,W/4]."""
+        lib = _lib.lib()
+        B = x.shape[0]
+        bufs = dict(self._alloc(B, x.device))
+        bufs["input"] = x
+        out = torch.empty((B,) + tuple(self.out_shape), dtype=torch.float32, device=x.device)
+        bufs[self.out_name] = out
+        stream = _lib.current_stream()
+        P = _lib.ptr
+        for op in self.ops:
+            if op.kind == "conv":
+                op.desc.batch = B
+                _lib.check(lib.sp_conv2d_fwd(op.desc, P(bufs[op.src]), P(op.w), P(op.scale), P(op.shift),
+                                             P(bufs[op.res]) if op.res else None, P(bufs[op.dst]), stream), op.name)
+            elif op.kind == "maxpool":
+                h, w, c = op.args
+                _lib.check(lib.sp_maxpool3x3s2_nhwc(P(bufs[op.src]), P(bufs[op.dst]), B, h, w, c, stream), op.name)
+            elif op.kind == "to_nhwc4":
+                c, h, w = op.args
+                _lib.check(lib.sp_nchw_to_nhwc4(P(bufs[op.src]), P(bufs[op.dst]), B, c, h, w, stream), op.name)
+            elif op.kind == "pixel_shuffle":
+                h, w, c = op.args
+                _lib.check(lib.sp_pixel_shuffle2_nhwc(P(bufs[op.src]), P(bufs[op.dst]), B, h, w, c, stream), op.name)
+            elif op.kind == "upsample_add":
+                h, w, c, f, relu = op.args
+                _lib.check(lib.sp_upsample_add_nhwc(P(bufs[op.src]), P(bufs[op.dst]), B, h, w, c, f, relu, stream), op.name)
+            else:
+                raise ValueError(op.kind)
+        return out
+
+    @property
+    def flops_per_image(self) -> int:
+        return sum(op.flops for op in self.ops)
+
+
+class ProgramBuilder:
+    """Appends launches to a Program while tracking NHWC buffer shapes."""
+
+    def __init__(self, in_h: int, in_w: int):
+        self.p = Program()
+        self.p.shapes["input"] = (in_h, in_w, 3)
+        self._n = 0
+
+    def _fresh(self, stem: str) -> str:
+        self._n += 1
+        return f"{stem}#{self._n}"
+
+    def to_nhwc4(self, src: str) -> str:
+        h, w, c = self.p.shapes[src]
+        dst = self._fresh("x4")
+        self.p.shapes[dst] = (h, w, 4)
+        self.p.ops.append(Op("to_nhwc4", src, dst, args=(c, h, w), name="to_nhwc4"))
+        return dst
+
+    def maxpool(self, src: str) -> str:
+        h, w, c = self.p.shapes[src]
+        dst = self._fresh("pool")
+        self.p.shapes[dst] = ((h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1, c)
+        self.p.ops.append(Op("maxpool", src, dst, args=(h, w, c), name="maxpool"))
+        return dst
+
+    def conv(self, src: str, weight: torch.Tensor, *, stride: int = 1, pad: int = 0, scale=None, shift=None,
+             relu: bool = False, res: Optional[str] = None, pixel_shuffle: bool = False, out_nchw: bool = False,
+             dst: Optional[str] = None, name: str = "conv") -> str:
+        h, w, c_buf = self.p.shapes[src]
+        O, I, kh, kw = weight.shape
+        if c_buf == 4 and I < 4:           # stem on NHWC4: pad channels to 4 and the tap row to 8 -> 128-B K rows
+            taps_w_pad = _round_up(kw, 8) if kw > 4 else 4
+            packed, th, tw, ci, k_pad = pack_conv(weight, c_in_pad=4, taps_w_pad=taps_w_pad)
+        else:
+            assert I == c_buf, (name, I, c_buf)
+            perm = pixel_shuffle_row_perm(O, weight.device) if pixel_shuffle else None
+            packed, th, tw, ci, k_pad = pack_conv(weight, row_perm=perm)
+            if pixel_shuffle:
+                scale = scale[perm].contiguous() if scale is not None else None
+                shift = shift[perm].contiguous() if shift is not None else None
+        gh, gw = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+        d = ConvDesc()
+        d.batch, d.in_h, d.in_w, d.c_in = 1, h, w, ci
+        d.grid_h, d.grid_w, d.c_out, d.n_pad = gh, gw, O, packed.shape[0]
+        d.taps_h, d.taps_w, d.k_pad, d.stride = th, tw, k_pad, stride
+        d.dy0, d.dy_step, d.dx0, d.dx_step = -pad, 1, -pad, 1
+        d.phases_y = d.phases_x = 1
+        flags = SP_CONV_RELU if relu else 0
+        if pixel_shuffle:
+            assert O % 4 == 0 and packed.shape[0] == O
+            d.out_h, d.out_w, d.out_c = gh * 2, gw * 2, O // 4
+            d.oy_mul = d.ox_mul = 2
+            flags |= SP_CONV_PIXEL_SHUFFLE
+        else:
+            d.out_h, d.out_w, d.out_c = gh, gw, O
+            d.oy_mul = d.ox_mul = 1
+        d.oy_add = d.ox_add = 0
+        if out_nchw:
+            flags |= SP_CONV_OUT_NCHW
+        d.flags = flags
+        dst = dst or self._fresh(name)
+        self.p.shapes[dst] = (d.out_h, d.out_w, d.out_c)
+        self.p.ops.append(Op("conv", src, dst, res=res, desc=d, w=packed, scale=scale, shift=shift, name=name,
+                             flops=2 * gh * gw * O * I * kh * kw))
+        return dst
+
+    def deconv_k4s2p1(self, src: str, weight: torch.Tensor, *, scale=None, shift=None, relu: bool = False,
+                      name: str = "deconv") -> str:
+        h, w, c = self.p.shapes[src]
+        I, O = weight.shape[:2]
+        assert I == c
+        packed, n_pad = pack_deconv_k4s2p1(weight)
+        d = ConvDesc()
+        d.batch, d.in_h, d.in_w, d.c_in = 1, h, w, I
+        d.grid_h, d.grid_w, d.c_out, d.n_pad = h, w, O, n_pad
+        d.taps_h, d.taps_w, d.k_pad, d.stride = 2, 2, 4 * I, 1
+        d.dy0, d.dy_step, d.dx0, d.dx_step = 0, -1, 0, -1       # + phase (py, px) inside the kernel
+        d.out_h, d.out_w, d.out_c = 2 * h, 2 * w, O
+        d.oy_mul, d.oy_add, d.ox_mul, d.ox_add = 2, 0, 2, 0    # + phase
+        d.phases_y = d.phases_x = 2
+        d.flags = SP_CONV_RELU if relu else 0
+        dst = self._fresh(name)
+        self.p.shapes[dst] = (2 * h, 2 * w, O)
+        self.p.ops.append(Op("conv", src, dst, desc=d, w=packed.reshape(4 * n_pad, 4 * I), scale=scale, shift=shift,
+                             name=name, flops=2 * h * w * I * O * 16))
+        return dst
+
+    def pixel_shuffle(self, src: str) -> str:
+        h, w, c = self.p.shapes[src]
+        dst = self._fresh("pshuf")
+        self.p.shapes[dst] = (2 * h, 2 * w, c // 4)
+        self.p.ops.append(Op("pixel_shuffle", src, dst, args=(h, w, c), name="pixel_shuffle"))
+        return dst
+
+    def upsample_add(self, src: str, dst: str, factor: int, relu: bool = False) -> str:
+        h, w, c = self.p.shapes[src]
+        assert self.p.shapes[dst] == (h * factor, w * factor, c)
+        self.p.ops.append(Op("upsample_add", src, dst, args=(h, w, c, factor, int(relu)), name="upsample_add"))
+        return dst
+
+
+# ------------------------------------------------------------------------------------------------
+# ResNet-50 (+ DConv / DUC head)
+# ------------------------------------------------------------------------------------------------
+def _bn(sd, prefix):
+    return fold_bn(sd[prefix + ".weight"], sd[prefix + ".bias"], sd[prefix + ".running_mean"], sd[prefix + ".running_var"])
+
+
+def _bottleneck(b: ProgramBuilder, sd, x: str, p: str, stride: int) -> str:
+    s1, h1 = _bn(sd, p + ".bn1")
+    t = b.conv(x, sd[p + ".conv1.weight"], scale=s1, shift=h1, relu=True, name=p + ".conv1")
+    s2, h2 = _bn(sd, p + ".bn2")
+    t = b.conv(t, sd[p + ".conv2.weight"], stride=stride, pad=1, scale=s2, shift=h2, relu=True, name=p + ".conv2")
+    idn = x
+    if (p + ".downsample.0.weight") in sd:
+        sdn, hdn = _bn(sd, p + ".downsample.1")
+        idn = b.conv(x, sd[p + ".downsample.0.weight"], stride=stride, scale=sdn, shift=hdn, name=p + ".downsample")
+    s3, h3 = _bn(sd, p + ".bn3")
+    # bn3 + residual add + relu fused in conv3's epilogue (pose_resnet_dconv.py:124-131)
+    return b.conv(t, sd[p + ".conv3.weight"], scale=s3, shift=h3, relu=True, res=idn, name=p + ".conv3")
+
+
+def resnet_program(sd: Dict[str, torch.Tensor], head: str, in_h: int = 256, in_w: int = 192,
+                   blocks=(3, 4, 6, 3)) -> Program:
+    """Lower a reference-layout state_dict into a Program.  `sd` tensors must be on the GPU."""
+    if any(k.endswith(".se.fc.0.weight") for k in sd):
+        raise NotImplementedError("SELayer (reduction=True) is not lowered yet")
+    b = ProgramBuilder(in_h, in_w)
+    x = b.to_nhwc4("input")
+    s, h = _bn(sd, "bn1")
+    x = b.conv(x, sd["conv1.weight"], stride=2, pad=3, scale=s, shift=h, relu=True, name="conv1")
+    x = b.maxpool(x)
+    for li, n in enumerate(blocks, start=1):
+        for bi in range(n):
+            x = _bottleneck(b, sd, x, f"layer{li}.{bi}", 2 if (bi == 0 and li > 1) else 1)
+    J = sd["final_layer.weight"].shape[0]
+    if head == "dconv":
+        for idx in (0, 3, 6):
+            s, h = _bn(sd, f"deconv_layers.{idx + 1}")
+            x = b.deconv_k4s2p1(x, sd[f"deconv_layers.{idx}.weight"], scale=s, shift=h, relu=True,
+                                name=f"deconv_layers.{idx}")
+        b.conv(x, sd["final_layer.weight"], shift=sd["final_layer.bias"].float().contiguous(), out_nchw=True,
+               dst="heat", name="final_layer")
+    elif head == "duc":
+        x = b.pixel_shuffle(x)
+        for idx in (1, 2):
+            s, h = _bn(sd, f"duc_layers.{idx}.bn")
+            x = b.conv(x, sd[f"duc_layers.{idx}.conv.weight"], pad=1, scale=s, shift=h, relu=True, pixel_shuffle=True,
+                       name=f"duc_layers.{idx}")
+        b.conv(x, sd["final_layer.weight"], pad=1, shift=sd["final_layer.bias"].float().contiguous(), out_nchw=True,
+               dst="heat", name="final_layer")
+    else:
+        raise ValueError(head)
+    hh, ww, _ = b.p.shapes["heat"]
+    b.p.out_shape = (J, hh, ww)
+    return b.p

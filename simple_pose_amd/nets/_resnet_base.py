@@ -1,0 +1,112 @@
+"""Parameter containers + HIP dispatch shared by the DConv and DUC ResNet pose nets.
+
+The module tree exists only to own parameters/buffers under the reference's exact names so that
+`state_dict()` / `load_state_dict()` / `.to()` / `.parameters()` behave like the reference's
+(`nets/pose_resnet_dconv.py:136-268`, `nets/pose_resnet_duc.py:136-251`).  No torch op computes anything in
+`forward`: the tensors are packed once into the HIP library's layout (simple_pose_amd.engine) and re-packed whenever
+a parameter changes (load_state_dict, optimizer step, .to()).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+
+from .. import engine
+from .._lib import HipLibraryError, require_cuda_f32
+
+
+class _Bottleneck(nn.Module):
+    """Parameter holder for one bottleneck block: conv1/bn1 (1x1), conv2/bn2 (3x3, carries the stride), conv3/bn3 (1x1 x4),
+    optional `downsample` = Sequential(conv1x1, bn).  Keys as in nets/pose_resnet_dconv.py:83-110."""
+    expansion = 4
+
+    def __init__(self, inplanes: int, planes: int, stride: int, with_downsample: bool):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        if with_downsample:
+            self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False),
+                                            nn.BatchNorm2d(planes * 4))
+        else:
+            self.downsample = None
+        self.stride = stride
+
+
+class PoseResNetBase(nn.Module):
+    """ResNet-50 trunk (conv1, bn1, layer1..4) + a head defined by the subclass (`_build_head`, `HEAD`)."""
+    HEAD = ""
+    BLOCKS = (3, 4, 6, 3)
+
+    def __init__(self, num_classes: int = 17, reduction: bool = False):
+        super().__init__()
+        if reduction:
+            raise NotImplementedError("SELayer variant (reduction=True, nets/commons.py:4-18) is not lowered to HIP yet")
+        self.num_classes = num_classes
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        inplanes = 64
+        for li, (planes, n) in enumerate(zip((64, 128, 256, 512), self.BLOCKS), start=1):
+            blocks = []
+            for bi in range(n):
+                stride = 2 if (bi == 0 and li > 1) else 1
+                blocks.append(_Bottleneck(inplanes, planes, stride, with_downsample=(bi == 0)))
+                inplanes = planes * 4
+            setattr(self, f"layer{li}", nn.Sequential(*blocks))
+        self._build_head(inplanes, num_classes)
+        self._init_like_reference()
+        self._program: Optional[engine.Program] = None
+        self._program_key = None
+
+    # -- reference init (pose_resnet_dconv.py:180-189): conv / deconv N(0, 0.001), conv bias 0, BN 1/0 --
+    def _init_like_reference(self):
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                nn.init.normal_(m.weight, std=0.001)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _build_head(self, inplanes: int, num_classes: int):
+        raise NotImplementedError
+
+    # -- HIP dispatch ------------------------------------------------------------------------------------
+    def _tensors_key(self, x):
+        sd = self.state_dict(keep_vars=True)
+        return (tuple(x.shape[2:]), str(x.device)) + tuple((v.data_ptr(), v._version) for v in sd.values())
+
+    def hip_program(self, x: torch.Tensor) -> engine.Program:
+        key = self._tensors_key(x)
+        if self._program is None or key != self._program_key:
+            sd = {k: v.detach() for k, v in self.state_dict(keep_vars=True).items()}
+            for k, v in sd.items():
+                if v.device != x.device:
+                    raise HipLibraryError(f"parameter {k} is on {v.device} but the input is on {x.device}; call .to(device)")
+            self._program = engine.resnet_program(sd, self.HEAD, in_h=x.shape[2], in_w=x.shape[3], blocks=self.BLOCKS)
+            self._program_key = key
+        return self._program
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """fp32 NCHW [B,3,H,W] (H,W multiples of 32) on the GPU -> heat maps [B,num_classes,H/4,W/4]."""
+        x = require_cuda_f32(x, "input")
+        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] % 32 or x.shape[3] % 32:
+            raise ValueError(f"expected [B,3,H,W] with H,W multiples of 32, got {tuple(x.shape)}")
+        if self.training:
+            raise NotImplementedError(
+                "train-mode forward/backward (batch-stat BN, dgrad/wgrad) is not lowered to HIP yet; call .eval()")
+        return self.hip_program(x).run(x)
+
+
+def load_pretrained_like_reference(model: nn.Module, arch: str):
+    """The reference downloads ImageNet weights with strict=False (pose_resnet_dconv.py:271-279).  There is no
+    network in the target environment, so `pretrained=True` needs a local file."""
+    raise RuntimeError(
+        f"pretrained=True would download {arch} ImageNet weights; no network here. Load a local checkpoint with "
+        "model.load_state_dict(torch.load(path), strict=False) instead.")

@@ -1,0 +1,37 @@
+"""ResNet-50 + 3 x [ConvTranspose2d(4,2,1) -> BN -> ReLU] + 1x1 head, MI355X-native.
+
+Drop-in for the reference's `nets/pose_resnet_dconv.py`: `resnet50(pretrained, num_classes, reduction)` (:306-315)
+returns a module with the reference's state_dict keys/shapes (338 entries; `deconv_layers.{0,3,6}.weight` are
+[Cin,Cout,4,4], `deconv_layers.{1,4,7}.*` BN, `final_layer.{weight,bias}`), whose `forward` runs entirely in
+libsimple_pose_hip.so.
+"""
+from __future__ import annotations
+
+from torch import nn
+
+from ._resnet_base import PoseResNetBase, load_pretrained_like_reference
+
+__all__ = ["ResNet", "resnet50"]
+
+
+class ResNet(PoseResNetBase):
+    HEAD = "dconv"
+
+    def _build_head(self, inplanes: int, num_classes: int):
+        layers = []
+        for _ in range(3):  # pose_resnet_dconv.py:230-249
+            layers += [nn.ConvTranspose2d(inplanes, 256, 4, stride=2, padding=1, output_padding=0, bias=False),
+                       nn.BatchNorm2d(256), nn.ReLU(inplace=True)]
+            inplanes = 256
+        self.deconv_layers = nn.Sequential(*layers)
+        self.final_layer = nn.Conv2d(256, num_classes, 1)  # :173-178
+
+
+def resnet50(pretrained: bool = False, progress: bool = True, **kwargs) -> ResNet:
+    """Same call shape as the reference factory: resnet50(pretrained=..., num_classes=J, reduction=bool)."""
+    model = ResNet(num_classes=kwargs.pop("num_classes", 1000), reduction=kwargs.pop("reduction", False))
+    if kwargs:
+        raise TypeError(f"unsupported arguments for the HIP ResNet-50: {sorted(kwargs)}")
+    if pretrained:
+        load_pretrained_like_reference(model, "resnet50")
+    return model

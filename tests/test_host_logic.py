@@ -1,0 +1,108 @@
+"""CPU tests of the host side: state_dict layout, weight packing + launch descriptors (through the CPU descriptor
+interpreter in tests/desc_interp.py) against the oracle forward, and the C-ABI surface of the built library."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets_oracle
+from simple_pose_amd import _lib, engine, synth
+from simple_pose_amd.build import LIB_PATH
+from simple_pose_amd.nets import pose_resnet_dconv, pose_resnet_duc
+from tests.desc_interp import run_program_cpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("mod,head,nkeys,nparams", [(pose_resnet_dconv, "dconv", 338, 33999697),
+                                                     (pose_resnet_duc, "duc", 332, 29428945)])
+def test_state_dict_layout_matches_reference(mod, head, nkeys, nparams):
+    m = mod.resnet50(pretrained=False, num_classes=17)
+    mine = [(k, tuple(v.shape), str(v.dtype)) for k, v in m.state_dict().items()]
+    assert len(mine) == nkeys
+    assert set(mine) == set(nets_oracle.state_dict_shapes_resnet50(head))
+    assert sum(p.numel() for p in m.parameters()) == nparams
+    # checkpoint convention of the reference: {"ema": state_dict, "epoch": n}, keys optionally prefixed "module."
+    sd = {k: torch.from_numpy(v) for k, v in synth.conditioned_state_dict(nets_oracle.state_dict_shapes_resnet50(head)).items()}
+    m.load_state_dict(sd, strict=True)
+
+
+@pytest.mark.parametrize("head", ["dconv", "duc"])
+def test_packing_and_descriptors_reproduce_oracle_forward(head):
+    """Program (packed weights + descriptors) interpreted on CPU == oracle forward, on a 64x64 crop, B=2."""
+    shapes = nets_oracle.state_dict_shapes_resnet50(head)
+    sd = {k: torch.from_numpy(v) for k, v in synth.conditioned_state_dict(shapes, seed=3).items()}
+    x = torch.from_numpy(synth.input_images(2, seed=3, h=64, w=64))
+    prog = engine.resnet_program(sd, head, in_h=64, in_w=64)
+    with torch.no_grad():
+        ref = nets_oracle.FORWARDS["resnet50_" + head](sd, x)
+        got, _ = run_program_cpu(prog, x)
+    assert got.shape == ref.shape == (2, 17, 16, 16)
+    rel = (got - ref).abs().max() / ref.abs().max()
+    assert rel < 1e-5, rel
+    # algorithmic FLOPs bookkeeping: per-image conv MACs scale with the image area
+    full = engine.resnet_program(sd, head, in_h=256, in_w=192)
+    expect = {"dconv": 10.8528e9, "duc": 11.7517e9}[head]
+    assert abs(full.flops_per_image - expect) / expect < 1e-4, full.flops_per_image
+
+
+def test_buffer_plan_never_aliases_live_tensors():
+    shapes = nets_oracle.state_dict_shapes_resnet50("dconv")
+    sd = {k: torch.from_numpy(v) for k, v in synth.conditioned_state_dict(shapes, seed=1).items()}
+    prog = engine.resnet_program(sd, "dconv", in_h=64, in_w=64)
+    bufs = prog._alloc(1, torch.device("cpu"))
+    live = {}
+    last = {}
+    for i, op in enumerate(prog.ops):
+        for nm in (op.src, op.res, op.dst):
+            if nm:
+                last[nm] = i
+    for i, op in enumerate(prog.ops):
+        if op.dst in bufs:
+            p = bufs[op.dst].data_ptr()
+            for nm, (q, until) in live.items():
+                assert not (q == p and until >= i and nm != op.dst), (op.name, nm)
+            live[op.dst] = (p, last[op.dst])
+    total = sum(t.numel() for t in {b.data_ptr(): b for b in bufs.values()}.values()) * 4
+    naive = sum(np.prod(prog.shapes[o.dst]) for o in prog.ops if o.dst != "heat") * 4
+    assert total < 0.35 * naive  # exact-size reuse only; ~27 % of the no-reuse footprint
+
+
+def test_library_exports_every_declared_symbol():
+    """The C-ABI library loads on a CPU-only box and exports exactly what include/simple_pose_hip.h declares."""
+    assert os.path.isfile(LIB_PATH), "build first: python -m simple_pose_amd.build"
+    hdr = open(os.path.join(ROOT, "include", "simple_pose_hip.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(sp_\w+)\s*\(", hdr, flags=re.M))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    handle = ctypes.CDLL(LIB_PATH)
+    for name in declared:
+        assert hasattr(handle, name), name
+    lib = _lib.lib()
+    assert lib.sp_abi_version() == _lib.ABI_VERSION
+    assert ctypes.sizeof(_lib.ConvDesc) == 26 * 4
+
+
+def test_bad_arguments_are_rejected_without_touching_the_gpu():
+    lib = _lib.lib()
+    d = _lib.ConvDesc()
+    rc = lib.sp_conv2d_fwd(ctypes.byref(d), None, None, None, None, None, None, None)
+    assert rc == -1 and b"null" in lib.sp_last_error()
+    one = ctypes.c_void_p(16)
+    d.batch = d.in_h = d.in_w = d.grid_h = d.grid_w = d.c_out = 1
+    d.c_in = 3
+    rc = lib.sp_conv2d_fwd(ctypes.byref(d), one, one, None, None, None, one, None)
+    assert rc == -1 and b"multiple of 4" in lib.sp_last_error()
+    rc = lib.sp_decode_gauss_taylor(one, one, 1, 17, 64, 48, 12, one, one, None)
+    assert rc == -1 and b"odd" in lib.sp_last_error()
+
+
+def test_product_path_refuses_cpu_tensors():
+    m = pose_resnet_dconv.resnet50(pretrained=False, num_classes=17).eval()
+    with pytest.raises(_lib.HipLibraryError):
+        m(torch.zeros(1, 3, 256, 192))
+    from simple_pose_amd.metrics import GaussTaylorKeyPointDecoder
+    with pytest.raises(_lib.HipLibraryError):
+        GaussTaylorKeyPointDecoder()(torch.zeros(1, 17, 64, 48), torch.zeros(1, 2, 3))
