@@ -31,6 +31,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=128, help="images per GPU per step")
     ap.add_argument("--arch", default="dconv", choices=["dconv", "duc"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layers-out", default=None, help="write the per-layer timing table (JSON) here")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (roofline object)")
     return ap.parse_args()
 
@@ -57,18 +58,25 @@ def cpu_baseline(arch: str):
             hm = fwd(sd, x)
         pose_oracle.decode_gauss_taylor(hm.numpy(), tinv)
 
-    for _ in range(2):
-        one()
-    n, t0 = 0, time.perf_counter()
-    while True:
-        one()
-        n += 1
-        el = time.perf_counter() - t0
-        if el > 10.0 or n >= 40:
-            break
-    return {"value": round(4 * n / el, 2), "unit": "images/s", "cores": threads, "kind": "port",
+    best = None
+    for nthreads in sorted({threads, min(threads, 32), min(threads, 16)}, reverse=True):
+        torch.set_num_threads(nthreads)   # bs=4 does not feed 128+ cores; report the best of a few thread counts
+        for _ in range(2):
+            one()
+        n, t0 = 0, time.perf_counter()
+        while True:
+            one()
+            n += 1
+            el = time.perf_counter() - t0
+            if el > 6.0 or n >= 30:
+                break
+        if best is None or 4 * n / el > best[0]:
+            best = (4 * n / el, nthreads, n)
+    torch.set_num_threads(threads)
+    rate, nthreads, n = best
+    return {"value": round(rate, 2), "unit": "images/s", "cores": nthreads, "kind": "port",
             "sample": f"{n} iterations of bs=4 ResNet50-{head} 256x192 fp32 forward (torch-CPU oracle) + C GaussTaylor decode, "
-                      f"{threads} threads of {os.cpu_count()} logical CPUs"}
+                      f"best of thread counts <= {threads} on {os.cpu_count()} logical CPUs"}
 
 
 def main():
@@ -145,7 +153,7 @@ def main():
     # ---- per-kernel roofline: HIP events around every conv launch, on the launch stream, same inputs ----
     roofline = None
     if rank == 0 and not args.no_kernel_events:
-        roofline = kernel_roofline(prog, x, steps=max(3, min(args.steps, 10)))
+        roofline = kernel_roofline(prog, x, steps=max(3, min(args.steps, 10)), layers_out=args.layers_out)
 
     if rank == 0:
         line = {
@@ -167,7 +175,7 @@ def main():
         dist.destroy_process_group()
 
 
-def kernel_roofline(prog, x, steps: int):
+def kernel_roofline(prog, x, steps: int, layers_out=None):
     """Average duration of the dominant kernel (the fp32 implicit-GEMM conv family) measured with HIP events recorded on
     the launch stream around each of its launches, and its achieved algorithmic TFLOP/s against the fp32 matrix peak."""
     import torch
@@ -212,6 +220,10 @@ def kernel_roofline(prog, x, steps: int):
     tot_flop = sum(f for _, _, f in per_layer)
     achieved = tot_flop / (tot_ms * 1e-3) / 1e12
     worst = sorted(per_layer, key=lambda t: -t[1])[:8]
+    if layers_out:
+        with open(layers_out, "w") as fh:
+            json.dump([{"layer": n, "us": round(1e3 * m, 1), "gflop": round(f / 1e9, 2),
+                        "tflops": round(f / (m * 1e-3) / 1e12, 1)} for n, m, f in per_layer], fh, indent=0)
     return {"bound": "mfma", "kernel": "conv_igemm_kernel (fp32 MFMA implicit GEMM, all %d launches of a step)" % len(per_layer),
             "achieved": round(achieved, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": None,

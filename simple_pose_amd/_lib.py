@@ -58,6 +58,12 @@ def lib():
             raise HipLibraryError(
                 f"{LIB_PATH} is missing: build it with `python -m simple_pose_amd.build` (hipcc, gfx950). "
                 "simple_pose_amd has no CPU/torch fallback.")
+        # PyTorch owns the device memory and the streams we launch on, so the process must run ONE HIP runtime: torch's
+        # bundled libamdhip64 (same SONAME as /opt/rocm's).  Importing torch first makes the loader bind our library's
+        # libamdhip64.so.7 dependency to that copy; loaded the other way round torch ends up on /opt/rocm's runtime next
+        # to its own bundled HSA/comgr and reports "no ROCm-capable device".
+        import torch  # noqa: F401
+
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported

@@ -45,6 +45,7 @@ struct ConvArgs {
     int phases_x;  // 1 or 2
     unsigned flags;
     int tiles_m, tiles_n;
+    int x_bytes, w_bytes, y_bytes;  // buffer-descriptor extents (w: one phase slab)
 };
 
 constexpr int BK = 32;  // floats per K tile (8 chunks of 16 B)
@@ -109,6 +110,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     __syncthreads();
 
     // ---- staging assignment: thread -> (row = tid/8 + 32 i, chunk = tid%8) ----
+    // All global traffic goes through buffer descriptors: an out-of-image tap (or a row beyond M) gets the byte offset
+    // OOB, which the hardware range check turns into zeros (loads) or drops (stores) - no branches, no selects, and the
+    // compiler keeps every load of a tile in flight behind the MFMAs instead of waiting at each exec-mask join.
+    constexpr unsigned OOB = 0x80000000u;  // every tensor is < 2 GiB (checked on the host)
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), (short)0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp), (short)0, p.w_bytes, 0x00020000);
     const int kc = tid & 7;
     const int srow = tid >> 3;
     int a_base[A_CH], a_iy[A_CH], a_ix[A_CH];
@@ -117,9 +124,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
         const int4 e = reinterpret_cast<const int4*>(rowtab)[srow + 32 * i];
         a_base[i] = e.x; a_iy[i] = e.y; a_ix[i] = e.z;
     }
-    const float* __restrict__ bsrc = wp + (size_t)(n0 + srow) * p.k_pad + kc * 4;
+    const unsigned b_voff = (unsigned)((srow * p.k_pad + kc * 4) * 4);
+    const unsigned b_soff0 = (unsigned)n0 * p.k_pad * 4;
 
-    f32x4 sa[A_CH], sb[B_CH];
+    u32x4 sa[A_CH], sb[B_CH];
     const int cin_chunks = p.c_in >> 2;
 
     auto load_tile = [&](int kt) {
@@ -142,20 +150,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
         for (int i = 0; i < A_CH; ++i) {
             const int iy = a_iy[i] + ddy, ix = a_ix[i] + ddx;
             const bool ok = tap_ok && (unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(p.x + ((size_t)(a_base[i] + iy * p.in_w + ix) * p.c_in + c_off));
-            sa[i] = v;
+            const unsigned off = ok ? (unsigned)(((a_base[i] + iy * p.in_w + ix) * p.c_in + c_off) * 4) : OOB;
+            sa[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < B_CH; ++i) sb[i] = *reinterpret_cast<const f32x4*>(bsrc + (size_t)(32 * i) * p.k_pad + k0);
+        for (int i = 0; i < B_CH; ++i)
+            sb[i] = __builtin_amdgcn_raw_buffer_load_b128(wr_, b_voff + (unsigned)(32 * i * p.k_pad * 4), b_soff0 + (unsigned)(k0 * 4), 0);
     };
     auto store_tile = [&](int buf) {
         float* a = As + buf * BM * BK;
         float* b = Bs + buf * BN * BK;
 #pragma unroll
-        for (int i = 0; i < A_CH; ++i) *reinterpret_cast<f32x4*>(a + swz(srow + 32 * i, kc)) = sa[i];
+        for (int i = 0; i < A_CH; ++i) *reinterpret_cast<u32x4*>(a + swz(srow + 32 * i, kc)) = sa[i];
 #pragma unroll
-        for (int i = 0; i < B_CH; ++i) *reinterpret_cast<f32x4*>(b + swz(srow + 32 * i, kc)) = sb[i];
+        for (int i = 0; i < B_CH; ++i) *reinterpret_cast<u32x4*>(b + swz(srow + 32 * i, kc)) = sb[i];
     };
 
     f32x16 acc[TM][TN];
@@ -202,6 +210,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     const bool pshuf = p.flags & SP_CONV_PIXEL_SHUFFLE;
     const bool relu = p.flags & SP_CONV_RELU;
     const int hw_out = p.out_h * p.out_w;
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, (short)0, p.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res : p.y), (short)0, p.y_bytes, 0x00020000);
 #pragma unroll
     for (int n = 0; n < TN; ++n) {
         const int col = n0 + wc * WN + n * 32 + fr;
@@ -219,22 +229,27 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
         } else col_off = col;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            unsigned off[16];  // byte offsets of this lane's 16 outputs of tile (i, n); OOB = masked
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int row = wr * WM + i * 32 + 8 * g + 4 * fh;
-                const int4 ro = make_int4(rowtab[(row + 0) * 4 + 3], rowtab[(row + 1) * 4 + 3],
-                                          rowtab[(row + 2) * 4 + 3], rowtab[(row + 3) * 4 + 3]);
-                const int roff[4] = {ro.x, ro.y, ro.z, ro.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    if (col_ok && roff[e] >= 0) {
-                        const size_t o = (size_t)roff[e] + col_off;
-                        float v = acc[i][n][4 * g + e] * sc + sh;
-                        if (p.res) v += p.res[o];
-                        if (relu) v = v > 0.f ? v : 0.f;
-                        p.y[o] = v;
-                    }
+                    const int ro = rowtab[(row + e) * 4 + 3];
+                    off[4 * g + e] = (col_ok && ro >= 0) ? (unsigned)((ro + col_off) * 4) : OOB;
                 }
+            }
+            float rv[16];
+            if (p.res) {  // all 16 residual loads in flight before the first use
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, off[r], 0, 0));
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[i][n][r] * sc + sh;
+                if (p.res) v += rv[r];
+                if (relu) v = v > 0.f ? v : 0.f;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, off[r], 0, 0);
             }
         }
     }
@@ -301,7 +316,9 @@ extern "C" int sp_conv2d_fwd(const sp_conv_desc* d, const float* x, const float*
     const long long M = (long long)d->batch * d->grid_h * d->grid_w;
     const long long in_elems = (long long)d->batch * d->in_h * d->in_w * d->c_in;
     const long long out_elems = (long long)d->batch * d->out_h * d->out_w * d->out_c;
-    SP_REQUIRE(M < (1ll << 31) && in_elems < (1ll << 31) && out_elems < (1ll << 31), "sp_conv2d_fwd: tensor too large for 32-bit indexing");
+    const long long w_elems = (long long)d->n_pad * d->k_pad;
+    SP_REQUIRE(M < (1ll << 29) && in_elems < (1ll << 29) && out_elems < (1ll << 29) && w_elems < (1ll << 29),
+               "sp_conv2d_fwd: tensor too large (each operand must stay below 2 GiB for 32-bit buffer offsets)");
 
     ConvArgs a;
     a.x = x; a.w = w_packed; a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
@@ -314,6 +331,7 @@ extern "C" int sp_conv2d_fwd(const sp_conv_desc* d, const float* x, const float*
     a.out_h = d->out_h; a.out_w = d->out_w; a.out_c = d->out_c;
     a.oy_mul = d->oy_mul; a.oy_add = d->oy_add; a.ox_mul = d->ox_mul; a.ox_add = d->ox_add;
     a.phases_x = d->phases_x; a.flags = d->flags; a.tiles_m = a.tiles_n = 0;
+    a.x_bytes = (int)(in_elems * 4); a.w_bytes = (int)(w_elems * 4); a.y_bytes = (int)(out_elems * 4);
     const int phases = d->phases_y * d->phases_x;
     hipStream_t s = (hipStream_t)stream;
 

@@ -115,19 +115,23 @@ def test_encoder_batched_vs_oracle_and_ragged_shapes():
 
 
 def test_encode_decode_round_trip_full_batch():
-    """Size-independent property at BASELINE batch (128): decode(encode(j)) == j for interior joints (SURVEY App. B:
-    6e-4 px typical, 2e-2 worst on sigma=2 targets)."""
+    """Size-independent property at BASELINE batch (128): decode(encode(j)) == j.  Joints >= 8 px from the border
+    (the 11x11 blur's zero padding biases the Taylor step closer in): < 5e-3 px; and the HIP round trip equals the
+    oracle's round trip."""
     B = 128
     j = synth.joints_batch(B, 17, seed=77)
-    j[..., 0] = np.clip(j[..., 0], 3.0, 44.0)
-    j[..., 1] = np.clip(j[..., 1], 3.0, 60.0)
+    j[..., 0] = np.clip(j[..., 0], 8.0, 39.0)
+    j[..., 1] = np.clip(j[..., 1], 8.0, 55.0)
     j[..., 2] = 1.0
     t, w = RefineSimpleTransform.get_heat_map(_cuda(j), 2.0, (48, 64))
     ident = np.zeros((B, 2, 3), np.float32); ident[:, 0, 0] = 1; ident[:, 1, 1] = 1
     kps, mv = GaussTaylorKeyPointDecoder()(t, _cuda(ident))
     err = np.abs(kps.cpu().numpy() - j[..., :2])
-    assert err.max() < 2e-2 and np.median(err) < 1e-3, (err.max(), np.median(err))
+    assert err.max() < 5e-3 and np.median(err) < 1e-3, (err.max(), np.median(err))
     assert torch.all(w == 1)
+    ot, _ = pose_oracle.encode_refine(j[:8], 2.0, (48, 64))
+    okps, _ = pose_oracle.decode_gauss_taylor(ot, ident[:8])
+    assert np.abs(kps[:8].cpu().numpy() - okps).max() <= 1e-4
 
 
 # ---------------------------------------------------------------------------------------------- conv family
@@ -225,7 +229,8 @@ def test_deconv_k4s2p1_phases_vs_torch_cpu(cin, cout, h, w, B):
     y = _run_conv(x, lambda b, src: b.deconv_k4s2p1(src, wt.to(DEV), scale=scale.to(DEV), shift=shift.to(DEV), relu=True))
     assert y.shape == (B, 2 * h, 2 * w, cout)
     err = (y.permute(0, 3, 1, 2).double() - ref).abs().max() / ref.abs().max()
-    assert err < 2e-6, err
+    # exact-fp32 MFMA = k-ordered fmaf chain: error vs fp64 grows with K (3.5e-7 * sum|a*b| at K=4096, guide section 3)
+    assert err < (1e-5 if cin * 4 >= 4096 else 2e-6), err
 
 
 def test_duc_conv_with_fused_pixel_shuffle_and_final_nchw():
@@ -321,7 +326,8 @@ def test_masked_mse_vs_oracle():
     loss = torch.zeros(1, device=DEV)
     grad = torch.empty((B, J, H, W), device=DEV)
     ws = torch.empty(4096, dtype=torch.uint8, device=DEV)
-    _lib.check(_lib.lib().sp_masked_mse(_lib.ptr(_cuda(pred)), _lib.ptr(_cuda(tgt)), _lib.ptr(_cuda(mask)), B, J, H * W,
+    dp, dt, dm = _cuda(pred), _cuda(tgt), _cuda(mask)   # keep alive: the library does not own its operands
+    _lib.check(_lib.lib().sp_masked_mse(_lib.ptr(dp), _lib.ptr(dt), _lib.ptr(dm), B, J, H * W,
                                         _lib.ptr(loss), _lib.ptr(grad), _lib.ptr(ws), _lib.current_stream()))
     assert abs(loss.item() - float(loss_ref)) <= 1e-6 * abs(float(loss_ref))
     assert np.abs(grad.cpu().numpy() - grad_ref).max() <= 1e-7 * np.abs(grad_ref).max() + 1e-12
