@@ -24,6 +24,8 @@
 // then ds_write t+1, one barrier per tile).  A tile's MFMA work is >= 2048 cycles per wave, so HBM/L2
 // latency hides behind it at 2 workgroups per CU.
 #include "sp_common.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -130,32 +132,35 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     u32x4 sa[A_CH], sb[B_CH];
     const int cin_chunks = p.c_in >> 2;
 
-    auto load_tile = [&](int kt) {
+    // tap decode of K tile kt (scalar when UNIFORM_TAP), then the loads in A_CH + B_CH independent pieces so that the
+    // main loop can drop them between MFMA groups
+    int t_ddy = 0, t_ddx = 0, t_coff = 0, t_k0 = 0;
+    bool t_ok = true;
+    auto tile_taps = [&](int kt) {
         const int k0 = kt * BK;
-        int ty, tx, c_off;
-        bool tap_ok = true;
+        int ty, tx;
+        t_ok = true;
         if (UNIFORM_TAP) {  // c_in % 32 == 0: the whole K tile sits inside one tap (scalar math)
             const int tap = k0 / p.c_in;
-            c_off = k0 - tap * p.c_in + kc * 4;
+            t_coff = k0 - tap * p.c_in + kc * 4;
             ty = tap / p.taps_w; tx = tap - ty * p.taps_w;
         } else {            // small c_in (stem: NHWC4): every 16-B chunk may be a different tap
             const int q = (k0 >> 2) + kc;
             const int tap = q / cin_chunks;
-            c_off = (q - tap * cin_chunks) << 2;
+            t_coff = (q - tap * cin_chunks) << 2;
             ty = tap / p.taps_w; tx = tap - ty * p.taps_w;
-            tap_ok = ty < p.taps_h;
+            t_ok = ty < p.taps_h;
         }
-        const int ddy = ty * p.dy_step, ddx = tx * p.dx_step;
-#pragma unroll
-        for (int i = 0; i < A_CH; ++i) {
-            const int iy = a_iy[i] + ddy, ix = a_ix[i] + ddx;
-            const bool ok = tap_ok && (unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w;
-            const unsigned off = ok ? (unsigned)(((a_base[i] + iy * p.in_w + ix) * p.c_in + c_off) * 4) : OOB;
-            sa[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < B_CH; ++i)
-            sb[i] = __builtin_amdgcn_raw_buffer_load_b128(wr_, b_voff + (unsigned)(32 * i * p.k_pad * 4), b_soff0 + (unsigned)(k0 * 4), 0);
+        t_ddy = ty * p.dy_step; t_ddx = tx * p.dx_step; t_k0 = k0;
+    };
+    auto load_a = [&](int i) {
+        const int iy = a_iy[i] + t_ddy, ix = a_ix[i] + t_ddx;
+        const bool ok = t_ok && (unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w;
+        const unsigned off = ok ? (unsigned)(((a_base[i] + iy * p.in_w + ix) * p.c_in + t_coff) * 4) : OOB;
+        sa[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
+    };
+    auto load_b = [&](int i) {
+        sb[i] = __builtin_amdgcn_raw_buffer_load_b128(wr_, b_voff + (unsigned)(32 * i * p.k_pad * 4), b_soff0 + (unsigned)(t_k0 * 4), 0);
     };
     auto store_tile = [&](int buf) {
         float* a = As + buf * BM * BK;
@@ -177,33 +182,97 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     const int fr = lane & 31, fh = lane >> 5;
     const int nk = p.k_pad / BK;
 
-    load_tile(0);
+    // Fragment registers are double-buffered by hand (slot = k-step parity): the ds_reads of k-step j+1 are issued
+    // before the MFMAs of k-step j, so LDS latency hides behind ~1000 cycles of matrix work.
+    f32x4 fa[2][TM], fb[2][TN];
+    auto read_frags = [&](const float* a, const float* b, int j, int slot) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[slot][i] = *reinterpret_cast<const f32x4*>(a + swz(i * 32 + fr, 2 * j + fh));
+#pragma unroll
+        for (int n = 0; n < TN; ++n) fb[slot][n] = *reinterpret_cast<const f32x4*>(b + swz(n * 32 + fr, 2 * j + fh));
+    };
+    auto mfma_s = [&](int slot, int s) {  // the TM x TN MFMAs of one k-pair (k = 2 per instruction)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+                acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][i][s], fb[slot][n][s], acc[i][n], 0, 0, 0);
+    };
+#define SP_SB() __builtin_amdgcn_sched_barrier(0)
+
+    // prologue: tile 0 -> LDS, first fragments -> registers
+    tile_taps(0);
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) load_a(i);
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) load_b(i);
     store_tile(0);
     __syncthreads();
+    read_frags(As + (wr * WM) * BK, Bs + (wc * WN) * BK, 0, 0);
 
-    for (int kt = 0; kt < nk; ++kt) {
+    // One K tile = 4 k-steps of TM*TN*4 MFMAs.  A wave issues in order, so everything that is not an MFMA is placed
+    // BETWEEN MFMA groups (the matrix pipe runs each MFMA for 64 cycles after a ~8-cycle issue):
+    //   step 0: global loads of tile kt+1 (address math + buffer_load), piece by piece between the 4 MFMA groups
+    //   step 1, 2: fragment prefetch only
+    //   step 3: ds_write of tile kt+1 -> the other LDS buffer, first half of the MFMAs, then lgkmcnt(0) + s_barrier,
+    //           then the first fragments of tile kt+1 are requested and the second half of step 3's MFMAs covers their
+    //           LDS latency.  All reads of the current buffer were issued (into registers) before step 2's MFMAs, so the
+    //           barrier also frees the current buffer for tile kt+2.
+    auto k_tile = [&](int kt, auto more_tag) {
+        constexpr bool MORE = decltype(more_tag)::value;
         const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
         const float* a = As + cur * BM * BK + (wr * WM) * BK;
         const float* b = Bs + cur * BN * BK + (wc * WN) * BK;
+        const float* an = As + (cur ^ 1) * BM * BK + (wr * WM) * BK;
+        const float* bn = Bs + (cur ^ 1) * BN * BK + (wc * WN) * BK;
+        // ---- step 0 (slot 0) ----
+        read_frags(a, b, 1, 1);
+        if (MORE) tile_taps(kt + 1);
+        SP_SB();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f32x4 af[TM], bf[TN];
+        for (int s = 0; s < 4; ++s) {
+            if (MORE) {
+                if (s < 2) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(a + swz(i * 32 + fr, 2 * j + fh));
+                    for (int i = s * (A_CH / 2); i < (s + 1) * (A_CH / 2); ++i) load_a(i);
+                    if (A_CH == 1 && s == 0) load_a(0);
+                } else {
 #pragma unroll
-            for (int n = 0; n < TN; ++n) bf[n] = *reinterpret_cast<const f32x4*>(b + swz(n * 32 + fr, 2 * j + fh));
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int n = 0; n < TN; ++n)
-                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[n][s], acc[i][n], 0, 0, 0);
+                    for (int i = (s - 2) * (B_CH / 2); i < (s - 1) * (B_CH / 2); ++i) load_b(i);
+                    if (B_CH == 1 && s == 2) load_b(0);
+                }
+            }
+            mfma_s(0, s);
+            SP_SB();
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
-        __syncthreads();
-    }
+        // ---- step 1 (slot 1) ----
+        read_frags(a, b, 2, 0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) mfma_s(1, s);
+        SP_SB();
+        // ---- step 2 (slot 0) ----
+        read_frags(a, b, 3, 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) mfma_s(0, s);
+        SP_SB();
+        // ---- step 3 (slot 1) ----
+        if (MORE) store_tile(cur ^ 1);
+        mfma_s(1, 0);
+        mfma_s(1, 1);
+        SP_SB();
+        if (MORE) {
+            __syncthreads();
+            read_frags(an, bn, 0, 0);
+            SP_SB();
+        }
+        mfma_s(1, 2);
+        mfma_s(1, 3);
+        SP_SB();
+    };
+    for (int kt = 0; kt + 1 < nk; ++kt) k_tile(kt, std::true_type{});
+    k_tile(nk - 1, std::false_type{});
+    __syncthreads();  // every wave is done with LDS before the epilogue touches anything else
+#undef SP_SB
 
     // ---- epilogue: y = act(acc * scale + shift (+ residual)); C/D map: col = lane&31, row = (r&3)+8(r>>2)+4(lane>>5)
     const bool nchw = p.flags & SP_CONV_OUT_NCHW;
@@ -331,12 +400,24 @@ extern "C" int sp_conv2d_fwd(const sp_conv_desc* d, const float* x, const float*
     a.out_h = d->out_h; a.out_w = d->out_w; a.out_c = d->out_c;
     a.oy_mul = d->oy_mul; a.oy_add = d->oy_add; a.ox_mul = d->ox_mul; a.ox_add = d->ox_add;
     a.phases_x = d->phases_x; a.flags = d->flags; a.tiles_m = a.tiles_n = 0;
+    if (const char* dbg = getenv("SP_CONV_DEBUG")) a.flags |= ((unsigned)atoi(dbg)) << 16;  // experiment bits
     a.x_bytes = (int)(in_elems * 4); a.w_bytes = (int)(w_elems * 4); a.y_bytes = (int)(out_elems * 4);
     const int phases = d->phases_y * d->phases_x;
     hipStream_t s = (hipStream_t)stream;
 
     // tile choice: widest N tile that divides n_pad; halve BM when the launch would not fill the 256 CUs twice
     const int np = d->n_pad;
+    if (const char* t = getenv("SP_CONV_TILE")) {  // EXPERIMENT: force a tile shape "BMxBN" where it is legal
+        int bm = 0, bn = 0;
+        if (sscanf(t, "%dx%d", &bm, &bn) == 2 && np % bn == 0) {
+            if (bm == 128 && bn == 128) return launch<128, 128, 2, 2>(a, phases, uniform, s);
+            if (bm == 64 && bn == 128) return launch<64, 128, 2, 2>(a, phases, uniform, s);
+            if (bm == 128 && bn == 64) return launch<128, 64, 2, 2>(a, phases, uniform, s);
+            if (bm == 64 && bn == 64) return launch<64, 64, 2, 2>(a, phases, uniform, s);
+            if (bm == 256 && bn == 64) return launch<256, 64, 4, 1>(a, phases, uniform, s);
+            if (bm == 128 && bn == 32) return launch<128, 32, 4, 1>(a, phases, uniform, s);
+        }
+    }
     if (np % 128 == 0) {
         const long long wgs = ((M + 127) / 128) * (np / 128) * phases;
         if (wgs >= 512) return launch<128, 128, 2, 2>(a, phases, uniform, s);
