@@ -27,7 +27,7 @@ extern "C" {
 #define SP_EINVAL (-1)   /* bad argument / unsupported shape (message in sp_last_error) */
 #define SP_ELAUNCH (-2)  /* HIP launch or runtime failure */
 
-#define SP_ABI_VERSION 1
+#define SP_ABI_VERSION 2
 
 /* epilogue / layout flags of sp_conv_desc.flags */
 #define SP_CONV_RELU 0x1u          /* y = max(y, 0) after scale/shift (+ residual) */
@@ -59,6 +59,8 @@ typedef struct sp_conv_desc {
     int32_t oy_mul, oy_add, ox_mul, ox_add;
     int32_t phases_y, phases_x;      /* 1,1 for conv; 2,2 for the k4s2p1 transposed conv (dy0/oy_add become per-phase) */
     uint32_t flags;
+    int32_t tile_m, tile_n;          /* workgroup tile (rows x columns); 0,0 = sp_conv2d_default_tile().  Results do not
+                                        depend on the tile: every output's K reduction order is the same for all shapes. */
 } sp_conv_desc;
 
 /* ---- library ---------------------------------------------------------------------------------- */
@@ -77,6 +79,10 @@ int sp_nchw_to_nhwc4(const float* x_nchw, float* y_nhwc4, int batch, int channel
  * scale/shift: [c_out] or NULL (scale NULL -> 1, shift NULL -> 0); residual: same layout as y or NULL. */
 int sp_conv2d_fwd(const sp_conv_desc* desc, const float* x, const float* w_packed, const float* scale,
                   const float* shift, const float* residual, float* y, void* stream);
+
+/* The tile sp_conv2d_fwd picks when desc->tile_m == tile_n == 0; legal tiles: 128x128 64x128 128x64 64x64 256x64 128x32
+ * (tile_n must divide n_pad).  Host code may time the legal tiles once per layer shape and pin the fastest. */
+int sp_conv2d_default_tile(const sp_conv_desc* desc, int* tile_m, int* tile_n);
 
 /* nn.MaxPool2d(3, 2, 1) on NHWC fp32 (pose_resnet_dconv.py:162,255) */
 int sp_maxpool3x3s2_nhwc(const float* x, float* y, int batch, int h, int w, int c, void* stream);

@@ -9,12 +9,16 @@ import ctypes
 import os
 from ctypes import c_float, c_int, c_int32, c_uint32, c_void_p
 
-from .build import LIB_PATH
+from .build import LIB_PATH as _DEFAULT_LIB_PATH
+
+# SIMPLE_POSE_HIP_LIB lets a diagnostic build of the same library (tools/) be loaded instead; never a fallback path.
+LIB_PATH = os.environ.get("SIMPLE_POSE_HIP_LIB", _DEFAULT_LIB_PATH)
 
 SP_CONV_RELU = 0x1
 SP_CONV_OUT_NCHW = 0x2
 SP_CONV_PIXEL_SHUFFLE = 0x4
-ABI_VERSION = 1
+CONV_TILES = ((128, 128), (64, 128), (128, 64), (64, 64), (256, 64), (128, 32))
+ABI_VERSION = 2
 
 
 class HipLibraryError(RuntimeError):
@@ -26,7 +30,7 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [(n, c_int32) for n in (
         "batch", "in_h", "in_w", "c_in", "grid_h", "grid_w", "c_out", "n_pad", "taps_h", "taps_w", "k_pad", "stride",
         "dy0", "dy_step", "dx0", "dx_step", "out_h", "out_w", "out_c", "oy_mul", "oy_add", "ox_mul", "ox_add",
-        "phases_y", "phases_x")] + [("flags", c_uint32)]
+        "phases_y", "phases_x")] + [("flags", c_uint32), ("tile_m", c_int32), ("tile_n", c_int32)]
 
 
 # every symbol include/simple_pose_hip.h declares: name -> (restype, argtypes)
@@ -36,6 +40,7 @@ SYMBOLS = {
     "sp_last_error": (ctypes.c_char_p, []),
     "sp_nchw_to_nhwc4": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "sp_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
+    "sp_conv2d_default_tile": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "sp_maxpool3x3s2_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "sp_pixel_shuffle2_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "sp_upsample_add_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),

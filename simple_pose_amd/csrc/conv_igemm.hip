@@ -27,6 +27,31 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#ifdef SP_DIAG
+// DIAGNOSTIC BUILD ONLY (never the shipped library): per-wave cycle sums of the K-tile segments, read back with
+// sp_debug_read().  [block % 4096][wave][8 segments]
+__device__ unsigned long long sp_dbg[4096 * 4 * 12];
+extern "C" int sp_debug_read(unsigned long long* dst, int n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(sp_dbg), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);
+}
+extern "C" int sp_debug_clear() {
+    static unsigned long long z[4096 * 4 * 12];
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(sp_dbg), z, sizeof(z), 0, hipMemcpyHostToDevice);
+}
+#define SP_STAMP_ALWAYS(var)                                                                \
+    unsigned long long var;                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");           \
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef SP_DIAG_LIGHT
+#define SP_STAMP(var) unsigned long long var = 0;
+#else
+#define SP_STAMP(var) SP_STAMP_ALWAYS(var)
+#endif
+#else
+#define SP_STAMP(var)
+#endif
+
 namespace {
 
 struct ConvArgs {
@@ -55,13 +80,20 @@ constexpr int BK = 32;  // floats per K tile (8 chunks of 16 B)
 __device__ __forceinline__ int swz(int row, int chunk) { return row * BK + ((chunk ^ ((row >> 1) & 7)) << 2); }
 
 template <int BM, int BN, int WR, int WC, bool UNIFORM_TAP>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm_kernel(const ConvArgs p) {
     static_assert(WR * WC == 4, "4 waves per workgroup");
     constexpr int WM = BM / WR, WN = BN / WC;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int A_CH = BM / 32, B_CH = BN / 32;  // 16-B chunks each thread stages per tile
     static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
 
+#ifdef SP_DIAG
+    SP_STAMP_ALWAYS(t_entry)
+#endif
+#ifdef SP_DIAG
+    unsigned long long rt_entry;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_entry)::"memory");
+#endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                    // [2][BM][32]
     float* Bs = smem + 2 * BM * BK;      // [2][BN][32]
@@ -91,6 +123,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     const float* __restrict__ wp = p.w + (size_t)phase * p.n_pad * p.k_pad;
 
     // ---- per-row table: one decode per row per workgroup ----
+    //   x: byte offset of tap (0,0), channel 0 of this output pixel's receptive field (only used through valid taps)
+    //   y: UNIFORM_TAP: bit (ty*taps_w + tx) set when that tap lies inside the image (taps <= 32, host-checked)
+    //   z: (iy0 << 16) | (ix0 & 0xffff)  (generic path)      w: output element offset of the pixel, -1 = row >= M
     if (tid < BM) {
         const int m = m0 + tid;
         int4 e;
@@ -98,14 +133,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
             const int gw = p.grid_w, ghw = p.grid_h * gw;
             const int b = m / ghw, rem = m - b * ghw;
             const int gy = rem / gw, gx = rem - gy * gw;
-            e.x = b * p.in_h * p.in_w;
-            e.y = gy * p.stride + dy0;
-            e.z = gx * p.stride + dx0;
+            const int iy0 = gy * p.stride + dy0, ix0 = gx * p.stride + dx0;
+            e.x = ((b * p.in_h + iy0) * p.in_w + ix0) * p.c_in * 4;
+            unsigned msk = 0;
+            if (UNIFORM_TAP) {
+                for (int ty = 0; ty < p.taps_h; ++ty)
+                    for (int tx = 0; tx < p.taps_w; ++tx) {
+                        const int iy = iy0 + ty * p.dy_step, ix = ix0 + tx * p.dx_step;
+                        if ((unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w) msk |= 1u << (ty * p.taps_w + tx);
+                    }
+            }
+            e.y = (int)msk;
+            e.z = (iy0 << 16) | (ix0 & 0xffff);
             const int oy = gy * p.oy_mul + oy_add, ox = gx * p.ox_mul + ox_add;
             e.w = (p.flags & SP_CONV_OUT_NCHW) ? (b * p.out_c * p.out_h + oy) * p.out_w + ox
                                                : ((b * p.out_h + oy) * p.out_w + ox) * p.out_c;
         } else {
-            e.x = 0; e.y = -(1 << 28); e.z = -(1 << 28); e.w = -1;
+            e.x = 0; e.y = 0; e.z = (int)0x80008000u; e.w = -1;   // no valid tap; iy0 = ix0 = -32768
         }
         reinterpret_cast<int4*>(rowtab)[tid] = e;
     }
@@ -120,11 +164,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     const __amdgpu_buffer_rsrc_t wr_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp), (short)0, p.w_bytes, 0x00020000);
     const int kc = tid & 7;
     const int srow = tid >> 3;
-    int a_base[A_CH], a_iy[A_CH], a_ix[A_CH];
+    // Per staged row: tap-(0,0) byte offset (+ this lane's 16-byte chunk) and the tap validity mask.  Per K tile a load
+    // then costs ~4 VALU (mask test, select, add) instead of two range checks and a multiply-add chain - the wave issues
+    // in order, so every VALU cycle here is a cycle the next MFMA waits.
+    int a_off0[A_CH];
+    unsigned a_mask[A_CH];
+    int a_iy[A_CH], a_ix[A_CH];
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
         const int4 e = reinterpret_cast<const int4*>(rowtab)[srow + 32 * i];
-        a_base[i] = e.x; a_iy[i] = e.y; a_ix[i] = e.z;
+        a_off0[i] = e.x + kc * 16;
+        a_mask[i] = (unsigned)e.y;
+        a_iy[i] = e.z >> 16;
+        a_ix[i] = (int)(short)(e.z & 0xffff);
     }
     const unsigned b_voff = (unsigned)((srow * p.k_pad + kc * 4) * 4);
     const unsigned b_soff0 = (unsigned)n0 * p.k_pad * 4;
@@ -132,35 +184,45 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     u32x4 sa[A_CH], sb[B_CH];
     const int cin_chunks = p.c_in >> 2;
 
-    // tap decode of K tile kt (scalar when UNIFORM_TAP), then the loads in A_CH + B_CH independent pieces so that the
-    // main loop can drop them between MFMA groups
-    int t_ddy = 0, t_ddx = 0, t_coff = 0, t_k0 = 0;
+    // tap decode of K tile kt (scalar when UNIFORM_TAP), then the loads as A_CH + B_CH independent pieces that the main
+    // loop drops one at a time into the shadows of the MFMAs
+    int t_shift = 0, t_ddy = 0, t_ddx = 0, t_coff = 0, t_k0 = 0;
+    unsigned t_bit = 0;
     bool t_ok = true;
     auto tile_taps = [&](int kt) {
         const int k0 = kt * BK;
-        int ty, tx;
-        t_ok = true;
-        if (UNIFORM_TAP) {  // c_in % 32 == 0: the whole K tile sits inside one tap (scalar math)
+        t_k0 = k0;
+        if (UNIFORM_TAP) {  // c_in % 32 == 0: the whole K tile sits inside one tap (all scalar)
             const int tap = k0 / p.c_in;
-            t_coff = k0 - tap * p.c_in + kc * 4;
-            ty = tap / p.taps_w; tx = tap - ty * p.taps_w;
+            const int ty = tap / p.taps_w, tx = tap - ty * p.taps_w;
+            t_bit = 1u << tap;
+            t_shift = ((ty * p.dy_step * p.in_w + tx * p.dx_step) * p.c_in + (k0 - tap * p.c_in)) * 4;
         } else {            // small c_in (stem: NHWC4): every 16-B chunk may be a different tap
             const int q = (k0 >> 2) + kc;
             const int tap = q / cin_chunks;
             t_coff = (q - tap * cin_chunks) << 2;
-            ty = tap / p.taps_w; tx = tap - ty * p.taps_w;
+            const int ty = tap / p.taps_w, tx = tap - ty * p.taps_w;
             t_ok = ty < p.taps_h;
+            t_ddy = ty * p.dy_step; t_ddx = tx * p.dx_step;
         }
-        t_ddy = ty * p.dy_step; t_ddx = tx * p.dx_step; t_k0 = k0;
     };
     auto load_a = [&](int i) {
-        const int iy = a_iy[i] + t_ddy, ix = a_ix[i] + t_ddx;
-        const bool ok = t_ok && (unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w;
-        const unsigned off = ok ? (unsigned)(((a_base[i] + iy * p.in_w + ix) * p.c_in + t_coff) * 4) : OOB;
+        unsigned off;
+        if (UNIFORM_TAP) {
+            off = (a_mask[i] & t_bit) ? (unsigned)(a_off0[i] + t_shift) : OOB;
+        } else {
+            const int iy = a_iy[i] + t_ddy, ix = a_ix[i] + t_ddx;
+            const bool ok = t_ok && (unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w;
+            off = ok ? (unsigned)(a_off0[i] + ((t_ddy * p.in_w + t_ddx) * p.c_in + t_coff) * 4 - kc * 16) : OOB;
+        }
         sa[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
     };
     auto load_b = [&](int i) {
         sb[i] = __builtin_amdgcn_raw_buffer_load_b128(wr_, b_voff + (unsigned)(32 * i * p.k_pad * 4), b_soff0 + (unsigned)(t_k0 * 4), 0);
+    };
+    auto store_piece = [&](int buf, int o) {  // o in [0, A_CH + B_CH)
+        if (o < A_CH) *reinterpret_cast<u32x4*>(As + buf * BM * BK + swz(srow + 32 * o, kc)) = sa[o];
+        else *reinterpret_cast<u32x4*>(Bs + buf * BN * BK + swz(srow + 32 * (o - A_CH), kc)) = sb[o - A_CH];
     };
     auto store_tile = [&](int buf) {
         float* a = As + buf * BM * BK;
@@ -191,12 +253,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
         for (int n = 0; n < TN; ++n) fb[slot][n] = *reinterpret_cast<const f32x4*>(b + swz(n * 32 + fr, 2 * j + fh));
     };
-    auto mfma_s = [&](int slot, int s) {  // the TM x TN MFMAs of one k-pair (k = 2 per instruction)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int n = 0; n < TN; ++n)
-                acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][i][s], fb[slot][n][s], acc[i][n], 0, 0, 0);
+    constexpr int NM = 4 * TM * TN;   // MFMAs per k-step
+    constexpr int NOPS = A_CH + B_CH;  // 16-byte staging pieces per thread per K tile
+    auto mfma_q = [&](int slot, int q) {  // q-th MFMA of a k-step: k-pair s = q / (TM*TN), tile (i, n)
+        const int s = q / (TM * TN), i = (q / TN) % TM, n = q % TN;
+        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][i][s], fb[slot][n][s], acc[i][n], 0, 0, 0);
     };
 #define SP_SB() __builtin_amdgcn_sched_barrier(0)
 
@@ -206,18 +267,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     for (int i = 0; i < A_CH; ++i) load_a(i);
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) load_b(i);
-    store_tile(0);
+#pragma unroll
+    for (int o = 0; o < NOPS; ++o) store_piece(0, o);
     __syncthreads();
     read_frags(As + (wr * WM) * BK, Bs + (wc * WN) * BK, 0, 0);
 
-    // One K tile = 4 k-steps of TM*TN*4 MFMAs.  A wave issues in order, so everything that is not an MFMA is placed
-    // BETWEEN MFMA groups (the matrix pipe runs each MFMA for 64 cycles after a ~8-cycle issue):
-    //   step 0: global loads of tile kt+1 (address math + buffer_load), piece by piece between the 4 MFMA groups
+    // One K tile = 4 k-steps of NM MFMAs.  A wave issues in order and a buffer_load / ds_write_b128 occupies the issue
+    // port for ~50-90 cycles (measured with s_memtime stamps), about one MFMA's 64 cycles in the matrix pipe.  So every
+    // slow instruction is placed in the shadow of its own MFMA, never two in a row:
+    //   step 0: the NOPS global loads of tile kt+1, one after every (NM/NOPS)-th MFMA
     //   step 1, 2: fragment prefetch only
-    //   step 3: ds_write of tile kt+1 -> the other LDS buffer, first half of the MFMAs, then lgkmcnt(0) + s_barrier,
-    //           then the first fragments of tile kt+1 are requested and the second half of step 3's MFMAs covers their
-    //           LDS latency.  All reads of the current buffer were issued (into registers) before step 2's MFMAs, so the
-    //           barrier also frees the current buffer for tile kt+2.
+    //   step 3: first half: the NOPS ds_writes of tile kt+1 (other LDS buffer), one per MFMA; then lgkmcnt(0) +
+    //           s_barrier; the first fragments of tile kt+1 are requested and the second half of step 3's MFMAs covers
+    //           their LDS latency.  All reads of the current buffer were issued (into registers) before step 2's MFMAs,
+    //           so the barrier also frees the current buffer for tile kt+2.
+#ifdef SP_DIAG
+    unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     auto k_tile = [&](int kt, auto more_tag) {
         constexpr bool MORE = decltype(more_tag)::value;
         const int cur = kt & 1;
@@ -226,102 +292,195 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
         const float* an = As + (cur ^ 1) * BM * BK + (wr * WM) * BK;
         const float* bn = Bs + (cur ^ 1) * BN * BK + (wc * WN) * BK;
         // ---- step 0 (slot 0) ----
+        SP_STAMP(s0)
         read_frags(a, b, 1, 1);
         if (MORE) tile_taps(kt + 1);
         SP_SB();
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int q = 0; q < NM; ++q) {
+            mfma_q(0, q);
             if (MORE) {
-                if (s < 2) {
 #pragma unroll
-                    for (int i = s * (A_CH / 2); i < (s + 1) * (A_CH / 2); ++i) load_a(i);
-                    if (A_CH == 1 && s == 0) load_a(0);
-                } else {
-#pragma unroll
-                    for (int i = (s - 2) * (B_CH / 2); i < (s - 1) * (B_CH / 2); ++i) load_b(i);
-                    if (B_CH == 1 && s == 2) load_b(0);
+                for (int o = (q * NOPS) / NM; o < ((q + 1) * NOPS) / NM; ++o) {
+                    if (o < A_CH) load_a(o); else load_b(o - A_CH);
                 }
             }
-            mfma_s(0, s);
             SP_SB();
         }
+        SP_STAMP(s1)
         // ---- step 1 (slot 1) ----
         read_frags(a, b, 2, 0);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) mfma_s(1, s);
+        for (int q = 0; q < NM; ++q) mfma_q(1, q);
         SP_SB();
+        SP_STAMP(s2)
         // ---- step 2 (slot 0) ----
         read_frags(a, b, 3, 1);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) mfma_s(0, s);
+        for (int q = 0; q < NM; ++q) mfma_q(0, q);
         SP_SB();
-        // ---- step 3 (slot 1) ----
-        if (MORE) store_tile(cur ^ 1);
-        mfma_s(1, 0);
-        mfma_s(1, 1);
-        SP_SB();
+        SP_STAMP(s3)
+        SP_STAMP(s3w)
+        // ---- step 3 (slot 1), first half + the ds_writes ----
+#pragma unroll
+        for (int q = 0; q < NM / 2; ++q) {
+            mfma_q(1, q);
+            if (MORE) {
+#pragma unroll
+                for (int o = (q * NOPS) / (NM / 2); o < ((q + 1) * NOPS) / (NM / 2); ++o) store_piece(cur ^ 1, o);
+            }
+            SP_SB();
+        }
+        SP_STAMP(s4)
         if (MORE) {
             __syncthreads();
+        }
+        SP_STAMP(s5)
+        if (MORE) {
             read_frags(an, bn, 0, 0);
             SP_SB();
         }
-        mfma_s(1, 2);
-        mfma_s(1, 3);
+#pragma unroll
+        for (int q = NM / 2; q < NM; ++q) mfma_q(1, q);
         SP_SB();
+#ifdef SP_DIAG
+        SP_STAMP(s6)
+        dg[0] += s1 - s0; dg[1] += s2 - s1; dg[2] += s3 - s2; dg[3] += s3w - s3; dg[4] += s4 - s3w; dg[5] += s5 - s4; dg[6] += s6 - s5; dg[7] += 1;
+#endif
     };
+#ifdef SP_DIAG
+    SP_STAMP_ALWAYS(t_loop0)
+#endif
     for (int kt = 0; kt + 1 < nk; ++kt) k_tile(kt, std::true_type{});
     k_tile(nk - 1, std::false_type{});
+#ifdef SP_DIAG
+    SP_STAMP_ALWAYS(t_loop1)
+#endif
     __syncthreads();  // every wave is done with LDS before the epilogue touches anything else
 #undef SP_SB
 
     // ---- epilogue: y = act(acc * scale + shift (+ residual)); C/D map: col = lane&31, row = (r&3)+8(r>>2)+4(lane>>5)
+    // Stores on this chip are ISSUE-bound (~70 cycles per wave-instruction per CU whatever its width), so the epilogue
+    // is built around 16-byte accesses:
+    //   NHWC (c_out % 4 == 0): the wave's WM x WN accumulator tile is transposed through its private slice of the (now
+    //       dead) A/B staging LDS, so that a lane owns 4 consecutive channels of one pixel -> dwordx4 residual loads and
+    //       stores, whole 128/256-byte row segments per instruction, 4x fewer instructions than the natural layout;
+    //   NCHW (heat maps): a lane already owns 4 consecutive pixels of one channel (accumulator rows) -> dwordx4 directly;
+    //   anything else: scalar fallback.
     const bool nchw = p.flags & SP_CONV_OUT_NCHW;
     const bool pshuf = p.flags & SP_CONV_PIXEL_SHUFFLE;
     const bool relu = p.flags & SP_CONV_RELU;
     const int hw_out = p.out_h * p.out_w;
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, (short)0, p.y_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res : p.y), (short)0, p.y_bytes, 0x00020000);
+    if (!nchw && (p.c_out & 3) == 0) {
+        static_assert(BM * BN <= 2 * (BM + BN) * BK, "transpose area must fit in the staging buffers");
+        float* tr = smem + wave * (WM * WN);
 #pragma unroll
-    for (int n = 0; n < TN; ++n) {
-        const int col = n0 + wc * WN + n * 32 + fr;
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    tr[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * WN + n * 32 + fr] = acc[i][n][r];
+        constexpr int CPR = WN / 4;    // 16-byte chunks per tile row
+        constexpr int RPI = 64 / CPR;  // tile rows covered by one wave-instruction
+        constexpr int NIT = WM / RPI;
+        const int chunk = lane % CPR, rsub = lane / CPR;
+        const int col = n0 + wc * WN + chunk * 4;
         const bool col_ok = col < p.c_out;
-        float sc = 1.f, sh = 0.f;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
         if (col_ok) {
-            if (p.scale) sc = p.scale[col];
-            if (p.shift) sh = p.shift[col];
+            if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
+            if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
         }
-        int col_off;
-        if (nchw) col_off = col * hw_out;
-        else if (pshuf) {
+        int col_off = col;
+        if (pshuf) {
             const int sub = col / p.out_c, c = col - sub * p.out_c;  // packed column order: sub-pixel major
             col_off = ((sub >> 1) * p.out_w + (sub & 1)) * p.out_c + c;
-        } else col_off = col;
+        }
+        unsigned off[NIT];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            unsigned off[16];  // byte offsets of this lane's 16 outputs of tile (i, n); OOB = masked
+        for (int it = 0; it < NIT; ++it) {
+            const int ro = rowtab[(wr * WM + it * RPI + rsub) * 4 + 3];
+            off[it] = (col_ok && ro >= 0) ? (unsigned)((ro + col_off) * 4) : OOB;
+        }
+        u32x4 rv[NIT];
+        if (p.res) {  // every residual load of the tile in flight before the first use
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int row = wr * WM + i * 32 + 8 * g + 4 * fh;
+            for (int it = 0; it < NIT; ++it) rv[it] = __builtin_amdgcn_raw_buffer_load_b128(rr, off[it], 0, 0);
+        }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int ro = rowtab[(row + e) * 4 + 3];
-                    off[4 * g + e] = (col_ok && ro >= 0) ? (unsigned)((ro + col_off) * 4) : OOB;
+        for (int it = 0; it < NIT; ++it) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(tr + (it * RPI + rsub) * WN + chunk * 4);
+            v = v * sc + sh;
+            if (p.res) v += __builtin_bit_cast(f32x4, rv[it]);
+            if (relu) {
+                v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f;
+                v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f;
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, off[it], 0, 0);
+        }
+    } else {
+        const bool vec4 = nchw && (hw_out & 3) == 0 && !p.res;  // rows 4g..4g+3 = 4 consecutive pixels of one image
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            const int col = n0 + wc * WN + n * 32 + fr;
+            const bool col_ok = col < p.c_out;
+            float sc = 1.f, sh = 0.f;
+            if (col_ok) {
+                if (p.scale) sc = p.scale[col];
+                if (p.shift) sh = p.shift[col];
+            }
+            int col_off;
+            if (nchw) col_off = col * hw_out;
+            else if (pshuf) {
+                const int sub = col / p.out_c, c = col - sub * p.out_c;
+                col_off = ((sub >> 1) * p.out_w + (sub & 1)) * p.out_c + c;
+            } else col_off = col;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int row = wr * WM + i * 32 + 8 * g + 4 * fh;
+                    if (vec4) {
+                        const int ro = rowtab[row * 4 + 3];
+                        const unsigned o = (col_ok && ro >= 0) ? (unsigned)((ro + col_off) * 4) : OOB;
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = acc[i][n][4 * g + e] * sc + sh;
+                            if (relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, o, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int ro = rowtab[(row + e) * 4 + 3];
+                            const unsigned o = (col_ok && ro >= 0) ? (unsigned)((ro + col_off) * 4) : OOB;
+                            float v = acc[i][n][4 * g + e] * sc + sh;
+                            if (p.res) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, o, 0, 0));
+                            if (relu) v = v > 0.f ? v : 0.f;
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, o, 0, 0);
+                        }
+                    }
                 }
-            }
-            float rv[16];
-            if (p.res) {  // all 16 residual loads in flight before the first use
-#pragma unroll
-                for (int r = 0; r < 16; ++r) rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, off[r], 0, 0));
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc[i][n][r] * sc + sh;
-                if (p.res) v += rv[r];
-                if (relu) v = v > 0.f ? v : 0.f;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, off[r], 0, 0);
             }
         }
     }
+#ifdef SP_DIAG
+    SP_STAMP_ALWAYS(t_issued)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SP_STAMP_ALWAYS(t_end)
+    unsigned long long rt_end;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_end)::"memory");
+    if (lane == 0 && blockIdx.y == 0) {
+        unsigned long long* o = sp_dbg + ((blockIdx.x & 4095) * 4 + wave) * 12;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = dg[q];
+        o[8] = t_loop0 - t_entry; o[9] = t_loop1 - t_loop0; o[10] = t_end - t_loop1; o[11] = t_end - t_issued; o[7] = (rt_end - rt_entry) | (rt_entry << 32);
+    }
+#endif
 }
 
 template <int BM, int BN, int WR, int WC>
@@ -349,6 +508,8 @@ int launch(const ConvArgs& a, int phases, bool uniform, hipStream_t stream) {
 
 }  // namespace
 
+extern "C" int sp_conv2d_default_tile(const sp_conv_desc* d, int* tile_m, int* tile_n);
+
 extern "C" int sp_conv2d_fwd(const sp_conv_desc* d, const float* x, const float* w_packed, const float* scale,
                              const float* shift, const float* residual, float* y, void* stream) {
     SP_REQUIRE(d && x && w_packed && y, "sp_conv2d_fwd: null pointer");
@@ -361,7 +522,7 @@ extern "C" int sp_conv2d_fwd(const sp_conv_desc* d, const float* x, const float*
                d->taps_h * d->taps_w * d->c_in);
     SP_REQUIRE(d->n_pad % 32 == 0 && d->n_pad >= d->c_out, "sp_conv2d_fwd: n_pad=%d must be a multiple of 32 >= c_out=%d",
                d->n_pad, d->c_out);
-    const bool uniform = (d->c_in % 32 == 0);
+    const bool uniform = (d->c_in % 32 == 0) && d->taps_h * d->taps_w <= 32;  // tap-validity bit mask is 32 bits wide
     if (uniform) SP_REQUIRE(d->k_pad == d->taps_h * d->taps_w * d->c_in, "sp_conv2d_fwd: k_pad must equal taps*c_in when c_in%%32==0");
     SP_REQUIRE((d->phases_y == 1 || d->phases_y == 2) && (d->phases_x == 1 || d->phases_x == 2), "sp_conv2d_fwd: phases must be 1 or 2");
     const unsigned known = SP_CONV_RELU | SP_CONV_OUT_NCHW | SP_CONV_PIXEL_SHUFFLE;
@@ -400,33 +561,44 @@ extern "C" int sp_conv2d_fwd(const sp_conv_desc* d, const float* x, const float*
     a.out_h = d->out_h; a.out_w = d->out_w; a.out_c = d->out_c;
     a.oy_mul = d->oy_mul; a.oy_add = d->oy_add; a.ox_mul = d->ox_mul; a.ox_add = d->ox_add;
     a.phases_x = d->phases_x; a.flags = d->flags; a.tiles_m = a.tiles_n = 0;
-    if (const char* dbg = getenv("SP_CONV_DEBUG")) a.flags |= ((unsigned)atoi(dbg)) << 16;  // experiment bits
     a.x_bytes = (int)(in_elems * 4); a.w_bytes = (int)(w_elems * 4); a.y_bytes = (int)(out_elems * 4);
     const int phases = d->phases_y * d->phases_x;
     hipStream_t s = (hipStream_t)stream;
 
-    // tile choice: widest N tile that divides n_pad; halve BM when the launch would not fill the 256 CUs twice
+    // ---- tile shape: caller's choice (autotuned by the host, sp_conv_desc.tile_m/tile_n) or the built-in heuristic ----
+    int bm = d->tile_m, bn = d->tile_n;
     const int np = d->n_pad;
-    if (const char* t = getenv("SP_CONV_TILE")) {  // EXPERIMENT: force a tile shape "BMxBN" where it is legal
-        int bm = 0, bn = 0;
-        if (sscanf(t, "%dx%d", &bm, &bn) == 2 && np % bn == 0) {
-            if (bm == 128 && bn == 128) return launch<128, 128, 2, 2>(a, phases, uniform, s);
-            if (bm == 64 && bn == 128) return launch<64, 128, 2, 2>(a, phases, uniform, s);
-            if (bm == 128 && bn == 64) return launch<128, 64, 2, 2>(a, phases, uniform, s);
-            if (bm == 64 && bn == 64) return launch<64, 64, 2, 2>(a, phases, uniform, s);
-            if (bm == 256 && bn == 64) return launch<256, 64, 4, 1>(a, phases, uniform, s);
-            if (bm == 128 && bn == 32) return launch<128, 32, 4, 1>(a, phases, uniform, s);
-        }
-    }
+    if (bm == 0 && bn == 0) sp_conv2d_default_tile(d, &bm, &bn);
+    SP_REQUIRE(bn > 0 && np % bn == 0, "sp_conv2d_fwd: tile_n=%d must divide n_pad=%d", bn, np);
+#define SP_TILE(BM_, BN_, WR_, WC_) \
+    if (bm == BM_ && bn == BN_) return launch<BM_, BN_, WR_, WC_>(a, phases, uniform, s);
+    SP_TILE(128, 128, 2, 2)
+    SP_TILE(64, 128, 2, 2)
+    SP_TILE(128, 64, 2, 2)
+    SP_TILE(64, 64, 2, 2)
+    SP_TILE(256, 64, 4, 1)
+    SP_TILE(128, 32, 4, 1)
+#undef SP_TILE
+    sp_set_error("sp_conv2d_fwd: unsupported tile %dx%d (supported: 128x128 64x128 128x64 64x64 256x64 128x32)", bm, bn);
+    return SP_EINVAL;
+}
+
+// Built-in tile heuristic (measured on MI355X, bs=128 ResNet-50 shapes): 128x128 when the launch is many rounds deep,
+// 64-row tiles when it is not (3 workgroups per CU instead of 2 balance the last round), 64x64 for the smallest M.
+extern "C" int sp_conv2d_default_tile(const sp_conv_desc* d, int* tile_m, int* tile_n) {
+    if (!d || !tile_m || !tile_n) { sp_set_error("sp_conv2d_default_tile: null pointer"); return SP_EINVAL; }
+    const long long M = (long long)d->batch * d->grid_h * d->grid_w;
+    const int phases = (d->phases_y > 0 ? d->phases_y : 1) * (d->phases_x > 0 ? d->phases_x : 1);
+    const int np = d->n_pad;
     if (np % 128 == 0) {
-        const long long wgs = ((M + 127) / 128) * (np / 128) * phases;
-        if (wgs >= 512) return launch<128, 128, 2, 2>(a, phases, uniform, s);
-        return launch<64, 128, 2, 2>(a, phases, uniform, s);
-    }
-    if (np % 64 == 0) {
-        const long long wgs = ((M + 127) / 128) * (np / 64) * phases;
-        if (wgs >= 512) return launch<128, 64, 2, 2>(a, phases, uniform, s);
-        return launch<64, 64, 2, 2>(a, phases, uniform, s);
-    }
-    return launch<128, 32, 4, 1>(a, phases, uniform, s);
+        const long long b128 = ((M + 127) / 128) * (np / 128) * phases;
+        const long long b64 = ((M + 63) / 64) * (np / 128) * phases;
+        if (b128 >= 2048) { *tile_m = 128; *tile_n = 128; }
+        else if (b64 >= 768) { *tile_m = 64; *tile_n = 128; }
+        else { *tile_m = 64; *tile_n = 64; }
+    } else if (np % 64 == 0) {
+        const long long b = ((M + 127) / 128) * (np / 64) * phases;
+        if (b >= 1024) { *tile_m = 128; *tile_n = 64; } else { *tile_m = 64; *tile_n = 64; }
+    } else { *tile_m = 128; *tile_n = 32; }
+    return SP_OK;
 }

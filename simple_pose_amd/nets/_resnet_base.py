@@ -60,6 +60,7 @@ class PoseResNetBase(nn.Module):
             setattr(self, f"layer{li}", nn.Sequential(*blocks))
         self._build_head(inplanes, num_classes)
         self._init_like_reference()
+        self.autotune = True  # time the legal tile shapes per layer on first use (batch >= 16); speed only
         self._program: Optional[engine.Program] = None
         self._program_key = None
 
@@ -101,7 +102,10 @@ class PoseResNetBase(nn.Module):
         if self.training:
             raise NotImplementedError(
                 "train-mode forward/backward (batch-stat BN, dgrad/wgrad) is not lowered to HIP yet; call .eval()")
-        return self.hip_program(x).run(x)
+        prog = self.hip_program(x)
+        if self.autotune and x.shape[0] >= 16 and prog.tuned_for_batch != x.shape[0]:
+            prog.autotune(x)  # once per (weights, input shape): pins the fastest tile per layer; results unchanged
+        return prog.run(x)
 
 
 def load_pretrained_like_reference(model: nn.Module, arch: str):
