@@ -31,6 +31,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=128, help="images per GPU per step")
     ap.add_argument("--arch", default="dconv", choices=["dconv", "duc"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tiles", default=None, help="JSON tile table: loaded if it exists (skips autotune), else written")
     ap.add_argument("--layers-out", default=None, help="write the per-layer timing table (JSON) here")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (roofline object)")
     return ap.parse_args()
@@ -119,7 +120,16 @@ def main():
     x = torch.from_numpy(np.concatenate([base] * ((B + 7) // 8), 0)[:B]).to(dev)
     tinv = torch.from_numpy(synth.trans_inv_batch(B)).to(dev)
     prog = model.hip_program(x)
-    tiles = prog.autotune(x)   # untimed setup: pin the fastest workgroup tile per layer shape
+    # untimed setup: pin the fastest workgroup tile per layer shape (or reuse a saved table: profiling runs do, so that
+    # the trial launches of the tuner stay out of the per-kernel statistics)
+    if args.tiles and os.path.isfile(args.tiles):
+        with open(args.tiles) as fh:
+            prog.set_tiles(json.load(fh), B)
+    else:
+        tiles = prog.autotune(x)
+        if args.tiles and rank == 0:
+            with open(args.tiles, "w") as fh:
+                json.dump(tiles, fh)
 
     def step():
         hm = prog.run(x)
@@ -176,9 +186,21 @@ def main():
         dist.destroy_process_group()
 
 
+def _variant_name(op):
+    """Kernel instantiation a conv launch resolves to (the name rocprofv3 reports)."""
+    d = op.desc
+    bm, bn = d.tile_m, d.tile_n
+    wr, wc = {(128, 128): (2, 2), (64, 128): (2, 2), (128, 64): (2, 2), (64, 64): (2, 2), (256, 64): (4, 1), (128, 32): (4, 1)}[(bm, bn)]
+    uniform = (d.c_in % 32 == 0) and d.taps_h * d.taps_w <= 32
+    return f"conv_igemm_kernel<{bm}, {bn}, {wr}, {wc}, {'true' if uniform else 'false'}>"
+
+
 def kernel_roofline(prog, x, steps: int, layers_out=None):
-    """Average duration of the dominant kernel (the fp32 implicit-GEMM conv family) measured with HIP events recorded on
-    the launch stream around each of its launches, and its achieved algorithmic TFLOP/s against the fp32 matrix peak."""
+    """HIP events recorded on the launch stream around every conv launch of `steps` forward passes (same inputs as the
+    timed region).  The dominant kernel = the conv_igemm instantiation with the largest total time; its achieved
+    TFLOP/s = algorithmic FLOPs of its launches / their summed durations, against the fp32 matrix peak.  The
+    rocprofv3 --kernel-trace --stats summary of this same command is committed under profiles/ (average duration of
+    that kernel name must agree); HBM traffic per launch comes from the PMC passes summarised in profiles/*.json."""
     import torch
 
     from simple_pose_amd import _lib
@@ -216,21 +238,38 @@ def kernel_roofline(prog, x, steps: int, layers_out=None):
     per_layer = []
     for ci, op in enumerate(conv_ops):
         ms = sorted(ev[s][ci][0].elapsed_time(ev[s][ci][1]) for s in range(steps))[steps // 2]
-        per_layer.append((op.name, ms, op.flops * B))
-    tot_ms = sum(m for _, m, _ in per_layer)
-    tot_flop = sum(f for _, _, f in per_layer)
-    achieved = tot_flop / (tot_ms * 1e-3) / 1e12
-    worst = sorted(per_layer, key=lambda t: -t[1])[:8]
+        per_layer.append((op.name, ms, op.flops * B, _variant_name(op)))
+    groups = {}
+    for n, m, f, v in per_layer:
+        g = groups.setdefault(v, [0.0, 0.0, 0])
+        g[0] += m; g[1] += f; g[2] += 1
+    dom = max(groups, key=lambda v: groups[v][0])
+    d_ms, d_flop, d_n = groups[dom]
+    tot_ms = sum(m for _, m, _, _ in per_layer)
+    tot_flop = sum(f for _, _, f, _ in per_layer)
+    achieved = d_flop / (d_ms * 1e-3) / 1e12
     if layers_out:
         with open(layers_out, "w") as fh:
-            json.dump([{"layer": n, "us": round(1e3 * m, 1), "gflop": round(f / 1e9, 2),
-                        "tflops": round(f / (m * 1e-3) / 1e12, 1)} for n, m, f in per_layer], fh, indent=0)
-    return {"bound": "mfma", "kernel": "conv_igemm_kernel (fp32 MFMA implicit GEMM, all %d launches of a step)" % len(per_layer),
-            "achieved": round(achieved, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
-            "launches_per_step": len(per_layer), "avg_launch_us": round(1e3 * tot_ms / len(per_layer), 2),
-            "conv_ms_per_step": round(tot_ms, 3),
-            "slowest_layers": [{"layer": n, "us": round(1e3 * m, 1), "tflops": round(f / (m * 1e-3) / 1e12, 1)} for n, m, f in worst]}
+            json.dump([{"layer": n, "us": round(1e3 * m, 1), "gflop": round(f / 1e9, 2), "tflops": round(f / (m * 1e-3) / 1e12, 1),
+                        "kernel": v} for n, m, f, v in per_layer], fh, indent=0)
+    traffic = None
+    prof = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if os.path.isfile(prof):
+        try:
+            with open(prof) as fh:
+                traffic = json.load(fh).get(dom, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    return {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic,
+            "launches_per_step": d_n, "avg_launch_us": round(1e3 * d_ms / d_n, 2),
+            "algorithmic_gflop_per_launch": round(d_flop / d_n / 1e9, 3),
+            "share_of_conv_time": round(d_ms / tot_ms, 3),
+            "all_conv_kernels": {"launches_per_step": len(per_layer), "ms_per_step": round(tot_ms, 3),
+                                 "achieved": round(tot_flop / (tot_ms * 1e-3) / 1e12, 2),
+                                 "frac": round(tot_flop / (tot_ms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4)},
+            "by_kernel": {v: {"launches": g[2], "avg_us": round(1e3 * g[0] / g[2], 1), "tflops": round(g[1] / (g[0] * 1e-3) / 1e12, 1)}
+                          for v, g in sorted(groups.items(), key=lambda kv: -kv[1][0])}}
 
 
 if __name__ == "__main__":

@@ -225,6 +225,16 @@ class Program:
         self.tuned_for_batch = B
         return report
 
+    def tiles(self) -> Dict[str, Tuple[int, int]]:
+        return {op.name: (op.desc.tile_m, op.desc.tile_n) for op in self.ops if op.kind == "conv"}
+
+    def set_tiles(self, tiles: Dict[str, Tuple[int, int]], batch: int) -> None:
+        """Re-apply a tile table produced by autotune() (e.g. loaded from a file) instead of re-timing."""
+        for op in self.ops:
+            if op.kind == "conv" and op.name in tiles:
+                op.desc.tile_m, op.desc.tile_n = (int(v) for v in tiles[op.name])
+        self.tuned_for_batch = batch
+
     @property
     def flops_per_image(self) -> int:
         return sum(op.flops for op in self.ops)
