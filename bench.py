@@ -152,14 +152,11 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from simple_pose_amd.sharding import aggregate_throughput
+    total_images, elapsed, value = aggregate_throughput(float(B * args.steps), elapsed, device=dev)  # SUM units / MAX time
     assert os.environ.get("SP_CONV_DEBUG") or torch.isfinite(out[0]).all()
 
     ms_per_step = 1e3 * elapsed / args.steps
-    value = world * B * args.steps / elapsed
 
     # ---- per-kernel roofline: HIP events around every conv launch, on the launch stream, same inputs ----
     roofline = None
