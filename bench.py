@@ -20,6 +20,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+ARCH_NAMES = {"dconv": "ResNet50-DConv", "duc": "ResNet50-DUC", "hrnet_w32": "HRNet-W32"}
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 FLOP/clk/CU x 256 CU x 2.4 GHz
 
 
@@ -29,7 +30,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=128, help="images per GPU per step")
-    ap.add_argument("--arch", default="dconv", choices=["dconv", "duc"])
+    ap.add_argument("--arch", default="dconv", choices=["dconv", "duc", "hrnet_w32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tiles", default=None, help="JSON tile table: loaded if it exists (skips autotune), else written")
     ap.add_argument("--layers-out", default=None, help="write the per-layer timing table (JSON) here")
@@ -47,11 +48,17 @@ def cpu_baseline(arch: str):
     from simple_pose_amd import synth
 
     head = arch
-    sd = {k: torch.from_numpy(v) for k, v in
-          synth.conditioned_state_dict(nets_oracle.state_dict_shapes_resnet50(head), 0).items()}
     x = torch.from_numpy(synth.input_images(4, 0))
     tinv = synth.trans_inv_batch(4)
-    fwd = nets_oracle.FORWARDS["resnet50_" + head]
+    if arch == "hrnet_w32":
+        from simple_pose_amd.nets.pose_hrnet import hrnet_state_dict_shapes, load_cfg
+        cfg = load_cfg(os.path.join(ROOT, "simple_pose_amd", "nets", "hrnet_w32.yaml"))
+        sd = {k: torch.from_numpy(v) for k, v in synth.conditioned_state_dict(hrnet_state_dict_shapes(cfg, 17), 0).items()}
+        fwd = lambda sd_, x_: nets_oracle.hrnet_forward(sd_, x_, cfg)
+    else:
+        sd = {k: torch.from_numpy(v) for k, v in
+              synth.conditioned_state_dict(nets_oracle.state_dict_shapes_resnet50(head), 0).items()}
+        fwd = nets_oracle.FORWARDS["resnet50_" + head]
     threads = torch.get_num_threads()
 
     def one():
@@ -76,7 +83,7 @@ def cpu_baseline(arch: str):
     torch.set_num_threads(threads)
     rate, nthreads, n = best
     return {"value": round(rate, 2), "unit": "images/s", "cores": nthreads, "kind": "port",
-            "sample": f"{n} iterations of bs=4 ResNet50-{head} 256x192 fp32 forward (torch-CPU oracle) + C GaussTaylor decode, "
+            "sample": f"{n} iterations of bs=4 {ARCH_NAMES[arch]} 256x192 fp32 forward (torch-CPU oracle) + C GaussTaylor decode, "
                       f"best of thread counts <= {threads} on {os.cpu_count()} logical CPUs"}
 
 
@@ -107,9 +114,14 @@ def main():
     from simple_pose_amd.nets import pose_resnet_dconv, pose_resnet_duc
 
     _lib.lib()  # fail loudly if the HIP library is missing
-    mod = {"dconv": pose_resnet_dconv, "duc": pose_resnet_duc}[args.arch]
-    model = mod.resnet50(pretrained=False, num_classes=17)
-    sd = synth.conditioned_state_dict(nets_oracle.state_dict_shapes_resnet50(args.arch), seed=0)
+    if args.arch == "hrnet_w32":
+        from simple_pose_amd.nets.pose_hrnet import get_pose_net, hrnet_state_dict_shapes
+        model = get_pose_net(os.path.join(ROOT, "simple_pose_amd", "nets", "hrnet_w32.yaml"), pretrained=None, joint_num=17)
+        sd = synth.conditioned_state_dict(hrnet_state_dict_shapes(model.cfg, 17), seed=0)
+    else:
+        mod = {"dconv": pose_resnet_dconv, "duc": pose_resnet_duc}[args.arch]
+        model = mod.resnet50(pretrained=False, num_classes=17)
+        sd = synth.conditioned_state_dict(nets_oracle.state_dict_shapes_resnet50(args.arch), seed=0)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     model = model.to(dev).eval()
     decoder = GaussTaylorKeyPointDecoder(kernel_size=11, num_joints=17)
@@ -165,11 +177,11 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "images/sec fwd+decode, ResNet50-%s 256x192 bs=%d" % ("DConv" if args.arch == "dconv" else "DUC", B),
+            "metric": "images/sec fwd+decode, %s 256x192 bs=%d" % (ARCH_NAMES[args.arch], B),
             "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"ResNet50-{'DConv' if args.arch == 'dconv' else 'DUC'} 256x192 bs={B} per GPU, fp32 forward "
+            "config": {"workload": f"{ARCH_NAMES[args.arch]} 256x192 bs={B} per GPU, fp32 forward "
                                    "(NCHW in -> heat maps) + GaussTaylor decode, eval-mode BN, conditioned random weights",
                        "images_per_gpu": B, "global_batch": B * world, "parallelism": f"replicas x{world} (no collective)"},
             "gflop_per_image": round(prog.flops_per_image / 1e9, 4),
@@ -231,6 +243,9 @@ def kernel_roofline(prog, x, steps: int, layers_out=None):
             elif op.kind == "pixel_shuffle":
                 h, w, c = op.args
                 lib.sp_pixel_shuffle2_nhwc(P(bufs[op.src]), P(bufs[op.dst]), B, h, w, c, stream)
+            elif op.kind == "upsample_add":
+                h, w, c, f, relu = op.args
+                lib.sp_upsample_add_nhwc(P(bufs[op.src]), P(bufs[op.res]), P(bufs[op.dst]), B, h, w, c, f, relu, stream)
     torch.cuda.synchronize()
     per_layer = []
     for ci, op in enumerate(conv_ops):

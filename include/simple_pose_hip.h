@@ -91,9 +91,10 @@ int sp_maxpool3x3s2_nhwc(const float* x, float* y, int batch, int h, int w, int 
  * (the bare shuffle that opens the DUC head, nets/pose_resnet_duc.py:228; the two DUC blocks fuse theirs into the conv) */
 int sp_pixel_shuffle2_nhwc(const float* x, float* y, int batch, int h, int w, int c, void* stream);
 
-/* nearest-neighbour upsample by `factor` of NHWC `x` [B,h,w,c] added into NHWC `y` [B,h*f,w*f,c]
- * (+ optional ReLU): HighResolutionModule fuse sum, nets/pose_hrnet.py:192-202,250-257 */
-int sp_upsample_add_nhwc(const float* x, float* y, int batch, int h, int w, int c, int factor, int relu, void* stream);
+/* y = base + nearest_upsample(x, factor) (+ ReLU): x NHWC [B,h,w,c], base / y NHWC [B,h*f,w*f,c] (base may alias y;
+ * factor 1 = plain add).  HighResolutionModule fuse sum, nets/pose_hrnet.py:192-202,250-257 */
+int sp_upsample_add_nhwc(const float* x, const float* base, float* y, int batch, int h, int w, int c, int factor, int relu,
+                         void* stream);
 
 /* ---- decoders: metrics/pose_metrics.py --------------------------------------------------------- */
 

@@ -10,6 +10,7 @@ is committed - never reference source.  Fixture inventory
   g2_duc_fwd.npz     same for R50-DUC
   g4_decode.npz      decoders (GaussTaylor + Basic + heat_map_to_axis) on: Gaussian maps + noise, noise-like
                      maps, edge cases; identity-scale and random trans_inv
+  g3_hrnet_w32_fwd.npz  HRNet-W32 eval forward, B=1, + the reference's state_dict key/shape list
   g5_encode.npz      encoders (Refine + Basic) incl. out-of-range / trunc-toward-zero / vis=0 cases
 """
 from __future__ import annotations
@@ -68,6 +69,27 @@ def gen_forward(ns):
                             n_state_keys=n_keys, **taps)
         print(fname, hm.shape, "absmax", np.abs(hm).max(), "std", hm.std(), "state keys", n_keys)
     return hm
+
+
+def gen_hrnet(ns):
+    """g3_hrnet_w32_fwd.npz: HRNet-W32 eval forward, B=1, + the reference's state_dict key list (names/shapes)."""
+    torch.set_num_threads(8)
+    net = ns.hrnet.get_pose_net(ns.hrnet_w32_yaml, pretrained=None, joint_num=17)
+    synth.load_conditioned(net, SEED)
+    net.eval()
+    x = torch.from_numpy(synth.input_images(1, SEED))
+    names = [("layer1", net.layer1)]
+    taps, handles = _stage_taps(net, names)
+    with torch.no_grad():
+        hm = net(x).numpy()
+    for h in handles:
+        h.remove()
+    sd = net.state_dict()
+    keys = np.array(list(sd.keys()))
+    shapes = np.array([",".join(str(d) for d in v.shape) for v in sd.values()])
+    np.savez_compressed(os.path.join(GOLD, "g3_hrnet_w32_fwd.npz"), heat_maps=hm, seed=SEED, batch=1, keys=keys,
+                        shapes=shapes, **taps)
+    print("g3_hrnet_w32_fwd.npz", hm.shape, "absmax", np.abs(hm).max(), "std", hm.std(), "keys", len(keys))
 
 
 def edge_maps():
@@ -188,6 +210,7 @@ def main():
     net_maps = np.load(os.path.join(GOLD, "g1_dconv_fwd.npz"))["heat_maps"]
     gen_decode(ns, net_maps)
     gen_encode(ns)
+    gen_hrnet(ns)
     del hm
 
 

@@ -131,3 +131,74 @@ def state_dict_shapes_resnet50(head: str, num_joints: int = 17, se: bool = False
         raise ValueError(head)
     out.append(("final_layer.bias", (num_joints,), "torch.float32"))
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# HRNet: nets/pose_hrnet.py:419-454 (PoseHighResolutionNet.forward), :241-259 (HighResolutionModule.forward),
+# :34-51 (BasicBlock), :71-92 (Bottleneck), :181-236 (fuse layers), :327-366 (transitions)
+# ------------------------------------------------------------------------------------------------------------------
+def _conv_bn(x, sd, conv_key, bn_key, stride=1, padding=0, relu=False, training=False):
+    y = _bn(F.conv2d(x, sd[conv_key + ".weight"], stride=stride, padding=padding), sd, bn_key, training)
+    return F.relu(y) if relu else y
+
+
+def _hr_basic_block(x, sd, p, training=False):
+    out = _conv_bn(x, sd, p + ".conv1", p + ".bn1", padding=1, relu=True, training=training)
+    out = _conv_bn(out, sd, p + ".conv2", p + ".bn2", padding=1, training=training)
+    return F.relu(out + x)
+
+
+def hrnet_forward(sd, x, cfg, training=False, tap=None):
+    extra = cfg["MODEL"]["EXTRA"]
+    x = _conv_bn(x, sd, "conv1", "bn1", stride=2, padding=1, relu=True, training=training)
+    x = _conv_bn(x, sd, "conv2", "bn2", stride=2, padding=1, relu=True, training=training)
+    for k in range(4):
+        x = _bottleneck(x, sd, f"layer1.{k}", 1, training)
+    if tap:
+        tap("layer1", x)
+    ys, pre_n = [x], 1
+    for si, st in enumerate((2, 3, 4)):
+        sc = extra[f"STAGE{st}"]
+        nb = sc["NUM_BRANCHES"]
+        t = f"transition{si + 1}"
+        xs = []
+        for i in range(nb):
+            if i < pre_n:
+                if f"{t}.{i}.0.weight" in sd:
+                    xs.append(_conv_bn(ys[i], sd, f"{t}.{i}.0", f"{t}.{i}.1", padding=1, relu=True, training=training))
+                else:
+                    xs.append(ys[i])
+            else:
+                v = ys[-1]
+                for j in range(i + 1 - pre_n):
+                    v = _conv_bn(v, sd, f"{t}.{i}.{j}.0", f"{t}.{i}.{j}.1", stride=2, padding=1, relu=True, training=training)
+                xs.append(v)
+        for m in range(sc["NUM_MODULES"]):
+            multi = not (st == 4 and m == sc["NUM_MODULES"] - 1)
+            base = f"stage{st}.{m}"
+            for i in range(nb):
+                for k in range(sc["NUM_BLOCKS"][i]):
+                    xs[i] = _hr_basic_block(xs[i], sd, f"{base}.branches.{i}.{k}", training)
+            fused = []
+            for i in range(nb if multi else 1):
+                y = None
+                for j in range(nb):
+                    f = f"{base}.fuse_layers.{i}.{j}"
+                    if j == i:
+                        term = xs[i]
+                    elif j > i:
+                        term = _conv_bn(xs[j], sd, f + ".0", f + ".1", training=training)
+                        term = F.interpolate(term, scale_factor=2 ** (j - i), mode="nearest")
+                    else:
+                        term = xs[j]
+                        for k in range(i - j):
+                            term = _conv_bn(term, sd, f"{f}.{k}.0", f"{f}.{k}.1", stride=2, padding=1,
+                                            relu=(k != i - j - 1), training=training)
+                    y = term if y is None else y + term
+                fused.append(F.relu(y))
+            xs = fused
+        ys, pre_n = xs, nb
+        if tap:
+            tap(f"stage{st}", ys[0])
+    kf = extra["FINAL_CONV_KERNEL"]
+    return F.conv2d(ys[0], sd["final_layer.weight"], sd["final_layer.bias"], padding=1 if kf == 3 else 0)

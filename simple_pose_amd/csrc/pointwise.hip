@@ -47,8 +47,8 @@ __global__ void maxpool3x3s2_kernel(const f32x4* __restrict__ x, f32x4* __restri
     }
 }
 
-// y[b, Y, X, :] (+)= x[b, Y/f, X/f, :]  (nearest upsample + add [+ relu])
-__global__ void upsample_add_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y, int h, int w, int C4, int f, int relu,
+// y[b, Y, X, :] = base[b, Y, X, :] + x[b, Y/f, X/f, :]  (nearest upsample + add [+ relu]); base may alias y
+__global__ void upsample_add_kernel(const f32x4* __restrict__ x, const f32x4* base, f32x4* y, int h, int w, int C4, int f, int relu,
                                     long long total) {
     const int W = w * f, H = h * f;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -58,7 +58,7 @@ __global__ void upsample_add_kernel(const f32x4* __restrict__ x, f32x4* __restri
         const int Y = (int)(r % H);
         const long long b = r / H;
         const f32x4 a = x[((b * h + Y / f) * w + X / f) * C4 + c];
-        f32x4 v = y[i];
+        f32x4 v = base[i];
         v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3];
         if (relu) {
             v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f;
@@ -148,13 +148,15 @@ extern "C" int sp_pixel_shuffle2_nhwc(const float* x, float* y, int batch, int h
     return sp_check_launch("pixel_shuffle2_kernel");
 }
 
-extern "C" int sp_upsample_add_nhwc(const float* x, float* y, int batch, int h, int w, int c, int factor, int relu, void* stream) {
-    SP_REQUIRE(x && y, "sp_upsample_add_nhwc: null pointer");
+extern "C" int sp_upsample_add_nhwc(const float* x, const float* base, float* y, int batch, int h, int w, int c, int factor, int relu,
+                                    void* stream) {
+    SP_REQUIRE(x && base && y, "sp_upsample_add_nhwc: null pointer");
     SP_REQUIRE(batch > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0 && factor >= 1, "sp_upsample_add_nhwc: bad shape");
     const long long total = (long long)batch * h * factor * w * factor * (c / 4);
     SP_REQUIRE(total * 4 < (1ll << 31), "sp_upsample_add_nhwc: tensor too large");
     hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const f32x4*>(x), reinterpret_cast<f32x4*>(y), h, w, c / 4, factor, relu, total);
+                       reinterpret_cast<const f32x4*>(x), reinterpret_cast<const f32x4*>(base), reinterpret_cast<f32x4*>(y), h, w, c / 4, factor,
+                       relu, total);
     return sp_check_launch("upsample_add_kernel");
 }
 

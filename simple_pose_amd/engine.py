@@ -136,7 +136,7 @@ class Program:
         free: Dict[int, List[torch.Tensor]] = {}
         bufs: Dict[str, torch.Tensor] = {}
         for i, op in enumerate(self.ops):
-            if op.dst not in bufs and op.dst != self.out_name and op.kind != "upsample_add":
+            if op.dst not in bufs and op.dst != self.out_name:
                 h, w, c = self.shapes[op.dst]
                 n = batch * h * w * c
                 pool = free.get(n)
@@ -173,7 +173,8 @@ class Program:
                 _lib.check(lib.sp_pixel_shuffle2_nhwc(P(bufs[op.src]), P(bufs[op.dst]), B, h, w, c, stream), op.name)
             elif op.kind == "upsample_add":
                 h, w, c, f, relu = op.args
-                _lib.check(lib.sp_upsample_add_nhwc(P(bufs[op.src]), P(bufs[op.dst]), B, h, w, c, f, relu, stream), op.name)
+                _lib.check(lib.sp_upsample_add_nhwc(P(bufs[op.src]), P(bufs[op.res]), P(bufs[op.dst]), B, h, w, c, f, relu,
+                                                    stream), op.name)
             else:
                 raise ValueError(op.kind)
         return out
@@ -335,10 +336,13 @@ class ProgramBuilder:
         self.p.ops.append(Op("pixel_shuffle", src, dst, args=(h, w, c), name="pixel_shuffle"))
         return dst
 
-    def upsample_add(self, src: str, dst: str, factor: int, relu: bool = False) -> str:
+    def upsample_add(self, src: str, base: str, factor: int, relu: bool = False) -> str:
+        """dst = base + nearest_upsample(src, factor) (+ relu); factor 1 = plain add."""
         h, w, c = self.p.shapes[src]
-        assert self.p.shapes[dst] == (h * factor, w * factor, c)
-        self.p.ops.append(Op("upsample_add", src, dst, args=(h, w, c, factor, int(relu)), name="upsample_add"))
+        assert self.p.shapes[base] == (h * factor, w * factor, c), (self.p.shapes[base], (h, w, c), factor)
+        dst = self._fresh("fuse")
+        self.p.shapes[dst] = self.p.shapes[base]
+        self.p.ops.append(Op("upsample_add", src, dst, res=base, args=(h, w, c, factor, int(relu)), name="upsample_add"))
         return dst
 
 
@@ -396,4 +400,95 @@ def resnet_program(sd: Dict[str, torch.Tensor], head: str, in_h: int = 256, in_w
         raise ValueError(head)
     hh, ww, _ = b.p.shapes["heat"]
     b.p.out_shape = (J, hh, ww)
+    return b.p
+
+
+# ------------------------------------------------------------------------------------------------
+# HRNet (nets/pose_hrnet.py)
+# ------------------------------------------------------------------------------------------------
+def _basic_block(b: ProgramBuilder, sd, x: str, p: str) -> str:
+    """BasicBlock.forward (pose_hrnet.py:34-51): conv3x3-bn-relu, conv3x3-bn, + x, relu (stride 1, no downsample)."""
+    s1, h1 = _bn(sd, p + ".bn1")
+    t = b.conv(x, sd[p + ".conv1.weight"], pad=1, scale=s1, shift=h1, relu=True, name=p + ".conv1")
+    s2, h2 = _bn(sd, p + ".bn2")
+    return b.conv(t, sd[p + ".conv2.weight"], pad=1, scale=s2, shift=h2, relu=True, res=x, name=p + ".conv2")
+
+
+def _hr_module(b: ProgramBuilder, sd, xs: List[str], base: str, num_blocks: List[int], multi: bool) -> List[str]:
+    """HighResolutionModule.forward (pose_hrnet.py:241-259)."""
+    nb = len(xs)
+    xs = list(xs)
+    for i in range(nb):
+        for k in range(num_blocks[i]):
+            xs[i] = _basic_block(b, sd, xs[i], f"{base}.branches.{i}.{k}")
+    outs = []
+    for i in range(nb if multi else 1):
+        y: Optional[str] = None
+        for j in range(nb):
+            last = (j == nb - 1)
+            f = f"{base}.fuse_layers.{i}.{j}"
+            if j == i:
+                if y is None:
+                    y = xs[i]
+                    if last:       # single term: cannot happen (nb >= 2), kept for completeness
+                        raise NotImplementedError
+                else:
+                    y = b.upsample_add(xs[i], y, 1, relu=last)
+            elif j > i:            # 1x1 conv + bn at the low resolution, nearest upsample, add (:192-202)
+                s, h = _bn(sd, f + ".1")
+                t = b.conv(xs[j], sd[f + ".0.weight"], scale=s, shift=h, name=f)
+                y = b.upsample_add(t, y, 2 ** (j - i), relu=last)
+            else:                  # chain of 3x3 stride-2 convs (+bn, +relu except the last) (:205-233)
+                t = xs[j]
+                for k in range(i - j):
+                    s, h = _bn(sd, f"{f}.{k}.1")
+                    fin = (k == i - j - 1)
+                    t = b.conv(t, sd[f"{f}.{k}.0.weight"], stride=2, pad=1, scale=s, shift=h,
+                               relu=(last if fin else True), res=(y if fin else None), name=f"{f}.{k}")
+                y = t
+        outs.append(y)
+    return outs
+
+
+def hrnet_program(sd: Dict[str, torch.Tensor], cfg: dict, in_h: int = 256, in_w: int = 192) -> Program:
+    """Lower a reference-layout HRNet state_dict into a Program (PoseHighResolutionNet.forward, pose_hrnet.py:419-454)."""
+    extra = cfg["MODEL"]["EXTRA"]
+    b = ProgramBuilder(in_h, in_w)
+    x = b.to_nhwc4("input")
+    s, h = _bn(sd, "bn1")
+    x = b.conv(x, sd["conv1.weight"], stride=2, pad=1, scale=s, shift=h, relu=True, name="conv1")
+    s, h = _bn(sd, "bn2")
+    x = b.conv(x, sd["conv2.weight"], stride=2, pad=1, scale=s, shift=h, relu=True, name="conv2")
+    for k in range(4):
+        x = _bottleneck(b, sd, x, f"layer1.{k}", 1)
+    ys = [x]
+    pre_n = 1
+    for si, st in enumerate((2, 3, 4)):
+        sc = extra[f"STAGE{st}"]
+        nb = sc["NUM_BRANCHES"]
+        t = f"transition{si + 1}"
+        xs: List[str] = []
+        for i in range(nb):                              # :427-432 / :436-441 / :445-450
+            if i < pre_n:
+                if (f"{t}.{i}.0.weight") in sd:
+                    s_, h_ = _bn(sd, f"{t}.{i}.1")
+                    xs.append(b.conv(ys[i], sd[f"{t}.{i}.0.weight"], pad=1, scale=s_, shift=h_, relu=True, name=f"{t}.{i}"))
+                else:
+                    xs.append(ys[i])
+            else:
+                v = ys[-1]
+                for j in range(i + 1 - pre_n):
+                    s_, h_ = _bn(sd, f"{t}.{i}.{j}.1")
+                    v = b.conv(v, sd[f"{t}.{i}.{j}.0.weight"], stride=2, pad=1, scale=s_, shift=h_, relu=True, name=f"{t}.{i}.{j}")
+                xs.append(v)
+        for m in range(sc["NUM_MODULES"]):
+            multi = not (st == 4 and m == sc["NUM_MODULES"] - 1)
+            xs = _hr_module(b, sd, xs, f"stage{st}.{m}", list(sc["NUM_BLOCKS"]), multi)
+        ys = xs
+        pre_n = nb
+    kf = extra["FINAL_CONV_KERNEL"]
+    b.conv(ys[0], sd["final_layer.weight"], pad=1 if kf == 3 else 0, shift=sd["final_layer.bias"].float().contiguous(),
+           out_nchw=True, dst="heat", name="final_layer")
+    hh, ww, _ = b.p.shapes["heat"]
+    b.p.out_shape = (sd["final_layer.weight"].shape[0], hh, ww)
     return b.p

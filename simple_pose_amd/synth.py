@@ -99,7 +99,10 @@ def conditioned_state_dict(shapes: Iterable[Tuple[str, Tuple[int, ...], str]], s
             out[key] = tensor_normal(seed, key, shape, std=0.1)  # BN beta
         elif leaf == "weight":
             g = tensor_uniform(seed, key, shape, 0.75, 1.25)
-            if parent.endswith("bn3"):
+            # damp the last BN of every residual block (Bottleneck.bn3; HRNet BasicBlock.bn2 inside `branches`) so that
+            # activations stay O(1) through dozens of residual additions
+            # ... and the BN of every HRNet fuse path (up to four branches are summed eight times over)
+            if parent.endswith("bn3") or (".branches." in key and parent.endswith("bn2")) or ".fuse_layers." in key:
                 g = (g * np.float32(0.25)).astype(np.float32)
             out[key] = g
         else:

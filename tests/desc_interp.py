@@ -75,7 +75,7 @@ def run_program_cpu(prog, x):
         elif op.kind == "upsample_add":
             h, w, c, f, relu = op.args
             up = bufs[op.src].repeat_interleave(f, 1).repeat_interleave(f, 2)
-            t = bufs[op.dst] + up
+            t = bufs[op.res] + up
             bufs[op.dst] = t.clamp(min=0) if relu else t
         elif op.kind == "conv":
             d = op.desc

@@ -331,3 +331,25 @@ def test_masked_mse_vs_oracle():
                                         _lib.ptr(loss), _lib.ptr(grad), _lib.ptr(ws), _lib.current_stream()))
     assert abs(loss.item() - float(loss_ref)) <= 1e-6 * abs(float(loss_ref))
     assert np.abs(grad.cpu().numpy() - grad_ref).max() <= 1e-7 * np.abs(grad_ref).max() + 1e-12
+
+
+def test_hrnet_w32_forward_vs_reference_golden(golden):
+    import os
+    from simple_pose_amd.nets.pose_hrnet import get_pose_net, hrnet_state_dict_shapes
+    g = golden("g3_hrnet_w32_fwd.npz")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    m = get_pose_net(os.path.join(root, "simple_pose_amd", "nets", "hrnet_w32.yaml"), pretrained=None, joint_num=17)
+    sd = synth.conditioned_state_dict(hrnet_state_dict_shapes(m.cfg, 17), int(g["seed"]))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m = m.to(DEV).eval()
+    with torch.no_grad():
+        hm = m(_cuda(synth.input_images(1, int(g["seed"]))))
+    ref = g["heat_maps"]
+    assert hm.shape == (1, 17, 64, 48)
+    rel = np.abs(hm.cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert rel <= 1e-4, rel
+    # batch of 16 (autotuned tiles) reproduces the single image bitwise
+    x16 = _cuda(np.repeat(synth.input_images(1, int(g["seed"])), 16, 0))
+    with torch.no_grad():
+        hm16 = m(x16)
+    assert torch.equal(hm16[3], hm[0]) and torch.equal(hm16[15], hm[0])

@@ -106,3 +106,28 @@ def test_product_path_refuses_cpu_tensors():
     from simple_pose_amd.metrics import GaussTaylorKeyPointDecoder
     with pytest.raises(_lib.HipLibraryError):
         GaussTaylorKeyPointDecoder()(torch.zeros(1, 17, 64, 48), torch.zeros(1, 2, 3))
+
+
+def test_hrnet_module_layout_and_lowering_reproduce_oracle(golden):
+    """HRNet-W32: product module has the reference's 1,754 keys in order; its Program, interpreted on CPU, equals the
+    oracle forward on a 64x64 crop."""
+    from simple_pose_amd.nets.pose_hrnet import get_pose_net, hrnet_state_dict_shapes
+    g = golden("g3_hrnet_w32_fwd.npz")
+    m = get_pose_net(os.path.join(ROOT, "simple_pose_amd", "nets", "hrnet_w32.yaml"), pretrained=None, joint_num=17)
+    sd0 = m.state_dict()
+    assert list(sd0.keys()) == list(g["keys"]) and len(sd0) == 1754
+    assert sum(p.numel() for p in m.parameters()) == 28536113 and len(list(m.parameters())) == 878
+    shapes = hrnet_state_dict_shapes(m.cfg, 17)
+    sd = {k: torch.from_numpy(v) for k, v in synth.conditioned_state_dict(shapes, seed=2).items()}
+    m.load_state_dict(sd, strict=True)
+    x = torch.from_numpy(synth.input_images(1, seed=2, h=64, w=64))
+    prog = engine.hrnet_program(sd, m.cfg, in_h=64, in_w=64)
+    with torch.no_grad():
+        ref = nets_oracle.hrnet_forward(sd, x, m.cfg)
+        got, _ = run_program_cpu(prog, x)
+    assert got.shape == ref.shape == (1, 17, 16, 16)
+    assert (got - ref).abs().max() / ref.abs().max() < 1e-5
+    full = engine.hrnet_program(sd, m.cfg, in_h=256, in_w=192)
+    assert abs(full.flops_per_image - 15.29e9) / 15.29e9 < 1e-3     # BASELINE.md section 3: 15.2900 GFLOP / image
+    with pytest.raises(_lib.HipLibraryError):
+        m.eval()(torch.zeros(1, 3, 256, 192))

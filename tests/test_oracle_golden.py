@@ -87,3 +87,20 @@ def test_forward_oracle_matches_reference(golden, arch, fname, head):
         ref_slice = g[name + "/slice"]
         assert np.abs(t[0, :8, :4, :4].numpy() - ref_slice).max() <= 1e-4 * max(1.0, float(g[name + "/absmax"]))
         assert abs(t.double().mean().item() - float(g[name + "/mean"])) < 1e-5
+
+
+def test_hrnet_forward_oracle_and_key_layout_match_reference(golden):
+    import yaml
+    from simple_pose_amd.nets.pose_hrnet import hrnet_state_dict_shapes, load_cfg
+    import os
+    g = golden("g3_hrnet_w32_fwd.npz")
+    cfg = load_cfg(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "simple_pose_amd", "nets", "hrnet_w32.yaml"))
+    shapes = hrnet_state_dict_shapes(cfg, 17)
+    assert [k for k, _, _ in shapes] == list(g["keys"])                       # names AND order of the reference
+    assert [",".join(str(d) for d in s) for _, s, _ in shapes] == list(g["shapes"])
+    sd = {k: torch.from_numpy(v) for k, v in synth.conditioned_state_dict(shapes, int(g["seed"])).items()}
+    x = torch.from_numpy(synth.input_images(1, int(g["seed"])))
+    with torch.no_grad():
+        hm = nets_oracle.hrnet_forward(sd, x, cfg).numpy()
+    ref = g["heat_maps"]
+    assert np.abs(hm - ref).max() / np.abs(ref).max() <= 1e-5
