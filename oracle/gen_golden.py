@@ -11,6 +11,7 @@ is committed - never reference source.  Fixture inventory
   g4_decode.npz      decoders (GaussTaylor + Basic + heat_map_to_axis) on: Gaussian maps + noise, noise-like
                      maps, edge cases; identity-scale and random trans_inv
   g3_hrnet_w32_fwd.npz  HRNet-W32 eval forward, B=1, + the reference's state_dict key/shape list
+  g6_train_step.npz  one reference training step (B=2): loss, gradient slices, BN running stats, params after Adam
   g5_encode.npz      encoders (Refine + Basic) incl. out-of-range / trunc-toward-zero / vis=0 cases
 """
 from __future__ import annotations
@@ -90,6 +91,46 @@ def gen_hrnet(ns):
     np.savez_compressed(os.path.join(GOLD, "g3_hrnet_w32_fwd.npz"), heat_maps=hm, seed=SEED, batch=1, keys=keys,
                         shapes=shapes, **taps)
     print("g3_hrnet_w32_fwd.npz", hm.shape, "absmax", np.abs(hm).max(), "std", hm.std(), "keys", len(keys))
+
+
+def gen_train(ns):
+    """g6_train_step.npz: ONE training step of the real reference (ddp...:110-119), B=2: loss, gradient slices, BN running
+    stats, parameter slices after torch.optim.Adam(lr=1e-3).step()."""
+    torch.set_num_threads(8)
+    net = ns.dconv.resnet50(pretrained=False, num_classes=17)
+    synth.load_conditioned(net, SEED)
+    net.train()
+    x = torch.from_numpy(synth.input_images(2, SEED))
+    joints = synth.joints_batch(2, 17, seed=41)
+    enc = ns.transforms.RefineSimpleTransform.get_heat_map
+    tw = [enc(joints[b], 2.0, (48, 64)) for b in range(2)]
+    targets = torch.from_numpy(np.stack([t for t, _ in tw]))
+    mask = torch.from_numpy(np.stack([w for _, w in tw]))
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    crit = torch.nn.MSELoss()
+    opt.zero_grad()
+    pred = net(x)
+    loss = 0.5 * crit(pred.mul(mask[[..., None, None]]), targets.mul(mask[[..., None, None]]))
+    loss.backward()
+    out = {"loss": np.float32(loss.item()), "joints": joints, "heat_train": pred.detach().numpy()}
+    named = dict(net.named_parameters())
+    picks = {"conv1.weight": (slice(0, 2),), "layer1.0.conv1.weight": (slice(0, 4),), "layer2.0.conv2.weight": (slice(0, 2), slice(0, 8)),
+             "layer2.0.downsample.0.weight": (slice(0, 2), slice(0, 16)), "layer4.2.conv3.weight": (slice(0, 2), slice(0, 8)),
+             "deconv_layers.0.weight": (slice(0, 2), slice(0, 2)), "deconv_layers.6.weight": (slice(0, 2), slice(0, 4)),
+             "final_layer.weight": (slice(None),), "final_layer.bias": (slice(None),), "bn1.weight": (slice(None),), "bn1.bias": (slice(None),),
+             "layer1.0.bn3.weight": (slice(0, 32),), "layer3.2.bn2.bias": (slice(0, 32),), "deconv_layers.4.weight": (slice(0, 32),)}
+    for k, sl in picks.items():
+        out["grad/" + k] = named[k].grad[sl].numpy().copy()
+        out["gradnorm/" + k] = np.float64(named[k].grad.double().norm().item())
+    opt.step()
+    for k, sl in picks.items():
+        out["param/" + k] = named[k].detach()[sl].numpy().copy()
+    bufs = dict(net.named_buffers())
+    for k in ("bn1.running_mean", "bn1.running_var", "layer3.5.bn3.running_var", "deconv_layers.7.running_mean"):
+        out["buf/" + k] = bufs[k].numpy().copy()
+    out["buf/bn1.num_batches_tracked"] = bufs["bn1.num_batches_tracked"].numpy().copy()
+    np.savez_compressed(os.path.join(GOLD, "g6_train_step.npz"), **out)
+    print("g6_train_step.npz loss", out["loss"], "gradnorm conv1", out["gradnorm/conv1.weight"])
 
 
 def edge_maps():
@@ -211,6 +252,7 @@ def main():
     gen_decode(ns, net_maps)
     gen_encode(ns)
     gen_hrnet(ns)
+    gen_train(ns)
     del hm
 
 

@@ -23,8 +23,9 @@ BN_EPS = 1e-5
 
 def _bn(x, sd, prefix, training=False):
     # nn.BatchNorm2d(eps=1e-5, momentum=0.1); eval mode uses running stats
-    if training:
-        return F.batch_norm(x, None, None, sd[prefix + ".weight"], sd[prefix + ".bias"], True, 0.1, BN_EPS)
+    if training:  # batch statistics; running stats (when present in sd) are updated in place like nn.BatchNorm2d does
+        return F.batch_norm(x, sd.get(prefix + ".running_mean"), sd.get(prefix + ".running_var"), sd[prefix + ".weight"],
+                            sd[prefix + ".bias"], True, 0.1, BN_EPS)
     return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"],
                         sd[prefix + ".weight"], sd[prefix + ".bias"], False, 0.1, BN_EPS)
 

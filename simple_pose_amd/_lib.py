@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_float, c_int, c_int32, c_uint32, c_void_p
+from ctypes import c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
 
 from .build import LIB_PATH as _DEFAULT_LIB_PATH
 
@@ -49,6 +49,14 @@ SYMBOLS = {
     "sp_decode_basic": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "sp_encode_gauss_refine": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P]),
     "sp_encode_gauss_basic": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, c_int, _P, _P, _P]),
+    "sp_bn_train_stats_nhwc": (c_int, [_P, c_int64, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P]),
+    "sp_bn_apply_nhwc": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, _P]),
+    "sp_bn_train_bwd_nhwc": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P, c_int, _P, _P]),
+    "sp_channel_sum_nhwc": (c_int, [_P, c_int64, c_int, _P, _P, _P]),
+    "sp_maxpool3x3s2_bwd_nhwc": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "sp_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int, c_float, _P]),
+    "sp_conv2d_wgrad": (c_int, [ctypes.POINTER(ConvDesc), _P, c_int, _P, c_int, c_int, c_int, c_int64, c_int64, _P, _P, c_int64, _P]),
+    "sp_permute4_f32": (c_int, [_P, _P, ctypes.POINTER(c_int32), ctypes.POINTER(c_int64), ctypes.POINTER(c_int32), c_int64, c_int64, _P]),
     "sp_masked_mse": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
 }
 

@@ -1,0 +1,322 @@
+// train.hip - HBM-bound kernels of the training step (processors/ddp_pose_resnet_solver.py:110-133):
+// train-mode BatchNorm forward/backward on NHWC fp32, max-pool backward, fused Adam, weight (re)packing, layout helpers.
+// All reductions accumulate in double and are deterministic (fixed grid, per-block partials, ordered final sum).
+#include "sp_common.h"
+
+namespace {
+
+constexpr int RED_BLOCKS = 256;  // partial-sum workgroups per channel reduction
+
+inline int grid_for(long long total, int block) {
+    long long g = (total + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// per-channel sums over the M rows of an NHWC tensor: thread = (4 channels) x (row stripe)
+//   mode 0: s0 = sum z,            s1 = sum z^2                         (BN forward statistics)
+//   mode 1: s0 = sum g,            s1 = sum g * xhat,  g = dy*(y>0?)    (BN backward: dbeta, dgamma)
+// part: [gridDim.x][C][2] doubles
+// ---------------------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void channel_reduce_kernel(const float* __restrict__ a, const float* __restrict__ relu_src,
+                                                             const float* __restrict__ z, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, int M, int C, double* __restrict__ part) {
+    const int C4 = C >> 2;
+    const int lanes_c = C4 < 256 ? C4 : 256;       // threads along channels
+    const int rows_par = 256 / lanes_c;            // row stripes inside the block
+    const int tc = threadIdx.x % lanes_c, tr = threadIdx.x / lanes_c;
+    __shared__ double sm[256 * 8];
+    for (int c4 = tc; c4 < C4; c4 += lanes_c) {
+        double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+        f32x4 mu = {0, 0, 0, 0}, is = {0, 0, 0, 0};
+        if (MODE == 1) { mu = reinterpret_cast<const f32x4*>(mean)[c4]; is = reinterpret_cast<const f32x4*>(invstd)[c4]; }
+        if (tr < rows_par) {
+            for (long long r = (long long)blockIdx.x * rows_par + tr; r < M; r += (long long)gridDim.x * rows_par) {
+                const f32x4 v = reinterpret_cast<const f32x4*>(a)[r * C4 + c4];
+                if (MODE == 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { s0[e] += (double)v[e]; s1[e] += (double)v[e] * (double)v[e]; }
+                } else {
+                    f32x4 g = v;
+                    if (relu_src) {
+                        const f32x4 y = reinterpret_cast<const f32x4*>(relu_src)[r * C4 + c4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g[e] = y[e] > 0.f ? g[e] : 0.f;
+                    }
+                    const f32x4 zz = reinterpret_cast<const f32x4*>(z)[r * C4 + c4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { s0[e] += (double)g[e]; s1[e] += (double)g[e] * (double)((zz[e] - mu[e]) * is[e]); }
+                }
+            }
+        }
+        // fold the row stripes of this block (fixed order)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sm[threadIdx.x * 8 + e] = s0[e]; sm[threadIdx.x * 8 + 4 + e] = s1[e]; }
+        __syncthreads();
+        if (tr == 0) {
+            for (int k = 1; k < rows_par; ++k)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sm[tc * 8 + e] += sm[(k * lanes_c + tc) * 8 + e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                part[((size_t)blockIdx.x * C + c4 * 4 + e) * 2 + 0] = sm[tc * 8 + e];
+                part[((size_t)blockIdx.x * C + c4 * 4 + e) * 2 + 1] = sm[tc * 8 + 4 + e];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// BN forward finalize: mean, invstd (biased var), running stats with momentum and UNBIASED var (torch semantics)
+__global__ void bn_stats_final_kernel(const double* __restrict__ part, int nblk, int C, double M, float eps, float momentum,
+                                      float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ run_mean,
+                                      float* __restrict__ run_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s0 = 0, s1 = 0;
+    for (int b = 0; b < nblk; ++b) { s0 += part[((size_t)b * C + c) * 2]; s1 += part[((size_t)b * C + c) * 2 + 1]; }
+    const double mu = s0 / M;
+    double var = s1 / M - mu * mu;
+    if (var < 0) var = 0;
+    mean[c] = (float)mu;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (run_mean) {
+        const double unb = M > 1 ? var * M / (M - 1) : var;
+        run_mean[c] = (float)((1.0 - momentum) * (double)run_mean[c] + (double)momentum * mu);
+        run_var[c] = (float)((1.0 - momentum) * (double)run_var[c] + (double)momentum * unb);
+    }
+}
+
+__global__ void pair_sum_final_kernel(const double* __restrict__ part, int nblk, int C, float* __restrict__ o0, float* __restrict__ o1) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s0 = 0, s1 = 0;
+    for (int b = 0; b < nblk; ++b) { s0 += part[((size_t)b * C + c) * 2]; s1 += part[((size_t)b * C + c) * 2 + 1]; }
+    if (o0) o0[c] = (float)s0;
+    if (o1) o1[c] = (float)s1;
+}
+
+// y = [relu]( (z - mean) * invstd * gamma + beta [+ res] )
+__global__ void bn_apply_kernel(const f32x4* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                const float* __restrict__ gamma, const float* __restrict__ beta, const f32x4* __restrict__ res,
+                                f32x4* __restrict__ y, int C4, int relu, long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c4], is = reinterpret_cast<const f32x4*>(invstd)[c4];
+        const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[c4], b = reinterpret_cast<const f32x4*>(beta)[c4];
+        f32x4 v = z[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (v[e] - mu[e]) * is[e] * g[e] + b[e];
+        if (res) { const f32x4 r = res[i]; v += r; }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+        y[i] = v;
+    }
+}
+
+// g = dy * (y > 0);  dz = gamma*invstd * (g - dbeta/M - xhat * dgamma/M);  dres (+)= g
+__global__ void bn_bwd_apply_kernel(const f32x4* __restrict__ dy, const f32x4* __restrict__ relu_src, const f32x4* __restrict__ z,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ dgamma, const float* __restrict__ dbeta, float inv_m, f32x4* __restrict__ dz,
+                                    f32x4* dres, int dres_accumulate, int C4, long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c4], is = reinterpret_cast<const f32x4*>(invstd)[c4];
+        const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[c4];
+        const f32x4 dg = reinterpret_cast<const f32x4*>(dgamma)[c4], db = reinterpret_cast<const f32x4*>(dbeta)[c4];
+        f32x4 g = dy[i];
+        if (relu_src) {
+            const f32x4 y = relu_src[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = y[e] > 0.f ? g[e] : 0.f;
+        }
+        const f32x4 zz = z[i];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (zz[e] - mu[e]) * is[e];
+            o[e] = ga[e] * is[e] * (g[e] - db[e] * inv_m - xh * dg[e] * inv_m);
+        }
+        dz[i] = o;
+        if (dres) {
+            if (dres_accumulate) { f32x4 r = dres[i]; r += g; dres[i] = r; } else dres[i] = g;
+        }
+    }
+}
+
+// dx[b,iy,ix,:] = sum over the (<= 4) windows that contain (iy,ix) and whose FIRST maximum (row-major scan, as
+// nn.MaxPool2d) is this pixel, of dy[window].  Gather form: deterministic, no atomics.
+__global__ void maxpool3x3s2_bwd_kernel(const f32x4* __restrict__ x, const f32x4* __restrict__ dy, f32x4* __restrict__ dx, int H, int W,
+                                        int C4, int Ho, int Wo, long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long long r = i / C4;
+        const int ix = (int)(r % W); r /= W;
+        const int iy = (int)(r % H);
+        const long long b = r / H;
+        const f32x4 me = x[i];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // windows oy with iy in [2oy-1, 2oy+1]
+        for (int oy = (iy) / 2; oy <= (iy + 1) / 2; ++oy) {
+            if (oy < 0 || oy >= Ho) continue;
+            for (int ox = (ix) / 2; ox <= (ix + 1) / 2; ++ox) {
+                if (ox < 0 || ox >= Wo) continue;
+                // is (iy,ix) the first max of window (oy,ox)?  per channel
+                bool win[4] = {true, true, true, true};
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int yy = oy * 2 - 1 + ky;
+                    if ((unsigned)yy >= (unsigned)H) continue;
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int xx = ox * 2 - 1 + kx;
+                        if ((unsigned)xx >= (unsigned)W) continue;
+                        if (yy == iy && xx == ix) continue;
+                        const f32x4 o = x[((b * H + yy) * W + xx) * C4 + c];
+                        const bool before = (yy < iy) || (yy == iy && xx < ix);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            // an earlier element wins ties; a later one must be strictly greater (NaN: torch picks NaN; ignored)
+                            if (before ? (o[e] >= me[e]) : (o[e] > me[e])) win[e] = false;
+                        }
+                    }
+                }
+                const f32x4 g = dy[((b * Ho + oy) * Wo + ox) * C4 + c];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (win[e]) acc[e] += g[e];
+            }
+        }
+        dx[i] = acc;
+    }
+}
+
+// torch.optim.Adam (no amsgrad, weight_decay 0) on flat buffers; g is multiplied by grad_scale first (1/world after a SUM all-reduce)
+__global__ void adam_kernel(f32x4* __restrict__ p, const f32x4* __restrict__ g, f32x4* __restrict__ m, f32x4* __restrict__ v, long long n4,
+                            float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, float grad_scale) {
+    const float step_size = lr / bc1;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        f32x4 pp = p[i], gg = g[i], mm = m[i], vv = v[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gr = gg[e] * grad_scale;
+            mm[e] = mm[e] * b1 + (1.f - b1) * gr;              // exp_avg.mul_(beta1).add_(grad, alpha=1-beta1)
+            vv[e] = vv[e] * b2 + (1.f - b2) * gr * gr;         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+            const float denom = sqrtf(vv[e]) / bc2_sqrt + eps; // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
+            pp[e] = pp[e] - step_size * (mm[e] / denom);       // param.addcdiv_(exp_avg, denom, value=-step_size)
+        }
+        p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+}
+
+// generic 4-D gather-copy: dst[((a*D1 + b)*D2 + c)*D3 + d] = (in range) ? src[a*s0 + b*s1 + c*s2 + d*s3 + base] : 0
+struct Permute4 {
+    int d[4];        // destination extents
+    long long s[4];  // source strides (elements) per destination index
+    int lim[4];      // valid extent per index (>= -> zero fill)
+    long long base;
+    long long dst_off;
+};
+__global__ void permute4_kernel(const float* __restrict__ src, float* __restrict__ dst, const Permute4 pm, long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long r = i;
+        const int i3 = (int)(r % pm.d[3]); r /= pm.d[3];
+        const int i2 = (int)(r % pm.d[2]); r /= pm.d[2];
+        const int i1 = (int)(r % pm.d[1]);
+        const int i0 = (int)(r / pm.d[1]);
+        float v = 0.f;
+        if (i0 < pm.lim[0] && i1 < pm.lim[1] && i2 < pm.lim[2] && i3 < pm.lim[3])
+            v = src[pm.base + i0 * pm.s[0] + i1 * pm.s[1] + i2 * pm.s[2] + i3 * pm.s[3]];
+        dst[pm.dst_off + i] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int sp_bn_train_stats_nhwc(const float* z, int64_t rows, int c, float eps, float momentum, float* mean, float* invstd,
+                                      float* running_mean, float* running_var, void* workspace, void* stream) {
+    SP_REQUIRE(z && mean && invstd && workspace, "sp_bn_train_stats_nhwc: null pointer");
+    SP_REQUIRE(rows > 0 && c > 0 && c % 4 == 0 && rows < (1ll << 31) && ((c / 4) <= 256 ? 256 % 1 == 0 : (c / 4) % 256 == 0),
+               "sp_bn_train_stats_nhwc: bad shape rows=%lld c=%d (c/4 must be <= 256 or a multiple of 256)", (long long)rows, c);
+    SP_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "sp_bn_train_stats_nhwc: running stats come in pairs");
+    hipStream_t s = (hipStream_t)stream;
+    double* part = reinterpret_cast<double*>(workspace);
+    hipLaunchKernelGGL(channel_reduce_kernel<0>, dim3(RED_BLOCKS), dim3(256), 0, s, z, nullptr, nullptr, nullptr, nullptr, (int)rows, c, part);
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((c + 255) / 256), dim3(256), 0, s, part, RED_BLOCKS, c, (double)rows, eps, momentum, mean,
+                       invstd, running_mean, running_var);
+    return sp_check_launch("bn_train_stats");
+}
+
+extern "C" int sp_bn_apply_nhwc(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                const float* residual, float* y, int64_t rows, int c, int relu, void* stream) {
+    SP_REQUIRE(z && mean && invstd && gamma && beta && y, "sp_bn_apply_nhwc: null pointer");
+    SP_REQUIRE(rows > 0 && c > 0 && c % 4 == 0, "sp_bn_apply_nhwc: bad shape");
+    const long long total = rows * (c / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f32x4*>(z), mean,
+                       invstd, gamma, beta, reinterpret_cast<const f32x4*>(residual), reinterpret_cast<f32x4*>(y), c / 4, relu, total);
+    return sp_check_launch("bn_apply_kernel");
+}
+
+extern "C" int sp_bn_train_bwd_nhwc(const float* dy, const float* relu_src, const float* z, const float* mean, const float* invstd,
+                                    const float* gamma, int64_t rows, int c, float* dz, float* dgamma, float* dbeta, float* dres,
+                                    int dres_accumulate, void* workspace, void* stream) {
+    SP_REQUIRE(dy && z && mean && invstd && gamma && dz && dgamma && dbeta && workspace, "sp_bn_train_bwd_nhwc: null pointer");
+    SP_REQUIRE(rows > 0 && c > 0 && c % 4 == 0 && rows < (1ll << 31), "sp_bn_train_bwd_nhwc: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    double* part = reinterpret_cast<double*>(workspace);
+    hipLaunchKernelGGL(channel_reduce_kernel<1>, dim3(RED_BLOCKS), dim3(256), 0, s, dy, relu_src, z, mean, invstd, (int)rows, c, part);
+    hipLaunchKernelGGL(pair_sum_final_kernel, dim3((c + 255) / 256), dim3(256), 0, s, part, RED_BLOCKS, c, dbeta, dgamma);
+    const long long total = rows * (c / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, reinterpret_cast<const f32x4*>(dy),
+                       reinterpret_cast<const f32x4*>(relu_src), reinterpret_cast<const f32x4*>(z), mean, invstd, gamma, dgamma, dbeta,
+                       (float)(1.0 / (double)rows), reinterpret_cast<f32x4*>(dz), reinterpret_cast<f32x4*>(dres), dres_accumulate, c / 4, total);
+    return sp_check_launch("bn_train_bwd");
+}
+
+extern "C" int sp_channel_sum_nhwc(const float* a, int64_t rows, int c, float* sum, void* workspace, void* stream) {
+    SP_REQUIRE(a && sum && workspace && rows > 0 && c > 0 && c % 4 == 0 && rows < (1ll << 31), "sp_channel_sum_nhwc: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    double* part = reinterpret_cast<double*>(workspace);
+    hipLaunchKernelGGL(channel_reduce_kernel<0>, dim3(RED_BLOCKS), dim3(256), 0, s, a, nullptr, nullptr, nullptr, nullptr, (int)rows, c, part);
+    hipLaunchKernelGGL(pair_sum_final_kernel, dim3((c + 255) / 256), dim3(256), 0, s, part, RED_BLOCKS, c, sum, nullptr);
+    return sp_check_launch("channel_sum");
+}
+
+extern "C" int sp_maxpool3x3s2_bwd_nhwc(const float* x, const float* dy, float* dx, int batch, int h, int w, int c, void* stream) {
+    SP_REQUIRE(x && dy && dx, "sp_maxpool3x3s2_bwd_nhwc: null pointer");
+    SP_REQUIRE(batch > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "sp_maxpool3x3s2_bwd_nhwc: bad shape");
+    const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+    const long long total = (long long)batch * h * w * (c / 4);
+    SP_REQUIRE(total * 4 < (1ll << 31), "sp_maxpool3x3s2_bwd_nhwc: tensor too large");
+    hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const f32x4*>(x), reinterpret_cast<const f32x4*>(dy), reinterpret_cast<f32x4*>(dx), h, w, c / 4, ho, wo,
+                       total);
+    return sp_check_launch("maxpool3x3s2_bwd_kernel");
+}
+
+extern "C" int sp_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                            float beta2, float eps, int step, float grad_scale, void* stream) {
+    SP_REQUIRE(param && grad && exp_avg && exp_avg_sq, "sp_adam_step: null pointer");
+    SP_REQUIRE(n > 0 && n % 4 == 0 && step >= 1, "sp_adam_step: n=%lld must be a positive multiple of 4 and step >= 1", (long long)n);
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<f32x4*>(param),
+                       reinterpret_cast<const f32x4*>(grad), reinterpret_cast<f32x4*>(exp_avg), reinterpret_cast<f32x4*>(exp_avg_sq), n / 4, lr,
+                       beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale);
+    return sp_check_launch("adam_kernel");
+}
+
+extern "C" int sp_permute4_f32(const float* src, float* dst, const int32_t* dst_dims, const int64_t* src_strides, const int32_t* valid,
+                               int64_t src_base, int64_t dst_offset, void* stream) {
+    SP_REQUIRE(src && dst && dst_dims && src_strides && valid, "sp_permute4_f32: null pointer");
+    Permute4 pm;
+    long long total = 1;
+    for (int i = 0; i < 4; ++i) {
+        SP_REQUIRE(dst_dims[i] > 0, "sp_permute4_f32: bad extent");
+        pm.d[i] = dst_dims[i]; pm.s[i] = src_strides[i]; pm.lim[i] = valid[i];
+        total *= dst_dims[i];
+    }
+    pm.base = src_base; pm.dst_off = dst_offset;
+    hipLaunchKernelGGL(permute4_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, pm, total);
+    return sp_check_launch("permute4_kernel");
+}

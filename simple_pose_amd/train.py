@@ -1,0 +1,446 @@
+"""Training step of the ResNet-50 DConv pose net on libsimple_pose_hip.so (fp32).
+
+Replaces the body of `DDPProcessor.train` (processors/ddp_pose_resnet_solver.py:110-133):
+
+    predicts = model(x)                                   -> train-mode forward: conv (MFMA) + batch-stat BN kernels
+    loss = 0.5 * MSE(predicts * mask, targets * mask)     -> sp_masked_mse (value + d loss / d predicts)
+    loss.backward()                                       -> dgrad (the forward conv kernel on re-packed weights),
+                                                             wgrad (conv_wgrad kernel), BN / ReLU / max-pool backward
+    DDP gradient all-reduce (:91-93)                      -> ONE all-reduce of the flat gradient buffer (RCCL)
+    optimizer.step()   (Adam, :70-72)                     -> sp_adam_step over the flat parameter buffer
+
+Parameters stay `nn.Parameter`s of the reference-layout module (views into one flat fp32 buffer, `.grad` views into a
+flat gradient buffer), so `state_dict()`, checkpoints and any torch optimizer keep working; the packed weight copies
+the kernels read are regenerated on the device after every update (sp_permute4_f32).
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, SP_CONV_OUT_NCHW, SP_CONV_RELU
+from .engine import _round_up, n_pad_for
+
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+P = _lib.ptr
+
+
+def _i32(*v):
+    return (ctypes.c_int32 * len(v))(*v)
+
+
+def _i64(*v):
+    return (ctypes.c_int64 * len(v))(*v)
+
+
+class FlatParams:
+    """All parameters of `model` as views into one flat fp32 buffer (+ a flat gradient buffer of the same layout)."""
+
+    def __init__(self, model: torch.nn.Module):
+        params = [(n, p) for n, p in model.named_parameters()]
+        dev = params[0][1].device
+        self.offsets: Dict[str, Tuple[int, int]] = {}
+        off = 0
+        for n, p in params:
+            self.offsets[n] = (off, p.numel())
+            off += _round_up(p.numel(), 4)          # keep every view 16-byte aligned
+        self.numel = _round_up(off, 4)
+        self.data = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        for n, p in params:
+            o, k = self.offsets[n]
+            self.data[o:o + k].copy_(p.detach().reshape(-1))
+            p.data = self.data[o:o + k].view(p.shape)
+            p.grad = self.grad[o:o + k].view(p.shape)
+
+    def view(self, name: str, grad: bool = False) -> torch.Tensor:
+        o, k = self.offsets[name]
+        return (self.grad if grad else self.data)[o:o + k]
+
+
+@dataclass
+class Act:
+    data: torch.Tensor                 # NHWC [B,H,W,C]
+    h: int
+    w: int
+    c: int
+    grad: Optional[torch.Tensor] = None
+    needs_grad: bool = True
+
+
+@dataclass
+class PackJob:
+    src_name: str
+    dst: torch.Tensor
+    dims: tuple
+    strides: tuple
+    valid: tuple
+    base: int
+    dst_off: int = 0
+
+
+class ConvT:
+    """One conv / transposed-conv layer in training: forward launch, dgrad launches, wgrad, and its pack jobs."""
+
+    def __init__(self, tr: "PoseTrainer", name: str, kind: str, weight: torch.Tensor, h: int, w: int, stride: int = 1, pad: int = 0,
+                 c_in_buf: Optional[int] = None, bias_name: Optional[str] = None, out_nchw: bool = False, need_dgrad: bool = True):
+        self.tr, self.name, self.kind, self.wname = tr, name, kind, name + ".weight"
+        self.stride, self.pad, self.h, self.w = stride, pad, h, w
+        self.bias_name, self.out_nchw, self.need_dgrad = bias_name, out_nchw, need_dgrad
+        dev = weight.device
+        self.pack_jobs: List[PackJob] = []
+        if kind == "conv":
+            O, I, kh, kw = weight.shape
+            self.O, self.I, self.kh, self.kw = O, I, kh, kw
+            ci = c_in_buf or I                                     # stem: 3 -> NHWC4
+            tw = _round_up(kw, 8) if (ci == 4 and kw > 4) else (4 if ci == 4 else kw)
+            self.ci, self.tw = ci, tw
+            k = kh * tw * ci
+            k_pad, n_pad = _round_up(k, 32), n_pad_for(O)
+            self.w_fwd = torch.zeros((n_pad, k_pad), dtype=torch.float32, device=dev)
+            # fwd pack: dst [n_pad][kh][tw][ci] <- W[o][c][ty][tx]
+            self.pack_jobs.append(PackJob(self.wname, self.w_fwd, (n_pad, kh, tw, ci), (I * kh * kw, kw, 1, kh * kw), (O, kh, kw, I), 0))
+            self.oh, self.ow = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+            d = ConvDesc()
+            d.batch, d.in_h, d.in_w, d.c_in = 1, h, w, ci
+            d.grid_h, d.grid_w, d.c_out, d.n_pad = self.oh, self.ow, O, n_pad
+            d.taps_h, d.taps_w, d.k_pad, d.stride = kh, tw, k_pad, stride
+            d.dy0, d.dy_step, d.dx0, d.dx_step = -pad, 1, -pad, 1
+            d.out_h, d.out_w, d.out_c = self.oh, self.ow, O
+            d.oy_mul = d.ox_mul = 1
+            d.oy_add = d.ox_add = 0
+            d.phases_y = d.phases_x = 1
+            d.flags = SP_CONV_OUT_NCHW if out_nchw else 0
+            self.d_fwd = d
+            self.c_out_buf = O
+            self.flops = 2 * self.oh * self.ow * O * I * kh * kw
+            # wgrad: g = dz [M, O_buf], a = x gathered with the forward geometry
+            self.d_wgrad = d
+            self.wg = dict(n_valid=O, c_valid=I, kw_valid=kw, s_n=I * kh * kw, s_c=kh * kw)
+            if need_dgrad:
+                self._build_conv_dgrad(weight)
+        elif kind == "deconv":                                   # ConvTranspose2d(k=4, s=2, p=1), weight [I,O,4,4]
+            I, O, kh, kw = weight.shape
+            assert (kh, kw) == (4, 4) and stride == 2 and pad == 1
+            self.O, self.I, self.kh, self.kw, self.ci = O, I, 4, 4, I
+            n_pad = n_pad_for(O)
+            self.w_fwd = torch.zeros((4 * n_pad, 4 * I), dtype=torch.float32, device=dev)
+            for py in range(2):
+                for px in range(2):
+                    ph = py * 2 + px                               # W[ci][co][2ty+1-py][2tx+1-px] -> [n][ty][tx][ci]
+                    self.pack_jobs.append(PackJob(self.wname, self.w_fwd, (n_pad, 2, 2, I), (16, 8, 2, O * 16), (O, 2, 2, I),
+                                                  (1 - py) * 4 + (1 - px), ph * n_pad * 4 * I))
+            self.oh, self.ow = 2 * h, 2 * w
+            d = ConvDesc()
+            d.batch, d.in_h, d.in_w, d.c_in = 1, h, w, I
+            d.grid_h, d.grid_w, d.c_out, d.n_pad = h, w, O, n_pad
+            d.taps_h, d.taps_w, d.k_pad, d.stride = 2, 2, 4 * I, 1
+            d.dy0, d.dy_step, d.dx0, d.dx_step = 0, -1, 0, -1
+            d.out_h, d.out_w, d.out_c = 2 * h, 2 * w, O
+            d.oy_mul, d.oy_add, d.ox_mul, d.ox_add = 2, 0, 2, 0
+            d.phases_y = d.phases_x = 2
+            d.flags = 0
+            self.d_fwd = d
+            self.c_out_buf = O
+            self.flops = 2 * h * w * I * O * 16
+            # dgrad = Conv2d(k=4, s=2, p=1) of dy with Wd[ci][(ky,kx,co)] = W[ci][co][ky][kx]
+            nd = n_pad_for(I)
+            self.w_dgrad = [torch.zeros((nd, 16 * O), dtype=torch.float32, device=dev)]
+            self.pack_jobs.append(PackJob(self.wname, self.w_dgrad[0], (nd, 4, 4, O), (O * 16, 4, 1, 16), (I, 4, 4, O), 0))
+            g = ConvDesc()
+            g.batch, g.in_h, g.in_w, g.c_in = 1, 2 * h, 2 * w, O
+            g.grid_h, g.grid_w, g.c_out, g.n_pad = h, w, I, nd
+            g.taps_h, g.taps_w, g.k_pad, g.stride = 4, 4, 16 * O, 2
+            g.dy0, g.dy_step, g.dx0, g.dx_step = -1, 1, -1, 1
+            g.out_h, g.out_w, g.out_c = h, w, I
+            g.oy_mul = g.ox_mul = 1
+            g.oy_add = g.ox_add = 0
+            g.phases_y = g.phases_x = 1
+            g.flags = 0
+            self.d_dgrad = [g]
+            self.dgrad_full_cover = True
+            # wgrad: dW[ci][co][ky][kx] = sum_m x[m][ci] * dy[(2iy-1+ky, 2ix-1+kx)][co]: g = x, a = dy gathered like the dgrad conv
+            self.d_wgrad = g
+            self.wg = dict(n_valid=I, c_valid=O, kw_valid=4, s_n=O * 16, s_c=16)
+        else:
+            raise ValueError(kind)
+
+    # dgrad of a Conv2d: stride 1 -> one conv with flipped taps; stride 2 -> one launch per output phase
+    def _build_conv_dgrad(self, weight):
+        O, I, kh, kw, s, p = self.O, self.I, self.kh, self.kw, self.stride, self.pad
+        dev = weight.device
+        nd = n_pad_for(I)
+        Ob = _round_up(O, 32) if O % 4 else O                    # channels of the incoming gradient buffer (17 -> 32)
+        self.c_out_buf = Ob
+        self.w_dgrad, self.d_dgrad = [], []
+        if s == 1:
+            wd = torch.zeros((nd, kh * kw * Ob), dtype=torch.float32, device=dev)
+            # Wd[c][(ty,tx,o)] = W[o][c][kh-1-ty][kw-1-tx]
+            self.pack_jobs.append(PackJob(self.wname, wd, (nd, kh, kw, Ob), (kh * kw, -kw, -1, I * kh * kw), (I, kh, kw, O),
+                                          (kh - 1) * kw + (kw - 1)))
+            g = ConvDesc()
+            g.batch, g.in_h, g.in_w, g.c_in = 1, self.oh, self.ow, Ob
+            g.grid_h, g.grid_w, g.c_out, g.n_pad = self.h, self.w, I, nd
+            g.taps_h, g.taps_w, g.k_pad, g.stride = kh, kw, kh * kw * Ob, 1
+            pp = kh - 1 - p
+            g.dy0, g.dy_step, g.dx0, g.dx_step = -pp, 1, -pp, 1
+            g.out_h, g.out_w, g.out_c = self.h, self.w, I
+            g.oy_mul = g.ox_mul = 1
+            g.oy_add = g.ox_add = 0
+            g.phases_y = g.phases_x = 1
+            g.flags = 0
+            self.w_dgrad.append(wd); self.d_dgrad.append(g)
+            self.dgrad_full_cover = True
+        else:
+            assert s == 2 and self.h % 2 == 0 and self.w % 2 == 0
+            # dx[2g+py] = sum over ky with (2g+py+p-ky) even: oy = (2g+py+p-ky)/2.  Tap t of phase py: ky = ky0 + 2t (ky < kh),
+            # oy = g + (py+p-ky0)/2 - t  ->  dy0 = (py+p-ky0)/2, dy_step = -1
+            self.dgrad_full_cover = True
+            for py in range(2):
+                for px in range(2):
+                    ky0, kx0 = (py + p) % 2, (px + p) % 2
+                    th, tw = len(range(ky0, kh, 2)), len(range(kx0, kw, 2))
+                    if th == 0 or tw == 0:
+                        self.dgrad_full_cover = False             # 1x1 stride 2: only phase (0,0) receives gradient
+                        continue
+                    wd = torch.zeros((nd, th * tw * Ob), dtype=torch.float32, device=dev)
+                    self.pack_jobs.append(PackJob(self.wname, wd, (nd, th, tw, Ob), (kh * kw, 2 * kw, 2, I * kh * kw), (I, th, tw, O),
+                                                  ky0 * kw + kx0))
+                    g = ConvDesc()
+                    g.batch, g.in_h, g.in_w, g.c_in = 1, self.oh, self.ow, Ob
+                    g.grid_h, g.grid_w, g.c_out, g.n_pad = self.h // 2, self.w // 2, I, nd
+                    g.taps_h, g.taps_w, g.k_pad, g.stride = th, tw, th * tw * Ob, 1
+                    g.dy0, g.dy_step, g.dx0, g.dx_step = (py + p - ky0) // 2, -1, (px + p - kx0) // 2, -1
+                    g.out_h, g.out_w, g.out_c = self.h, self.w, I
+                    g.oy_mul, g.oy_add, g.ox_mul, g.ox_add = 2, py, 2, px
+                    g.phases_y = g.phases_x = 1
+                    g.flags = 0
+                    self.w_dgrad.append(wd); self.d_dgrad.append(g)
+
+    # ---- launches ----
+    def forward(self, x: torch.Tensor, B: int, out: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None) -> torch.Tensor:
+        lib, d = _lib.lib(), self.d_fwd
+        d.batch = B
+        if out is None:
+            out = torch.empty((B, d.out_h, d.out_w, d.out_c), dtype=torch.float32, device=x.device)
+        _lib.check(lib.sp_conv2d_fwd(d, P(x), P(self.w_fwd), None, P(shift), None, P(out), _lib.current_stream()), self.name)
+        return out
+
+    def dgrad(self, dz: torch.Tensor, B: int, acc: Optional[torch.Tensor]) -> torch.Tensor:
+        """dx (+= into `acc` when given)."""
+        lib = _lib.lib()
+        if acc is None:
+            d0 = self.d_dgrad[0]
+            shape = (B, d0.out_h, d0.out_w, d0.out_c)
+            acc_t = torch.empty(shape, dtype=torch.float32, device=dz.device) if self.dgrad_full_cover else \
+                torch.zeros(shape, dtype=torch.float32, device=dz.device)
+            res = None
+        else:
+            acc_t, res = acc, acc
+        for d, w in zip(self.d_dgrad, self.w_dgrad):
+            d.batch = B
+            _lib.check(lib.sp_conv2d_fwd(d, P(dz), P(w), None, None, P(res), P(acc_t), _lib.current_stream()), self.name + ".dgrad")
+        return acc_t
+
+    def wgrad(self, x: torch.Tensor, dz: torch.Tensor, B: int):
+        lib, tr = _lib.lib(), self.tr
+        d = self.d_wgrad
+        d.batch = B
+        g, a = (dz, x) if self.kind == "conv" else (x, dz)
+        gc = g.shape[-1]
+        _lib.check(lib.sp_conv2d_wgrad(d, P(g), gc, P(a), self.wg["n_valid"], self.wg["c_valid"], self.wg["kw_valid"], self.wg["s_n"],
+                                       self.wg["s_c"], P(tr.flat.view(self.wname, grad=True)), P(tr.wgrad_ws), tr.wgrad_ws.numel() * 4,
+                                       _lib.current_stream()), self.name + ".wgrad")
+
+
+class PoseTrainer:
+    """fp32 train step for `simple_pose_amd.nets.pose_resnet_dconv.ResNet` on one GPU (+ optional process group)."""
+
+    def __init__(self, model, in_h: int = 256, in_w: int = 192, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 process_group=None):
+        if getattr(model, "HEAD", None) != "dconv":
+            raise NotImplementedError("PoseTrainer lowers the ResNet-50 DConv net (BASELINE config 4); other heads pending")
+        self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
+        self.pg = process_group
+        self.flat = FlatParams(model)
+        dev = self.flat.data.device
+        self.exp_avg = torch.zeros_like(self.flat.data)
+        self.exp_avg_sq = torch.zeros_like(self.flat.data)
+        self.step_count = 0
+        self.red_ws = torch.empty(256 * 2048 * 2, dtype=torch.float64, device=dev)        # SP_REDUCE_WORKSPACE_BYTES(2048)
+        self.wgrad_ws = torch.empty(48 * 1024 * 1024, dtype=torch.float32, device=dev)    # 192 MB of split slabs
+        self.loss_buf = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.mse_ws = torch.empty(4096, dtype=torch.uint8, device=dev)
+        self.sd = dict(model.named_parameters())
+        self.buffers = dict(model.named_buffers())
+        self.in_h, self.in_w = in_h, in_w
+        self.layers: Dict[str, ConvT] = {}
+        self._build(in_h, in_w)
+        self.repack()
+
+    # ---- static structure -------------------------------------------------------------------------------------------
+    def _conv(self, name, h, w, **kw) -> ConvT:
+        layer = ConvT(self, name, kw.pop("kind", "conv"), self.sd[name + ".weight"].detach(), h, w, **kw)
+        self.layers[name] = layer
+        return layer
+
+    def _build(self, H, W):
+        self._conv("conv1", H, W, stride=2, pad=3, c_in_buf=4, need_dgrad=False)
+        h, w = H // 4, W // 4
+        inpl = 64
+        for li, (planes, n) in enumerate(zip((64, 128, 256, 512), self.model.BLOCKS), start=1):
+            for bi in range(n):
+                s = 2 if (bi == 0 and li > 1) else 1
+                p = f"layer{li}.{bi}"
+                self._conv(p + ".conv1", h, w)
+                self._conv(p + ".conv2", h, w, stride=s, pad=1)
+                self._conv(p + ".conv3", h // s, w // s)
+                if bi == 0:
+                    self._conv(p + ".downsample.0", h, w, stride=s)
+                h, w = h // s, w // s
+                inpl = planes * 4
+        for idx in (0, 3, 6):
+            self._conv(f"deconv_layers.{idx}", h, w, kind="deconv", stride=2, pad=1)
+            h, w = 2 * h, 2 * w
+        self._conv("final_layer", h, w, bias_name="final_layer.bias", out_nchw=True)
+        self.heat_hw = (h, w)
+
+    def repack(self):
+        """Regenerate every packed weight copy from the (just updated) flat parameter buffer."""
+        lib, stream = _lib.lib(), _lib.current_stream()
+        for layer in self.layers.values():
+            for j in layer.pack_jobs:
+                o, _ = self.flat.offsets[j.src_name]
+                _lib.check(lib.sp_permute4_f32(P(self.flat.data), P(j.dst), _i32(*j.dims), _i64(*j.strides), _i32(*j.valid), o + j.base,
+                                               j.dst_off, stream), "repack " + j.src_name)
+
+    # ---- one step -----------------------------------------------------------------------------------------------------
+    def forward_backward(self, x: torch.Tensor, targets: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        """x [B,3,H,W], targets [B,J,H/4,W/4], mask [B,J] on the GPU -> loss (device scalar); gradients land in the flat
+        gradient buffer (every element is overwritten, no zero_grad needed)."""
+        lib, stream = _lib.lib(), _lib.current_stream()
+        x = _lib.require_cuda_f32(x, "input")
+        targets = _lib.require_cuda_f32(targets, "targets")
+        mask = _lib.require_cuda_f32(mask, "mask")
+        B, dev = x.shape[0], x.device
+        tape: List[Callable[[], None]] = []
+        nbt: List[torch.Tensor] = []
+        L = self.layers
+        ws = self.red_ws
+
+        def new(shape):
+            return torch.empty(shape, dtype=torch.float32, device=dev)
+
+        def conv_bn(xa: Act, cname: str, bname: str, relu: bool, res: Optional[Act] = None) -> Act:
+            layer = L[cname]
+            z = layer.forward(xa.data, B)
+            rows, C = z.shape[0] * z.shape[1] * z.shape[2], z.shape[3]
+            mean, invstd = new(C), new(C)
+            gamma, beta = self.sd[bname + ".weight"], self.sd[bname + ".bias"]
+            _lib.check(lib.sp_bn_train_stats_nhwc(P(z), rows, C, BN_EPS, BN_MOMENTUM, P(mean), P(invstd),
+                                                  P(self.buffers[bname + ".running_mean"]), P(self.buffers[bname + ".running_var"]),
+                                                  P(ws), stream), bname)
+            nbt.append(self.buffers[bname + ".num_batches_tracked"])
+            y = new(z.shape)
+            _lib.check(lib.sp_bn_apply_nhwc(P(z), P(mean), P(invstd), P(gamma), P(beta), P(res.data) if res else None, P(y), rows, C,
+                                            int(relu), stream), bname)
+            ya = Act(y, z.shape[1], z.shape[2], C)
+
+            def bwd():
+                dz = new(z.shape)
+                dres = None
+                acc = 0
+                if res is not None:
+                    if res.grad is None:
+                        res.grad = new(res.data.shape)
+                    else:
+                        acc = 1
+                    dres = res.grad
+                _lib.check(lib.sp_bn_train_bwd_nhwc(P(ya.grad), P(y) if relu else None, P(z), P(mean), P(invstd), P(gamma), rows, C, P(dz),
+                                                    P(self.flat.view(bname + ".weight", True)), P(self.flat.view(bname + ".bias", True)),
+                                                    P(dres), acc, P(ws), stream), bname + ".bwd")
+                ya.grad = None
+                layer.wgrad(xa.data, dz, B)
+                if xa.needs_grad and layer.need_dgrad:
+                    xa.grad = layer.dgrad(dz, B, xa.grad)
+            tape.append(bwd)
+            return ya
+
+        # ---- forward ----
+        x4 = new((B, self.in_h, self.in_w, 4))
+        _lib.check(lib.sp_nchw_to_nhwc4(P(x), P(x4), B, 3, self.in_h, self.in_w, stream), "to_nhwc4")
+        a = conv_bn(Act(x4, self.in_h, self.in_w, 4, needs_grad=False), "conv1", "bn1", True)
+        pooled = new((B, a.h // 2, a.w // 2, a.c))
+        _lib.check(lib.sp_maxpool3x3s2_nhwc(P(a.data), P(pooled), B, a.h, a.w, a.c, stream), "maxpool")
+        pa = Act(pooled, a.h // 2, a.w // 2, a.c)
+        stem_out = a
+
+        def pool_bwd():
+            stem_out.grad = new(stem_out.data.shape)
+            _lib.check(lib.sp_maxpool3x3s2_bwd_nhwc(P(stem_out.data), P(pa.grad), P(stem_out.grad), B, stem_out.h, stem_out.w, stem_out.c,
+                                                    stream), "maxpool.bwd")
+            pa.grad = None
+        tape.append(pool_bwd)
+        a = pa
+        for li, n in enumerate(self.model.BLOCKS, start=1):
+            for bi in range(n):
+                p = f"layer{li}.{bi}"
+                t = conv_bn(a, p + ".conv1", p + ".bn1", True)
+                t = conv_bn(t, p + ".conv2", p + ".bn2", True)
+                idn = conv_bn(a, p + ".downsample.0", p + ".downsample.1", False) if bi == 0 else a
+                a = conv_bn(t, p + ".conv3", p + ".bn3", True, res=idn)
+        for idx in (0, 3, 6):
+            a = conv_bn(a, f"deconv_layers.{idx}", f"deconv_layers.{idx + 1}", True)
+        fl = L["final_layer"]
+        J = fl.O
+        hh, ww = self.heat_hw
+        heat = torch.empty((B, J, hh, ww), dtype=torch.float32, device=dev)
+        fl.forward(a.data, B, out=heat, shift=self.sd["final_layer.bias"])
+        # ---- loss + d loss / d heat ----
+        dheat = new((B, J, hh, ww))
+        _lib.check(lib.sp_masked_mse(P(heat), P(targets), P(mask), B, J, hh * ww, P(self.loss_buf), P(dheat), P(self.mse_ws), stream), "mse")
+        self.last_heat = heat
+        # ---- backward ----
+        Jb = fl.c_out_buf
+        dh = torch.zeros((B, hh, ww, Jb), dtype=torch.float32, device=dev)
+        dh[..., :J] = dheat.permute(0, 2, 3, 1)           # tiny layout glue ([B,17,64,48] -> NHWC, channels padded to 32)
+        bsum = new(Jb)
+        _lib.check(lib.sp_channel_sum_nhwc(P(dh), B * hh * ww, Jb, P(bsum), P(ws), stream), "final_layer.bias.grad")
+        self.flat.view("final_layer.bias", True).copy_(bsum[:J])
+        fl.wgrad(a.data, dh, B)
+        a.grad = fl.dgrad(dh, B, None)
+        for fn in reversed(tape):
+            fn()
+        torch._foreach_add_(nbt, 1)
+        return self.loss_buf
+
+    def all_reduce_grads(self) -> float:
+        """DDP semantics: gradients are averaged over ranks.  One SUM all-reduce of the flat buffer (RCCL over xGMI);
+        the 1/world factor is folded into the Adam kernel."""
+        import torch.distributed as dist
+
+        if self.pg is None and not (dist.is_available() and dist.is_initialized()):
+            return 1.0
+        world = dist.get_world_size(self.pg)
+        if world == 1:
+            return 1.0
+        dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.pg)
+        return 1.0 / world
+
+    def optimizer_step(self, grad_scale: float = 1.0):
+        self.step_count += 1
+        _lib.check(_lib.lib().sp_adam_step(P(self.flat.data), P(self.flat.grad), P(self.exp_avg), P(self.exp_avg_sq), self.flat.numel,
+                                           self.lr, self.betas[0], self.betas[1], self.eps, self.step_count, grad_scale,
+                                           _lib.current_stream()), "adam")
+        self.repack()
+
+    def step(self, x, targets, mask) -> torch.Tensor:
+        """optimizer.zero_grad(); loss = ...; loss.backward(); optimizer.step()  (ddp...:114-119)."""
+        loss = self.forward_backward(x, targets, mask)
+        scale = self.all_reduce_grads()
+        self.optimizer_step(scale)
+        return loss

@@ -104,3 +104,31 @@ def test_hrnet_forward_oracle_and_key_layout_match_reference(golden):
         hm = nets_oracle.hrnet_forward(sd, x, cfg).numpy()
     ref = g["heat_maps"]
     assert np.abs(hm - ref).max() / np.abs(ref).max() <= 1e-5
+
+
+def test_train_step_oracle_matches_reference(golden):
+    """oracle/train_oracle.py (functional forward + autograd + restated Adam) against one step of the real reference."""
+    from oracle import train_oracle
+    g = golden("g6_train_step.npz")
+    shapes = nets_oracle.state_dict_shapes_resnet50("dconv")
+    sd = {k: torch.from_numpy(v) for k, v in synth.conditioned_state_dict(shapes, 0).items()}
+    x = torch.from_numpy(synth.input_images(2, 0))
+    t, w = pose_oracle.encode_refine(g["joints"], 2.0, (48, 64))
+    loss, grads, heat = train_oracle.forward_backward(sd, x, torch.from_numpy(t), torch.from_numpy(w))
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    assert np.abs(heat.numpy() - g["heat_train"]).max() <= 1e-4 * np.abs(g["heat_train"]).max()
+    picks = [k[5:] for k in g.files if k.startswith("grad/")]
+    for k in picks:
+        ref = g["grad/" + k]
+        got = grads[k].numpy()[tuple(slice(0, s) for s in ref.shape)]
+        scale = float(g["gradnorm/" + k]) / np.sqrt(grads[k].numel())
+        assert np.abs(got - ref).max() <= 2e-3 * scale + 1e-12, k
+    params = {k: sd[k] for k in grads}
+    train_oracle.adam_step(params, grads, {}, lr=1e-3)
+    for k in picks:
+        ref = g["param/" + k]
+        got = params[k].numpy()[tuple(slice(0, s) for s in ref.shape)]
+        assert np.abs(got - ref).max() <= 2e-5, k          # |update| = lr = 1e-3 on the first Adam step
+    for k in ("bn1.running_mean", "bn1.running_var", "layer3.5.bn3.running_var", "deconv_layers.7.running_mean"):
+        assert np.abs(sd[k].numpy() - g["buf/" + k]).max() <= 1e-5 * max(1.0, np.abs(g["buf/" + k]).max()), k
+    assert int(sd["bn1.num_batches_tracked"]) == int(g["buf/bn1.num_batches_tracked"]) == 1
