@@ -32,6 +32,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=128, help="images per GPU per step")
     ap.add_argument("--arch", default="dconv", choices=["dconv", "duc", "hrnet_w32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
+                    help="infer = forward + GaussTaylor decode (BASELINE metric, default); train = fwd+bwd+Adam step (config 4, fp32)")
     ap.add_argument("--tiles", default=None, help="JSON tile table: loaded if it exists (skips autotune), else written")
     ap.add_argument("--layers-out", default=None, help="write the per-layer timing table (JSON) here")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (roofline object)")
@@ -131,21 +133,36 @@ def main():
     base = synth.input_images(8, seed=100 + rank)  # 8 distinct random images per rank, tiled to the batch
     x = torch.from_numpy(np.concatenate([base] * ((B + 7) // 8), 0)[:B]).to(dev)
     tinv = torch.from_numpy(synth.trans_inv_batch(B)).to(dev)
-    prog = model.hip_program(x)
-    # untimed setup: pin the fastest workgroup tile per layer shape (or reuse a saved table: profiling runs do, so that
-    # the trial launches of the tuner stay out of the per-kernel statistics)
-    if args.tiles and os.path.isfile(args.tiles):
-        with open(args.tiles) as fh:
-            prog.set_tiles(json.load(fh), B)
-    else:
-        tiles = prog.autotune(x)
-        if args.tiles and rank == 0:
-            with open(args.tiles, "w") as fh:
-                json.dump(tiles, fh)
+    if args.mode == "train":
+        if args.arch != "dconv":
+            raise SystemExit("--mode train lowers ResNet50-DConv (BASELINE config 4)")
+        from simple_pose_amd.commons.transforms import RefineSimpleTransform
+        from simple_pose_amd.train import PoseTrainer
+        model.train()
+        trainer = PoseTrainer(model, lr=1e-3)
+        joints = torch.from_numpy(synth.joints_batch(B, 17, seed=200 + rank)).to(dev)
+        targets, mask = RefineSimpleTransform.get_heat_map(joints, 2.0, (48, 64))   # HIP encoder, on device
+        prog = None
 
-    def step():
-        hm = prog.run(x)
-        return decoder(hm, tinv)
+        def step():
+            loss = trainer.step(x, targets, mask)      # fwd + loss + bwd + gradient all-reduce (N > 1) + Adam + repack
+            return (loss,)
+    else:
+        prog = model.hip_program(x)
+        # untimed setup: pin the fastest workgroup tile per layer shape (or reuse a saved table: profiling runs do, so that
+        # the trial launches of the tuner stay out of the per-kernel statistics)
+        if args.tiles and os.path.isfile(args.tiles):
+            with open(args.tiles) as fh:
+                prog.set_tiles(json.load(fh), B)
+        else:
+            tiles = prog.autotune(x)
+            if args.tiles and rank == 0:
+                with open(args.tiles, "w") as fh:
+                    json.dump(tiles, fh)
+
+        def step():
+            hm = prog.run(x)
+            return decoder(hm, tinv)
 
     with torch.no_grad():
         for _ in range(args.warmup):
@@ -172,24 +189,38 @@ def main():
 
     # ---- per-kernel roofline: HIP events around every conv launch, on the launch stream, same inputs ----
     roofline = None
-    if rank == 0 and not args.no_kernel_events:
+    if rank == 0 and not args.no_kernel_events and prog is not None:
         roofline = kernel_roofline(prog, x, steps=max(3, min(args.steps, 10)), layers_out=args.layers_out)
 
     if rank == 0:
-        line = {
-            "metric": "images/sec fwd+decode, %s 256x192 bs=%d" % (ARCH_NAMES[args.arch], B),
-            "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{ARCH_NAMES[args.arch]} 256x192 bs={B} per GPU, fp32 forward "
-                                   "(NCHW in -> heat maps) + GaussTaylor decode, eval-mode BN, conditioned random weights",
-                       "images_per_gpu": B, "global_batch": B * world, "parallelism": f"replicas x{world} (no collective)"},
-            "gflop_per_image": round(prog.flops_per_image / 1e9, 4),
-            "network_tflops": round(value * prog.flops_per_image / 1e12, 2),
-            "network_frac_of_fp32_matrix_peak": round(value * prog.flops_per_image / 1e12 / (FP32_MATRIX_PEAK_TFLOPS * world), 4),
-            "roofline": roofline,
-            "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(args.arch),
-        }
+        name = ARCH_NAMES[args.arch]
+        if args.mode == "train":
+            gflop = 3 * 10.8528   # train step ~ 3 x forward (fwd + dgrad + wgrad) = 32.56 GFLOP / image
+            line = {
+                "metric": f"images/sec train step (fwd+bwd+Adam), {name} 256x192 bs={B}/GPU", "value": round(value, 1), "unit": "images/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"{name} 256x192 train step, bs={B} per GPU, fp32, train-mode BN (batch statistics), Adam lr 1e-3, "
+                                       "targets from the HIP encoder, gradients all-reduced over ranks (RCCL) when N > 1",
+                           "images_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
+                "gflop_per_image": round(gflop, 3), "network_tflops": round(value * gflop / 1e3, 2),
+                "network_frac_of_fp32_matrix_peak": round(value * gflop / 1e3 / (FP32_MATRIX_PEAK_TFLOPS * world), 4),
+                "roofline": None, "cpu_baseline": None, "final_loss": float(out[0].item())}
+        else:
+            line = {
+                "metric": "images/sec fwd+decode, %s 256x192 bs=%d" % (name, B),
+                "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"{name} 256x192 bs={B} per GPU, fp32 forward "
+                                       "(NCHW in -> heat maps) + GaussTaylor decode, eval-mode BN, conditioned random weights",
+                           "images_per_gpu": B, "global_batch": B * world, "parallelism": f"replicas x{world} (no collective)"},
+                "gflop_per_image": round(prog.flops_per_image / 1e9, 4),
+                "network_tflops": round(value * prog.flops_per_image / 1e12, 2),
+                "network_frac_of_fp32_matrix_peak": round(value * prog.flops_per_image / 1e12 / (FP32_MATRIX_PEAK_TFLOPS * world), 4),
+                "roofline": roofline,
+                "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(args.arch),
+            }
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

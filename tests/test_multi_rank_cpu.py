@@ -50,3 +50,37 @@ def test_whole_job_throughput_is_sum_of_units_over_max_time():
         res = dict(out)
     assert res[0] == res[1] == (2560.0, 2.0, 1280.0)
     assert aggregate_throughput(10.0, 2.0) == (10.0, 2.0, 5.0)   # no process group -> local
+
+
+def _grad_worker(rank, world, port, out):
+    """DDP semantics of the train step's collective: SUM all-reduce of the flat gradient buffer, 1/world folded into the
+    optimizer (simple_pose_amd.train.PoseTrainer.all_reduce_grads), on a tiny CPU module standing in for the net."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from simple_pose_amd.train import FlatParams, PoseTrainer
+        torch.manual_seed(0)
+        m = torch.nn.Sequential(torch.nn.Conv2d(3, 5, 3), torch.nn.BatchNorm2d(5), torch.nn.Conv2d(5, 2, 1))
+        flat = FlatParams(m)
+        names = [n for n, _ in m.named_parameters()]
+        assert all(p.data_ptr() == flat.view(n).data_ptr() for n, p in m.named_parameters())      # params are views
+        for n, p in m.named_parameters():
+            p.grad.fill_(float(rank + 1) * (names.index(n) + 1))                                     # per-rank gradients
+        shim = PoseTrainer.__new__(PoseTrainer)
+        shim.flat, shim.pg = flat, None
+        scale = PoseTrainer.all_reduce_grads(shim)
+        out[rank] = (scale, [float(p.grad.flatten()[0]) for p in m.parameters()], flat.numel % 4)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_all_reduce_is_sum_with_scale_one_over_world():
+    world, port = 2, _free_port()
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_grad_worker, args=(world, port, out), nprocs=world, join=True)
+        res = dict(out)
+    for rank in range(world):
+        scale, g0, pad = res[rank]
+        assert scale == 0.5 and pad == 0
+        assert g0 == [3.0 * (i + 1) for i in range(len(g0))]     # (1 + 2) * (index + 1): SUM over the two ranks
