@@ -91,6 +91,13 @@ int sp_maxpool3x3s2_nhwc(const float* x, float* y, int batch, int h, int w, int 
  * (the bare shuffle that opens the DUC head, nets/pose_resnet_duc.py:228; the two DUC blocks fuse theirs into the conv) */
 int sp_pixel_shuffle2_nhwc(const float* x, float* y, int batch, int h, int w, int c, void* stream);
 
+/* SELayer (nets/commons.py:4-18; first block of each layer when reduction=True, pose_resnet_dconv.py:108-110,126-127):
+ * squeeze y[b,c] = mean_hw x[b,hw,c]; the two 1x1 FCs run through sp_conv2d_fwd on the [B,1,1,C] tensor;
+ * excite + block tail y = relu(x * sigmoid(gate_logits[b,c]) + identity). */
+int sp_global_avg_pool_nhwc(const float* x, float* y, int batch, int hw, int c, void* stream);
+int sp_se_gate_add_relu_nhwc(const float* x, const float* gate_logits, const float* identity, float* y, int batch, int hw,
+                             int c, void* stream);
+
 /* y = base + nearest_upsample(x, factor) (+ ReLU): x NHWC [B,h,w,c], base / y NHWC [B,h*f,w*f,c] (base may alias y;
  * factor 1 = plain add).  HighResolutionModule fuse sum, nets/pose_hrnet.py:192-202,250-257 */
 int sp_upsample_add_nhwc(const float* x, const float* base, float* y, int batch, int h, int w, int c, int factor, int relu,

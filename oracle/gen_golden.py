@@ -10,6 +10,7 @@ is committed - never reference source.  Fixture inventory
   g2_duc_fwd.npz     same for R50-DUC
   g4_decode.npz      decoders (GaussTaylor + Basic + heat_map_to_axis) on: Gaussian maps + noise, noise-like
                      maps, edge cases; identity-scale and random trans_inv
+  g1s_dconv_se_fwd.npz  ResNet50-DConv + SELayer (reduction=True) eval forward, B=1, + key list
   g3_hrnet_w32_fwd.npz  HRNet-W32 eval forward, B=1, + the reference's state_dict key/shape list
   g6_train_step.npz  one reference training step (B=2): loss, gradient slices, BN running stats, params after Adam
   g5_encode.npz      encoders (Refine + Basic) incl. out-of-range / trunc-toward-zero / vis=0 cases
@@ -70,6 +71,21 @@ def gen_forward(ns):
                             n_state_keys=n_keys, **taps)
         print(fname, hm.shape, "absmax", np.abs(hm).max(), "std", hm.std(), "state keys", n_keys)
     return hm
+
+
+def gen_se(ns):
+    """g1s_dconv_se_fwd.npz: ResNet50-DConv with reduction=True (SELayer on the first block of each layer), B=1."""
+    torch.set_num_threads(8)
+    net = ns.dconv.resnet50(pretrained=False, num_classes=17, reduction=True)
+    synth.load_conditioned(net, SEED)
+    net.eval()
+    x = torch.from_numpy(synth.input_images(1, SEED))
+    with torch.no_grad():
+        hm = net(x).numpy()
+    sd = net.state_dict()
+    np.savez_compressed(os.path.join(GOLD, "g1s_dconv_se_fwd.npz"), heat_maps=hm, seed=SEED, batch=1, keys=np.array(list(sd.keys())),
+                        shapes=np.array([",".join(str(d) for d in v.shape) for v in sd.values()]))
+    print("g1s_dconv_se_fwd.npz", hm.shape, "absmax", np.abs(hm).max(), "keys", len(sd))
 
 
 def gen_hrnet(ns):
@@ -252,6 +268,7 @@ def main():
     gen_decode(ns, net_maps)
     gen_encode(ns)
     gen_hrnet(ns)
+    gen_se(ns)
     gen_train(ns)
     del hm
 

@@ -84,6 +84,52 @@ __global__ void pixel_shuffle2_kernel(const float* __restrict__ x, f32x4* __rest
     }
 }
 
+// SELayer squeeze (nets/commons.py:8,15): y[b, c] = mean over the HW pixels of x[b, :, c].  One workgroup per (b, 256-channel
+// slab... up to 64 float4 lanes x 4 pixel stripes), double accumulation, fixed order.
+__global__ __launch_bounds__(256) void global_avg_pool_kernel(const f32x4* __restrict__ x, float* __restrict__ y, int HW, int C4) {
+    const int b = blockIdx.y;
+    const int lanes_c = C4 < 64 ? C4 : 64;
+    const int stripes = 256 / lanes_c;
+    const int tc = threadIdx.x % lanes_c, ts = threadIdx.x / lanes_c;
+    const int c4 = blockIdx.x * lanes_c + tc;
+    __shared__ double sm[256 * 4];
+    double acc[4] = {0, 0, 0, 0};
+    if (c4 < C4 && ts < stripes)
+        for (int p = ts; p < HW; p += stripes) {
+            const f32x4 v = x[((size_t)b * HW + p) * C4 + c4];
+            acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+        }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sm[threadIdx.x * 4 + e] = acc[e];
+    __syncthreads();
+    if (ts == 0 && c4 < C4) {
+        for (int k = 1; k < stripes; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += sm[(k * lanes_c + tc) * 4 + e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[((size_t)b * C4 + c4) * 4 + e] = (float)(acc[e] / (double)HW);
+    }
+}
+
+// SELayer excite + block tail: y = relu(x * sigmoid(g[b, c]) + identity)   (nets/commons.py:17-18, pose_resnet_dconv.py:126-131)
+__global__ void se_gate_add_relu_kernel(const f32x4* __restrict__ x, const float* __restrict__ g, const f32x4* __restrict__ idn,
+                                        f32x4* __restrict__ y, int HW, int C4, long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const long long b = i / ((long long)HW * C4);
+        const f32x4 gv = reinterpret_cast<const f32x4*>(g)[b * C4 + c4];
+        const f32x4 v = x[i], r = idn[i];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float sg = 1.f / (1.f + expf(-gv[e]));
+            const float t = v[e] * sg + r[e];
+            o[e] = t > 0.f ? t : 0.f;
+        }
+        y[i] = o;
+    }
+}
+
 // masked MSE: per-block double partial sums (deterministic), then one block folds them.
 __global__ void mse_partial_kernel(const float* __restrict__ pred, const float* __restrict__ tgt, const float* __restrict__ mask,
                                    float* __restrict__ grad, int hw, long long total, double inv_n, double* __restrict__ part) {
@@ -146,6 +192,27 @@ extern "C" int sp_pixel_shuffle2_nhwc(const float* x, float* y, int batch, int h
     hipLaunchKernelGGL(pixel_shuffle2_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
                        reinterpret_cast<f32x4*>(y), h, w, c, total);
     return sp_check_launch("pixel_shuffle2_kernel");
+}
+
+extern "C" int sp_global_avg_pool_nhwc(const float* x, float* y, int batch, int hw, int c, void* stream) {
+    SP_REQUIRE(x && y, "sp_global_avg_pool_nhwc: null pointer");
+    SP_REQUIRE(batch > 0 && hw > 0 && c > 0 && c % 4 == 0, "sp_global_avg_pool_nhwc: bad shape");
+    const int c4 = c / 4, lanes = c4 < 64 ? c4 : 64;
+    hipLaunchKernelGGL(global_avg_pool_kernel, dim3((c4 + lanes - 1) / lanes, batch), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const f32x4*>(x), y, hw, c4);
+    return sp_check_launch("global_avg_pool_kernel");
+}
+
+extern "C" int sp_se_gate_add_relu_nhwc(const float* x, const float* gate_logits, const float* identity, float* y, int batch, int hw, int c,
+                                        void* stream) {
+    SP_REQUIRE(x && gate_logits && identity && y, "sp_se_gate_add_relu_nhwc: null pointer");
+    SP_REQUIRE(batch > 0 && hw > 0 && c > 0 && c % 4 == 0, "sp_se_gate_add_relu_nhwc: bad shape");
+    const long long total = (long long)batch * hw * (c / 4);
+    SP_REQUIRE(total * 4 < (1ll << 31), "sp_se_gate_add_relu_nhwc: tensor too large");
+    hipLaunchKernelGGL(se_gate_add_relu_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const f32x4*>(x), gate_logits, reinterpret_cast<const f32x4*>(identity), reinterpret_cast<f32x4*>(y), hw,
+                       c / 4, total);
+    return sp_check_launch("se_gate_add_relu_kernel");
 }
 
 extern "C" int sp_upsample_add_nhwc(const float* x, const float* base, float* y, int batch, int h, int w, int c, int factor, int relu,

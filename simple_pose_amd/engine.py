@@ -130,7 +130,7 @@ class Program:
             return self._pools[key]
         last_use: Dict[str, int] = {}
         for i, op in enumerate(self.ops):
-            for nm in (op.src, op.res, op.dst):
+            for nm in (op.src, op.res, op.dst) + ((op.args[2],) if op.kind == "se_gate" else ()):
                 if nm:
                     last_use[nm] = i
         free: Dict[int, List[torch.Tensor]] = {}
@@ -141,7 +141,7 @@ class Program:
                 n = batch * h * w * c
                 pool = free.get(n)
                 bufs[op.dst] = pool.pop() if pool else torch.empty(n, dtype=torch.float32, device=device)
-            for nm in (op.src, op.res):
+            for nm in (op.src, op.res) + ((op.args[2],) if op.kind == "se_gate" else ()):
                 if nm and nm in bufs and last_use[nm] == i and nm != "input":
                     free.setdefault(bufs[nm].numel(), []).append(bufs[nm])
         self._pools[key] = bufs
@@ -171,6 +171,13 @@ class Program:
             elif op.kind == "pixel_shuffle":
                 h, w, c = op.args
                 _lib.check(lib.sp_pixel_shuffle2_nhwc(P(bufs[op.src]), P(bufs[op.dst]), B, h, w, c, stream), op.name)
+            elif op.kind == "gap":
+                hw, c = op.args
+                _lib.check(lib.sp_global_avg_pool_nhwc(P(bufs[op.src]), P(bufs[op.dst]), B, hw, c, stream), op.name)
+            elif op.kind == "se_gate":
+                hw, c, gate = op.args
+                _lib.check(lib.sp_se_gate_add_relu_nhwc(P(bufs[op.src]), P(bufs[gate]), P(bufs[op.res]), P(bufs[op.dst]), B, hw, c,
+                                                        stream), op.name)
             elif op.kind == "upsample_add":
                 h, w, c, f, relu = op.args
                 _lib.check(lib.sp_upsample_add_nhwc(P(bufs[op.src]), P(bufs[op.res]), P(bufs[op.dst]), B, h, w, c, f, relu,
@@ -336,6 +343,20 @@ class ProgramBuilder:
         self.p.ops.append(Op("pixel_shuffle", src, dst, args=(h, w, c), name="pixel_shuffle"))
         return dst
 
+    def gap(self, src: str) -> str:
+        h, w, c = self.p.shapes[src]
+        dst = self._fresh("gap")
+        self.p.shapes[dst] = (1, 1, c)
+        self.p.ops.append(Op("gap", src, dst, args=(h * w, c), name="se.avg_pool"))
+        return dst
+
+    def se_gate(self, x: str, gate_logits: str, identity: str) -> str:
+        h, w, c = self.p.shapes[x]
+        dst = self._fresh("se")
+        self.p.shapes[dst] = (h, w, c)
+        self.p.ops.append(Op("se_gate", x, dst, res=identity, args=(h * w, c, gate_logits), name="se.gate_add_relu"))
+        return dst
+
     def upsample_add(self, src: str, base: str, factor: int, relu: bool = False) -> str:
         """dst = base + nearest_upsample(src, factor) (+ relu); factor 1 = plain add."""
         h, w, c = self.p.shapes[src]
@@ -363,6 +384,13 @@ def _bottleneck(b: ProgramBuilder, sd, x: str, p: str, stride: int) -> str:
         sdn, hdn = _bn(sd, p + ".downsample.1")
         idn = b.conv(x, sd[p + ".downsample.0.weight"], stride=stride, scale=sdn, shift=hdn, name=p + ".downsample")
     s3, h3 = _bn(sd, p + ".bn3")
+    if (p + ".se.fc.0.weight") in sd:
+        # SE variant (reduction=True): out = relu(se(bn3(conv3(t))) + identity), pose_resnet_dconv.py:124-131
+        z = b.conv(t, sd[p + ".conv3.weight"], scale=s3, shift=h3, name=p + ".conv3")
+        g = b.gap(z)
+        g = b.conv(g, sd[p + ".se.fc.0.weight"], shift=sd[p + ".se.fc.0.bias"].float().contiguous(), relu=True, name=p + ".se.fc.0")
+        g = b.conv(g, sd[p + ".se.fc.2.weight"], shift=sd[p + ".se.fc.2.bias"].float().contiguous(), name=p + ".se.fc.2")
+        return b.se_gate(z, g, idn)
     # bn3 + residual add + relu fused in conv3's epilogue (pose_resnet_dconv.py:124-131)
     return b.conv(t, sd[p + ".conv3.weight"], scale=s3, shift=h3, relu=True, res=idn, name=p + ".conv3")
 
@@ -370,8 +398,6 @@ def _bottleneck(b: ProgramBuilder, sd, x: str, p: str, stride: int) -> str:
 def resnet_program(sd: Dict[str, torch.Tensor], head: str, in_h: int = 256, in_w: int = 192,
                    blocks=(3, 4, 6, 3)) -> Program:
     """Lower a reference-layout state_dict into a Program.  `sd` tensors must be on the GPU."""
-    if any(k.endswith(".se.fc.0.weight") for k in sd):
-        raise NotImplementedError("SELayer (reduction=True) is not lowered yet")
     b = ProgramBuilder(in_h, in_w)
     x = b.to_nhwc4("input")
     s, h = _bn(sd, "bn1")

@@ -22,7 +22,7 @@ class _Bottleneck(nn.Module):
     optional `downsample` = Sequential(conv1x1, bn).  Keys as in nets/pose_resnet_dconv.py:83-110."""
     expansion = 4
 
-    def __init__(self, inplanes: int, planes: int, stride: int, with_downsample: bool):
+    def __init__(self, inplanes: int, planes: int, stride: int, with_downsample: bool, with_se: bool = False):
         super().__init__()
         self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
         self.bn1 = nn.BatchNorm2d(planes)
@@ -36,6 +36,9 @@ class _Bottleneck(nn.Module):
         else:
             self.downsample = None
         self.stride = stride
+        if with_se:                      # registered after `downsample`, as in the reference (pose_resnet_dconv.py:105-110)
+            from .commons import SELayer
+            self.se = SELayer(planes * 4)
 
 
 class PoseResNetBase(nn.Module):
@@ -45,8 +48,7 @@ class PoseResNetBase(nn.Module):
 
     def __init__(self, num_classes: int = 17, reduction: bool = False):
         super().__init__()
-        if reduction:
-            raise NotImplementedError("SELayer variant (reduction=True, nets/commons.py:4-18) is not lowered to HIP yet")
+        self.reduction = reduction     # SELayer on the first block of every layer (pose_resnet_dconv.py:215-218)
         self.num_classes = num_classes
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
@@ -55,7 +57,7 @@ class PoseResNetBase(nn.Module):
             blocks = []
             for bi in range(n):
                 stride = 2 if (bi == 0 and li > 1) else 1
-                blocks.append(_Bottleneck(inplanes, planes, stride, with_downsample=(bi == 0)))
+                blocks.append(_Bottleneck(inplanes, planes, stride, with_downsample=(bi == 0), with_se=(reduction and bi == 0)))
                 inplanes = planes * 4
             setattr(self, f"layer{li}", nn.Sequential(*blocks))
         self._build_head(inplanes, num_classes)

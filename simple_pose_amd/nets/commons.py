@@ -12,3 +12,13 @@ class DUC(nn.Module):
         self.bn = nn.BatchNorm2d(planes)
         self.relu = nn.ReLU(inplace=True)
         self.pixel_shuffle = nn.PixelShuffle(upscale_factor)
+
+
+class SELayer(nn.Module):
+    """Parameter holder for the reference's SELayer (`nets/commons.py:4-18`, reduction=1: C -> C -> C):
+    keys fc.0.{weight [C,C,1,1], bias}, fc.2.{weight, bias}."""
+
+    def __init__(self, channel: int, reduction: int = 1):
+        super().__init__()
+        self.fc = nn.Sequential(nn.Conv2d(channel, channel // reduction, 1, 1, 0), nn.ReLU(inplace=True),
+                                nn.Conv2d(channel // reduction, channel, 1, 1, 0), nn.Sigmoid())

@@ -72,6 +72,11 @@ def run_program_cpu(prog, x):
         elif op.kind == "pixel_shuffle":
             t = torch.nn.functional.pixel_shuffle(bufs[op.src].permute(0, 3, 1, 2), 2)
             bufs[op.dst] = t.permute(0, 2, 3, 1).contiguous()
+        elif op.kind == "gap":
+            bufs[op.dst] = bufs[op.src].mean(dim=(1, 2), keepdim=True)
+        elif op.kind == "se_gate":
+            hw, c, gate = op.args
+            bufs[op.dst] = torch.relu(bufs[op.src] * torch.sigmoid(bufs[gate]) + bufs[op.res])
         elif op.kind == "upsample_add":
             h, w, c, f, relu = op.args
             up = bufs[op.src].repeat_interleave(f, 1).repeat_interleave(f, 2)

@@ -353,3 +353,17 @@ def test_hrnet_w32_forward_vs_reference_golden(golden):
     with torch.no_grad():
         hm16 = m(x16)
     assert torch.equal(hm16[3], hm[0]) and torch.equal(hm16[15], hm[0])
+
+
+def test_se_variant_forward_vs_reference_golden(golden):
+    g = golden("g1s_dconv_se_fwd.npz")
+    m = pose_resnet_dconv.resnet50(pretrained=False, num_classes=17, reduction=True)
+    sd = synth.conditioned_state_dict(nets_oracle.state_dict_shapes_resnet50("dconv", se=True), int(g["seed"]))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m = m.to(DEV).eval()
+    with torch.no_grad():
+        hm = m(_cuda(synth.input_images(1, int(g["seed"]))))
+        hm32 = m(_cuda(np.repeat(synth.input_images(1, int(g["seed"])), 32, 0)))
+    ref = g["heat_maps"]
+    assert np.abs(hm.cpu().numpy() - ref).max() / np.abs(ref).max() <= 1e-4
+    assert torch.equal(hm32[17], hm[0])

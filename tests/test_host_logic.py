@@ -131,3 +131,18 @@ def test_hrnet_module_layout_and_lowering_reproduce_oracle(golden):
     assert abs(full.flops_per_image - 15.29e9) / 15.29e9 < 1e-3     # 15.2900 GFLOP / image
     with pytest.raises(_lib.HipLibraryError):
         m.eval()(torch.zeros(1, 3, 256, 192))
+
+
+def test_se_variant_module_layout_and_lowering(golden):
+    """reduction=True: reference key order (SE after downsample), Program interpreted on CPU == oracle."""
+    g = golden("g1s_dconv_se_fwd.npz")
+    m = pose_resnet_dconv.resnet50(pretrained=False, num_classes=17, reduction=True)
+    assert list(m.state_dict().keys()) == list(g["keys"]) and sum(p.numel() for p in m.parameters()) == 45148497
+    shapes = nets_oracle.state_dict_shapes_resnet50("dconv", se=True)
+    sd = {k: torch.from_numpy(v) for k, v in synth.conditioned_state_dict(shapes, seed=4).items()}
+    x = torch.from_numpy(synth.input_images(2, seed=4, h=64, w=64))
+    prog = engine.resnet_program(sd, "dconv", in_h=64, in_w=64)
+    with torch.no_grad():
+        ref = nets_oracle.resnet_dconv_forward(sd, x)
+        got, _ = run_program_cpu(prog, x)
+    assert (got - ref).abs().max() / ref.abs().max() < 1e-5

@@ -132,3 +132,14 @@ def test_train_step_oracle_matches_reference(golden):
     for k in ("bn1.running_mean", "bn1.running_var", "layer3.5.bn3.running_var", "deconv_layers.7.running_mean"):
         assert np.abs(sd[k].numpy() - g["buf/" + k]).max() <= 1e-5 * max(1.0, np.abs(g["buf/" + k]).max()), k
     assert int(sd["bn1.num_batches_tracked"]) == int(g["buf/bn1.num_batches_tracked"]) == 1
+
+
+def test_se_variant_oracle_and_key_layout_match_reference(golden):
+    g = golden("g1s_dconv_se_fwd.npz")
+    shapes = nets_oracle.state_dict_shapes_resnet50("dconv", se=True)
+    assert [k for k, _, _ in shapes] == list(g["keys"])
+    assert [",".join(str(d) for d in s) for _, s, _ in shapes] == list(g["shapes"])
+    sd = {k: torch.from_numpy(v) for k, v in synth.conditioned_state_dict(shapes, int(g["seed"])).items()}
+    with torch.no_grad():
+        hm = nets_oracle.resnet_dconv_forward(sd, torch.from_numpy(synth.input_images(1, int(g["seed"])))).numpy()
+    assert np.abs(hm - g["heat_maps"]).max() / np.abs(g["heat_maps"]).max() <= 1e-5
