@@ -21,7 +21,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 ARCH_NAMES = {"dconv": "ResNet50-DConv", "duc": "ResNet50-DUC", "hrnet_w32": "HRNet-W32"}
-FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 FLOP/clk/CU x 256 CU x 2.4 GHz
+FP32_MATRIX_PEAK_TFLOPS = 157.3
+BF16_MATRIX_PEAK_TFLOPS = 2500.0  # dense (MI355X_MICROARCH.md); the bf16 path is HBM/L2-bound long before this  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 FLOP/clk/CU x 256 CU x 2.4 GHz
 
 
 def parse():
@@ -32,6 +33,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=128, help="images per GPU per step")
     ap.add_argument("--arch", default="dconv", choices=["dconv", "duc", "hrnet_w32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="compute dtype of the network (BASELINE metric: f32)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
                     help="infer = forward + GaussTaylor decode (BASELINE metric, default); train = fwd+bwd+Adam step (config 4, fp32)")
     ap.add_argument("--tiles", default=None, help="JSON tile table: loaded if it exists (skips autotune), else written")
@@ -126,6 +128,8 @@ def main():
         sd = synth.conditioned_state_dict(nets_oracle.state_dict_shapes_resnet50(args.arch), seed=0)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     model = model.to(dev).eval()
+    if args.dtype == "bf16":
+        model.compute_dtype = "bf16"
     decoder = GaussTaylorKeyPointDecoder(kernel_size=11, num_joints=17)
 
     B = args.batch
@@ -190,7 +194,8 @@ def main():
     # ---- per-kernel roofline: HIP events around every conv launch, on the launch stream, same inputs ----
     roofline = None
     if rank == 0 and not args.no_kernel_events and prog is not None:
-        roofline = kernel_roofline(prog, x, steps=max(3, min(args.steps, 10)), layers_out=args.layers_out)
+        roofline = kernel_roofline(prog, x, steps=max(3, min(args.steps, 10)), layers_out=args.layers_out,
+                                   peak=FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else BF16_MATRIX_PEAK_TFLOPS)
 
     if rank == 0:
         name = ARCH_NAMES[args.arch]
@@ -207,17 +212,18 @@ def main():
                 "network_frac_of_fp32_matrix_peak": round(value * gflop / 1e3 / (FP32_MATRIX_PEAK_TFLOPS * world), 4),
                 "roofline": None, "cpu_baseline": None, "final_loss": float(out[0].item())}
         else:
+            peak = FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else BF16_MATRIX_PEAK_TFLOPS
             line = {
                 "metric": "images/sec fwd+decode, %s 256x192 bs=%d" % (name, B),
                 "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "f32", "data": "synthetic",
-                "config": {"workload": f"{name} 256x192 bs={B} per GPU, fp32 forward "
+                "dtype": args.dtype, "data": "synthetic",
+                "config": {"workload": f"{name} 256x192 bs={B} per GPU, {'fp32' if args.dtype == 'f32' else 'bf16 (fp32 accumulate)'} forward "
                                        "(NCHW in -> heat maps) + GaussTaylor decode, eval-mode BN, conditioned random weights",
                            "images_per_gpu": B, "global_batch": B * world, "parallelism": f"replicas x{world} (no collective)"},
                 "gflop_per_image": round(prog.flops_per_image / 1e9, 4),
                 "network_tflops": round(value * prog.flops_per_image / 1e12, 2),
-                "network_frac_of_fp32_matrix_peak": round(value * prog.flops_per_image / 1e12 / (FP32_MATRIX_PEAK_TFLOPS * world), 4),
+                "network_frac_of_matrix_peak": round(value * prog.flops_per_image / 1e12 / (peak * world), 4),
                 "roofline": roofline,
                 "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(args.arch),
             }
@@ -231,11 +237,12 @@ def _variant_name(op):
     d = op.desc
     bm, bn = d.tile_m, d.tile_n
     wr, wc = {(128, 128): (2, 2), (64, 128): (2, 2), (128, 64): (2, 2), (64, 64): (2, 2), (256, 64): (4, 1), (128, 32): (4, 1)}[(bm, bn)]
-    uniform = (d.c_in % 32 == 0) and d.taps_h * d.taps_w <= 32
-    return f"conv_igemm_kernel<{bm}, {bn}, {wr}, {wc}, {'true' if uniform else 'false'}>"
+    bf16 = bool(d.flags & 0x8)
+    uniform = (d.c_in % (64 if bf16 else 32) == 0) and d.taps_h * d.taps_w <= 32
+    return f"conv_igemm_kernel<{bm}, {bn}, {wr}, {wc}, {'true' if uniform else 'false'}, {'true' if bf16 else 'false'}>"
 
 
-def kernel_roofline(prog, x, steps: int, layers_out=None):
+def kernel_roofline(prog, x, steps: int, layers_out=None, peak=FP32_MATRIX_PEAK_TFLOPS):
     """HIP events recorded on the launch stream around every conv launch of `steps` forward passes (same inputs as the
     timed region).  The dominant kernel = the conv_igemm instantiation with the largest total time; its achieved
     TFLOP/s = algorithmic FLOPs of its launches / their summed durations, against the fp32 matrix peak.  The
@@ -251,6 +258,7 @@ def kernel_roofline(prog, x, steps: int, layers_out=None):
     bufs["input"] = x
     bufs[prog.out_name] = torch.empty((B,) + tuple(prog.out_shape), dtype=torch.float32, device=x.device)
     P = _lib.ptr
+    bf = prog.dtype == "bf16"
     conv_ops = [op for op in prog.ops if op.kind == "conv"]
     ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in conv_ops]
           for _ in range(steps)]
@@ -267,16 +275,17 @@ def kernel_roofline(prog, x, steps: int, layers_out=None):
                 ci += 1
             elif op.kind == "maxpool":
                 h, w, c = op.args
-                lib.sp_maxpool3x3s2_nhwc(P(bufs[op.src]), P(bufs[op.dst]), B, h, w, c, stream)
+                (lib.sp_maxpool3x3s2_nhwc_bf16 if bf else lib.sp_maxpool3x3s2_nhwc)(P(bufs[op.src]), P(bufs[op.dst]), B, h, w, c, stream)
             elif op.kind == "to_nhwc4":
                 c, h, w = op.args
-                lib.sp_nchw_to_nhwc4(P(bufs[op.src]), P(bufs[op.dst]), B, c, h, w, stream)
+                (lib.sp_nchw_to_nhwc8_bf16 if bf else lib.sp_nchw_to_nhwc4)(P(bufs[op.src]), P(bufs[op.dst]), B, c, h, w, stream)
             elif op.kind == "pixel_shuffle":
                 h, w, c = op.args
-                lib.sp_pixel_shuffle2_nhwc(P(bufs[op.src]), P(bufs[op.dst]), B, h, w, c, stream)
+                (lib.sp_pixel_shuffle2_nhwc_bf16 if bf else lib.sp_pixel_shuffle2_nhwc)(P(bufs[op.src]), P(bufs[op.dst]), B, h, w, c, stream)
             elif op.kind == "upsample_add":
                 h, w, c, f, relu = op.args
-                lib.sp_upsample_add_nhwc(P(bufs[op.src]), P(bufs[op.res]), P(bufs[op.dst]), B, h, w, c, f, relu, stream)
+                (lib.sp_upsample_add_nhwc_bf16 if bf else lib.sp_upsample_add_nhwc)(P(bufs[op.src]), P(bufs[op.res]), P(bufs[op.dst]), B, h, w, c,
+                                                                                      f, relu, stream)
     torch.cuda.synchronize()
     per_layer = []
     for ci, op in enumerate(conv_ops):
@@ -303,14 +312,14 @@ def kernel_roofline(prog, x, steps: int, layers_out=None):
                 traffic = json.load(fh).get(dom, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    return {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic,
+    return {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": traffic,
             "launches_per_step": d_n, "avg_launch_us": round(1e3 * d_ms / d_n, 2),
             "algorithmic_gflop_per_launch": round(d_flop / d_n / 1e9, 3),
             "share_of_conv_time": round(d_ms / tot_ms, 3),
             "all_conv_kernels": {"launches_per_step": len(per_layer), "ms_per_step": round(tot_ms, 3),
                                  "achieved": round(tot_flop / (tot_ms * 1e-3) / 1e12, 2),
-                                 "frac": round(tot_flop / (tot_ms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4)},
+                                 "frac": round(tot_flop / (tot_ms * 1e-3) / 1e12 / peak, 4)},
             "by_kernel": {v: {"launches": g[2], "avg_us": round(1e3 * g[0] / g[2], 1), "tflops": round(g[1] / (g[0] * 1e-3) / 1e12, 1)}
                           for v, g in sorted(groups.items(), key=lambda kv: -kv[1][0])}}
 

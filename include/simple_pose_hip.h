@@ -27,12 +27,14 @@ extern "C" {
 #define SP_EINVAL (-1)   /* bad argument / unsupported shape (message in sp_last_error) */
 #define SP_ELAUNCH (-2)  /* HIP launch or runtime failure */
 
-#define SP_ABI_VERSION 2
+#define SP_ABI_VERSION 3
 
 /* epilogue / layout flags of sp_conv_desc.flags */
 #define SP_CONV_RELU 0x1u          /* y = max(y, 0) after scale/shift (+ residual) */
 #define SP_CONV_OUT_NCHW 0x2u      /* store y as NCHW [B, N, out_h, out_w] (final_layer -> heat maps) */
 #define SP_CONV_PIXEL_SHUFFLE 0x4u /* fused nn.PixelShuffle(2): weights packed with sp_pack order, see below */
+#define SP_CONV_BF16 0x8u          /* x, w_packed, residual and NHWC y are bf16 (fp32 accumulate; scale/shift and the NCHW
+                                      output stay fp32); c_in % 8 == 0, k_pad % 64 == 0 */
 
 /*
  * One launch of the fp32 implicit-GEMM convolution family:
@@ -77,8 +79,8 @@ int sp_nchw_to_nhwc4(const float* x_nchw, float* y_nhwc4, int batch, int channel
  * + residual add + nn.ReLU + nn.PixelShuffle(2), one kernel.  Replaces: conv1/bn1/relu (:252-254),
  * Bottleneck.forward (:112-133), deconv_layers (:230-249), final_layer (:173-178), DUC (nets/commons.py:36-41).
  * scale/shift: [c_out] or NULL (scale NULL -> 1, shift NULL -> 0); residual: same layout as y or NULL. */
-int sp_conv2d_fwd(const sp_conv_desc* desc, const float* x, const float* w_packed, const float* scale,
-                  const float* shift, const float* residual, float* y, void* stream);
+int sp_conv2d_fwd(const sp_conv_desc* desc, const void* x, const void* w_packed, const float* scale,
+                  const float* shift, const void* residual, void* y, void* stream);
 
 /* The tile sp_conv2d_fwd picks when desc->tile_m == tile_n == 0; legal tiles: 128x128 64x128 128x64 64x64 256x64 128x32
  * (tile_n must divide n_pad).  Host code may time the legal tiles once per layer shape and pin the fastest. */
@@ -102,6 +104,14 @@ int sp_se_gate_add_relu_nhwc(const float* x, const float* gate_logits, const flo
  * factor 1 = plain add).  HighResolutionModule fuse sum, nets/pose_hrnet.py:192-202,250-257 */
 int sp_upsample_add_nhwc(const float* x, const float* base, float* y, int batch, int h, int w, int c, int factor, int relu,
                          void* stream);
+
+/* bf16 NHWC (8 channels = 16 B per lane) variants of the layout / pooling / fuse kernels, for SP_CONV_BF16 networks.
+ * The network input stays the reference's fp32 NCHW tensor; channels are padded to 8. */
+int sp_nchw_to_nhwc8_bf16(const float* x_nchw, void* y_nhwc8, int batch, int channels, int h, int w, void* stream);
+int sp_maxpool3x3s2_nhwc_bf16(const void* x, void* y, int batch, int h, int w, int c, void* stream);
+int sp_pixel_shuffle2_nhwc_bf16(const void* x, void* y, int batch, int h, int w, int c, void* stream);
+int sp_upsample_add_nhwc_bf16(const void* x, const void* base, void* y, int batch, int h, int w, int c, int factor,
+                              int relu, void* stream);
 
 /* ---- decoders: metrics/pose_metrics.py --------------------------------------------------------- */
 

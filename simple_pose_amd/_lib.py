@@ -17,8 +17,9 @@ LIB_PATH = os.environ.get("SIMPLE_POSE_HIP_LIB", _DEFAULT_LIB_PATH)
 SP_CONV_RELU = 0x1
 SP_CONV_OUT_NCHW = 0x2
 SP_CONV_PIXEL_SHUFFLE = 0x4
+SP_CONV_BF16 = 0x8
 CONV_TILES = ((128, 128), (64, 128), (128, 64), (64, 64), (256, 64), (128, 32))
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class HipLibraryError(RuntimeError):
@@ -46,6 +47,10 @@ SYMBOLS = {
     "sp_global_avg_pool_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "sp_se_gate_add_relu_nhwc": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "sp_upsample_add_nhwc": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "sp_nchw_to_nhwc8_bf16": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "sp_maxpool3x3s2_nhwc_bf16": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "sp_pixel_shuffle2_nhwc_bf16": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "sp_upsample_add_nhwc_bf16": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "sp_heat_map_to_axis": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "sp_decode_gauss_taylor": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "sp_decode_basic": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),

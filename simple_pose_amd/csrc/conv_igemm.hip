@@ -13,6 +13,9 @@
 // its 4 output phases (blockIdx.y), each a dense 2x2-tap conv, so no multiply is wasted on the zeros a
 // naive "dilate the input" formulation inserts.
 //
+// bf16 variant (SP_CONV_BF16): the same kernel with bf16 activations/weights (8 elements per 16-B chunk, K tile 64),
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation, bf16 NHWC output (the NCHW heat-map output stays fp32).
+//
 // Math: v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate) - 256 FLOP/clk/CU, the fp32
 // matrix peak of the chip (157 TFLOP/s).  Block tile BM x BN x 32, 4 waves, each wave (BM/WR)x(BN/WC).
 //
@@ -55,12 +58,12 @@ extern "C" int sp_debug_clear() {
 namespace {
 
 struct ConvArgs {
-    const float* x;
-    const float* w;
+    const void* x;       // NHWC activations, fp32 or bf16
+    const void* w;       // packed weights, same dtype as x
     const float* scale;
     const float* shift;
-    const float* res;
-    float* y;
+    const void* res;     // same dtype/layout as y
+    void* y;             // NHWC (dtype of x) or NCHW fp32
     int M;  // batch * grid_h * grid_w
     int in_h, in_w, c_in;
     int grid_h, grid_w;
@@ -79,8 +82,13 @@ constexpr int BK = 32;  // floats per K tile (8 chunks of 16 B)
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * BK + ((chunk ^ ((row >> 1) & 7)) << 2); }
 
-template <int BM, int BN, int WR, int WC, bool UNIFORM_TAP>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int BM, int BN, int WR, int WC, bool UNIFORM_TAP, bool BF16>
 __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm_kernel(const ConvArgs p) {
+    constexpr int ES = BF16 ? 2 : 4;     // element size of activations / weights
+    constexpr int EPC = 16 / ES;         // elements per 16-byte chunk
+    constexpr int BKE = 128 / ES;        // elements per K tile (one 128-byte LDS row)
     static_assert(WR * WC == 4, "4 waves per workgroup");
     constexpr int WM = BM / WR, WN = BN / WC;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -120,7 +128,7 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
     const int py = phase / p.phases_x, px = phase % p.phases_x;
     const int dy0 = p.dy0 + py, dx0 = p.dx0 + px;
     const int oy_add = p.oy_add + py, ox_add = p.ox_add + px;
-    const float* __restrict__ wp = p.w + (size_t)phase * p.n_pad * p.k_pad;
+    const char* __restrict__ wp = reinterpret_cast<const char*>(p.w) + (size_t)phase * p.n_pad * p.k_pad * ES;
 
     // ---- per-row table: one decode per row per workgroup ----
     //   x: byte offset of tap (0,0), channel 0 of this output pixel's receptive field (only used through valid taps)
@@ -134,7 +142,7 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
             const int b = m / ghw, rem = m - b * ghw;
             const int gy = rem / gw, gx = rem - gy * gw;
             const int iy0 = gy * p.stride + dy0, ix0 = gx * p.stride + dx0;
-            e.x = ((b * p.in_h + iy0) * p.in_w + ix0) * p.c_in * 4;
+            e.x = ((b * p.in_h + iy0) * p.in_w + ix0) * p.c_in * ES;
             unsigned msk = 0;
             if (UNIFORM_TAP) {
                 for (int ty = 0; ty < p.taps_h; ++ty)
@@ -160,8 +168,8 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
     // OOB, which the hardware range check turns into zeros (loads) or drops (stores) - no branches, no selects, and the
     // compiler keeps every load of a tile in flight behind the MFMAs instead of waiting at each exec-mask join.
     constexpr unsigned OOB = 0x80000000u;  // every tensor is < 2 GiB (checked on the host)
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), (short)0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wr_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp), (short)0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), (short)0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wp), (short)0, p.w_bytes, 0x00020000);
     const int kc = tid & 7;
     const int srow = tid >> 3;
     // Per staged row: tap-(0,0) byte offset (+ this lane's 16-byte chunk) and the tap validity mask.  Per K tile a load
@@ -178,11 +186,11 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
         a_iy[i] = e.z >> 16;
         a_ix[i] = (int)(short)(e.z & 0xffff);
     }
-    const unsigned b_voff = (unsigned)((srow * p.k_pad + kc * 4) * 4);
-    const unsigned b_soff0 = (unsigned)n0 * p.k_pad * 4;
+    const unsigned b_voff = (unsigned)((srow * p.k_pad + kc * EPC) * ES);
+    const unsigned b_soff0 = (unsigned)n0 * p.k_pad * ES;
 
     u32x4 sa[A_CH], sb[B_CH];
-    const int cin_chunks = p.c_in >> 2;
+    const int cin_chunks = p.c_in / EPC;
 
     // tap decode of K tile kt (scalar when UNIFORM_TAP), then the loads as A_CH + B_CH independent pieces that the main
     // loop drops one at a time into the shadows of the MFMAs
@@ -190,17 +198,17 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
     unsigned t_bit = 0;
     bool t_ok = true;
     auto tile_taps = [&](int kt) {
-        const int k0 = kt * BK;
+        const int k0 = kt * BKE;
         t_k0 = k0;
         if (UNIFORM_TAP) {  // c_in % 32 == 0: the whole K tile sits inside one tap (all scalar)
             const int tap = k0 / p.c_in;
             const int ty = tap / p.taps_w, tx = tap - ty * p.taps_w;
             t_bit = 1u << tap;
-            t_shift = ((ty * p.dy_step * p.in_w + tx * p.dx_step) * p.c_in + (k0 - tap * p.c_in)) * 4;
+            t_shift = ((ty * p.dy_step * p.in_w + tx * p.dx_step) * p.c_in + (k0 - tap * p.c_in)) * ES;
         } else {            // small c_in (stem: NHWC4): every 16-B chunk may be a different tap
-            const int q = (k0 >> 2) + kc;
+            const int q = k0 / EPC + kc;
             const int tap = q / cin_chunks;
-            t_coff = (q - tap * cin_chunks) << 2;
+            t_coff = (q - tap * cin_chunks) * EPC;
             const int ty = tap / p.taps_w, tx = tap - ty * p.taps_w;
             t_ok = ty < p.taps_h;
             t_ddy = ty * p.dy_step; t_ddx = tx * p.dx_step;
@@ -213,12 +221,12 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
         } else {
             const int iy = a_iy[i] + t_ddy, ix = a_ix[i] + t_ddx;
             const bool ok = t_ok && (unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w;
-            off = ok ? (unsigned)(a_off0[i] + ((t_ddy * p.in_w + t_ddx) * p.c_in + t_coff) * 4 - kc * 16) : OOB;
+            off = ok ? (unsigned)(a_off0[i] + ((t_ddy * p.in_w + t_ddx) * p.c_in + t_coff) * ES - kc * 16) : OOB;
         }
         sa[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
     };
     auto load_b = [&](int i) {
-        sb[i] = __builtin_amdgcn_raw_buffer_load_b128(wr_, b_voff + (unsigned)(32 * i * p.k_pad * 4), b_soff0 + (unsigned)(t_k0 * 4), 0);
+        sb[i] = __builtin_amdgcn_raw_buffer_load_b128(wr_, b_voff + (unsigned)(32 * i * p.k_pad * ES), b_soff0 + (unsigned)(t_k0 * ES), 0);
     };
     auto store_piece = [&](int buf, int o) {  // o in [0, A_CH + B_CH)
         if (o < A_CH) *reinterpret_cast<u32x4*>(As + buf * BM * BK + swz(srow + 32 * o, kc)) = sa[o];
@@ -242,7 +250,7 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
             for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.f;
 
     const int fr = lane & 31, fh = lane >> 5;
-    const int nk = p.k_pad / BK;
+    const int nk = p.k_pad / BKE;
 
     // Fragment registers are double-buffered by hand (slot = k-step parity): the ds_reads of k-step j+1 are issued
     // before the MFMAs of k-step j, so LDS latency hides behind ~1000 cycles of matrix work.
@@ -253,11 +261,15 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
 #pragma unroll
         for (int n = 0; n < TN; ++n) fb[slot][n] = *reinterpret_cast<const f32x4*>(b + swz(n * 32 + fr, 2 * j + fh));
     };
-    constexpr int NM = 4 * TM * TN;   // MFMAs per k-step
-    constexpr int NOPS = A_CH + B_CH;  // 16-byte staging pieces per thread per K tile
-    auto mfma_q = [&](int slot, int q) {  // q-th MFMA of a k-step: k-pair s = q / (TM*TN), tile (i, n)
+    constexpr int NM = (BF16 ? 1 : 4) * TM * TN;   // MFMAs per k-step (fp32: 4 k-pairs per 16-byte fragment; bf16: one k=16 MFMA)
+    constexpr int NOPS = A_CH + B_CH;              // 16-byte staging pieces per thread per K tile
+    auto mfma_q = [&](int slot, int q) {           // q-th MFMA of a k-step: k-pair s = q / (TM*TN), tile (i, n)
         const int s = q / (TM * TN), i = (q / TN) % TM, n = q % TN;
-        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][i][s], fb[slot][n][s], acc[i][n], 0, 0, 0);
+        if constexpr (BF16)
+            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[slot][i]), __builtin_bit_cast(bf16x8, fb[slot][n]),
+                                                                acc[i][n], 0, 0, 0);
+        else
+            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][i][s], fb[slot][n][s], acc[i][n], 0, 0, 0);
     };
 #define SP_SB() __builtin_amdgcn_sched_barrier(0)
 
@@ -322,14 +334,22 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
         SP_STAMP(s3)
         SP_STAMP(s3w)
         // ---- step 3 (slot 1), first half + the ds_writes ----
-#pragma unroll
-        for (int q = 0; q < NM / 2; ++q) {
-            mfma_q(1, q);
+        constexpr int H3 = NM / 2;   // MFMAs of step 3 issued before the barrier (0 for the single-MFMA bf16 64x64 tile)
+        if constexpr (H3 == 0) {
             if (MORE) {
 #pragma unroll
-                for (int o = (q * NOPS) / (NM / 2); o < ((q + 1) * NOPS) / (NM / 2); ++o) store_piece(cur ^ 1, o);
+                for (int o = 0; o < NOPS; ++o) store_piece(cur ^ 1, o);
             }
-            SP_SB();
+        } else {
+#pragma unroll
+            for (int q = 0; q < H3; ++q) {
+                mfma_q(1, q);
+                if (MORE) {
+#pragma unroll
+                    for (int o = (q * NOPS) / H3; o < ((q + 1) * NOPS) / H3; ++o) store_piece(cur ^ 1, o);
+                }
+                SP_SB();
+            }
         }
         SP_STAMP(s4)
         if (MORE) {
@@ -372,8 +392,8 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
     const bool relu = p.flags & SP_CONV_RELU;
     const int hw_out = p.out_h * p.out_w;
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, (short)0, p.y_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res : p.y), (short)0, p.y_bytes, 0x00020000);
-    if (!nchw && (p.c_out & 3) == 0) {
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res ? p.res : p.y), (short)0, p.y_bytes, 0x00020000);
+    if (!nchw && (p.c_out % EPC) == 0) {
         static_assert(BM * BN <= 2 * (BM + BN) * BK, "transpose area must fit in the staging buffers");
         float* tr = smem + wave * (WM * WN);
 #pragma unroll
@@ -383,16 +403,22 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     tr[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * WN + n * 32 + fr] = acc[i][n][r];
-        constexpr int CPR = WN / 4;    // 16-byte chunks per tile row
-        constexpr int RPI = 64 / CPR;  // tile rows covered by one wave-instruction
+        constexpr int CPL = EPC;         // channels per lane = one 16-byte store (4 fp32 / 8 bf16)
+        constexpr int CPR = WN / CPL;    // 16-byte output chunks per tile row
+        constexpr int RPI = 64 / CPR;    // tile rows covered by one wave-instruction
         constexpr int NIT = WM / RPI;
         const int chunk = lane % CPR, rsub = lane / CPR;
-        const int col = n0 + wc * WN + chunk * 4;
+        const int col = n0 + wc * WN + chunk * CPL;
         const bool col_ok = col < p.c_out;
-        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        float sc[CPL], sh[CPL];
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
         if (col_ok) {
-            if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
-            if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
+#pragma unroll
+            for (int e4 = 0; e4 < CPL / 4; ++e4) {
+                if (p.scale) { const f32x4 t = *reinterpret_cast<const f32x4*>(p.scale + col + 4 * e4); sc[4 * e4] = t[0]; sc[4 * e4 + 1] = t[1]; sc[4 * e4 + 2] = t[2]; sc[4 * e4 + 3] = t[3]; }
+                if (p.shift) { const f32x4 t = *reinterpret_cast<const f32x4*>(p.shift + col + 4 * e4); sh[4 * e4] = t[0]; sh[4 * e4 + 1] = t[1]; sh[4 * e4 + 2] = t[2]; sh[4 * e4 + 3] = t[3]; }
+            }
         }
         int col_off = col;
         if (pshuf) {
@@ -403,7 +429,7 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int ro = rowtab[(wr * WM + it * RPI + rsub) * 4 + 3];
-            off[it] = (col_ok && ro >= 0) ? (unsigned)((ro + col_off) * 4) : OOB;
+            off[it] = (col_ok && ro >= 0) ? (unsigned)((ro + col_off) * ES) : OOB;
         }
         u32x4 rv[NIT];
         if (p.res) {  // every residual load of the tile in flight before the first use
@@ -412,14 +438,40 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(tr + (it * RPI + rsub) * WN + chunk * 4);
-            v = v * sc + sh;
-            if (p.res) v += __builtin_bit_cast(f32x4, rv[it]);
-            if (relu) {
-                v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f;
-                v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f;
+            float v[CPL];
+#pragma unroll
+            for (int e4 = 0; e4 < CPL / 4; ++e4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(tr + (it * RPI + rsub) * WN + chunk * CPL + 4 * e4);
+                v[4 * e4] = t[0]; v[4 * e4 + 1] = t[1]; v[4 * e4 + 2] = t[2]; v[4 * e4 + 3] = t[3];
             }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, off[it], 0, 0);
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) v[e] = v[e] * sc[e] + sh[e];
+            if (p.res) {
+                if constexpr (BF16) {
+                    const bf16x8 r8 = __builtin_bit_cast(bf16x8, rv[it]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
+                } else {
+                    const f32x4 r4 = __builtin_bit_cast(f32x4, rv[it]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += r4[e];
+                }
+            }
+            if (relu) {
+#pragma unroll
+                for (int e = 0; e < CPL; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            }
+            u32x4 o;
+            if constexpr (BF16) {
+                bf16x8 o8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o8[e] = (__bf16)v[e];
+                o = __builtin_bit_cast(u32x4, o8);
+            } else {
+                const f32x4 o4 = {v[0], v[1], v[2], v[3]};
+                o = __builtin_bit_cast(u32x4, o4);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(o, yr, off[it], 0, 0);
         }
     } else {
         const bool vec4 = nchw && (hw_out & 3) == 0 && !p.res;  // rows 4g..4g+3 = 4 consecutive pixels of one image
@@ -483,49 +535,58 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
 #endif
 }
 
-template <int BM, int BN, int WR, int WC>
-int launch(const ConvArgs& a, int phases, bool uniform, hipStream_t stream) {
+template <int BM, int BN, int WR, int WC, bool BF16>
+int launch_t(const ConvArgs& a, int phases, bool uniform, hipStream_t stream) {
     ConvArgs p = a;
     p.tiles_m = (a.M + BM - 1) / BM;
     p.tiles_n = a.n_pad / BN;
     const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float) + (size_t)BM * 4 * sizeof(int);
     dim3 grid(p.tiles_m * p.tiles_n, phases, 1), block(256, 1, 1);
     // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel instantiation
-    static const hipError_t attr_u = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, true>),
+    static const hipError_t attr_u = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, true, BF16>),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    static const hipError_t attr_c = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, false>),
+    static const hipError_t attr_c = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, false, BF16>),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr_u != hipSuccess || attr_c != hipSuccess) {
         sp_set_error("conv_igemm: hipFuncSetAttribute(max dynamic LDS = %zu) failed", lds);
         return SP_ELAUNCH;
     }
     if (uniform)
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, true>), grid, block, lds, stream, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, true, BF16>), grid, block, lds, stream, p);
     else
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, false>), grid, block, lds, stream, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, false, BF16>), grid, block, lds, stream, p);
     return sp_check_launch("conv_igemm_kernel");
+}
+
+template <int BM, int BN, int WR, int WC>
+int launch(const ConvArgs& a, int phases, bool uniform, hipStream_t stream) {
+    if (a.flags & SP_CONV_BF16) return launch_t<BM, BN, WR, WC, true>(a, phases, uniform, stream);
+    return launch_t<BM, BN, WR, WC, false>(a, phases, uniform, stream);
 }
 
 }  // namespace
 
 extern "C" int sp_conv2d_default_tile(const sp_conv_desc* d, int* tile_m, int* tile_n);
 
-extern "C" int sp_conv2d_fwd(const sp_conv_desc* d, const float* x, const float* w_packed, const float* scale,
-                             const float* shift, const float* residual, float* y, void* stream) {
+extern "C" int sp_conv2d_fwd(const sp_conv_desc* d, const void* x, const void* w_packed, const float* scale,
+                             const float* shift, const void* residual, void* y, void* stream) {
     SP_REQUIRE(d && x && w_packed && y, "sp_conv2d_fwd: null pointer");
     SP_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->grid_h > 0 && d->grid_w > 0 && d->c_out > 0,
                "sp_conv2d_fwd: non-positive dimension");
-    SP_REQUIRE(d->c_in > 0 && d->c_in % 4 == 0, "sp_conv2d_fwd: c_in=%d must be a positive multiple of 4", d->c_in);
+    const bool bf16 = d->flags & SP_CONV_BF16;
+    const int es = bf16 ? 2 : 4, epc = 16 / es, bke = 128 / es;
+    SP_REQUIRE(d->c_in > 0 && d->c_in % epc == 0, "sp_conv2d_fwd: c_in=%d must be a positive multiple of %d", d->c_in, epc);
     SP_REQUIRE(d->taps_h > 0 && d->taps_w > 0 && d->stride > 0, "sp_conv2d_fwd: bad taps/stride");
-    SP_REQUIRE(d->k_pad % 32 == 0 && d->k_pad >= d->taps_h * d->taps_w * d->c_in,
-               "sp_conv2d_fwd: k_pad=%d must be a multiple of 32 and >= taps*c_in=%d", d->k_pad,
+    SP_REQUIRE(d->k_pad % bke == 0 && d->k_pad >= d->taps_h * d->taps_w * d->c_in,
+               "sp_conv2d_fwd: k_pad=%d must be a multiple of %d and >= taps*c_in=%d", d->k_pad, bke,
                d->taps_h * d->taps_w * d->c_in);
     SP_REQUIRE(d->n_pad % 32 == 0 && d->n_pad >= d->c_out, "sp_conv2d_fwd: n_pad=%d must be a multiple of 32 >= c_out=%d",
                d->n_pad, d->c_out);
-    const bool uniform = (d->c_in % 32 == 0) && d->taps_h * d->taps_w <= 32;  // tap-validity bit mask is 32 bits wide
-    if (uniform) SP_REQUIRE(d->k_pad == d->taps_h * d->taps_w * d->c_in, "sp_conv2d_fwd: k_pad must equal taps*c_in when c_in%%32==0");
+    const bool uniform = (d->c_in % bke == 0) && d->taps_h * d->taps_w <= 32;  // tap-validity bit mask is 32 bits wide
+    if (uniform) SP_REQUIRE(d->k_pad == d->taps_h * d->taps_w * d->c_in, "sp_conv2d_fwd: k_pad must equal taps*c_in when c_in fills whole K tiles");
     SP_REQUIRE((d->phases_y == 1 || d->phases_y == 2) && (d->phases_x == 1 || d->phases_x == 2), "sp_conv2d_fwd: phases must be 1 or 2");
-    const unsigned known = SP_CONV_RELU | SP_CONV_OUT_NCHW | SP_CONV_PIXEL_SHUFFLE;
+    const unsigned known = SP_CONV_RELU | SP_CONV_OUT_NCHW | SP_CONV_PIXEL_SHUFFLE | SP_CONV_BF16;
+    if (bf16 && !(d->flags & SP_CONV_OUT_NCHW)) SP_REQUIRE(d->c_out % 8 == 0, "sp_conv2d_fwd: bf16 NHWC output needs c_out %% 8 == 0 (got %d)", d->c_out);
     SP_REQUIRE((d->flags & ~known) == 0, "sp_conv2d_fwd: unknown flag bits 0x%x", d->flags);
     SP_REQUIRE(!((d->flags & SP_CONV_OUT_NCHW) && (d->flags & SP_CONV_PIXEL_SHUFFLE)), "sp_conv2d_fwd: NCHW output and pixel shuffle are exclusive");
     SP_REQUIRE(!((d->flags & SP_CONV_OUT_NCHW) && residual), "sp_conv2d_fwd: residual needs NHWC output");
@@ -561,7 +622,8 @@ extern "C" int sp_conv2d_fwd(const sp_conv_desc* d, const float* x, const float*
     a.out_h = d->out_h; a.out_w = d->out_w; a.out_c = d->out_c;
     a.oy_mul = d->oy_mul; a.oy_add = d->oy_add; a.ox_mul = d->ox_mul; a.ox_add = d->ox_add;
     a.phases_x = d->phases_x; a.flags = d->flags; a.tiles_m = a.tiles_n = 0;
-    a.x_bytes = (int)(in_elems * 4); a.w_bytes = (int)(w_elems * 4); a.y_bytes = (int)(out_elems * 4);
+    a.x_bytes = (int)(in_elems * es); a.w_bytes = (int)(w_elems * es);
+    a.y_bytes = (int)(out_elems * ((d->flags & SP_CONV_OUT_NCHW) ? 4 : es));
     const int phases = d->phases_y * d->phases_x;
     hipStream_t s = (hipStream_t)stream;
 

@@ -1,0 +1,140 @@
+// pointwise_bf16.hip - bf16 NHWC variants of the HBM-bound layout / pooling / fuse kernels (16 B = 8 channels per lane).
+#include "sp_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+inline int grid_for(long long total, int block) {
+    long long g = (total + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+// fp32 NCHW [B,C,H,W] (C <= 8) -> bf16 NHWC8 [B,H,W,8], zero tail channels
+__global__ void nchw_to_nhwc8_bf16_kernel(const float* __restrict__ x, u32x4* __restrict__ y, int C, int hw, long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / hw;
+        const int pix = (int)(i - b * hw);
+        const float* src = x + b * C * hw + pix;
+        bf16x8 v;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = (__bf16)(c < C ? src[(long long)c * hw] : 0.f);
+        y[i] = __builtin_bit_cast(u32x4, v);
+    }
+}
+
+__device__ __forceinline__ float pmax(float m, float v) { return (v > m || v != v) ? v : m; }
+
+__global__ void maxpool3x3s2_bf16_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ y, int H, int W, int C8, int Ho, int Wo,
+                                         long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C8);
+        long long r = i / C8;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho);
+        const long long b = r / Ho;
+        float m[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = -__builtin_inff();
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * 2 - 1 + ky;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * 2 - 1 + kx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const bf16x8 v = __builtin_bit_cast(bf16x8, x[((b * H + iy) * W + ix) * C8 + c]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = pmax(m[e], (float)v[e]);
+            }
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)m[e];
+        y[i] = __builtin_bit_cast(u32x4, o);
+    }
+}
+
+// nn.PixelShuffle(2): y[b,2Y+i,2X+j,k] = x[b,Y,X,4k+2i+j]; one lane = 8 output channels
+__global__ void pixel_shuffle2_bf16_kernel(const __bf16* __restrict__ x, u32x4* __restrict__ y, int h, int w, int C, long long total) {
+    const int Co8 = C >> 5, W2 = 2 * w, H2 = 2 * h;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int k8 = (int)(i % Co8);
+        long long r = i / Co8;
+        const int X = (int)(r % W2); r /= W2;
+        const int Y = (int)(r % H2);
+        const long long b = r / H2;
+        const int sub = ((Y & 1) << 1) | (X & 1);
+        const __bf16* src = x + ((b * h + (Y >> 1)) * w + (X >> 1)) * C + (k8 << 5) + sub;
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = src[4 * e];
+        y[i] = __builtin_bit_cast(u32x4, v);
+    }
+}
+
+__global__ void upsample_add_bf16_kernel(const u32x4* __restrict__ x, const u32x4* base, u32x4* y, int h, int w, int C8, int f, int relu,
+                                         long long total) {
+    const int W = w * f, H = h * f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C8);
+        long long r = i / C8;
+        const int X = (int)(r % W); r /= W;
+        const int Y = (int)(r % H);
+        const long long b = r / H;
+        const bf16x8 a = __builtin_bit_cast(bf16x8, x[((b * h + Y / f) * w + X / f) * C8 + c]);
+        const bf16x8 v = __builtin_bit_cast(bf16x8, base[i]);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float t = (float)v[e] + (float)a[e];
+            if (relu) t = t > 0.f ? t : 0.f;
+            o[e] = (__bf16)t;
+        }
+        y[i] = __builtin_bit_cast(u32x4, o);
+    }
+}
+
+}  // namespace
+
+extern "C" int sp_nchw_to_nhwc8_bf16(const float* x, void* y, int batch, int channels, int h, int w, void* stream) {
+    SP_REQUIRE(x && y, "sp_nchw_to_nhwc8_bf16: null pointer");
+    SP_REQUIRE(batch > 0 && h > 0 && w > 0 && channels >= 1 && channels <= 8, "sp_nchw_to_nhwc8_bf16: bad shape");
+    const long long total = (long long)batch * h * w;
+    SP_REQUIRE(total * 8 < (1ll << 30), "sp_nchw_to_nhwc8_bf16: tensor too large");
+    hipLaunchKernelGGL(nchw_to_nhwc8_bf16_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, reinterpret_cast<u32x4*>(y),
+                       channels, h * w, total);
+    return sp_check_launch("nchw_to_nhwc8_bf16_kernel");
+}
+
+extern "C" int sp_maxpool3x3s2_nhwc_bf16(const void* x, void* y, int batch, int h, int w, int c, void* stream) {
+    SP_REQUIRE(x && y, "sp_maxpool3x3s2_nhwc_bf16: null pointer");
+    SP_REQUIRE(batch > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0, "sp_maxpool3x3s2_nhwc_bf16: bad shape (c %% 8 != 0?)");
+    const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+    const long long total = (long long)batch * ho * wo * (c / 8);
+    SP_REQUIRE((long long)batch * h * w * c < (1ll << 30), "sp_maxpool3x3s2_nhwc_bf16: tensor too large");
+    hipLaunchKernelGGL(maxpool3x3s2_bf16_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const u32x4*>(x), reinterpret_cast<u32x4*>(y), h, w, c / 8, ho, wo, total);
+    return sp_check_launch("maxpool3x3s2_bf16_kernel");
+}
+
+extern "C" int sp_pixel_shuffle2_nhwc_bf16(const void* x, void* y, int batch, int h, int w, int c, void* stream) {
+    SP_REQUIRE(x && y, "sp_pixel_shuffle2_nhwc_bf16: null pointer");
+    SP_REQUIRE(batch > 0 && h > 0 && w > 0 && c > 0 && c % 32 == 0, "sp_pixel_shuffle2_nhwc_bf16: c=%d must be a multiple of 32", c);
+    const long long total = (long long)batch * h * w * c / 8;
+    hipLaunchKernelGGL(pixel_shuffle2_bf16_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const __bf16*>(x), reinterpret_cast<u32x4*>(y), h, w, c, total);
+    return sp_check_launch("pixel_shuffle2_bf16_kernel");
+}
+
+extern "C" int sp_upsample_add_nhwc_bf16(const void* x, const void* base, void* y, int batch, int h, int w, int c, int factor, int relu,
+                                         void* stream) {
+    SP_REQUIRE(x && base && y, "sp_upsample_add_nhwc_bf16: null pointer");
+    SP_REQUIRE(batch > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0 && factor >= 1, "sp_upsample_add_nhwc_bf16: bad shape");
+    const long long total = (long long)batch * h * factor * w * factor * (c / 8);
+    hipLaunchKernelGGL(upsample_add_bf16_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const u32x4*>(x), reinterpret_cast<const u32x4*>(base), reinterpret_cast<u32x4*>(y), h, w, c / 8, factor,
+                       relu, total);
+    return sp_check_launch("upsample_add_bf16_kernel");
+}

@@ -19,7 +19,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, SP_CONV_OUT_NCHW, SP_CONV_PIXEL_SHUFFLE, SP_CONV_RELU
+from ._lib import ConvDesc, SP_CONV_BF16, SP_CONV_OUT_NCHW, SP_CONV_PIXEL_SHUFFLE, SP_CONV_RELU
 
 BN_EPS = 1e-5
 
@@ -50,7 +50,7 @@ def fold_bn(weight, bias, running_mean, running_var, eps: float = BN_EPS):
 
 
 def pack_conv(w: torch.Tensor, c_in_pad: Optional[int] = None, taps_w_pad: Optional[int] = None,
-              row_perm: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, int, int, int, int]:
+              row_perm: Optional[torch.Tensor] = None, k_mult: int = 32) -> Tuple[torch.Tensor, int, int, int, int]:
     """Conv2d weight [O,I,kh,kw] -> packed [n_pad, k_pad] with K ordered (ky, kx, c), c fastest.
     Returns (packed, taps_h, taps_w, c_in_packed, k_pad)."""
     O, I, kh, kw = w.shape
@@ -63,7 +63,7 @@ def pack_conv(w: torch.Tensor, c_in_pad: Optional[int] = None, taps_w_pad: Optio
     if row_perm is not None:
         p = p[row_perm]
     k = kh * tw * ci
-    k_pad = _round_up(k, 32)
+    k_pad = _round_up(k, k_mult)   # one K tile = 128 bytes: 32 fp32 / 64 bf16
     n_pad = n_pad_for(O)
     out = torch.zeros((n_pad, k_pad), dtype=torch.float32, device=w.device)
     out[:O, :k] = p
@@ -122,6 +122,7 @@ class Program:
     out_shape: Tuple[int, int, int] = (17, 64, 48)                          # NCHW per image
     _pools: Dict[int, Dict[str, torch.Tensor]] = field(default_factory=dict)
     tuned_for_batch: int = 0
+    dtype: str = "fp32"                                                     # activation / weight dtype: "fp32" | "bf16"
 
     # -- buffer planning: greedy reuse of dead activations (keeps the working set small for L2 / MALL) --
     def _alloc(self, batch: int, device) -> Dict[str, torch.Tensor]:
@@ -140,7 +141,8 @@ class Program:
                 h, w, c = self.shapes[op.dst]
                 n = batch * h * w * c
                 pool = free.get(n)
-                bufs[op.dst] = pool.pop() if pool else torch.empty(n, dtype=torch.float32, device=device)
+                bufs[op.dst] = pool.pop() if pool else torch.empty(
+                    n, dtype=torch.bfloat16 if self.dtype == "bf16" else torch.float32, device=device)
             for nm in (op.src, op.res) + ((op.args[2],) if op.kind == "se_gate" else ()):
                 if nm and nm in bufs and last_use[nm] == i and nm != "input":
                     free.setdefault(bufs[nm].numel(), []).append(bufs[nm])
@@ -164,13 +166,16 @@ class Program:
                                              P(bufs[op.res]) if op.res else None, P(bufs[op.dst]), stream), op.name)
             elif op.kind == "maxpool":
                 h, w, c = op.args
-                _lib.check(lib.sp_maxpool3x3s2_nhwc(P(bufs[op.src]), P(bufs[op.dst]), B, h, w, c, stream), op.name)
+                fn = lib.sp_maxpool3x3s2_nhwc_bf16 if self.dtype == "bf16" else lib.sp_maxpool3x3s2_nhwc
+                _lib.check(fn(P(bufs[op.src]), P(bufs[op.dst]), B, h, w, c, stream), op.name)
             elif op.kind == "to_nhwc4":
                 c, h, w = op.args
-                _lib.check(lib.sp_nchw_to_nhwc4(P(bufs[op.src]), P(bufs[op.dst]), B, c, h, w, stream), op.name)
+                fn = lib.sp_nchw_to_nhwc8_bf16 if self.dtype == "bf16" else lib.sp_nchw_to_nhwc4
+                _lib.check(fn(P(bufs[op.src]), P(bufs[op.dst]), B, c, h, w, stream), op.name)
             elif op.kind == "pixel_shuffle":
                 h, w, c = op.args
-                _lib.check(lib.sp_pixel_shuffle2_nhwc(P(bufs[op.src]), P(bufs[op.dst]), B, h, w, c, stream), op.name)
+                fn = lib.sp_pixel_shuffle2_nhwc_bf16 if self.dtype == "bf16" else lib.sp_pixel_shuffle2_nhwc
+                _lib.check(fn(P(bufs[op.src]), P(bufs[op.dst]), B, h, w, c, stream), op.name)
             elif op.kind == "gap":
                 hw, c = op.args
                 _lib.check(lib.sp_global_avg_pool_nhwc(P(bufs[op.src]), P(bufs[op.dst]), B, hw, c, stream), op.name)
@@ -180,8 +185,8 @@ class Program:
                                                         stream), op.name)
             elif op.kind == "upsample_add":
                 h, w, c, f, relu = op.args
-                _lib.check(lib.sp_upsample_add_nhwc(P(bufs[op.src]), P(bufs[op.res]), P(bufs[op.dst]), B, h, w, c, f, relu,
-                                                    stream), op.name)
+                fn = lib.sp_upsample_add_nhwc_bf16 if self.dtype == "bf16" else lib.sp_upsample_add_nhwc
+                _lib.check(fn(P(bufs[op.src]), P(bufs[op.res]), P(bufs[op.dst]), B, h, w, c, f, relu, stream), op.name)
             else:
                 raise ValueError(op.kind)
         return out
@@ -251,8 +256,12 @@ class Program:
 class ProgramBuilder:
     """Appends launches to a Program while tracking NHWC buffer shapes."""
 
-    def __init__(self, in_h: int, in_w: int):
-        self.p = Program()
+    def __init__(self, in_h: int, in_w: int, dtype: str = "fp32"):
+        if dtype not in ("fp32", "bf16"):
+            raise ValueError(dtype)
+        self.p = Program(dtype=dtype)
+        self.bf16 = dtype == "bf16"
+        self.cpad = 8 if self.bf16 else 4           # channels per 16-byte chunk
         self.p.shapes["input"] = (in_h, in_w, 3)
         self._n = 0
 
@@ -263,7 +272,7 @@ class ProgramBuilder:
     def to_nhwc4(self, src: str) -> str:
         h, w, c = self.p.shapes[src]
         dst = self._fresh("x4")
-        self.p.shapes[dst] = (h, w, 4)
+        self.p.shapes[dst] = (h, w, self.cpad)
         self.p.ops.append(Op("to_nhwc4", src, dst, args=(c, h, w), name="to_nhwc4"))
         return dst
 
@@ -279,13 +288,14 @@ class ProgramBuilder:
              dst: Optional[str] = None, name: str = "conv") -> str:
         h, w, c_buf = self.p.shapes[src]
         O, I, kh, kw = weight.shape
-        if c_buf == 4 and I < 4:           # stem on NHWC4: pad channels to 4 and the tap row to 8 -> 128-B K rows
+        k_mult = 64 if self.bf16 else 32
+        if c_buf == self.cpad and I < self.cpad:   # stem on NHWC4 / NHWC8: pad channels to one chunk and the tap row to 8 / 4
             taps_w_pad = _round_up(kw, 8) if kw > 4 else 4
-            packed, th, tw, ci, k_pad = pack_conv(weight, c_in_pad=4, taps_w_pad=taps_w_pad)
+            packed, th, tw, ci, k_pad = pack_conv(weight, c_in_pad=self.cpad, taps_w_pad=taps_w_pad, k_mult=k_mult)
         else:
             assert I == c_buf, (name, I, c_buf)
             perm = pixel_shuffle_row_perm(O, weight.device) if pixel_shuffle else None
-            packed, th, tw, ci, k_pad = pack_conv(weight, row_perm=perm)
+            packed, th, tw, ci, k_pad = pack_conv(weight, row_perm=perm, k_mult=k_mult)
             if pixel_shuffle:
                 scale = scale[perm].contiguous() if scale is not None else None
                 shift = shift[perm].contiguous() if shift is not None else None
@@ -308,6 +318,9 @@ class ProgramBuilder:
         d.oy_add = d.ox_add = 0
         if out_nchw:
             flags |= SP_CONV_OUT_NCHW
+        if self.bf16:
+            flags |= SP_CONV_BF16
+            packed = packed.to(torch.bfloat16)
         d.flags = flags
         dst = dst or self._fresh(name)
         self.p.shapes[dst] = (d.out_h, d.out_w, d.out_c)
@@ -329,7 +342,9 @@ class ProgramBuilder:
         d.out_h, d.out_w, d.out_c = 2 * h, 2 * w, O
         d.oy_mul, d.oy_add, d.ox_mul, d.ox_add = 2, 0, 2, 0    # + phase
         d.phases_y = d.phases_x = 2
-        d.flags = SP_CONV_RELU if relu else 0
+        d.flags = (SP_CONV_RELU if relu else 0) | (SP_CONV_BF16 if self.bf16 else 0)
+        if self.bf16:
+            packed = packed.to(torch.bfloat16)
         dst = self._fresh(name)
         self.p.shapes[dst] = (2 * h, 2 * w, O)
         self.p.ops.append(Op("conv", src, dst, desc=d, w=packed.reshape(4 * n_pad, 4 * I), scale=scale, shift=shift,
@@ -344,6 +359,8 @@ class ProgramBuilder:
         return dst
 
     def gap(self, src: str) -> str:
+        if self.bf16:
+            raise NotImplementedError("SELayer is lowered in fp32 only")
         h, w, c = self.p.shapes[src]
         dst = self._fresh("gap")
         self.p.shapes[dst] = (1, 1, c)
@@ -396,9 +413,9 @@ def _bottleneck(b: ProgramBuilder, sd, x: str, p: str, stride: int) -> str:
 
 
 def resnet_program(sd: Dict[str, torch.Tensor], head: str, in_h: int = 256, in_w: int = 192,
-                   blocks=(3, 4, 6, 3)) -> Program:
+                   blocks=(3, 4, 6, 3), dtype: str = "fp32") -> Program:
     """Lower a reference-layout state_dict into a Program.  `sd` tensors must be on the GPU."""
-    b = ProgramBuilder(in_h, in_w)
+    b = ProgramBuilder(in_h, in_w, dtype)
     x = b.to_nhwc4("input")
     s, h = _bn(sd, "bn1")
     x = b.conv(x, sd["conv1.weight"], stride=2, pad=3, scale=s, shift=h, relu=True, name="conv1")
@@ -476,10 +493,10 @@ def _hr_module(b: ProgramBuilder, sd, xs: List[str], base: str, num_blocks: List
     return outs
 
 
-def hrnet_program(sd: Dict[str, torch.Tensor], cfg: dict, in_h: int = 256, in_w: int = 192) -> Program:
+def hrnet_program(sd: Dict[str, torch.Tensor], cfg: dict, in_h: int = 256, in_w: int = 192, dtype: str = "fp32") -> Program:
     """Lower a reference-layout HRNet state_dict into a Program (PoseHighResolutionNet.forward, pose_hrnet.py:419-454)."""
     extra = cfg["MODEL"]["EXTRA"]
-    b = ProgramBuilder(in_h, in_w)
+    b = ProgramBuilder(in_h, in_w, dtype)
     x = b.to_nhwc4("input")
     s, h = _bn(sd, "bn1")
     x = b.conv(x, sd["conv1.weight"], stride=2, pad=1, scale=s, shift=h, relu=True, name="conv1")

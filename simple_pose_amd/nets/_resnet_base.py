@@ -62,6 +62,7 @@ class PoseResNetBase(nn.Module):
             setattr(self, f"layer{li}", nn.Sequential(*blocks))
         self._build_head(inplanes, num_classes)
         self._init_like_reference()
+        self.compute_dtype = "fp32"   # "bf16": bf16 activations/weights with fp32 accumulation (master weights stay fp32)
         self.autotune = True  # time the legal tile shapes per layer on first use (batch >= 16); speed only
         self._program: Optional[engine.Program] = None
         self._program_key = None
@@ -83,7 +84,7 @@ class PoseResNetBase(nn.Module):
     # -- HIP dispatch ------------------------------------------------------------------------------------
     def _tensors_key(self, x):
         sd = self.state_dict(keep_vars=True)
-        return (tuple(x.shape[2:]), str(x.device)) + tuple((v.data_ptr(), v._version) for v in sd.values())
+        return (tuple(x.shape[2:]), str(x.device), self.compute_dtype) + tuple((v.data_ptr(), v._version) for v in sd.values())
 
     def hip_program(self, x: torch.Tensor) -> engine.Program:
         key = self._tensors_key(x)
@@ -92,7 +93,8 @@ class PoseResNetBase(nn.Module):
             for k, v in sd.items():
                 if v.device != x.device:
                     raise HipLibraryError(f"parameter {k} is on {v.device} but the input is on {x.device}; call .to(device)")
-            self._program = engine.resnet_program(sd, self.HEAD, in_h=x.shape[2], in_w=x.shape[3], blocks=self.BLOCKS)
+            self._program = engine.resnet_program(sd, self.HEAD, in_h=x.shape[2], in_w=x.shape[3], blocks=self.BLOCKS,
+                                                   dtype=self.compute_dtype)
             self._program_key = key
         return self._program
 

@@ -98,6 +98,7 @@ class PoseHighResolutionNet(ParamTree):
         super().__init__(hrnet_state_dict_shapes(cfg, joint_num))
         self.cfg = cfg
         self.joint_num = joint_num
+        self.compute_dtype = "fp32"   # "bf16": bf16 activations/weights with fp32 accumulation (master weights stay fp32)
         self.autotune = True
         self._program: Optional[engine.Program] = None
         self._program_key = None
@@ -111,12 +112,13 @@ class PoseHighResolutionNet(ParamTree):
 
     def hip_program(self, x: torch.Tensor) -> engine.Program:
         sd = self.state_dict(keep_vars=True)
-        key = (tuple(x.shape[2:]), str(x.device)) + tuple((v.data_ptr(), v._version) for v in sd.values())
+        key = (tuple(x.shape[2:]), str(x.device), self.compute_dtype) + tuple((v.data_ptr(), v._version) for v in sd.values())
         if self._program is None or key != self._program_key:
             for k, v in sd.items():
                 if v.device != x.device:
                     raise HipLibraryError(f"parameter {k} is on {v.device} but the input is on {x.device}; call .to(device)")
-            self._program = engine.hrnet_program({k: v.detach() for k, v in sd.items()}, self.cfg, x.shape[2], x.shape[3])
+            self._program = engine.hrnet_program({k: v.detach() for k, v in sd.items()}, self.cfg, x.shape[2], x.shape[3],
+                                                  dtype=self.compute_dtype)
             self._program_key = key
         return self._program
 

@@ -6,7 +6,7 @@ product path and not a fallback: simple_pose_amd never imports it.
 """
 import torch
 
-from simple_pose_amd._lib import SP_CONV_OUT_NCHW, SP_CONV_PIXEL_SHUFFLE, SP_CONV_RELU
+from simple_pose_amd._lib import SP_CONV_BF16, SP_CONV_OUT_NCHW, SP_CONV_PIXEL_SHUFFLE, SP_CONV_RELU
 
 
 def conv_desc_cpu(d, x, w, scale, shift, res, y, B):
@@ -24,7 +24,7 @@ def conv_desc_cpu(d, x, w, scale, shift, res, y, B):
                 ix = gx * d.stride + d.dx0 + px + tx * d.dx_step
                 ok = ((iy >= 0) & (iy < d.in_h) & (ix >= 0) & (ix < d.in_w))
                 iyc, ixc = iy.clamp(0, d.in_h - 1).expand(d.grid_h, d.grid_w), ix.clamp(0, d.in_w - 1).expand(d.grid_h, d.grid_w)
-                g = x[:, iyc, ixc, :] * ok.expand(d.grid_h, d.grid_w)[None, :, :, None]
+                g = x[:, iyc, ixc, :].float() * ok.expand(d.grid_h, d.grid_w)[None, :, :, None]
                 cols.append(g)
         A = torch.cat(cols, dim=-1)  # [B,gh,gw,taps*c_in]
         k = A.shape[-1]
@@ -45,7 +45,7 @@ def conv_desc_cpu(d, x, w, scale, shift, res, y, B):
                     part = part + res[:, yy][:, :, xx].double()
                 if d.flags & SP_CONV_RELU:
                     part = part.clamp(min=0)
-                y[:, yy.view(-1, 1), xx.view(1, -1), :] = part.float()
+                y[:, yy.view(-1, 1), xx.view(1, -1), :] = part.float().to(y.dtype)
             continue
         if res is not None:
             acc = acc + res[:, oy][:, :, ox].double()
@@ -54,23 +54,25 @@ def conv_desc_cpu(d, x, w, scale, shift, res, y, B):
         if d.flags & SP_CONV_OUT_NCHW:
             y[:, :, oy.view(-1, 1), ox.view(1, -1)] = acc.permute(0, 3, 1, 2).float()
         else:
-            y[:, oy.view(-1, 1), ox.view(1, -1), :] = acc.float()
+            y[:, oy.view(-1, 1), ox.view(1, -1), :] = acc.float().to(y.dtype)
 
 
 def run_program_cpu(prog, x):
     B = x.shape[0]
+    act_dt = torch.bfloat16 if prog.dtype == "bf16" else torch.float32
     bufs = {"input": x}
     for op in prog.ops:
         if op.kind == "to_nhwc4":
             c, h, w = op.args
-            t = torch.zeros((B, h, w, 4))
+            cp = prog.shapes[op.dst][2]
+            t = torch.zeros((B, h, w, cp))
             t[..., :c] = bufs[op.src].permute(0, 2, 3, 1)
-            bufs[op.dst] = t
+            bufs[op.dst] = t.to(act_dt)
         elif op.kind == "maxpool":
-            t = torch.nn.functional.max_pool2d(bufs[op.src].permute(0, 3, 1, 2), 3, 2, 1)
+            t = torch.nn.functional.max_pool2d(bufs[op.src].float().permute(0, 3, 1, 2), 3, 2, 1).to(act_dt)
             bufs[op.dst] = t.permute(0, 2, 3, 1).contiguous()
         elif op.kind == "pixel_shuffle":
-            t = torch.nn.functional.pixel_shuffle(bufs[op.src].permute(0, 3, 1, 2), 2)
+            t = torch.nn.functional.pixel_shuffle(bufs[op.src].float().permute(0, 3, 1, 2), 2).to(act_dt)
             bufs[op.dst] = t.permute(0, 2, 3, 1).contiguous()
         elif op.kind == "gap":
             bufs[op.dst] = bufs[op.src].mean(dim=(1, 2), keepdim=True)
@@ -79,16 +81,16 @@ def run_program_cpu(prog, x):
             bufs[op.dst] = torch.relu(bufs[op.src] * torch.sigmoid(bufs[gate]) + bufs[op.res])
         elif op.kind == "upsample_add":
             h, w, c, f, relu = op.args
-            up = bufs[op.src].repeat_interleave(f, 1).repeat_interleave(f, 2)
-            t = bufs[op.res] + up
-            bufs[op.dst] = t.clamp(min=0) if relu else t
+            up = bufs[op.src].float().repeat_interleave(f, 1).repeat_interleave(f, 2)
+            t = bufs[op.res].float() + up
+            bufs[op.dst] = (t.clamp(min=0) if relu else t).to(act_dt)
         elif op.kind == "conv":
             d = op.desc
             d.batch = B
             if op.dst == prog.out_name:
                 y = torch.full((B,) + tuple(prog.out_shape), float("nan"))
             else:
-                y = torch.full((B, d.out_h, d.out_w, d.out_c), float("nan"))
+                y = torch.full((B, d.out_h, d.out_w, d.out_c), float("nan"), dtype=act_dt)
             conv_desc_cpu(d, bufs[op.src], op.w, op.scale, op.shift, bufs[op.res] if op.res else None, y, B)
             assert not torch.isnan(y).any(), f"{op.name}: launch does not cover its output"
             bufs[op.dst] = y

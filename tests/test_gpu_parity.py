@@ -367,3 +367,78 @@ def test_se_variant_forward_vs_reference_golden(golden):
     ref = g["heat_maps"]
     assert np.abs(hm.cpu().numpy() - ref).max() / np.abs(ref).max() <= 1e-4
     assert torch.equal(hm32[17], hm[0])
+
+
+# ---------------------------------------------------------------------------------------------- bf16 operand path
+def _bf16_round(t):
+    return t.to(torch.bfloat16).float()
+
+
+BF16_CASES = [("1x1_64_256", 2, 64, 16, 12, 256, 1, 1, 0), ("3x3_s1_64", 2, 64, 16, 12, 64, 3, 1, 1), ("3x3_s2_128", 2, 128, 16, 12, 128, 3, 2, 1),
+              ("1x1_s2_256_512", 2, 256, 16, 12, 512, 1, 2, 0), ("3x3_512_ragged_M", 1, 512, 8, 6, 512, 3, 1, 1),
+              ("3x3_32_32_hrnet", 2, 32, 16, 12, 32, 3, 1, 1), ("1x1_2048_512", 2, 2048, 8, 6, 512, 1, 1, 0), ("3x3_bigM_128", 8, 128, 32, 24, 128, 3, 1, 1)]
+
+
+@pytest.mark.parametrize("case", BF16_CASES, ids=[c[0] for c in BF16_CASES])
+def test_bf16_conv_vs_torch_on_rounded_operands(case):
+    """SP_CONV_BF16: bf16 operands, fp32 accumulation.  Reference = fp64 conv of the SAME bf16-rounded operands, so the
+    only differences are fp32 accumulation order and the final bf16 rounding of the output (2^-9 relative)."""
+    name, B, Cin, H, W, Cout, k, s, p = case
+    w = _bf16_round(torch.from_numpy(synth.tensor_normal(1, name + "/w", (Cout, Cin, k, k), std=(2.0 / (Cin * k * k)) ** 0.5)))
+    x = _bf16_round(torch.from_numpy(synth.tensor_normal(1, name + "/x", (B, Cin, H, W))))
+    scale = torch.from_numpy(synth.tensor_uniform(1, name + "/s", (Cout,), 0.5, 1.5))
+    shift = torch.from_numpy(synth.tensor_normal(1, name + "/b", (Cout,), std=0.3))
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), stride=s, padding=p)
+    ref = ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    res = _bf16_round(torch.from_numpy(synth.tensor_normal(1, name + "/r", tuple(ref.shape))))
+    ref = torch.relu(ref + res.double())
+    bld = engine.ProgramBuilder(H, W, dtype="bf16")
+    bld.p.shapes["input"] = (H, W, Cin)
+    bld.p.shapes["res"] = tuple(ref.shape[2:]) + (Cout,)
+    out = bld.conv("input", w.to(DEV), stride=s, pad=p, scale=scale.to(DEV), shift=shift.to(DEV), relu=True, res="res")
+    prog = bld.p
+    prog.out_name = out
+    prog.out_shape = prog.shapes[out]
+    pool = prog._alloc(B, torch.device(DEV))
+    pool["res"] = res.permute(0, 2, 3, 1).contiguous().to(DEV).to(torch.bfloat16)
+    xin = x.permute(0, 2, 3, 1).contiguous().to(DEV).to(torch.bfloat16)
+    # run by hand: the program's generic run() allocates an fp32 output for out_name; here the output is a bf16 NHWC buffer
+    y = torch.empty((B,) + tuple(prog.out_shape), dtype=torch.bfloat16, device=DEV)
+    op = prog.ops[-1]
+    op.desc.batch = B
+    _lib.check(_lib.lib().sp_conv2d_fwd(op.desc, _lib.ptr(xin), _lib.ptr(op.w), _lib.ptr(op.scale), _lib.ptr(op.shift), _lib.ptr(pool["res"]),
+                                        _lib.ptr(y), _lib.current_stream()))
+    torch.cuda.synchronize()
+    got = y.float().cpu().permute(0, 3, 1, 2).double()
+    err = (got - ref).abs().max() / ref.abs().max()
+    assert err < 6e-3, err            # output rounding to bf16: 2^-8 of the value
+
+
+@pytest.mark.parametrize("arch", ["dconv", "duc", "hrnet_w32"])
+def test_bf16_forward_vs_fp32_reference_golden(golden, arch):
+    """BASELINE configs 3 and 5 (bf16 compute): heat maps against the fp32 reference within the bf16 tolerance the CPU
+    autocast path itself shows (1.07e-2 relative), and against our own fp32 path."""
+    import os
+    if arch == "hrnet_w32":
+        from simple_pose_amd.nets.pose_hrnet import get_pose_net, hrnet_state_dict_shapes
+        g = golden("g3_hrnet_w32_fwd.npz")
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        m = get_pose_net(os.path.join(root, "simple_pose_amd", "nets", "hrnet_w32.yaml"), pretrained=None, joint_num=17)
+        sd = synth.conditioned_state_dict(hrnet_state_dict_shapes(m.cfg, 17), int(g["seed"]))
+    else:
+        g = golden({"dconv": "g1_dconv_fwd.npz", "duc": "g2_duc_fwd.npz"}[arch])
+        m = {"dconv": pose_resnet_dconv, "duc": pose_resnet_duc}[arch].resnet50(pretrained=False, num_classes=17)
+        sd = synth.conditioned_state_dict(nets_oracle.state_dict_shapes_resnet50(arch), int(g["seed"]))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m = m.to(DEV).eval()
+    B = int(g["batch"])
+    x = _cuda(synth.input_images(B, int(g["seed"])))
+    with torch.no_grad():
+        hm32 = m(x)
+        m.compute_dtype = "bf16"
+        hm16 = m(x)
+    assert hm16.dtype == torch.float32 and hm16.shape == hm32.shape
+    ref = g["heat_maps"]
+    rel = np.abs(hm16.cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert 1e-5 < rel <= 4e-2, rel
+    assert np.abs(hm32.cpu().numpy() - ref).max() / np.abs(ref).max() <= 1e-4     # switching back and forth re-packs
