@@ -33,6 +33,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=128, help="images per GPU per step")
     ap.add_argument("--arch", default="dconv", choices=["dconv", "duc", "hrnet_w32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL over xGMI, default); gloo only to exercise the N > 1 code path on a single-GPU box")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="compute dtype of the network (BASELINE metric: f32)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
                     help="infer = forward + GaussTaylor decode (BASELINE metric, default); train = fwd+bwd+Adam step (config 4, fp32)")
@@ -101,16 +103,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank % max(n_dev, 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     elif args.gpus > 1:
         raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
+    red_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")   # where the measurement's scalar reductions live
 
     from oracle import nets_oracle  # only for the reference state_dict LAYOUT (names/shapes) of the synthetic weights
     from simple_pose_amd import _lib, synth
@@ -186,7 +193,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     from simple_pose_amd.sharding import aggregate_throughput
-    total_images, elapsed, value = aggregate_throughput(float(B * args.steps), elapsed, device=dev)  # SUM units / MAX time
+    total_images, elapsed, value = aggregate_throughput(float(B * args.steps), elapsed, device=red_dev)  # SUM units / MAX time
     assert os.environ.get("SP_CONV_DEBUG") or torch.isfinite(out[0]).all()
 
     ms_per_step = 1e3 * elapsed / args.steps

@@ -125,6 +125,17 @@ int sp_decode_gauss_taylor(const float* heat_nchw, const float* trans_inv, int b
 int sp_decode_basic(const float* heat_nchw, const float* trans_inv, int batch, int joints, int h, int w, float* kps,
                     float* max_val, void* stream);
 
+/* HeatMapAcc.__call__ (:212-245) on the arg-max coordinates of predictions and targets (two sp_heat_map_to_axis calls):
+ * acc_out = one device float, no host sync (the reference's .item() calls at :237 are gone) */
+int sp_heat_map_acc(const float* pred_coords, const float* label_coords, int batch, int joints, int h, int w,
+                    float distance_thresh, float norm_frac, float* acc_out, void* stream);
+
+/* ---- input contract: datasets/coco.py:124-148 (collate_fn) -----------------------------------------
+ * BGR u8 HWC crops [B,h,w,3] (device) -> RGB fp32 NCHW [B,3,h,w] = x/255 - mean_rgb[c] (no std division, coco.py:136);
+ * mean_rgb_host: 3 floats in HOST memory */
+int sp_u8hwc_bgr_to_nchw_f32(const unsigned char* img, float* out, int batch, int h, int w, const float* mean_rgb_host,
+                             void* stream);
+
 /* ---- encoders: commons/transforms.py ----------------------------------------------------------- */
 
 /* RefineSimpleTransform.get_heat_map (:167-191), batched: joints [B,J,3] (x,y,vis in heat-map px) ->

@@ -12,6 +12,7 @@ is committed - never reference source.  Fixture inventory
                      maps, edge cases; identity-scale and random trans_inv
   g1s_dconv_se_fwd.npz  ResNet50-DConv + SELayer (reduction=True) eval forward, B=1, + key list
   g3_hrnet_w32_fwd.npz  HRNet-W32 eval forward, B=1, + the reference's state_dict key/shape list
+  g7_next.npz        HeatMapAcc values and collate_fn normalisation
   g6_train_step.npz  one reference training step (B=2): loss, gradient slices, BN running stats, params after Adam
   g5_encode.npz      encoders (Refine + Basic) incl. out-of-range / trunc-toward-zero / vis=0 cases
 """
@@ -86,6 +87,36 @@ def gen_se(ns):
     np.savez_compressed(os.path.join(GOLD, "g1s_dconv_se_fwd.npz"), heat_maps=hm, seed=SEED, batch=1, keys=np.array(list(sd.keys())),
                         shapes=np.array([",".join(str(d) for d in v.shape) for v in sd.values()]))
     print("g1s_dconv_se_fwd.npz", hm.shape, "absmax", np.abs(hm).max(), "keys", len(sd))
+
+
+def gen_next(ns):
+    """g7_next.npz: SURVEY 8(f) rows - HeatMapAcc on network maps vs encoder targets, and the collate_fn normalisation."""
+    import importlib, types
+    pm = ns.pose_metrics
+    acc = pm.HeatMapAcc()
+    g1 = np.load(os.path.join(GOLD, "g1_dconv_fwd.npz"))["heat_maps"]
+    out = {}
+    enc = ns.transforms.RefineSimpleTransform.get_heat_map
+    for tag, seed in (("a", 51), ("b", 52)):
+        joints = synth.joints_batch(2, 17, seed=seed)
+        tgt = np.stack([enc(joints[b], 2.0, (48, 64))[0] for b in range(2)])
+        # predictions = targets shifted / perturbed so that some joints hit and some miss
+        pred = np.roll(tgt, shift=(2 if tag == "a" else 7), axis=3) + 0.05 * g1
+        out[f"acc/{tag}/joints"] = joints
+        out[f"acc/{tag}/pred"] = pred.astype(np.float32)
+        out[f"acc/{tag}/value"] = np.float32(acc(torch.from_numpy(pred.astype(np.float32)), torch.from_numpy(tgt)).item())
+    coco = importlib.import_module("datasets.coco")
+    imgs = (synth.tensor_uniform(61, "u8img", (2, 32, 24, 3)) * 255.999).astype(np.uint8)
+    items = []
+    for i in range(2):
+        it = types.SimpleNamespace(img=imgs[i], img_path=f"/x/{i:012d}.jpg", heat_map=np.zeros((17, 8, 6), np.float32),
+                                   mask=np.ones(17, np.float32), trans_inv=np.eye(2, 3))
+        items.append(it)
+    inp, _, _, _, _ = coco.MSCOCO.collate_fn(items)
+    out["collate/img_u8"] = imgs
+    out["collate/input"] = inp.numpy()
+    np.savez_compressed(os.path.join(GOLD, "g7_next.npz"), **out)
+    print("g7_next.npz acc", out["acc/a/value"], out["acc/b/value"], "collate", inp.shape, inp.dtype)
 
 
 def gen_hrnet(ns):
@@ -269,6 +300,7 @@ def main():
     gen_encode(ns)
     gen_hrnet(ns)
     gen_se(ns)
+    gen_next(ns)
     gen_train(ns)
     del hm
 

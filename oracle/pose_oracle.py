@@ -105,3 +105,27 @@ def masked_mse(pred, target, mask, want_grad: bool = False):
     g = np.empty_like(pred) if want_grad else None
     loss = lib().sp_oracle_masked_mse(_p(pred), _p(target), _p(mask), B, J, H * W, _p(g) if want_grad else None)
     return (np.float32(loss), g) if want_grad else np.float32(loss)
+
+
+def heat_map_acc(pred, target, distance_thresh: float = 0.5, norm_frac: float = 10.0) -> np.float32:
+    """HeatMapAcc.__call__, metrics/pose_metrics.py:212-245 (numpy restatement on top of heat_map_to_axis)."""
+    p, _ = heat_map_to_axis(pred)
+    l, _ = heat_map_to_axis(target)
+    H, W = pred.shape[-2:]
+    norm = np.array([W, H], np.float32) / np.float32(norm_frac)            # :225-228
+    valid = (l[..., 0] > 1) & (l[..., 1] > 1)                              # :229
+    d = np.sqrt((((p / norm) - (l / norm)) ** 2).sum(-1, dtype=np.float32))  # :230
+    acc_sum, cnt = np.float32(0), 0
+    for j in range(d.shape[1]):                                           # :234-241
+        v = valid[:, j]
+        if v.sum() < 1:
+            continue
+        acc_sum += np.float32((d[v, j] < distance_thresh).sum()) / np.float32(v.sum())
+        cnt += 1
+    return np.float32(acc_sum / cnt) if cnt > 0 else np.float32(0)
+
+
+def normalize_crops(img_u8_bhwc_bgr, mean=(0.485, 0.456, 0.406)):
+    """datasets/coco.py:136 + :137: (img[..., ::-1].astype(float32) / 255.0 - rgb_mean), HWC -> CHW."""
+    x = img_u8_bhwc_bgr[..., ::-1].astype(np.float32) / np.float32(255.0) - np.asarray(mean, np.float32)
+    return np.ascontiguousarray(x.transpose(0, 3, 1, 2))

@@ -54,6 +54,8 @@ SYMBOLS = {
     "sp_heat_map_to_axis": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "sp_decode_gauss_taylor": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "sp_decode_basic": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "sp_heat_map_acc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P]),
+    "sp_u8hwc_bgr_to_nchw_f32": (c_int, [_P, _P, c_int, c_int, c_int, ctypes.POINTER(c_float), _P]),
     "sp_encode_gauss_refine": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P]),
     "sp_encode_gauss_basic": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, c_int, _P, _P, _P]),
     "sp_bn_train_stats_nhwc": (c_int, [_P, c_int64, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P]),

@@ -130,6 +130,48 @@ __global__ void se_gate_add_relu_kernel(const f32x4* __restrict__ x, const float
     }
 }
 
+// datasets/coco.py:136 collate normalisation on the GPU: BGR u8 HWC -> RGB fp32 NCHW, x/255 - mean[c] (no std division)
+__global__ void u8hwc_bgr_to_nchw_kernel(const unsigned char* __restrict__ img, float* __restrict__ out, int hw, float m0, float m1, float m2,
+                                         long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / hw;
+        const int pix = (int)(i - b * hw);
+        const unsigned char* p = img + i * 3;
+        float* o = out + b * 3 * hw + pix;
+        o[0] = (float)p[2] / 255.0f - m0;
+        o[hw] = (float)p[1] / 255.0f - m1;
+        o[2 * (long long)hw] = (float)p[0] / 255.0f - m2;
+    }
+}
+
+// metrics/pose_metrics.py:212-245 HeatMapAcc on arg-max coordinates: per joint, share of valid samples (label x,y > 1) whose
+// normalised distance |pred - label| / (W/f, H/f) is below the threshold; mean over joints that have a valid sample.
+__global__ __launch_bounds__(256) void heat_map_acc_kernel(const float* __restrict__ pred, const float* __restrict__ label, int B, int J,
+                                                           float nx, float ny, float thresh, float* __restrict__ acc) {
+    __shared__ float jacc[256];
+    __shared__ int jok[256];
+    for (int j = threadIdx.x; j < J; j += 256) {
+        int valid = 0, hit = 0;
+        for (int b = 0; b < B; ++b) {
+            const float lx = label[(b * J + j) * 2], ly = label[(b * J + j) * 2 + 1];
+            if (lx > 1.f && ly > 1.f) {
+                const float dx = pred[(b * J + j) * 2] / nx - lx / nx, dy = pred[(b * J + j) * 2 + 1] / ny - ly / ny;
+                ++valid;
+                if (sqrtf(dx * dx + dy * dy) < thresh) ++hit;
+            }
+        }
+        jok[j] = valid > 0;
+        jacc[j] = valid > 0 ? (float)hit / (float)valid : 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        int cnt = 0;
+        for (int j = 0; j < J; ++j) if (jok[j]) { s += jacc[j]; ++cnt; }
+        *acc = cnt > 0 ? s / (float)cnt : 0.f;
+    }
+}
+
 // masked MSE: per-block double partial sums (deterministic), then one block folds them.
 __global__ void mse_partial_kernel(const float* __restrict__ pred, const float* __restrict__ tgt, const float* __restrict__ mask,
                                    float* __restrict__ grad, int hw, long long total, double inv_n, double* __restrict__ part) {
@@ -192,6 +234,24 @@ extern "C" int sp_pixel_shuffle2_nhwc(const float* x, float* y, int batch, int h
     hipLaunchKernelGGL(pixel_shuffle2_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
                        reinterpret_cast<f32x4*>(y), h, w, c, total);
     return sp_check_launch("pixel_shuffle2_kernel");
+}
+
+extern "C" int sp_u8hwc_bgr_to_nchw_f32(const unsigned char* img, float* out, int batch, int h, int w, const float* mean_rgb_host, void* stream) {
+    SP_REQUIRE(img && out && mean_rgb_host, "sp_u8hwc_bgr_to_nchw_f32: null pointer");
+    SP_REQUIRE(batch > 0 && h > 0 && w > 0, "sp_u8hwc_bgr_to_nchw_f32: bad shape");
+    const long long total = (long long)batch * h * w;
+    hipLaunchKernelGGL(u8hwc_bgr_to_nchw_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, img, out, h * w,
+                       mean_rgb_host[0], mean_rgb_host[1], mean_rgb_host[2], total);
+    return sp_check_launch("u8hwc_bgr_to_nchw_kernel");
+}
+
+extern "C" int sp_heat_map_acc(const float* pred_coords, const float* label_coords, int batch, int joints, int h, int w, float distance_thresh,
+                               float norm_frac, float* acc_out, void* stream) {
+    SP_REQUIRE(pred_coords && label_coords && acc_out, "sp_heat_map_acc: null pointer");
+    SP_REQUIRE(batch > 0 && joints > 0 && joints <= 256 && h > 0 && w > 0 && norm_frac > 0.f, "sp_heat_map_acc: bad argument (joints <= 256)");
+    hipLaunchKernelGGL(heat_map_acc_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pred_coords, label_coords, batch, joints,
+                       (float)w / norm_frac, (float)h / norm_frac, distance_thresh, acc_out);
+    return sp_check_launch("heat_map_acc_kernel");
 }
 
 extern "C" int sp_global_avg_pool_nhwc(const float* x, float* y, int batch, int hw, int c, void* stream) {

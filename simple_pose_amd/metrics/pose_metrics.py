@@ -70,3 +70,22 @@ class GaussTaylorKeyPointDecoder(BasicKeyPointDecoder):
                                                      _lib.ptr(kps), _lib.ptr(max_val), _lib.current_stream()),
                    "sp_decode_gauss_taylor")
         return kps, max_val
+
+
+class HeatMapAcc(object):
+    """PCK-style training accuracy, drop-in for `metrics/pose_metrics.py:212-245`: arg-max of predictions and targets (HIP),
+    then the per-joint hit rate in one small kernel.  Returns a 0-dim device tensor; nothing syncs with the host."""
+
+    def __init__(self, distance_thresh=0.5, norm_frac=10.):
+        self.distance_thresh = distance_thresh
+        self.norm_frac = norm_frac
+
+    @torch.no_grad()
+    def __call__(self, predicts: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+        preds, _ = BasicKeyPointDecoder.heat_map_to_axis(predicts)
+        labels, _ = BasicKeyPointDecoder.heat_map_to_axis(targets)
+        B, J, H, W = predicts.shape
+        acc = torch.empty((), dtype=torch.float32, device=predicts.device)
+        _lib.check(_lib.lib().sp_heat_map_acc(_lib.ptr(preds), _lib.ptr(labels), B, J, H, W, float(self.distance_thresh),
+                                              float(self.norm_frac), _lib.ptr(acc), _lib.current_stream()), "sp_heat_map_acc")
+        return acc

@@ -442,3 +442,17 @@ def test_bf16_forward_vs_fp32_reference_golden(golden, arch):
     rel = np.abs(hm16.cpu().numpy() - ref).max() / np.abs(ref).max()
     assert 1e-5 < rel <= 4e-2, rel
     assert np.abs(hm32.cpu().numpy() - ref).max() / np.abs(ref).max() <= 1e-4     # switching back and forth re-packs
+
+
+def test_heat_map_acc_and_collate_normalisation_vs_reference_golden(golden):
+    from simple_pose_amd.datasets.coco import normalize_crops
+    from simple_pose_amd.metrics.pose_metrics import HeatMapAcc
+    g = golden("g7_next.npz")
+    acc = HeatMapAcc()
+    for tag in ("a", "b"):
+        tgt, _ = RefineSimpleTransform.get_heat_map(_cuda(g[f"acc/{tag}/joints"]), 2.0, (48, 64))
+        val = acc(_cuda(g[f"acc/{tag}/pred"]), tgt)
+        assert val.is_cuda and val.dim() == 0
+        assert abs(val.item() - float(g[f"acc/{tag}/value"])) < 1e-6
+    x = normalize_crops(_cuda(g["collate/img_u8"]))
+    assert np.array_equal(x.cpu().numpy(), g["collate/input"])          # bit exact: x/255 - mean in fp32

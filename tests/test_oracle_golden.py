@@ -143,3 +143,12 @@ def test_se_variant_oracle_and_key_layout_match_reference(golden):
     with torch.no_grad():
         hm = nets_oracle.resnet_dconv_forward(sd, torch.from_numpy(synth.input_images(1, int(g["seed"])))).numpy()
     assert np.abs(hm - g["heat_maps"]).max() / np.abs(g["heat_maps"]).max() <= 1e-5
+
+
+def test_next_rows_oracle_matches_reference(golden):
+    """HeatMapAcc and the collate_fn normalisation."""
+    g = golden("g7_next.npz")
+    for tag in ("a", "b"):
+        tgt, _ = pose_oracle.encode_refine(g[f"acc/{tag}/joints"], 2.0, (48, 64))
+        assert abs(float(pose_oracle.heat_map_acc(g[f"acc/{tag}/pred"], tgt)) - float(g[f"acc/{tag}/value"])) < 1e-6
+    assert np.array_equal(pose_oracle.normalize_crops(g["collate/img_u8"]), g["collate/input"])
