@@ -135,7 +135,7 @@ def main():
         sd = synth.conditioned_state_dict(nets_oracle.state_dict_shapes_resnet50(args.arch), seed=0)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     model = model.to(dev).eval()
-    if args.dtype == "bf16":
+    if args.dtype == "bf16" and args.mode == "infer":
         model.compute_dtype = "bf16"
     decoder = GaussTaylorKeyPointDecoder(kernel_size=11, num_joints=17)
 
@@ -150,7 +150,7 @@ def main():
         from simple_pose_amd.commons.transforms import RefineSimpleTransform
         from simple_pose_amd.train import PoseTrainer
         model.train()
-        trainer = PoseTrainer(model, lr=1e-3)
+        trainer = PoseTrainer(model, lr=1e-3, dtype="bf16" if args.dtype == "bf16" else "fp32")
         joints = torch.from_numpy(synth.joints_batch(B, 17, seed=200 + rank)).to(dev)
         targets, mask = RefineSimpleTransform.get_heat_map(joints, 2.0, (48, 64))   # HIP encoder, on device
         prog = None
@@ -211,12 +211,12 @@ def main():
             line = {
                 "metric": f"images/sec train step (fwd+bwd+Adam), {name} 256x192 bs={B}/GPU", "value": round(value, 1), "unit": "images/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": f"{name} 256x192 train step, bs={B} per GPU, fp32, train-mode BN (batch statistics), Adam lr 1e-3, "
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                "config": {"workload": f"{name} 256x192 train step, bs={B} per GPU, {'fp32' if args.dtype == 'f32' else 'bf16 compute + fp32 master weights/Adam'}, train-mode BN (batch statistics), Adam lr 1e-3, "
                                        "targets from the HIP encoder, gradients all-reduced over ranks (RCCL) when N > 1",
                            "images_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
                 "gflop_per_image": round(gflop, 3), "network_tflops": round(value * gflop / 1e3, 2),
-                "network_frac_of_fp32_matrix_peak": round(value * gflop / 1e3 / (FP32_MATRIX_PEAK_TFLOPS * world), 4),
+                "network_frac_of_matrix_peak": round(value * gflop / 1e3 / ((FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else BF16_MATRIX_PEAK_TFLOPS) * world), 4),
                 "roofline": None, "cpu_baseline": None, "final_loss": float(out[0].item())}
         else:
             peak = FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else BF16_MATRIX_PEAK_TFLOPS

@@ -27,12 +27,14 @@ extern "C" {
 #define SP_EINVAL (-1)   /* bad argument / unsupported shape (message in sp_last_error) */
 #define SP_ELAUNCH (-2)  /* HIP launch or runtime failure */
 
-#define SP_ABI_VERSION 3
+#define SP_ABI_VERSION 4
 
 /* epilogue / layout flags of sp_conv_desc.flags */
 #define SP_CONV_RELU 0x1u          /* y = max(y, 0) after scale/shift (+ residual) */
 #define SP_CONV_OUT_NCHW 0x2u      /* store y as NCHW [B, N, out_h, out_w] (final_layer -> heat maps) */
 #define SP_CONV_PIXEL_SHUFFLE 0x4u /* fused nn.PixelShuffle(2): weights packed with sp_pack order, see below */
+#define SP_CONV_OUT_F32 0x10u      /* with SP_CONV_BF16: NHWC y and residual are fp32 (activation gradients in the bf16
+                                      train step keep fp32 until the BatchNorm backward has removed their mean) */
 #define SP_CONV_BF16 0x8u          /* x, w_packed, residual and NHWC y are bf16 (fp32 accumulate; scale/shift and the NCHW
                                       output stay fp32); c_in % 8 == 0, k_pad % 64 == 0 */
 
@@ -154,39 +156,42 @@ int sp_masked_mse(const float* pred, const float* target, const float* mask, int
 
 /* ---- training step: processors/ddp_pose_resnet_solver.py:110-133 (model.train() forward, loss.backward(),
  *      optimizer.step()) ---------------------------------------------------------------------------------------------
- * Activations NHWC fp32, `rows` = B*H*W.  `workspace` of the reductions: >= SP_REDUCE_WORKSPACE_BYTES(c) bytes. */
+ * Activations NHWC; argument `bf16`: bit 0 = activations (z, relu_src, dz, pool input) are bf16, bit 1 = activation
+ * gradients (dy, dres, pool dx/dy) are bf16; statistics and the gradients of the affine parameters are always fp32;
+ * `rows` = B*H*W.  `workspace` of the reductions: >= SP_REDUCE_WORKSPACE_BYTES(c) bytes. */
 #define SP_REDUCE_WORKSPACE_BYTES(c) ((int64_t)256 * (c) * 2 * 8)
 
 /* nn.BatchNorm2d in train mode, statistics half: per-channel batch mean and 1/sqrt(biased var + eps) of z [rows, c];
  * running_mean/var (may both be NULL) are updated with `momentum` and the UNBIASED variance, as torch does. */
-int sp_bn_train_stats_nhwc(const float* z, int64_t rows, int c, float eps, float momentum, float* mean, float* invstd,
+int sp_bn_train_stats_nhwc(const void* z, int bf16, int64_t rows, int c, float eps, float momentum, float* mean, float* invstd,
                            float* running_mean, float* running_var, void* workspace, void* stream);
 /* y = [relu]((z - mean) * invstd * gamma + beta [+ residual])   (Bottleneck.forward tail, pose_resnet_dconv.py:124-131) */
-int sp_bn_apply_nhwc(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                     const float* residual, float* y, int64_t rows, int c, int relu, void* stream);
+int sp_bn_apply_nhwc(const void* z, int bf16, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                     const void* residual, void* y, int64_t rows, int c, int relu, void* stream);
 /* backward of [relu](bn(z) [+ residual]): g = dy * (relu_src > 0) (relu_src NULL: g = dy); dgamma = sum g*xhat,
  * dbeta = sum g, dz = gamma*invstd*(g - dbeta/rows - xhat*dgamma/rows); dres (NULL or tensor) = g or += g */
-int sp_bn_train_bwd_nhwc(const float* dy, const float* relu_src, const float* z, const float* mean, const float* invstd,
-                         const float* gamma, int64_t rows, int c, float* dz, float* dgamma, float* dbeta, float* dres,
+int sp_bn_train_bwd_nhwc(const void* dy, int bf16, const void* relu_src, const void* z, const float* mean, const float* invstd,
+                         const float* gamma, int64_t rows, int c, void* dz, float* dgamma, float* dbeta, void* dres,
                          int dres_accumulate, void* workspace, void* stream);
 /* sum over rows of a [rows, c] tensor (conv bias gradient) */
 int sp_channel_sum_nhwc(const float* a, int64_t rows, int c, float* sum, void* workspace, void* stream);
 /* backward of nn.MaxPool2d(3,2,1) (first maximum of a window wins, as torch); x = the pool's input */
-int sp_maxpool3x3s2_bwd_nhwc(const float* x, const float* dy, float* dx, int batch, int h, int w, int c, void* stream);
+int sp_maxpool3x3s2_bwd_nhwc(const void* x, int bf16, const void* dy, void* dx, int batch, int h, int w, int c, void* stream);
 /* torch.optim.Adam (amsgrad False, weight_decay 0) over flat buffers of n (multiple of 4) floats, `step` = 1,2,...;
  * grad is multiplied by grad_scale first (1/world_size after a SUM all-reduce) - ddp...:70-72,119 */
 int sp_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                  float beta2, float eps, int step, float grad_scale, void* stream);
 /* weight gradient of one conv / transposed-conv launch family: dW[n][(ty,tx,c)] = sum_m g[m][n] * im2col(a)[m][(ty,tx,c)],
- * `desc` describing how `a` is gathered (as in sp_conv2d_fwd; tile/flags/out_* ignored), g = [rows, g_channels] NHWC.
+ * `desc` describing how `a` is gathered (as in sp_conv2d_fwd; tile/out_* ignored; flags & SP_CONV_BF16: g and a are
+ * bf16, dW stays fp32), g = [rows, g_channels] NHWC.
  * The result is written in the reference's weight layout: dw[n*dst_stride_n + c*dst_stride_c + ty*kw_valid + tx]
  * for n < n_valid, c < c_valid, tx < kw_valid.  workspace: split partial slabs (error message states the need). */
-int sp_conv2d_wgrad(const sp_conv_desc* desc, const float* g, int g_channels, const float* a, int n_valid, int c_valid,
+int sp_conv2d_wgrad(const sp_conv_desc* desc, const void* g, int g_channels, const void* a, int n_valid, int c_valid,
                     int kw_valid, int64_t dst_stride_n, int64_t dst_stride_c, float* dw, void* workspace,
                     int64_t workspace_bytes, void* stream);
 /* generic 4-D gather-copy used to (re)pack weights after every optimizer step:
  * dst[dst_offset + ((i0*d1 + i1)*d2 + i2)*d3 + i3] = all(i_k < valid[k]) ? src[src_base + sum i_k*src_strides[k]] : 0 */
-int sp_permute4_f32(const float* src, float* dst, const int32_t* dst_dims, const int64_t* src_strides,
+int sp_permute4_f32(const float* src, void* dst, int dst_bf16, const int32_t* dst_dims, const int64_t* src_strides,
                     const int32_t* valid, int64_t src_base, int64_t dst_offset, void* stream);
 
 #ifdef __cplusplus

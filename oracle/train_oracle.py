@@ -13,8 +13,10 @@ from . import nets_oracle
 
 
 def forward_backward(sd: Dict[str, torch.Tensor], x: torch.Tensor, targets: torch.Tensor, mask: torch.Tensor,
-                     arch: str = "resnet50_dconv") -> Tuple[torch.Tensor, Dict[str, torch.Tensor], torch.Tensor]:
-    """Returns (loss, grads by parameter name, heat maps).  `sd` buffers (running stats) are updated in place."""
+                     arch: str = "resnet50_dconv", amp_bf16: bool = False) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], torch.Tensor]:
+    """Returns (loss, grads by parameter name, heat maps).  `sd` buffers (running stats) are updated in place.
+    amp_bf16: run the forward under torch.autocast(bfloat16) - the CPU stand-in for the reference's `optim.amp` branch
+    (ddp...:121-127: autocast + GradScaler; bf16 needs no scaler)."""
     leaves = {}
     work = {}
     for k, v in sd.items():
@@ -23,14 +25,16 @@ def forward_backward(sd: Dict[str, torch.Tensor], x: torch.Tensor, targets: torc
         else:
             leaves[k] = v.detach().clone().requires_grad_(True)
             work[k] = leaves[k]
-    heat = nets_oracle.FORWARDS[arch](work, x, training=True)
+    with torch.autocast("cpu", dtype=torch.bfloat16, enabled=amp_bf16):
+        heat = nets_oracle.FORWARDS[arch](work, x, training=True)
+    heat = heat.float()
     m = mask[..., None, None]
     loss = 0.5 * torch.nn.functional.mse_loss(heat * m, targets * m)
     loss.backward()
     for k in sd:
         if k.endswith("num_batches_tracked"):
             sd[k] += 1
-    return loss.detach(), {k: v.grad for k, v in leaves.items()}, heat.detach()
+    return loss.detach(), {k: v.grad.float() for k, v in leaves.items()}, heat.detach()
 
 
 def adam_step(params: Dict[str, torch.Tensor], grads: Dict[str, torch.Tensor], state: dict, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):

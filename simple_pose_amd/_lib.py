@@ -18,8 +18,9 @@ SP_CONV_RELU = 0x1
 SP_CONV_OUT_NCHW = 0x2
 SP_CONV_PIXEL_SHUFFLE = 0x4
 SP_CONV_BF16 = 0x8
+SP_CONV_OUT_F32 = 0x10
 CONV_TILES = ((128, 128), (64, 128), (128, 64), (64, 64), (256, 64), (128, 32))
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class HipLibraryError(RuntimeError):
@@ -58,14 +59,14 @@ SYMBOLS = {
     "sp_u8hwc_bgr_to_nchw_f32": (c_int, [_P, _P, c_int, c_int, c_int, ctypes.POINTER(c_float), _P]),
     "sp_encode_gauss_refine": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P]),
     "sp_encode_gauss_basic": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, c_int, _P, _P, _P]),
-    "sp_bn_train_stats_nhwc": (c_int, [_P, c_int64, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P]),
-    "sp_bn_apply_nhwc": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, _P]),
-    "sp_bn_train_bwd_nhwc": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P, c_int, _P, _P]),
+    "sp_bn_train_stats_nhwc": (c_int, [_P, c_int, c_int64, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P]),
+    "sp_bn_apply_nhwc": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, _P]),
+    "sp_bn_train_bwd_nhwc": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P, c_int, _P, _P]),
     "sp_channel_sum_nhwc": (c_int, [_P, c_int64, c_int, _P, _P, _P]),
-    "sp_maxpool3x3s2_bwd_nhwc": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "sp_maxpool3x3s2_bwd_nhwc": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "sp_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int, c_float, _P]),
     "sp_conv2d_wgrad": (c_int, [ctypes.POINTER(ConvDesc), _P, c_int, _P, c_int, c_int, c_int, c_int64, c_int64, _P, _P, c_int64, _P]),
-    "sp_permute4_f32": (c_int, [_P, _P, ctypes.POINTER(c_int32), ctypes.POINTER(c_int64), ctypes.POINTER(c_int32), c_int64, c_int64, _P]),
+    "sp_permute4_f32": (c_int, [_P, _P, c_int, ctypes.POINTER(c_int32), ctypes.POINTER(c_int64), ctypes.POINTER(c_int32), c_int64, c_int64, _P]),
     "sp_masked_mse": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
 }
 

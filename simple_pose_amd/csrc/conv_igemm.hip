@@ -84,11 +84,13 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * BK + ((chu
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int BM, int BN, int WR, int WC, bool UNIFORM_TAP, bool BF16>
+template <int BM, int BN, int WR, int WC, bool UNIFORM_TAP, bool BF16, bool OUT16>
 __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm_kernel(const ConvArgs p) {
     constexpr int ES = BF16 ? 2 : 4;     // element size of activations / weights
     constexpr int EPC = 16 / ES;         // elements per 16-byte chunk
     constexpr int BKE = 128 / ES;        // elements per K tile (one 128-byte LDS row)
+    constexpr int ESO = OUT16 ? 2 : 4;   // element size of the NHWC output / residual (bf16 inputs may write fp32: SP_CONV_OUT_F32)
+    static_assert(BF16 || !OUT16, "bf16 output needs bf16 inputs");
     static_assert(WR * WC == 4, "4 waves per workgroup");
     constexpr int WM = BM / WR, WN = BN / WC;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
     const int hw_out = p.out_h * p.out_w;
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, (short)0, p.y_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res ? p.res : p.y), (short)0, p.y_bytes, 0x00020000);
-    if (!nchw && (p.c_out % EPC) == 0) {
+    if (!nchw && (p.c_out % (16 / ESO)) == 0) {
         static_assert(BM * BN <= 2 * (BM + BN) * BK, "transpose area must fit in the staging buffers");
         float* tr = smem + wave * (WM * WN);
 #pragma unroll
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     tr[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * WN + n * 32 + fr] = acc[i][n][r];
-        constexpr int CPL = EPC;         // channels per lane = one 16-byte store (4 fp32 / 8 bf16)
+        constexpr int CPL = 16 / ESO;    // channels per lane = one 16-byte store (4 fp32 / 8 bf16)
         constexpr int CPR = WN / CPL;    // 16-byte output chunks per tile row
         constexpr int RPI = 64 / CPR;    // tile rows covered by one wave-instruction
         constexpr int NIT = WM / RPI;
@@ -429,7 +431,7 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int ro = rowtab[(wr * WM + it * RPI + rsub) * 4 + 3];
-            off[it] = (col_ok && ro >= 0) ? (unsigned)((ro + col_off) * ES) : OOB;
+            off[it] = (col_ok && ro >= 0) ? (unsigned)((ro + col_off) * ESO) : OOB;
         }
         u32x4 rv[NIT];
         if (p.res) {  // every residual load of the tile in flight before the first use
@@ -447,7 +449,7 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
 #pragma unroll
             for (int e = 0; e < CPL; ++e) v[e] = v[e] * sc[e] + sh[e];
             if (p.res) {
-                if constexpr (BF16) {
+                if constexpr (OUT16) {
                     const bf16x8 r8 = __builtin_bit_cast(bf16x8, rv[it]);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
@@ -462,7 +464,7 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
                 for (int e = 0; e < CPL; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
             }
             u32x4 o;
-            if constexpr (BF16) {
+            if constexpr (OUT16) {
                 bf16x8 o8;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o8[e] = (__bf16)v[e];
@@ -535,7 +537,7 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
 #endif
 }
 
-template <int BM, int BN, int WR, int WC, bool BF16>
+template <int BM, int BN, int WR, int WC, bool BF16, bool OUT16>
 int launch_t(const ConvArgs& a, int phases, bool uniform, hipStream_t stream) {
     ConvArgs p = a;
     p.tiles_m = (a.M + BM - 1) / BM;
@@ -543,25 +545,28 @@ int launch_t(const ConvArgs& a, int phases, bool uniform, hipStream_t stream) {
     const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float) + (size_t)BM * 4 * sizeof(int);
     dim3 grid(p.tiles_m * p.tiles_n, phases, 1), block(256, 1, 1);
     // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel instantiation
-    static const hipError_t attr_u = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, true, BF16>),
+    static const hipError_t attr_u = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, true, BF16, OUT16>),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    static const hipError_t attr_c = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, false, BF16>),
+    static const hipError_t attr_c = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, false, BF16, OUT16>),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr_u != hipSuccess || attr_c != hipSuccess) {
         sp_set_error("conv_igemm: hipFuncSetAttribute(max dynamic LDS = %zu) failed", lds);
         return SP_ELAUNCH;
     }
     if (uniform)
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, true, BF16>), grid, block, lds, stream, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, true, BF16, OUT16>), grid, block, lds, stream, p);
     else
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, false, BF16>), grid, block, lds, stream, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, false, BF16, OUT16>), grid, block, lds, stream, p);
     return sp_check_launch("conv_igemm_kernel");
 }
 
 template <int BM, int BN, int WR, int WC>
 int launch(const ConvArgs& a, int phases, bool uniform, hipStream_t stream) {
-    if (a.flags & SP_CONV_BF16) return launch_t<BM, BN, WR, WC, true>(a, phases, uniform, stream);
-    return launch_t<BM, BN, WR, WC, false>(a, phases, uniform, stream);
+    if (a.flags & SP_CONV_BF16) {
+        if (a.flags & SP_CONV_OUT_F32) return launch_t<BM, BN, WR, WC, true, false>(a, phases, uniform, stream);
+        return launch_t<BM, BN, WR, WC, true, true>(a, phases, uniform, stream);
+    }
+    return launch_t<BM, BN, WR, WC, false, false>(a, phases, uniform, stream);
 }
 
 }  // namespace
@@ -585,8 +590,9 @@ extern "C" int sp_conv2d_fwd(const sp_conv_desc* d, const void* x, const void* w
     const bool uniform = (d->c_in % bke == 0) && d->taps_h * d->taps_w <= 32;  // tap-validity bit mask is 32 bits wide
     if (uniform) SP_REQUIRE(d->k_pad == d->taps_h * d->taps_w * d->c_in, "sp_conv2d_fwd: k_pad must equal taps*c_in when c_in fills whole K tiles");
     SP_REQUIRE((d->phases_y == 1 || d->phases_y == 2) && (d->phases_x == 1 || d->phases_x == 2), "sp_conv2d_fwd: phases must be 1 or 2");
-    const unsigned known = SP_CONV_RELU | SP_CONV_OUT_NCHW | SP_CONV_PIXEL_SHUFFLE | SP_CONV_BF16;
-    if (bf16 && !(d->flags & SP_CONV_OUT_NCHW)) SP_REQUIRE(d->c_out % 8 == 0, "sp_conv2d_fwd: bf16 NHWC output needs c_out %% 8 == 0 (got %d)", d->c_out);
+    const unsigned known = SP_CONV_RELU | SP_CONV_OUT_NCHW | SP_CONV_PIXEL_SHUFFLE | SP_CONV_BF16 | SP_CONV_OUT_F32;
+    const bool out16 = bf16 && !(d->flags & SP_CONV_OUT_F32);
+    if (out16 && !(d->flags & SP_CONV_OUT_NCHW)) SP_REQUIRE(d->c_out % 8 == 0, "sp_conv2d_fwd: bf16 NHWC output needs c_out %% 8 == 0 (got %d)", d->c_out);
     SP_REQUIRE((d->flags & ~known) == 0, "sp_conv2d_fwd: unknown flag bits 0x%x", d->flags);
     SP_REQUIRE(!((d->flags & SP_CONV_OUT_NCHW) && (d->flags & SP_CONV_PIXEL_SHUFFLE)), "sp_conv2d_fwd: NCHW output and pixel shuffle are exclusive");
     SP_REQUIRE(!((d->flags & SP_CONV_OUT_NCHW) && residual), "sp_conv2d_fwd: residual needs NHWC output");
@@ -623,7 +629,7 @@ extern "C" int sp_conv2d_fwd(const sp_conv_desc* d, const void* x, const void* w
     a.oy_mul = d->oy_mul; a.oy_add = d->oy_add; a.ox_mul = d->ox_mul; a.ox_add = d->ox_add;
     a.phases_x = d->phases_x; a.flags = d->flags; a.tiles_m = a.tiles_n = 0;
     a.x_bytes = (int)(in_elems * es); a.w_bytes = (int)(w_elems * es);
-    a.y_bytes = (int)(out_elems * ((d->flags & SP_CONV_OUT_NCHW) ? 4 : es));
+    a.y_bytes = (int)(out_elems * (((d->flags & SP_CONV_OUT_NCHW) || !out16) ? 4 : 2));
     const int phases = d->phases_y * d->phases_x;
     hipStream_t s = (hipStream_t)stream;
 

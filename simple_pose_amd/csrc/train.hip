@@ -7,6 +7,29 @@ namespace {
 
 constexpr int RED_BLOCKS = 256;  // partial-sum workgroups per channel reduction
 
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// 4 consecutive channels of an NHWC tensor, fp32 (16 B) or bf16 (8 B), as floats; i4 = index in units of 4 channels
+template <bool BF16>
+__device__ __forceinline__ f32x4 ld4(const void* p, long long i4) {
+    if constexpr (BF16) {
+        const bf16x4 v = __builtin_bit_cast(bf16x4, reinterpret_cast<const u32x2*>(p)[i4]);
+        return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    } else {
+        return reinterpret_cast<const f32x4*>(p)[i4];
+    }
+}
+template <bool BF16>
+__device__ __forceinline__ void st4(void* p, long long i4, f32x4 v) {
+    if constexpr (BF16) {
+        const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        reinterpret_cast<u32x2*>(p)[i4] = __builtin_bit_cast(u32x2, o);
+    } else {
+        reinterpret_cast<f32x4*>(p)[i4] = v;
+    }
+}
+
 inline int grid_for(long long total, int block) {
     long long g = (total + block - 1) / block;
     return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
@@ -18,9 +41,9 @@ inline int grid_for(long long total, int block) {
 //   mode 1: s0 = sum g,            s1 = sum g * xhat,  g = dy*(y>0?)    (BN backward: dbeta, dgamma)
 // part: [gridDim.x][C][2] doubles
 // ---------------------------------------------------------------------------------------------------------------
-template <int MODE>
-__global__ __launch_bounds__(256) void channel_reduce_kernel(const float* __restrict__ a, const float* __restrict__ relu_src,
-                                                             const float* __restrict__ z, const float* __restrict__ mean,
+template <int MODE, bool BF16, bool G16 = BF16>   // BF16: dtype of z / relu_src (and of `a` in mode 0); G16: dtype of `a` in mode 1 (dy)
+__global__ __launch_bounds__(256) void channel_reduce_kernel(const void* __restrict__ a, const void* __restrict__ relu_src,
+                                                             const void* __restrict__ z, const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, int M, int C, double* __restrict__ part) {
     const int C4 = C >> 2;
     const int lanes_c = C4 < 256 ? C4 : 256;       // threads along channels
@@ -33,18 +56,18 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(const float* __rest
         if (MODE == 1) { mu = reinterpret_cast<const f32x4*>(mean)[c4]; is = reinterpret_cast<const f32x4*>(invstd)[c4]; }
         if (tr < rows_par) {
             for (long long r = (long long)blockIdx.x * rows_par + tr; r < M; r += (long long)gridDim.x * rows_par) {
-                const f32x4 v = reinterpret_cast<const f32x4*>(a)[r * C4 + c4];
+                const f32x4 v = (MODE == 0) ? ld4<BF16>(a, r * C4 + c4) : ld4<G16>(a, r * C4 + c4);
                 if (MODE == 0) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { s0[e] += (double)v[e]; s1[e] += (double)v[e] * (double)v[e]; }
                 } else {
                     f32x4 g = v;
                     if (relu_src) {
-                        const f32x4 y = reinterpret_cast<const f32x4*>(relu_src)[r * C4 + c4];
+                        const f32x4 y = ld4<BF16>(relu_src, r * C4 + c4);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) g[e] = y[e] > 0.f ? g[e] : 0.f;
                     }
-                    const f32x4 zz = reinterpret_cast<const f32x4*>(z)[r * C4 + c4];
+                    const f32x4 zz = ld4<BF16>(z, r * C4 + c4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { s0[e] += (double)g[e]; s1[e] += (double)g[e] * (double)((zz[e] - mu[e]) * is[e]); }
                 }
@@ -110,58 +133,61 @@ __global__ void pair_sum_final_kernel(const double* __restrict__ part, int nblk,
 }
 
 // y = [relu]( (z - mean) * invstd * gamma + beta [+ res] )
-__global__ void bn_apply_kernel(const f32x4* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ invstd,
-                                const float* __restrict__ gamma, const float* __restrict__ beta, const f32x4* __restrict__ res,
-                                f32x4* __restrict__ y, int C4, int relu, long long total) {
+template <bool BF16>
+__global__ void bn_apply_kernel(const void* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                const float* __restrict__ gamma, const float* __restrict__ beta, const void* __restrict__ res,
+                                void* __restrict__ y, int C4, int relu, long long total) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % C4);
         const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c4], is = reinterpret_cast<const f32x4*>(invstd)[c4];
         const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[c4], b = reinterpret_cast<const f32x4*>(beta)[c4];
-        f32x4 v = z[i];
+        f32x4 v = ld4<BF16>(z, i);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (v[e] - mu[e]) * is[e] * g[e] + b[e];
-        if (res) { const f32x4 r = res[i]; v += r; }
+        if (res) { const f32x4 r = ld4<BF16>(res, i); v += r; }
         if (relu) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
         }
-        y[i] = v;
+        st4<BF16>(y, i, v);
     }
 }
 
 // g = dy * (y > 0);  dz = gamma*invstd * (g - dbeta/M - xhat * dgamma/M);  dres (+)= g
-__global__ void bn_bwd_apply_kernel(const f32x4* __restrict__ dy, const f32x4* __restrict__ relu_src, const f32x4* __restrict__ z,
+template <bool BF16, bool G16>   // BF16: z, relu_src, dz;  G16: dy, dres
+__global__ void bn_bwd_apply_kernel(const void* __restrict__ dy, const void* __restrict__ relu_src, const void* __restrict__ z,
                                     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                    const float* __restrict__ dgamma, const float* __restrict__ dbeta, float inv_m, f32x4* __restrict__ dz,
-                                    f32x4* dres, int dres_accumulate, int C4, long long total) {
+                                    const float* __restrict__ dgamma, const float* __restrict__ dbeta, float inv_m, void* __restrict__ dz,
+                                    void* dres, int dres_accumulate, int C4, long long total) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % C4);
         const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c4], is = reinterpret_cast<const f32x4*>(invstd)[c4];
         const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[c4];
         const f32x4 dg = reinterpret_cast<const f32x4*>(dgamma)[c4], db = reinterpret_cast<const f32x4*>(dbeta)[c4];
-        f32x4 g = dy[i];
+        f32x4 g = ld4<G16>(dy, i);
         if (relu_src) {
-            const f32x4 y = relu_src[i];
+            const f32x4 y = ld4<BF16>(relu_src, i);
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = y[e] > 0.f ? g[e] : 0.f;
         }
-        const f32x4 zz = z[i];
+        const f32x4 zz = ld4<BF16>(z, i);
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float xh = (zz[e] - mu[e]) * is[e];
             o[e] = ga[e] * is[e] * (g[e] - db[e] * inv_m - xh * dg[e] * inv_m);
         }
-        dz[i] = o;
+        st4<BF16>(dz, i, o);
         if (dres) {
-            if (dres_accumulate) { f32x4 r = dres[i]; r += g; dres[i] = r; } else dres[i] = g;
+            if (dres_accumulate) { f32x4 r = ld4<G16>(dres, i); r += g; st4<G16>(dres, i, r); } else st4<G16>(dres, i, g);
         }
     }
 }
 
 // dx[b,iy,ix,:] = sum over the (<= 4) windows that contain (iy,ix) and whose FIRST maximum (row-major scan, as
 // nn.MaxPool2d) is this pixel, of dy[window].  Gather form: deterministic, no atomics.
-__global__ void maxpool3x3s2_bwd_kernel(const f32x4* __restrict__ x, const f32x4* __restrict__ dy, f32x4* __restrict__ dx, int H, int W,
+template <bool BF16, bool G16>   // BF16: pool input x;  G16: dy, dx
+__global__ void maxpool3x3s2_bwd_kernel(const void* __restrict__ x, const void* __restrict__ dy, void* __restrict__ dx, int H, int W,
                                         int C4, int Ho, int Wo, long long total) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4);
@@ -169,7 +195,7 @@ __global__ void maxpool3x3s2_bwd_kernel(const f32x4* __restrict__ x, const f32x4
         const int ix = (int)(r % W); r /= W;
         const int iy = (int)(r % H);
         const long long b = r / H;
-        const f32x4 me = x[i];
+        const f32x4 me = ld4<BF16>(x, i);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         // windows oy with iy in [2oy-1, 2oy+1]
         for (int oy = (iy) / 2; oy <= (iy + 1) / 2; ++oy) {
@@ -185,7 +211,7 @@ __global__ void maxpool3x3s2_bwd_kernel(const f32x4* __restrict__ x, const f32x4
                         const int xx = ox * 2 - 1 + kx;
                         if ((unsigned)xx >= (unsigned)W) continue;
                         if (yy == iy && xx == ix) continue;
-                        const f32x4 o = x[((b * H + yy) * W + xx) * C4 + c];
+                        const f32x4 o = ld4<BF16>(x, ((b * H + yy) * W + xx) * C4 + c);
                         const bool before = (yy < iy) || (yy == iy && xx < ix);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -194,12 +220,12 @@ __global__ void maxpool3x3s2_bwd_kernel(const f32x4* __restrict__ x, const f32x4
                         }
                     }
                 }
-                const f32x4 g = dy[((b * Ho + oy) * Wo + ox) * C4 + c];
+                const f32x4 g = ld4<G16>(dy, ((b * Ho + oy) * Wo + ox) * C4 + c);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) if (win[e]) acc[e] += g[e];
             }
         }
-        dx[i] = acc;
+        st4<G16>(dx, i, acc);
     }
 }
 
@@ -229,7 +255,8 @@ struct Permute4 {
     long long base;
     long long dst_off;
 };
-__global__ void permute4_kernel(const float* __restrict__ src, float* __restrict__ dst, const Permute4 pm, long long total) {
+template <bool BF16OUT>
+__global__ void permute4_kernel(const float* __restrict__ src, void* __restrict__ dst, const Permute4 pm, long long total) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         long long r = i;
         const int i3 = (int)(r % pm.d[3]); r /= pm.d[3];
@@ -239,13 +266,14 @@ __global__ void permute4_kernel(const float* __restrict__ src, float* __restrict
         float v = 0.f;
         if (i0 < pm.lim[0] && i1 < pm.lim[1] && i2 < pm.lim[2] && i3 < pm.lim[3])
             v = src[pm.base + i0 * pm.s[0] + i1 * pm.s[1] + i2 * pm.s[2] + i3 * pm.s[3]];
-        dst[pm.dst_off + i] = v;
+        if constexpr (BF16OUT) reinterpret_cast<__bf16*>(dst)[pm.dst_off + i] = (__bf16)v;
+        else reinterpret_cast<float*>(dst)[pm.dst_off + i] = v;
     }
 }
 
 }  // namespace
 
-extern "C" int sp_bn_train_stats_nhwc(const float* z, int64_t rows, int c, float eps, float momentum, float* mean, float* invstd,
+extern "C" int sp_bn_train_stats_nhwc(const void* z, int bf16, int64_t rows, int c, float eps, float momentum, float* mean, float* invstd,
                                       float* running_mean, float* running_var, void* workspace, void* stream) {
     SP_REQUIRE(z && mean && invstd && workspace, "sp_bn_train_stats_nhwc: null pointer");
     SP_REQUIRE(rows > 0 && c > 0 && c % 4 == 0 && rows < (1ll << 31) && ((c / 4) <= 256 ? 256 % 1 == 0 : (c / 4) % 256 == 0),
@@ -253,35 +281,46 @@ extern "C" int sp_bn_train_stats_nhwc(const float* z, int64_t rows, int c, float
     SP_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "sp_bn_train_stats_nhwc: running stats come in pairs");
     hipStream_t s = (hipStream_t)stream;
     double* part = reinterpret_cast<double*>(workspace);
-    hipLaunchKernelGGL(channel_reduce_kernel<0>, dim3(RED_BLOCKS), dim3(256), 0, s, z, nullptr, nullptr, nullptr, nullptr, (int)rows, c, part);
+    if (bf16 & 1) hipLaunchKernelGGL((channel_reduce_kernel<0, true>), dim3(RED_BLOCKS), dim3(256), 0, s, z, nullptr, nullptr, nullptr, nullptr, (int)rows, c, part);
+    else hipLaunchKernelGGL((channel_reduce_kernel<0, false>), dim3(RED_BLOCKS), dim3(256), 0, s, z, nullptr, nullptr, nullptr, nullptr, (int)rows, c, part);
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3((c + 3) / 4), dim3(256), 0, s, part, RED_BLOCKS, c, (double)rows, eps, momentum, mean,
                        invstd, running_mean, running_var);
     return sp_check_launch("bn_train_stats");
 }
 
-extern "C" int sp_bn_apply_nhwc(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                                const float* residual, float* y, int64_t rows, int c, int relu, void* stream) {
+extern "C" int sp_bn_apply_nhwc(const void* z, int bf16, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                const void* residual, void* y, int64_t rows, int c, int relu, void* stream) {
     SP_REQUIRE(z && mean && invstd && gamma && beta && y, "sp_bn_apply_nhwc: null pointer");
     SP_REQUIRE(rows > 0 && c > 0 && c % 4 == 0, "sp_bn_apply_nhwc: bad shape");
     const long long total = rows * (c / 4);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f32x4*>(z), mean,
-                       invstd, gamma, beta, reinterpret_cast<const f32x4*>(residual), reinterpret_cast<f32x4*>(y), c / 4, relu, total);
+    if (bf16 & 1) hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, z, mean, invstd, gamma, beta,
+                                 residual, y, c / 4, relu, total);
+    else hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, z, mean, invstd, gamma, beta,
+                            residual, y, c / 4, relu, total);
     return sp_check_launch("bn_apply_kernel");
 }
 
-extern "C" int sp_bn_train_bwd_nhwc(const float* dy, const float* relu_src, const float* z, const float* mean, const float* invstd,
-                                    const float* gamma, int64_t rows, int c, float* dz, float* dgamma, float* dbeta, float* dres,
+extern "C" int sp_bn_train_bwd_nhwc(const void* dy, int bf16, const void* relu_src, const void* z, const float* mean, const float* invstd,
+                                    const float* gamma, int64_t rows, int c, void* dz, float* dgamma, float* dbeta, void* dres,
                                     int dres_accumulate, void* workspace, void* stream) {
     SP_REQUIRE(dy && z && mean && invstd && gamma && dz && dgamma && dbeta && workspace, "sp_bn_train_bwd_nhwc: null pointer");
     SP_REQUIRE(rows > 0 && c > 0 && c % 4 == 0 && rows < (1ll << 31), "sp_bn_train_bwd_nhwc: bad shape");
     hipStream_t s = (hipStream_t)stream;
     double* part = reinterpret_cast<double*>(workspace);
-    hipLaunchKernelGGL(channel_reduce_kernel<1>, dim3(RED_BLOCKS), dim3(256), 0, s, dy, relu_src, z, mean, invstd, (int)rows, c, part);
+    const bool a16 = bf16 & 1, g16 = bf16 & 2;
+    SP_REQUIRE(a16 || !g16, "sp_bn_train_bwd_nhwc: bf16 gradients with fp32 activations is not a supported mix");
+    if (a16 && g16) hipLaunchKernelGGL((channel_reduce_kernel<1, true, true>), dim3(RED_BLOCKS), dim3(256), 0, s, dy, relu_src, z, mean, invstd, (int)rows, c, part);
+    else if (a16) hipLaunchKernelGGL((channel_reduce_kernel<1, true, false>), dim3(RED_BLOCKS), dim3(256), 0, s, dy, relu_src, z, mean, invstd, (int)rows, c, part);
+    else hipLaunchKernelGGL((channel_reduce_kernel<1, false, false>), dim3(RED_BLOCKS), dim3(256), 0, s, dy, relu_src, z, mean, invstd, (int)rows, c, part);
     hipLaunchKernelGGL(pair_sum_final_kernel, dim3((c + 3) / 4), dim3(256), 0, s, part, RED_BLOCKS, c, dbeta, dgamma);
     const long long total = rows * (c / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, reinterpret_cast<const f32x4*>(dy),
-                       reinterpret_cast<const f32x4*>(relu_src), reinterpret_cast<const f32x4*>(z), mean, invstd, gamma, dgamma, dbeta,
-                       (float)(1.0 / (double)rows), reinterpret_cast<f32x4*>(dz), reinterpret_cast<f32x4*>(dres), dres_accumulate, c / 4, total);
+#define SP_BWD_APPLY(A, G)                                                                                                             \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<A, G>), dim3(grid_for(total, 256)), dim3(256), 0, s, dy, relu_src, z, mean, invstd, gamma, dgamma, \
+                       dbeta, (float)(1.0 / (double)rows), dz, dres, dres_accumulate, c / 4, total)
+    if (a16 && g16) SP_BWD_APPLY(true, true);
+    else if (a16) SP_BWD_APPLY(true, false);
+    else SP_BWD_APPLY(false, false);
+#undef SP_BWD_APPLY
     return sp_check_launch("bn_train_bwd");
 }
 
@@ -289,20 +328,24 @@ extern "C" int sp_channel_sum_nhwc(const float* a, int64_t rows, int c, float* s
     SP_REQUIRE(a && sum && workspace && rows > 0 && c > 0 && c % 4 == 0 && rows < (1ll << 31), "sp_channel_sum_nhwc: bad argument");
     hipStream_t s = (hipStream_t)stream;
     double* part = reinterpret_cast<double*>(workspace);
-    hipLaunchKernelGGL(channel_reduce_kernel<0>, dim3(RED_BLOCKS), dim3(256), 0, s, a, nullptr, nullptr, nullptr, nullptr, (int)rows, c, part);
+    hipLaunchKernelGGL((channel_reduce_kernel<0, false>), dim3(RED_BLOCKS), dim3(256), 0, s, a, nullptr, nullptr, nullptr, nullptr, (int)rows, c, part);
     hipLaunchKernelGGL(pair_sum_final_kernel, dim3((c + 3) / 4), dim3(256), 0, s, part, RED_BLOCKS, c, sum, nullptr);
     return sp_check_launch("channel_sum");
 }
 
-extern "C" int sp_maxpool3x3s2_bwd_nhwc(const float* x, const float* dy, float* dx, int batch, int h, int w, int c, void* stream) {
+extern "C" int sp_maxpool3x3s2_bwd_nhwc(const void* x, int bf16, const void* dy, void* dx, int batch, int h, int w, int c, void* stream) {
     SP_REQUIRE(x && dy && dx, "sp_maxpool3x3s2_bwd_nhwc: null pointer");
     SP_REQUIRE(batch > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "sp_maxpool3x3s2_bwd_nhwc: bad shape");
     const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
     const long long total = (long long)batch * h * w * (c / 4);
     SP_REQUIRE(total * 4 < (1ll << 31), "sp_maxpool3x3s2_bwd_nhwc: tensor too large");
-    hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const f32x4*>(x), reinterpret_cast<const f32x4*>(dy), reinterpret_cast<f32x4*>(dx), h, w, c / 4, ho, wo,
-                       total);
+    const bool a16 = bf16 & 1, g16 = bf16 & 2;
+#define SP_POOL_BWD(A, G) \
+    hipLaunchKernelGGL((maxpool3x3s2_bwd_kernel<A, G>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, h, w, c / 4, ho, wo, total)
+    if (a16 && g16) SP_POOL_BWD(true, true);
+    else if (a16) SP_POOL_BWD(true, false);
+    else SP_POOL_BWD(false, false);
+#undef SP_POOL_BWD
     return sp_check_launch("maxpool3x3s2_bwd_kernel");
 }
 
@@ -318,7 +361,7 @@ extern "C" int sp_adam_step(float* param, const float* grad, float* exp_avg, flo
     return sp_check_launch("adam_kernel");
 }
 
-extern "C" int sp_permute4_f32(const float* src, float* dst, const int32_t* dst_dims, const int64_t* src_strides, const int32_t* valid,
+extern "C" int sp_permute4_f32(const float* src, void* dst, int dst_bf16, const int32_t* dst_dims, const int64_t* src_strides, const int32_t* valid,
                                int64_t src_base, int64_t dst_offset, void* stream) {
     SP_REQUIRE(src && dst && dst_dims && src_strides && valid, "sp_permute4_f32: null pointer");
     Permute4 pm;
@@ -329,6 +372,7 @@ extern "C" int sp_permute4_f32(const float* src, float* dst, const int32_t* dst_
         total *= dst_dims[i];
     }
     pm.base = src_base; pm.dst_off = dst_offset;
-    hipLaunchKernelGGL(permute4_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, pm, total);
+    if (dst_bf16) hipLaunchKernelGGL(permute4_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, pm, total);
+    else hipLaunchKernelGGL(permute4_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, pm, total);
     return sp_check_launch("permute4_kernel");
 }

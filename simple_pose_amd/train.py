@@ -22,7 +22,7 @@ from typing import Callable, Dict, List, Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, SP_CONV_OUT_NCHW, SP_CONV_RELU
+from ._lib import ConvDesc, SP_CONV_BF16, SP_CONV_OUT_F32, SP_CONV_OUT_NCHW, SP_CONV_RELU
 from .engine import _round_up, n_pad_for
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
@@ -93,15 +93,22 @@ class ConvT:
         self.bias_name, self.out_nchw, self.need_dgrad = bias_name, out_nchw, need_dgrad
         dev = weight.device
         self.pack_jobs: List[PackJob] = []
+        self.bf16 = tr.bf16
+        wdt = torch.bfloat16 if self.bf16 else torch.float32
+        kmul = 64 if self.bf16 else 32                 # K tile = 128 bytes
+        fbf = SP_CONV_BF16 if self.bf16 else 0
+        self._wdt, self._kmul, self._fbf = wdt, kmul, fbf
         if kind == "conv":
             O, I, kh, kw = weight.shape
             self.O, self.I, self.kh, self.kw = O, I, kh, kw
             ci = c_in_buf or I                                     # stem: 3 -> NHWC4
-            tw = _round_up(kw, 8) if (ci == 4 and kw > 4) else (4 if ci == 4 else kw)
+            stem = c_in_buf is not None and c_in_buf > I
+            tw = (_round_up(kw, 8) if kw > 4 else 4) if stem else kw
             self.ci, self.tw = ci, tw
             k = kh * tw * ci
-            k_pad, n_pad = _round_up(k, 32), n_pad_for(O)
-            self.w_fwd = torch.zeros((n_pad, k_pad), dtype=torch.float32, device=dev)
+            k_pad, n_pad = _round_up(k, kmul), n_pad_for(O)
+            assert k_pad == k, (name, k, k_pad)   # the pack job writes dense [n][kh][tw][ci] rows
+            self.w_fwd = torch.zeros((n_pad, k_pad), dtype=wdt, device=dev)
             # fwd pack: dst [n_pad][kh][tw][ci] <- W[o][c][ty][tx]
             self.pack_jobs.append(PackJob(self.wname, self.w_fwd, (n_pad, kh, tw, ci), (I * kh * kw, kw, 1, kh * kw), (O, kh, kw, I), 0))
             self.oh, self.ow = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
@@ -114,7 +121,7 @@ class ConvT:
             d.oy_mul = d.ox_mul = 1
             d.oy_add = d.ox_add = 0
             d.phases_y = d.phases_x = 1
-            d.flags = SP_CONV_OUT_NCHW if out_nchw else 0
+            d.flags = (SP_CONV_OUT_NCHW if out_nchw else 0) | fbf
             self.d_fwd = d
             self.c_out_buf = O
             self.flops = 2 * self.oh * self.ow * O * I * kh * kw
@@ -128,7 +135,7 @@ class ConvT:
             assert (kh, kw) == (4, 4) and stride == 2 and pad == 1
             self.O, self.I, self.kh, self.kw, self.ci = O, I, 4, 4, I
             n_pad = n_pad_for(O)
-            self.w_fwd = torch.zeros((4 * n_pad, 4 * I), dtype=torch.float32, device=dev)
+            self.w_fwd = torch.zeros((4 * n_pad, 4 * I), dtype=wdt, device=dev)
             for py in range(2):
                 for px in range(2):
                     ph = py * 2 + px                               # W[ci][co][2ty+1-py][2tx+1-px] -> [n][ty][tx][ci]
@@ -143,13 +150,13 @@ class ConvT:
             d.out_h, d.out_w, d.out_c = 2 * h, 2 * w, O
             d.oy_mul, d.oy_add, d.ox_mul, d.ox_add = 2, 0, 2, 0
             d.phases_y = d.phases_x = 2
-            d.flags = 0
+            d.flags = fbf
             self.d_fwd = d
             self.c_out_buf = O
             self.flops = 2 * h * w * I * O * 16
             # dgrad = Conv2d(k=4, s=2, p=1) of dy with Wd[ci][(ky,kx,co)] = W[ci][co][ky][kx]
             nd = n_pad_for(I)
-            self.w_dgrad = [torch.zeros((nd, 16 * O), dtype=torch.float32, device=dev)]
+            self.w_dgrad = [torch.zeros((nd, 16 * O), dtype=wdt, device=dev)]
             self.pack_jobs.append(PackJob(self.wname, self.w_dgrad[0], (nd, 4, 4, O), (O * 16, 4, 1, 16), (I, 4, 4, O), 0))
             g = ConvDesc()
             g.batch, g.in_h, g.in_w, g.c_in = 1, 2 * h, 2 * w, O
@@ -160,7 +167,7 @@ class ConvT:
             g.oy_mul = g.ox_mul = 1
             g.oy_add = g.ox_add = 0
             g.phases_y = g.phases_x = 1
-            g.flags = 0
+            g.flags = fbf | (SP_CONV_OUT_F32 if self.bf16 else 0)   # activation gradients stay fp32
             self.d_dgrad = [g]
             self.dgrad_full_cover = True
             # wgrad: dW[ci][co][ky][kx] = sum_m x[m][ci] * dy[(2iy-1+ky, 2ix-1+kx)][co]: g = x, a = dy gathered like the dgrad conv
@@ -173,12 +180,13 @@ class ConvT:
     def _build_conv_dgrad(self, weight):
         O, I, kh, kw, s, p = self.O, self.I, self.kh, self.kw, self.stride, self.pad
         dev = weight.device
+        wdt, kmul, fbf = self._wdt, self._kmul, self._fbf
         nd = n_pad_for(I)
-        Ob = _round_up(O, 32) if O % 4 else O                    # channels of the incoming gradient buffer (17 -> 32)
+        Ob = _round_up(O, kmul) if O % kmul else O        # 17 heat-map channels -> one whole K tile (32 fp32 / 64 bf16)                    # channels of the incoming gradient buffer (17 -> 32)
         self.c_out_buf = Ob
         self.w_dgrad, self.d_dgrad = [], []
         if s == 1:
-            wd = torch.zeros((nd, kh * kw * Ob), dtype=torch.float32, device=dev)
+            wd = torch.zeros((nd, kh * kw * Ob), dtype=wdt, device=dev)
             # Wd[c][(ty,tx,o)] = W[o][c][kh-1-ty][kw-1-tx]
             self.pack_jobs.append(PackJob(self.wname, wd, (nd, kh, kw, Ob), (kh * kw, -kw, -1, I * kh * kw), (I, kh, kw, O),
                                           (kh - 1) * kw + (kw - 1)))
@@ -192,7 +200,7 @@ class ConvT:
             g.oy_mul = g.ox_mul = 1
             g.oy_add = g.ox_add = 0
             g.phases_y = g.phases_x = 1
-            g.flags = 0
+            g.flags = fbf | (SP_CONV_OUT_F32 if self.bf16 else 0)
             self.w_dgrad.append(wd); self.d_dgrad.append(g)
             self.dgrad_full_cover = True
         else:
@@ -207,7 +215,7 @@ class ConvT:
                     if th == 0 or tw == 0:
                         self.dgrad_full_cover = False             # 1x1 stride 2: only phase (0,0) receives gradient
                         continue
-                    wd = torch.zeros((nd, th * tw * Ob), dtype=torch.float32, device=dev)
+                    wd = torch.zeros((nd, th * tw * Ob), dtype=wdt, device=dev)
                     self.pack_jobs.append(PackJob(self.wname, wd, (nd, th, tw, Ob), (kh * kw, 2 * kw, 2, I * kh * kw), (I, th, tw, O),
                                                   ky0 * kw + kx0))
                     g = ConvDesc()
@@ -218,7 +226,7 @@ class ConvT:
                     g.out_h, g.out_w, g.out_c = self.h, self.w, I
                     g.oy_mul, g.oy_add, g.ox_mul, g.ox_add = 2, py, 2, px
                     g.phases_y = g.phases_x = 1
-                    g.flags = 0
+                    g.flags = fbf | (SP_CONV_OUT_F32 if self.bf16 else 0)
                     self.w_dgrad.append(wd); self.d_dgrad.append(g)
 
     # ---- launches ----
@@ -226,7 +234,7 @@ class ConvT:
         lib, d = _lib.lib(), self.d_fwd
         d.batch = B
         if out is None:
-            out = torch.empty((B, d.out_h, d.out_w, d.out_c), dtype=torch.float32, device=x.device)
+            out = torch.empty((B, d.out_h, d.out_w, d.out_c), dtype=self._wdt, device=x.device)
         _lib.check(lib.sp_conv2d_fwd(d, P(x), P(self.w_fwd), None, P(shift), None, P(out), _lib.current_stream()), self.name)
         return out
 
@@ -261,7 +269,16 @@ class PoseTrainer:
     """fp32 train step for `simple_pose_amd.nets.pose_resnet_dconv.ResNet` on one GPU (+ optional process group)."""
 
     def __init__(self, model, in_h: int = 256, in_w: int = 192, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 process_group=None):
+                 process_group=None, dtype: str = "fp32"):
+        """dtype "bf16": bf16 activations and packed weights (v_mfma_f32_32x32x16_bf16 for forward, dgrad and wgrad); the
+        gradient w.r.t. a block output stays fp32 until the BatchNorm backward has subtracted its per-channel mean (rounding
+        it to bf16 first costs 10-50 % gradient error in this net: the useful part is a small difference of large terms), the
+        BN-input gradient dz that feeds the MFMAs is bf16; fp32 master weights / weight gradients / BN statistics / Adam.
+        The reference's `optim.amp` mode (ddp...:121-127) without a GradScaler (bf16 keeps fp32's exponent range)."""
+        if dtype not in ("fp32", "bf16"):
+            raise ValueError(dtype)
+        self.bf16 = dtype == "bf16"
+        self.act_dtype = torch.bfloat16 if self.bf16 else torch.float32
         if getattr(model, "HEAD", None) != "dconv":
             raise NotImplementedError("PoseTrainer lowers the ResNet-50 DConv net (BASELINE config 4); other heads pending")
         self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
@@ -289,7 +306,7 @@ class PoseTrainer:
         return layer
 
     def _build(self, H, W):
-        self._conv("conv1", H, W, stride=2, pad=3, c_in_buf=4, need_dgrad=False)
+        self._conv("conv1", H, W, stride=2, pad=3, c_in_buf=8 if self.bf16 else 4, need_dgrad=False)
         h, w = H // 4, W // 4
         inpl = 64
         for li, (planes, n) in enumerate(zip((64, 128, 256, 512), self.model.BLOCKS), start=1):
@@ -315,8 +332,8 @@ class PoseTrainer:
         for layer in self.layers.values():
             for j in layer.pack_jobs:
                 o, _ = self.flat.offsets[j.src_name]
-                _lib.check(lib.sp_permute4_f32(P(self.flat.data), P(j.dst), _i32(*j.dims), _i64(*j.strides), _i32(*j.valid), o + j.base,
-                                               j.dst_off, stream), "repack " + j.src_name)
+                _lib.check(lib.sp_permute4_f32(P(self.flat.data), P(j.dst), int(self.bf16), _i32(*j.dims), _i64(*j.strides), _i32(*j.valid),
+                                               o + j.base, j.dst_off, stream), "repack " + j.src_name)
 
     # ---- one step -----------------------------------------------------------------------------------------------------
     def forward_backward(self, x: torch.Tensor, targets: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
@@ -332,35 +349,40 @@ class PoseTrainer:
         L = self.layers
         ws = self.red_ws
 
-        def new(shape):
+        bf = int(self.bf16)
+
+        def new(shape, dtype=None):
+            return torch.empty(shape, dtype=dtype or self.act_dtype, device=dev)
+
+        def newf(shape):
             return torch.empty(shape, dtype=torch.float32, device=dev)
 
         def conv_bn(xa: Act, cname: str, bname: str, relu: bool, res: Optional[Act] = None) -> Act:
             layer = L[cname]
             z = layer.forward(xa.data, B)
             rows, C = z.shape[0] * z.shape[1] * z.shape[2], z.shape[3]
-            mean, invstd = new(C), new(C)
+            mean, invstd = newf(C), newf(C)
             gamma, beta = self.sd[bname + ".weight"], self.sd[bname + ".bias"]
-            _lib.check(lib.sp_bn_train_stats_nhwc(P(z), rows, C, BN_EPS, BN_MOMENTUM, P(mean), P(invstd),
+            _lib.check(lib.sp_bn_train_stats_nhwc(P(z), bf, rows, C, BN_EPS, BN_MOMENTUM, P(mean), P(invstd),
                                                   P(self.buffers[bname + ".running_mean"]), P(self.buffers[bname + ".running_var"]),
                                                   P(ws), stream), bname)
             nbt.append(self.buffers[bname + ".num_batches_tracked"])
             y = new(z.shape)
-            _lib.check(lib.sp_bn_apply_nhwc(P(z), P(mean), P(invstd), P(gamma), P(beta), P(res.data) if res else None, P(y), rows, C,
+            _lib.check(lib.sp_bn_apply_nhwc(P(z), bf, P(mean), P(invstd), P(gamma), P(beta), P(res.data) if res else None, P(y), rows, C,
                                             int(relu), stream), bname)
             ya = Act(y, z.shape[1], z.shape[2], C)
 
             def bwd():
-                dz = new(z.shape)
+                dz = new(z.shape)                      # MFMA operand of dgrad / wgrad: activation dtype
                 dres = None
                 acc = 0
                 if res is not None:
                     if res.grad is None:
-                        res.grad = new(res.data.shape)
+                        res.grad = newf(res.data.shape)   # activation gradients are fp32 in both modes
                     else:
                         acc = 1
                     dres = res.grad
-                _lib.check(lib.sp_bn_train_bwd_nhwc(P(ya.grad), P(y) if relu else None, P(z), P(mean), P(invstd), P(gamma), rows, C, P(dz),
+                _lib.check(lib.sp_bn_train_bwd_nhwc(P(ya.grad), bf, P(y) if relu else None, P(z), P(mean), P(invstd), P(gamma), rows, C, P(dz),
                                                     P(self.flat.view(bname + ".weight", True)), P(self.flat.view(bname + ".bias", True)),
                                                     P(dres), acc, P(ws), stream), bname + ".bwd")
                 ya.grad = None
@@ -371,17 +393,19 @@ class PoseTrainer:
             return ya
 
         # ---- forward ----
-        x4 = new((B, self.in_h, self.in_w, 4))
-        _lib.check(lib.sp_nchw_to_nhwc4(P(x), P(x4), B, 3, self.in_h, self.in_w, stream), "to_nhwc4")
-        a = conv_bn(Act(x4, self.in_h, self.in_w, 4, needs_grad=False), "conv1", "bn1", True)
+        cp = 8 if self.bf16 else 4
+        x4 = new((B, self.in_h, self.in_w, cp))
+        _lib.check((lib.sp_nchw_to_nhwc8_bf16 if self.bf16 else lib.sp_nchw_to_nhwc4)(P(x), P(x4), B, 3, self.in_h, self.in_w, stream), "to_nhwc")
+        a = conv_bn(Act(x4, self.in_h, self.in_w, cp, needs_grad=False), "conv1", "bn1", True)
         pooled = new((B, a.h // 2, a.w // 2, a.c))
-        _lib.check(lib.sp_maxpool3x3s2_nhwc(P(a.data), P(pooled), B, a.h, a.w, a.c, stream), "maxpool")
+        _lib.check((lib.sp_maxpool3x3s2_nhwc_bf16 if self.bf16 else lib.sp_maxpool3x3s2_nhwc)(P(a.data), P(pooled), B, a.h, a.w, a.c, stream),
+                   "maxpool")
         pa = Act(pooled, a.h // 2, a.w // 2, a.c)
         stem_out = a
 
         def pool_bwd():
-            stem_out.grad = new(stem_out.data.shape)
-            _lib.check(lib.sp_maxpool3x3s2_bwd_nhwc(P(stem_out.data), P(pa.grad), P(stem_out.grad), B, stem_out.h, stem_out.w, stem_out.c,
+            stem_out.grad = newf(stem_out.data.shape)
+            _lib.check(lib.sp_maxpool3x3s2_bwd_nhwc(P(stem_out.data), bf, P(pa.grad), P(stem_out.grad), B, stem_out.h, stem_out.w, stem_out.c,
                                                     stream), "maxpool.bwd")
             pa.grad = None
         tape.append(pool_bwd)
@@ -401,16 +425,18 @@ class PoseTrainer:
         heat = torch.empty((B, J, hh, ww), dtype=torch.float32, device=dev)
         fl.forward(a.data, B, out=heat, shift=self.sd["final_layer.bias"])
         # ---- loss + d loss / d heat ----
-        dheat = new((B, J, hh, ww))
+        dheat = newf((B, J, hh, ww))
         _lib.check(lib.sp_masked_mse(P(heat), P(targets), P(mask), B, J, hh * ww, P(self.loss_buf), P(dheat), P(self.mse_ws), stream), "mse")
         self.last_heat = heat
         # ---- backward ----
         Jb = fl.c_out_buf
         dh = torch.zeros((B, hh, ww, Jb), dtype=torch.float32, device=dev)
-        dh[..., :J] = dheat.permute(0, 2, 3, 1)           # tiny layout glue ([B,17,64,48] -> NHWC, channels padded to 32)
-        bsum = new(Jb)
+        dh[..., :J] = dheat.permute(0, 2, 3, 1)           # tiny layout glue ([B,17,64,48] -> NHWC, channels padded to a K tile)
+        bsum = newf(Jb)
         _lib.check(lib.sp_channel_sum_nhwc(P(dh), B * hh * ww, Jb, P(bsum), P(ws), stream), "final_layer.bias.grad")
         self.flat.view("final_layer.bias", True).copy_(bsum[:J])
+        if self.bf16:
+            dh = dh.to(torch.bfloat16)
         fl.wgrad(a.data, dh, B)
         a.grad = fl.dgrad(dh, B, None)
         for fn in reversed(tape):
