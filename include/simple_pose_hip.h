@@ -194,6 +194,11 @@ int sp_conv2d_wgrad(const sp_conv_desc* desc, const void* g, int g_channels, con
 int sp_permute4_f32(const float* src, void* dst, int dst_bf16, const int32_t* dst_dims, const int64_t* src_strides,
                     const int32_t* valid, int64_t src_base, int64_t dst_offset, void* stream);
 
+/* every pack job of a network in one launch: `jobs_device` = device array of n_jobs records
+ *   { int32 dst_dims[4]; int64 src_strides[4]; int32 valid[4]; int64 src_base; int64 dst_address; int64 total; int32 dst_bf16; int32 pad; }
+ * (dst_address = device pointer of the destination incl. its offset), blocks_per_job workgroups grid-stride over a job */
+int sp_permute4_batched(const float* src, const void* jobs_device, int n_jobs, int blocks_per_job, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

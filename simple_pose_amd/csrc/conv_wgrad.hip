@@ -254,9 +254,17 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, 
         const int tap = k / c_in, c = k - tap * c_in;
         const int ty = tap / taps_w, tx = tap - ty * taps_w;
         if (n >= n_valid || c >= c_valid || ty >= taps_h || tx >= kw) continue;
-        float s = 0.f;
-        for (int sp = 0; sp < splits; ++sp) s += slab[((size_t)sp * n_rows + n) * k_pad + k];
-        dst[n * s_n + c * s_c + ty * kw + tx] = s;
+        // fixed summation order (deterministic); 4 independent partial chains keep 4 loads in flight
+        const size_t stride = (size_t)n_rows * k_pad;
+        const float* src = slab + (size_t)n * k_pad + k;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int sp = 0;
+        for (; sp + 4 <= splits; sp += 4) {
+            s0 += src[(size_t)sp * stride]; s1 += src[(size_t)(sp + 1) * stride];
+            s2 += src[(size_t)(sp + 2) * stride]; s3 += src[(size_t)(sp + 3) * stride];
+        }
+        for (; sp < splits; ++sp) s0 += src[(size_t)sp * stride];
+        dst[n * s_n + c * s_c + ty * kw + tx] = (s0 + s1) + (s2 + s3);
     }
 }
 
@@ -278,8 +286,10 @@ extern "C" int sp_conv2d_wgrad(const sp_conv_desc* d, const void* g, int g_chann
     const int k_pad128 = (d->k_pad + 127) / 128 * 128;
     const int n_rows = (n_valid + 127) / 128 * 128;
     const int tiles = (n_rows / 128) * (k_pad128 / 128);
-    // split the pixel range so that ~1024 workgroups exist; each split a multiple of 32 pixels
-    long long splits = (1024 + tiles - 1) / tiles;
+    // split the pixel range so that ~768 (fp32) / ~384 (bf16: the MFMA part is 4x shorter, slab traffic dominates) workgroups
+    // exist; each split a multiple of 32 pixels
+    const int target = bf16 ? 384 : 768;
+    long long splits = (target + tiles - 1) / tiles;
     const long long max_splits = (M + 255) / 256;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;

@@ -271,7 +271,41 @@ __global__ void permute4_kernel(const float* __restrict__ src, void* __restrict_
     }
 }
 
+// All pack jobs of a network in ONE launch: job table in device memory, blockIdx.y = job, grid-stride inside the job.
+struct PackJobDev {
+    int d[4];
+    long long s[4];
+    int lim[4];
+    long long base;      // element offset into src
+    long long dst_ptr;   // device address of the destination buffer (already offset)
+    long long total;
+    int dst_bf16;
+    int pad;
+};
+__global__ void permute4_batched_kernel(const float* __restrict__ src, const PackJobDev* __restrict__ jobs) {
+    const PackJobDev pm = jobs[blockIdx.y];
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < pm.total; i += (long long)gridDim.x * blockDim.x) {
+        long long r = i;
+        const int i3 = (int)(r % pm.d[3]); r /= pm.d[3];
+        const int i2 = (int)(r % pm.d[2]); r /= pm.d[2];
+        const int i1 = (int)(r % pm.d[1]);
+        const int i0 = (int)(r / pm.d[1]);
+        float v = 0.f;
+        if (i0 < pm.lim[0] && i1 < pm.lim[1] && i2 < pm.lim[2] && i3 < pm.lim[3])
+            v = src[pm.base + i0 * pm.s[0] + i1 * pm.s[1] + i2 * pm.s[2] + i3 * pm.s[3]];
+        if (pm.dst_bf16) reinterpret_cast<__bf16*>(pm.dst_ptr)[i] = (__bf16)v;
+        else reinterpret_cast<float*>(pm.dst_ptr)[i] = v;
+    }
+}
+
 }  // namespace
+
+extern "C" int sp_permute4_batched(const float* src, const void* jobs_device, int n_jobs, int blocks_per_job, void* stream) {
+    SP_REQUIRE(src && jobs_device && n_jobs > 0 && n_jobs <= 65535 && blocks_per_job > 0, "sp_permute4_batched: bad argument");
+    hipLaunchKernelGGL(permute4_batched_kernel, dim3(blocks_per_job, n_jobs), dim3(256), 0, (hipStream_t)stream, src,
+                       reinterpret_cast<const PackJobDev*>(jobs_device));
+    return sp_check_launch("permute4_batched_kernel");
+}
 
 extern "C" int sp_bn_train_stats_nhwc(const void* z, int bf16, int64_t rows, int c, float eps, float momentum, float* mean, float* invstd,
                                       float* running_mean, float* running_var, void* workspace, void* stream) {

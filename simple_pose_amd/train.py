@@ -327,13 +327,24 @@ class PoseTrainer:
         self.heat_hw = (h, w)
 
     def repack(self):
-        """Regenerate every packed weight copy from the (just updated) flat parameter buffer."""
-        lib, stream = _lib.lib(), _lib.current_stream()
-        for layer in self.layers.values():
-            for j in layer.pack_jobs:
+        """Regenerate every packed weight copy from the (just updated) flat parameter buffer: one launch over a device-side
+        job table (141 jobs for ResNet50-DConv)."""
+        if getattr(self, "_pack_table", None) is None:
+            import numpy as np
+            rec = np.dtype([("d", "<i4", 4), ("s", "<i8", 4), ("lim", "<i4", 4), ("base", "<i8"), ("dst", "<i8"), ("total", "<i8"),
+                            ("bf16", "<i4"), ("pad", "<i4")], align=True)
+            jobs = [j for layer in self.layers.values() for j in layer.pack_jobs]
+            tab = np.zeros(len(jobs), dtype=rec)
+            for i, j in enumerate(jobs):
                 o, _ = self.flat.offsets[j.src_name]
-                _lib.check(lib.sp_permute4_f32(P(self.flat.data), P(j.dst), int(self.bf16), _i32(*j.dims), _i64(*j.strides), _i32(*j.valid),
-                                               o + j.base, j.dst_off, stream), "repack " + j.src_name)
+                es = 2 if j.dst.dtype == torch.bfloat16 else 4
+                tab[i]["d"], tab[i]["s"], tab[i]["lim"] = j.dims, j.strides, j.valid
+                tab[i]["base"], tab[i]["dst"] = o + j.base, j.dst.data_ptr() + j.dst_off * es
+                tab[i]["total"], tab[i]["bf16"] = int(np.prod(j.dims)), int(j.dst.dtype == torch.bfloat16)
+            assert rec.itemsize == 96, rec.itemsize
+            self._pack_table = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(self.flat.data.device)
+            self._pack_n = len(jobs)
+        _lib.check(_lib.lib().sp_permute4_batched(P(self.flat.data), P(self._pack_table), self._pack_n, 32, _lib.current_stream()), "repack")
 
     # ---- one step -----------------------------------------------------------------------------------------------------
     def forward_backward(self, x: torch.Tensor, targets: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
