@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="compute dtype of the network (BASELINE metric: f32)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
                     help="infer = forward + GaussTaylor decode (BASELINE metric, default); train = fwd+bwd+Adam step (config 4, fp32)")
+    ap.add_argument("--no-sync-bn", action="store_true", help="train mode, N > 1: per-rank BN statistics (the reference's DDP solver syncs them)")
+    ap.add_argument("--bucket-mb", type=float, default=32.0, help="train mode, N > 1: gradient all-reduce bucket size")
     ap.add_argument("--tiles", default=None, help="JSON tile table: loaded if it exists (skips autotune), else written")
     ap.add_argument("--layers-out", default=None, help="write the per-layer timing table (JSON) here")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (roofline object)")
@@ -150,7 +152,8 @@ def main():
         from simple_pose_amd.commons.transforms import RefineSimpleTransform
         from simple_pose_amd.train import PoseTrainer
         model.train()
-        trainer = PoseTrainer(model, lr=1e-3, dtype="bf16" if args.dtype == "bf16" else "fp32")
+        trainer = PoseTrainer(model, lr=1e-3, dtype="bf16" if args.dtype == "bf16" else "fp32", sync_bn=not args.no_sync_bn,
+                              bucket_mb=args.bucket_mb)
         joints = torch.from_numpy(synth.joints_batch(B, 17, seed=200 + rank)).to(dev)
         targets, mask = RefineSimpleTransform.get_heat_map(joints, 2.0, (48, 64))   # HIP encoder, on device
         prog = None
@@ -213,7 +216,8 @@ def main():
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                 "config": {"workload": f"{name} 256x192 train step, bs={B} per GPU, {'fp32' if args.dtype == 'f32' else 'bf16 compute + fp32 master weights/Adam'}, train-mode BN (batch statistics), Adam lr 1e-3, "
-                                       "targets from the HIP encoder, gradients all-reduced over ranks (RCCL) when N > 1",
+                                       "targets from the HIP encoder; N > 1: SyncBatchNorm " + ("off" if args.no_sync_bn else "on") +
+                                       f", gradients all-reduced in {args.bucket_mb:g} MB buckets overlapped with backward (RCCL)",
                            "images_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
                 "gflop_per_image": round(gflop, 3), "network_tflops": round(value * gflop / 1e3, 2),
                 "network_frac_of_matrix_peak": round(value * gflop / 1e3 / ((FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else BF16_MATRIX_PEAK_TFLOPS) * world), 4),

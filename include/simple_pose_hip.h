@@ -27,7 +27,7 @@ extern "C" {
 #define SP_EINVAL (-1)   /* bad argument / unsupported shape (message in sp_last_error) */
 #define SP_ELAUNCH (-2)  /* HIP launch or runtime failure */
 
-#define SP_ABI_VERSION 4
+#define SP_ABI_VERSION 5
 
 /* epilogue / layout flags of sp_conv_desc.flags */
 #define SP_CONV_RELU 0x1u          /* y = max(y, 0) after scale/shift (+ residual) */
@@ -173,6 +173,19 @@ int sp_bn_apply_nhwc(const void* z, int bf16, const float* mean, const float* in
 int sp_bn_train_bwd_nhwc(const void* dy, int bf16, const void* relu_src, const void* z, const float* mean, const float* invstd,
                          const float* gamma, int64_t rows, int c, void* dz, float* dgamma, float* dbeta, void* dres,
                          int dres_accumulate, void* workspace, void* stream);
+/* nn.SyncBatchNorm (ddp...:89-90) = the same three steps with a cross-rank SUM between the halves:
+ *   forward : sp_bn_train_partial_nhwc -> all-reduce(sums [c][2] fp64: sum, sum of squares) -> sp_bn_train_finalize(total_rows)
+ *   backward: sp_bn_train_bwd_reduce_nhwc (LOCAL dgamma, dbeta = this rank's parameter gradients) -> all-reduce(copy of them)
+ *             -> sp_bn_train_bwd_apply_nhwc(global sums, total_rows = rows over all ranks)
+ * sp_bn_train_stats_nhwc / sp_bn_train_bwd_nhwc are exactly these halves back to back with total_rows = rows. */
+int sp_bn_train_partial_nhwc(const void* z, int bf16, int64_t rows, int c, double* sums, void* workspace, void* stream);
+int sp_bn_train_finalize(const double* sums, int64_t total_rows, int c, float eps, float momentum, float* mean, float* invstd,
+                         float* running_mean, float* running_var, void* stream);
+int sp_bn_train_bwd_reduce_nhwc(const void* dy, int bf16, const void* relu_src, const void* z, const float* mean, const float* invstd,
+                                int64_t rows, int c, float* dgamma, float* dbeta, void* workspace, void* stream);
+int sp_bn_train_bwd_apply_nhwc(const void* dy, int bf16, const void* relu_src, const void* z, const float* mean, const float* invstd,
+                               const float* gamma, const float* sum_dgamma, const float* sum_dbeta, int64_t total_rows, int64_t rows,
+                               int c, void* dz, void* dres, int dres_accumulate, void* stream);
 /* sum over rows of a [rows, c] tensor (conv bias gradient) */
 int sp_channel_sum_nhwc(const float* a, int64_t rows, int c, float* sum, void* workspace, void* stream);
 /* backward of nn.MaxPool2d(3,2,1) (first maximum of a window wins, as torch); x = the pool's input */

@@ -20,7 +20,7 @@ SP_CONV_PIXEL_SHUFFLE = 0x4
 SP_CONV_BF16 = 0x8
 SP_CONV_OUT_F32 = 0x10
 CONV_TILES = ((128, 128), (64, 128), (128, 64), (64, 64), (256, 64), (128, 32))
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class HipLibraryError(RuntimeError):
@@ -61,6 +61,10 @@ SYMBOLS = {
     "sp_encode_gauss_basic": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, c_int, _P, _P, _P]),
     "sp_bn_train_stats_nhwc": (c_int, [_P, c_int, c_int64, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P]),
     "sp_bn_apply_nhwc": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, _P]),
+    "sp_bn_train_partial_nhwc": (c_int, [_P, c_int, c_int64, c_int, _P, _P, _P]),
+    "sp_bn_train_finalize": (c_int, [_P, c_int64, c_int, c_float, c_float, _P, _P, _P, _P, _P]),
+    "sp_bn_train_bwd_reduce_nhwc": (c_int, [_P, c_int, _P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P]),
+    "sp_bn_train_bwd_apply_nhwc": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, _P, _P, c_int, _P]),
     "sp_bn_train_bwd_nhwc": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P, c_int, _P, _P]),
     "sp_channel_sum_nhwc": (c_int, [_P, c_int64, c_int, _P, _P, _P]),
     "sp_maxpool3x3s2_bwd_nhwc": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),

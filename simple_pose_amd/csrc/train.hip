@@ -132,6 +132,17 @@ __global__ void pair_sum_final_kernel(const double* __restrict__ part, int nblk,
     if (o1) o1[c] = (float)s1;
 }
 
+// SyncBatchNorm halves: per-rank (sum, sum of squares) kept in fp64 so that the cross-rank SUM is order-insensitive to ~1e-16
+__global__ void pair_sum_final_f64_kernel(const double* __restrict__ part, int nblk, int C, double* __restrict__ sums) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    double s0, s1;
+    fold_partials(part, nblk, C, c, s0, s1);
+    if ((threadIdx.x & 63) != 0) return;
+    sums[2 * c] = s0;
+    sums[2 * c + 1] = s1;
+}
+
 // y = [relu]( (z - mean) * invstd * gamma + beta [+ res] )
 template <bool BF16>
 __global__ void bn_apply_kernel(const void* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -322,6 +333,27 @@ extern "C" int sp_bn_train_stats_nhwc(const void* z, int bf16, int64_t rows, int
     return sp_check_launch("bn_train_stats");
 }
 
+extern "C" int sp_bn_train_partial_nhwc(const void* z, int bf16, int64_t rows, int c, double* sums, void* workspace, void* stream) {
+    SP_REQUIRE(z && sums && workspace, "sp_bn_train_partial_nhwc: null pointer");
+    SP_REQUIRE(rows > 0 && c > 0 && c % 4 == 0 && rows < (1ll << 31), "sp_bn_train_partial_nhwc: bad shape rows=%lld c=%d", (long long)rows, c);
+    hipStream_t s = (hipStream_t)stream;
+    double* part = reinterpret_cast<double*>(workspace);
+    if (bf16 & 1) hipLaunchKernelGGL((channel_reduce_kernel<0, true>), dim3(RED_BLOCKS), dim3(256), 0, s, z, nullptr, nullptr, nullptr, nullptr, (int)rows, c, part);
+    else hipLaunchKernelGGL((channel_reduce_kernel<0, false>), dim3(RED_BLOCKS), dim3(256), 0, s, z, nullptr, nullptr, nullptr, nullptr, (int)rows, c, part);
+    hipLaunchKernelGGL(pair_sum_final_f64_kernel, dim3((c + 3) / 4), dim3(256), 0, s, part, RED_BLOCKS, c, sums);
+    return sp_check_launch("bn_train_partial");
+}
+
+extern "C" int sp_bn_train_finalize(const double* sums, int64_t total_rows, int c, float eps, float momentum, float* mean, float* invstd,
+                                    float* running_mean, float* running_var, void* stream) {
+    SP_REQUIRE(sums && mean && invstd, "sp_bn_train_finalize: null pointer");
+    SP_REQUIRE(total_rows > 0 && c > 0, "sp_bn_train_finalize: bad shape");
+    SP_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "sp_bn_train_finalize: running stats come in pairs");
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((c + 3) / 4), dim3(256), 0, (hipStream_t)stream, sums, 1, c, (double)total_rows, eps, momentum,
+                       mean, invstd, running_mean, running_var);
+    return sp_check_launch("bn_train_finalize");
+}
+
 extern "C" int sp_bn_apply_nhwc(const void* z, int bf16, const float* mean, const float* invstd, const float* gamma, const float* beta,
                                 const void* residual, void* y, int64_t rows, int c, int relu, void* stream) {
     SP_REQUIRE(z && mean && invstd && gamma && beta && y, "sp_bn_apply_nhwc: null pointer");
@@ -334,28 +366,46 @@ extern "C" int sp_bn_apply_nhwc(const void* z, int bf16, const float* mean, cons
     return sp_check_launch("bn_apply_kernel");
 }
 
-extern "C" int sp_bn_train_bwd_nhwc(const void* dy, int bf16, const void* relu_src, const void* z, const float* mean, const float* invstd,
-                                    const float* gamma, int64_t rows, int c, void* dz, float* dgamma, float* dbeta, void* dres,
-                                    int dres_accumulate, void* workspace, void* stream) {
-    SP_REQUIRE(dy && z && mean && invstd && gamma && dz && dgamma && dbeta && workspace, "sp_bn_train_bwd_nhwc: null pointer");
-    SP_REQUIRE(rows > 0 && c > 0 && c % 4 == 0 && rows < (1ll << 31), "sp_bn_train_bwd_nhwc: bad shape");
+extern "C" int sp_bn_train_bwd_reduce_nhwc(const void* dy, int bf16, const void* relu_src, const void* z, const float* mean, const float* invstd,
+                                           int64_t rows, int c, float* dgamma, float* dbeta, void* workspace, void* stream) {
+    SP_REQUIRE(dy && z && mean && invstd && dgamma && dbeta && workspace, "sp_bn_train_bwd_reduce_nhwc: null pointer");
+    SP_REQUIRE(rows > 0 && c > 0 && c % 4 == 0 && rows < (1ll << 31), "sp_bn_train_bwd_reduce_nhwc: bad shape");
     hipStream_t s = (hipStream_t)stream;
     double* part = reinterpret_cast<double*>(workspace);
     const bool a16 = bf16 & 1, g16 = bf16 & 2;
-    SP_REQUIRE(a16 || !g16, "sp_bn_train_bwd_nhwc: bf16 gradients with fp32 activations is not a supported mix");
+    SP_REQUIRE(a16 || !g16, "sp_bn_train_bwd_reduce_nhwc: bf16 gradients with fp32 activations is not a supported mix");
     if (a16 && g16) hipLaunchKernelGGL((channel_reduce_kernel<1, true, true>), dim3(RED_BLOCKS), dim3(256), 0, s, dy, relu_src, z, mean, invstd, (int)rows, c, part);
     else if (a16) hipLaunchKernelGGL((channel_reduce_kernel<1, true, false>), dim3(RED_BLOCKS), dim3(256), 0, s, dy, relu_src, z, mean, invstd, (int)rows, c, part);
     else hipLaunchKernelGGL((channel_reduce_kernel<1, false, false>), dim3(RED_BLOCKS), dim3(256), 0, s, dy, relu_src, z, mean, invstd, (int)rows, c, part);
     hipLaunchKernelGGL(pair_sum_final_kernel, dim3((c + 3) / 4), dim3(256), 0, s, part, RED_BLOCKS, c, dbeta, dgamma);
+    return sp_check_launch("bn_train_bwd_reduce");
+}
+
+extern "C" int sp_bn_train_bwd_apply_nhwc(const void* dy, int bf16, const void* relu_src, const void* z, const float* mean, const float* invstd,
+                                          const float* gamma, const float* sum_dgamma, const float* sum_dbeta, int64_t total_rows, int64_t rows,
+                                          int c, void* dz, void* dres, int dres_accumulate, void* stream) {
+    SP_REQUIRE(dy && z && mean && invstd && gamma && dz && sum_dgamma && sum_dbeta, "sp_bn_train_bwd_apply_nhwc: null pointer");
+    SP_REQUIRE(rows > 0 && total_rows >= rows && c > 0 && c % 4 == 0 && rows < (1ll << 31), "sp_bn_train_bwd_apply_nhwc: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    const bool a16 = bf16 & 1, g16 = bf16 & 2;
+    SP_REQUIRE(a16 || !g16, "sp_bn_train_bwd_apply_nhwc: bf16 gradients with fp32 activations is not a supported mix");
     const long long total = rows * (c / 4);
 #define SP_BWD_APPLY(A, G)                                                                                                             \
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<A, G>), dim3(grid_for(total, 256)), dim3(256), 0, s, dy, relu_src, z, mean, invstd, gamma, dgamma, \
-                       dbeta, (float)(1.0 / (double)rows), dz, dres, dres_accumulate, c / 4, total)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<A, G>), dim3(grid_for(total, 256)), dim3(256), 0, s, dy, relu_src, z, mean, invstd, gamma, sum_dgamma, \
+                       sum_dbeta, (float)(1.0 / (double)total_rows), dz, dres, dres_accumulate, c / 4, total)
     if (a16 && g16) SP_BWD_APPLY(true, true);
     else if (a16) SP_BWD_APPLY(true, false);
     else SP_BWD_APPLY(false, false);
 #undef SP_BWD_APPLY
-    return sp_check_launch("bn_train_bwd");
+    return sp_check_launch("bn_train_bwd_apply");
+}
+
+extern "C" int sp_bn_train_bwd_nhwc(const void* dy, int bf16, const void* relu_src, const void* z, const float* mean, const float* invstd,
+                                    const float* gamma, int64_t rows, int c, void* dz, float* dgamma, float* dbeta, void* dres,
+                                    int dres_accumulate, void* workspace, void* stream) {
+    const int rc = sp_bn_train_bwd_reduce_nhwc(dy, bf16, relu_src, z, mean, invstd, rows, c, dgamma, dbeta, workspace, stream);
+    if (rc) return rc;
+    return sp_bn_train_bwd_apply_nhwc(dy, bf16, relu_src, z, mean, invstd, gamma, dgamma, dbeta, rows, rows, c, dz, dres, dres_accumulate, stream);
 }
 
 extern "C" int sp_channel_sum_nhwc(const float* a, int64_t rows, int c, float* sum, void* workspace, void* stream) {

@@ -269,12 +269,20 @@ class PoseTrainer:
     """fp32 train step for `simple_pose_amd.nets.pose_resnet_dconv.ResNet` on one GPU (+ optional process group)."""
 
     def __init__(self, model, in_h: int = 256, in_w: int = 192, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 process_group=None, dtype: str = "fp32"):
+                 process_group=None, dtype: str = "fp32", sync_bn: Optional[bool] = None, bucket_mb: float = 32.0,
+                 broadcast_init: bool = True):
         """dtype "bf16": bf16 activations and packed weights (v_mfma_f32_32x32x16_bf16 for forward, dgrad and wgrad); the
         gradient w.r.t. a block output stays fp32 until the BatchNorm backward has subtracted its per-channel mean (rounding
         it to bf16 first costs 10-50 % gradient error in this net: the useful part is a small difference of large terms), the
         BN-input gradient dz that feeds the MFMAs is bf16; fp32 master weights / weight gradients / BN statistics / Adam.
-        The reference's `optim.amp` mode (ddp...:121-127) without a GradScaler (bf16 keeps fp32's exponent range)."""
+        The reference's `optim.amp` mode (ddp...:121-127) without a GradScaler (bf16 keeps fp32's exponent range).
+
+        With a process group of W > 1 ranks (one process per GPU):
+          * parameters and BN buffers are broadcast from rank 0 at construction (DistributedDataParallel's init, ddp...:91-93);
+          * `sync_bn` (default: on, as `SyncBatchNorm.convert_sync_batchnorm` at ddp...:89-90): batch statistics and the two
+            backward sums of every BN layer are summed over ranks (one [2C] all-reduce each way per layer);
+          * the flat gradient buffer is all-reduced in `bucket_mb`-sized contiguous slices, each launched (async, on RCCL's
+            own stream) as soon as backward has produced its last gradient - final_layer's end of the buffer first."""
         if dtype not in ("fp32", "bf16"):
             raise ValueError(dtype)
         self.bf16 = dtype == "bf16"
@@ -283,6 +291,9 @@ class PoseTrainer:
             raise NotImplementedError("PoseTrainer lowers the ResNet-50 DConv net (BASELINE config 4); other heads pending")
         self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
         self.pg = process_group
+        import torch.distributed as dist
+        self.world = dist.get_world_size(self.pg) if (dist.is_available() and dist.is_initialized()) else 1
+        self.sync_bn = (self.world > 1) if sync_bn is None else (bool(sync_bn) and self.world > 1)
         self.flat = FlatParams(model)
         dev = self.flat.data.device
         self.exp_avg = torch.zeros_like(self.flat.data)
@@ -297,7 +308,45 @@ class PoseTrainer:
         self.in_h, self.in_w = in_h, in_w
         self.layers: Dict[str, ConvT] = {}
         self._build(in_h, in_w)
+        if self.world > 1 and broadcast_init:
+            dist.broadcast(self.flat.data, src=dist.get_global_rank(self.pg, 0) if self.pg is not None else 0, group=self.pg)
+            for b in self.buffers.values():
+                dist.broadcast(b, src=dist.get_global_rank(self.pg, 0) if self.pg is not None else 0, group=self.pg)
+        self._plan_buckets(bucket_mb)
         self.repack()
+
+    # ---- gradient buckets (DDP reducer, reverse parameter order) ---------------------------------------------------------
+    def _plan_buckets(self, bucket_mb: float):
+        """Contiguous slices of the flat gradient buffer, cut at parameter boundaries walking from the END of the buffer (backward
+        produces final_layer first).  Each bucket knows which parameter gradients it waits for."""
+        names = list(self.flat.offsets.keys())
+        cap = max(1, int(bucket_mb * (1 << 20) / 4))
+        self.buckets: List[dict] = []
+        hi = self.flat.numel
+        cur: List[str] = []
+        lo = hi
+        for n in reversed(names):
+            o, _ = self.flat.offsets[n]
+            cur.append(n)
+            lo = o
+            if hi - lo >= cap:
+                self.buckets.append({"lo": lo, "hi": hi, "names": set(cur)})
+                hi, cur = lo, []
+        if cur or hi > 0:
+            self.buckets.append({"lo": 0, "hi": hi, "names": set(cur)})
+        self._bucket_of = {n: i for i, b in enumerate(self.buckets) for n in b["names"]}
+
+    def _grads_ready(self, *names: str):
+        """Called by the backward tape when the gradients of `names` have been enqueued on the compute stream."""
+        if self.world == 1:
+            return
+        import torch.distributed as dist
+        for n in names:
+            i = self._bucket_of[n]
+            self._pending[i].discard(n)
+            if not self._pending[i] and self._works[i] is None:
+                b = self.buckets[i]
+                self._works[i] = dist.all_reduce(self.flat.grad[b["lo"]:b["hi"]], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
     # ---- static structure -------------------------------------------------------------------------------------------
     def _conv(self, name, h, w, **kw) -> ConvT:
@@ -361,6 +410,12 @@ class PoseTrainer:
         ws = self.red_ws
 
         bf = int(self.bf16)
+        self._pending = [set(b["names"]) for b in self.buckets]
+        self._works: List[Optional[object]] = [None] * len(self.buckets)
+        sync = self.sync_bn
+        if sync:
+            import torch.distributed as dist
+        W = self.world
 
         def new(shape, dtype=None):
             return torch.empty(shape, dtype=dtype or self.act_dtype, device=dev)
@@ -374,9 +429,17 @@ class PoseTrainer:
             rows, C = z.shape[0] * z.shape[1] * z.shape[2], z.shape[3]
             mean, invstd = newf(C), newf(C)
             gamma, beta = self.sd[bname + ".weight"], self.sd[bname + ".bias"]
-            _lib.check(lib.sp_bn_train_stats_nhwc(P(z), bf, rows, C, BN_EPS, BN_MOMENTUM, P(mean), P(invstd),
-                                                  P(self.buffers[bname + ".running_mean"]), P(self.buffers[bname + ".running_var"]),
-                                                  P(ws), stream), bname)
+            if sync:
+                sums = torch.empty(2 * C, dtype=torch.float64, device=dev)
+                _lib.check(lib.sp_bn_train_partial_nhwc(P(z), bf, rows, C, P(sums), P(ws), stream), bname)
+                dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.pg)
+                _lib.check(lib.sp_bn_train_finalize(P(sums), rows * W, C, BN_EPS, BN_MOMENTUM, P(mean), P(invstd),
+                                                    P(self.buffers[bname + ".running_mean"]), P(self.buffers[bname + ".running_var"]),
+                                                    stream), bname)
+            else:
+                _lib.check(lib.sp_bn_train_stats_nhwc(P(z), bf, rows, C, BN_EPS, BN_MOMENTUM, P(mean), P(invstd),
+                                                      P(self.buffers[bname + ".running_mean"]), P(self.buffers[bname + ".running_var"]),
+                                                      P(ws), stream), bname)
             nbt.append(self.buffers[bname + ".num_batches_tracked"])
             y = new(z.shape)
             _lib.check(lib.sp_bn_apply_nhwc(P(z), bf, P(mean), P(invstd), P(gamma), P(beta), P(res.data) if res else None, P(y), rows, C,
@@ -393,11 +456,22 @@ class PoseTrainer:
                     else:
                         acc = 1
                     dres = res.grad
-                _lib.check(lib.sp_bn_train_bwd_nhwc(P(ya.grad), bf, P(y) if relu else None, P(z), P(mean), P(invstd), P(gamma), rows, C, P(dz),
-                                                    P(self.flat.view(bname + ".weight", True)), P(self.flat.view(bname + ".bias", True)),
-                                                    P(dres), acc, P(ws), stream), bname + ".bwd")
+                dgamma, dbeta = self.flat.view(bname + ".weight", True), self.flat.view(bname + ".bias", True)
+                rs = P(y) if relu else None
+                if sync:
+                    # local sums are this rank's parameter gradients (DDP averages them later); dz needs the global ones
+                    _lib.check(lib.sp_bn_train_bwd_reduce_nhwc(P(ya.grad), bf, rs, P(z), P(mean), P(invstd), rows, C, P(dgamma), P(dbeta), P(ws),
+                                                               stream), bname + ".bwd")
+                    both = torch.cat([dgamma, dbeta])
+                    dist.all_reduce(both, op=dist.ReduceOp.SUM, group=self.pg)
+                    _lib.check(lib.sp_bn_train_bwd_apply_nhwc(P(ya.grad), bf, rs, P(z), P(mean), P(invstd), P(gamma), P(both[:C]), P(both[C:]),
+                                                              rows * W, rows, C, P(dz), P(dres), acc, stream), bname + ".bwd")
+                else:
+                    _lib.check(lib.sp_bn_train_bwd_nhwc(P(ya.grad), bf, rs, P(z), P(mean), P(invstd), P(gamma), rows, C, P(dz), P(dgamma), P(dbeta),
+                                                        P(dres), acc, P(ws), stream), bname + ".bwd")
                 ya.grad = None
                 layer.wgrad(xa.data, dz, B)
+                self._grads_ready(bname + ".weight", bname + ".bias", cname + ".weight")
                 if xa.needs_grad and layer.need_dgrad:
                     xa.grad = layer.dgrad(dz, B, xa.grad)
             tape.append(bwd)
@@ -449,6 +523,7 @@ class PoseTrainer:
         if self.bf16:
             dh = dh.to(torch.bfloat16)
         fl.wgrad(a.data, dh, B)
+        self._grads_ready("final_layer.bias", "final_layer.weight")
         a.grad = fl.dgrad(dh, B, None)
         for fn in reversed(tape):
             fn()
@@ -456,17 +531,24 @@ class PoseTrainer:
         return self.loss_buf
 
     def all_reduce_grads(self) -> float:
-        """DDP semantics: gradients are averaged over ranks.  One SUM all-reduce of the flat buffer (RCCL over xGMI);
-        the 1/world factor is folded into the Adam kernel."""
+        """DDP semantics: gradients are averaged over ranks.  SUM all-reduces of the flat buffer's buckets (RCCL over xGMI) were
+        launched during backward; wait for them here (launch whatever backward did not cover).  The 1/world factor is folded
+        into the Adam kernel."""
         import torch.distributed as dist
 
-        if self.pg is None and not (dist.is_available() and dist.is_initialized()):
+        if self.world == 1:
             return 1.0
-        world = dist.get_world_size(self.pg)
-        if world == 1:
-            return 1.0
-        dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.pg)
-        return 1.0 / world
+        works = getattr(self, "_works", None)
+        if works is None:                                  # gradients filled by hand (tests): one all-reduce of everything
+            dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.pg)
+            return 1.0 / self.world
+        for i, b in enumerate(self.buckets):
+            if works[i] is None:
+                works[i] = dist.all_reduce(self.flat.grad[b["lo"]:b["hi"]], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        for w in works:
+            w.wait()
+        self._works = None
+        return 1.0 / self.world
 
     def optimizer_step(self, grad_scale: float = 1.0):
         self.step_count += 1

@@ -151,3 +151,71 @@ def test_bf16_training_is_deterministic_and_decreases_loss():
     losses2 = [tr2.step(xs, ts, ws).item() for _ in range(8)]
     assert losses == losses2
     assert losses[-1] < losses[0]
+
+
+# ---- N > 1: two ranks sharing the one GPU of the box (gloo carries the collectives) ---------------------------------------
+def _ddp_worker(rank, world, port, sync_bn, bucket_mb, out_dir):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from simple_pose_amd.sharding import rank_indices
+        model, _ = _model(3 + rank)                  # deliberately different initial weights per rank: the ctor broadcasts rank 0's
+        x, t, w = _batch(4, 64, 64, 11)
+        idx = rank_indices(4, rank, world)
+        xs, ts, ws = (torch.from_numpy(v[idx]).to(DEV) for v in (x, t, w))
+        tr = PoseTrainer(model, in_h=64, in_w=64, lr=1e-3, sync_bn=sync_bn, bucket_mb=bucket_mb)
+        loss = tr.forward_backward(xs, ts, ws).item()
+        n_launched = sum(wk is not None for wk in tr._works)
+        scale = tr.all_reduce_grads()
+        grad = (tr.flat.grad * scale).cpu().numpy()
+        tr.optimizer_step(scale)
+        torch.cuda.synchronize()
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), loss=loss, grad=grad, param=tr.flat.data.cpu().numpy(),
+                 rm=tr.buffers["layer4.2.bn3.running_mean"].cpu().numpy(), rv=tr.buffers["bn1.running_var"].cpu().numpy(),
+                 n_buckets=len(tr.buckets), n_launched=n_launched)
+    finally:
+        dist.destroy_process_group()
+
+
+def _l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.sqrt(((a - b) ** 2).sum()) / (np.sqrt((b * b).sum()) + 1e-30))
+
+
+@pytest.mark.parametrize("sync_bn", [True, False])
+def test_two_rank_step_matches_single_rank(sync_bn, tmp_path):
+    """DDP + SyncBatchNorm semantics (ddp...:89-93): 2 ranks x 2 images == 1 rank x 4 images when BN statistics are synced;
+    without SyncBN both ranks still end with identical parameters (same averaged gradient, same Adam)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_ddp_worker, args=(2, port, sync_bn, 8.0, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (np.load(tmp_path / f"rank{r}.npz") for r in (0, 1))
+    assert int(r0["n_buckets"]) > 4 and int(r0["n_launched"]) >= int(r0["n_buckets"]) - 1      # buckets went out during backward
+    np.testing.assert_array_equal(r0["grad"], r1["grad"])
+    np.testing.assert_array_equal(r0["param"], r1["param"])
+    if not sync_bn:
+        return
+    np.testing.assert_array_equal(r0["rm"], r1["rm"])
+    model, _ = _model(3)
+    x, t, w = _batch(4, 64, 64, 11)
+    xs, ts, ws = (torch.from_numpy(v).to(DEV) for v in (x, t, w))
+    tr = PoseTrainer(model, in_h=64, in_w=64, lr=1e-3)
+    loss = tr.forward_backward(xs, ts, ws).item()
+    grad = tr.flat.grad.cpu().numpy().copy()
+    tr.optimizer_step(1.0)
+    assert abs(0.5 * (float(r0["loss"]) + float(r1["loss"])) - loss) < 1e-5 * abs(loss)
+    # same arithmetic up to the order of the per-channel sums; the net amplifies that (see the fp32-vs-fp64 note above)
+    assert _l2(r0["grad"], grad) < 2e-3, _l2(r0["grad"], grad)
+    np.testing.assert_allclose(r0["rm"], tr.buffers["layer4.2.bn3.running_mean"].cpu().numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(r0["rv"], tr.buffers["bn1.running_var"].cpu().numpy(), rtol=1e-4, atol=1e-7)
+    agree = np.mean(np.sign(r0["param"] - _flat_init(3)) == np.sign(tr.flat.data.cpu().numpy() - _flat_init(3)))
+    assert agree > 0.99, agree                     # first Adam step = lr * sign(grad): the update direction agrees
+
+
+def _flat_init(seed):
+    from simple_pose_amd.train import FlatParams
+    m, _ = _model(seed)
+    return FlatParams(m).data.cpu().numpy()

@@ -162,3 +162,28 @@ def test_bf16_lowering_tracks_fp32_oracle(head):
     assert got.dtype == torch.float32
     rel = (got - ref).abs().max() / ref.abs().max()
     assert 1e-4 < rel < 5e-2, rel     # CPU bf16 autocast vs fp32 = 1.07e-2
+
+
+def test_gradient_buckets_tile_the_flat_buffer_in_reverse_parameter_order():
+    """DDP-style reducer plan (simple_pose_amd.train.PoseTrainer._plan_buckets): contiguous slices, cut at parameter
+    boundaries from the end of the buffer, every parameter in exactly one bucket; a bucket fires when its last gradient lands."""
+    import torch
+    from simple_pose_amd.train import FlatParams, PoseTrainer
+
+    m = torch.nn.Sequential(torch.nn.Conv2d(3, 64, 3), torch.nn.BatchNorm2d(64), torch.nn.Conv2d(64, 64, 3), torch.nn.Conv2d(64, 17, 1))
+    shim = PoseTrainer.__new__(PoseTrainer)
+    shim.flat = FlatParams(m)
+    shim._plan_buckets(bucket_mb=4096 * 4 / (1 << 20))            # 4096-float buckets
+    names = [n for n, _ in m.named_parameters()]
+    assert shim.buckets[0]["hi"] == shim.flat.numel and shim.buckets[-1]["lo"] == 0
+    for a, b in zip(shim.buckets, shim.buckets[1:]):
+        assert a["lo"] == b["hi"]
+    assert sorted(n for b in shim.buckets for n in b["names"]) == sorted(names)
+    assert "3.bias" in shim.buckets[0]["names"] and "0.weight" in shim.buckets[-1]["names"]
+    for b in shim.buckets:
+        for n in b["names"]:
+            o, k = shim.flat.offsets[n]
+            assert b["lo"] <= o and o + k <= b["hi"]
+    assert len(shim.buckets) >= 2
+    shim.world = 1
+    shim._grads_ready("3.bias")                                    # single rank: nothing to launch, no state needed

@@ -67,7 +67,7 @@ def _grad_worker(rank, world, port, out):
         for n, p in m.named_parameters():
             p.grad.fill_(float(rank + 1) * (names.index(n) + 1))                                     # per-rank gradients
         shim = PoseTrainer.__new__(PoseTrainer)
-        shim.flat, shim.pg = flat, None
+        shim.flat, shim.pg, shim.world = flat, None, dist.get_world_size()
         scale = PoseTrainer.all_reduce_grads(shim)
         out[rank] = (scale, [float(p.grad.flatten()[0]) for p in m.parameters()], flat.numel % 4)
     finally:
