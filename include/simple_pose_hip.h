@@ -27,7 +27,7 @@ extern "C" {
 #define SP_EINVAL (-1)   /* bad argument / unsupported shape (message in sp_last_error) */
 #define SP_ELAUNCH (-2)  /* HIP launch or runtime failure */
 
-#define SP_ABI_VERSION 5
+#define SP_ABI_VERSION 6
 
 /* epilogue / layout flags of sp_conv_desc.flags */
 #define SP_CONV_RELU 0x1u          /* y = max(y, 0) after scale/shift (+ residual) */
@@ -137,6 +137,23 @@ int sp_heat_map_acc(const float* pred_coords, const float* label_coords, int bat
  * mean_rgb_host: 3 floats in HOST memory */
 int sp_u8hwc_bgr_to_nchw_f32(const unsigned char* img, float* out, int batch, int h, int w, const float* mean_rgb_host,
                              void* stream);
+
+/* ---- after decode: result scores and per-image OKS-NMS -----------------------------------
+ * kps_to_dict_ (metrics/pose_metrics.py:172-179): score[b] = mean_j(max_val[b,j]) + max_j(max_val[b,j]) */
+int sp_pose_score(const float* max_val, int batch, int joints, float* score, void* stream);
+/* eval.py:166-174: score[p] = box_score[p] * mean(kps[p,:,2][kps[p,:,2] > in_vis_thre]) (0 without a visible joint), float64 as
+ * the reference computes after its JSON round trip; kps [P,J,3] = (x, y, max_val) fp32 from the decoder; kps64 (may be NULL)
+ * receives the float64 copy sp_oks_nms consumes */
+int sp_pose_rescore(const float* kps, const double* box_score, int persons, int joints, double in_vis_thre, double* kps64,
+                    double* score, void* stream);
+/* oks_nms (datasets/naive_data.py:153-173; oks_iou :120-150) for `groups` images in one launch; the persons of image g are
+ * rows seg[g]..seg[g+1]-1 (seg: device int32 [groups+1]; max_group = the largest image, <= 2048, known to the host).
+ * sigmas_host: `joints` doubles in HOST memory or NULL (COCO's 17); vis_thresh < 0 = in_vis_thresh None.
+ * keep [P]: for image g the picked GLOBAL row indices in pick order at keep[seg[g]..], padded with -1; keep_count [groups].
+ * Order: descending score, equal scores: higher index first (numpy's own tie order is unspecified). */
+int sp_oks_nms(const double* kps, const double* scores, const double* areas, const int32_t* seg, int groups, int max_group,
+               int joints, const double* sigmas_host, double thresh, double vis_thresh, int32_t* keep, int32_t* keep_count,
+               void* stream);
 
 /* ---- encoders: commons/transforms.py ----------------------------------------------------------- */
 

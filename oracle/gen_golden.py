@@ -290,6 +290,69 @@ def gen_encode(ns):
     print("g5_encode.npz", t.shape, "refine weights", out["refine/weights"][:18])
 
 
+def gen_nms(ns):
+    """g8_nms.npz: SURVEY 8(f)4 - eval.py:153-197 (per-image rescoring + OKS-NMS through the reference's own function, run in
+    a scratch directory with COCOeval switched off), direct oks_nms calls with in_vis_thresh / custom sigmas, and
+    kps_to_dict_'s score rule (metrics/pose_metrics.py:172-179)."""
+    import importlib, json, tempfile
+    ev = importlib.import_module("eval")
+    nd = importlib.import_module("datasets.naive_data")
+    rng = np.random.default_rng(8)
+    sizes, ids = [9, 1, 7, 6, 30], [139, 285, 632, 724, 785]
+    kps_all, box, area, img = [], [], [], []
+    for n, iid in zip(sizes, ids):
+        base = rng.random((max(1, n // 3), 17, 3)) * np.array([400.0, 600.0, 1.0])
+        pick = rng.integers(0, len(base), n)
+        k = base[pick] + rng.normal(size=(n, 17, 3)) * np.array([rng.choice([0.5, 4.0]), rng.choice([0.5, 4.0]), 0.04])
+        k[..., 2] = np.clip(k[..., 2], 0.0, 1.0)
+        kps_all.append(k.astype(np.float32)); box.append(rng.random(n)); img += [iid] * n
+        area.append((rng.random(n) * 30000 + 800).astype(np.float32))
+    kps_all, box, area = np.concatenate(kps_all), np.concatenate(box), np.concatenate(area)
+    kps_all[3, :, 2] = 0.1                                   # a person without a visible joint -> score 0
+    kps_all[5, :, 2] = 0.15
+    out = {"kps": kps_all, "box_score": box, "area": area, "img_id": np.array(img)}
+    cwd = os.getcwd()
+    ev.eval_kps = lambda *a, **k: None
+    for tag, (vis, thr) in {"a": (0.2, 0.9), "b": (0.2, 0.5), "c": (0.5, 0.7)}.items():
+        with tempfile.TemporaryDirectory() as td:
+            os.chdir(td)
+            try:
+                items = [{"kps": kp.reshape(-1).tolist(), "area": float(a), "score": float(b), "img_id": int(i)}
+                         for kp, a, b, i in zip(kps_all, area, box, img)]                    # as eval.py:139-147 builds them
+                with open("predicts_kps_temp.json", "w") as wf:
+                    json.dump(items, wf)
+                ev.temp_read_in_and_filter(in_vis_thre=vis, oks_thre=thr)
+                with open("filter_kps_predicts.json") as rf:
+                    res = json.load(rf)
+            finally:
+                os.chdir(cwd)
+        out[f"filter/{tag}/params"] = np.array([vis, thr])
+        out[f"filter/{tag}/image_id"] = np.array([r["image_id"] for r in res])
+        out[f"filter/{tag}/score"] = np.array([r["score"] for r in res], np.float64)
+        out[f"filter/{tag}/keypoints"] = np.array([r["keypoints"] for r in res], np.float64)
+    grp = slice(sum(sizes[:4]), sum(sizes))                 # the 30-person image, called directly
+    sc = rng.random(30)
+    sig = rng.random(17) * 0.1 + 0.02
+    out["direct/scores"], out["direct/sigmas"] = sc, sig
+    k64, a64 = kps_all[grp].astype(np.float64), area[grp].astype(np.float64)
+    out["direct/keep_vis"] = np.array(nd.oks_nms(k64, sc, a64, 0.6, None, 0.3), np.int64)
+    out["direct/keep_sig"] = np.array(nd.oks_nms(k64, sc, a64, 0.8, sig, None), np.int64)
+    out["direct/oks_row"] = nd.oks_iou(k64[0], k64[1:], a64[0], a64[1:], None, None)
+    out["direct/oks_row_vis"] = nd.oks_iou(k64[0], k64[1:], a64[0], a64[1:], None, 0.3)
+    # kps_to_dict_
+    pm = ns.pose_metrics
+    pred = torch.from_numpy(kps_all[:8, :, :2].copy())
+    mv = torch.from_numpy(kps_all[:8, :, 2:].copy())
+    lst = []
+    pm.kps_to_dict_(pred, mv, [int(i) for i in img[:8]], lst)
+    out["dict/score"] = np.array([d["score"] for d in lst], np.float64)
+    out["dict/keypoints"] = np.array([d["keypoints"] for d in lst], np.float64)
+    out["dict/image_id"] = np.array([d["image_id"] for d in lst])
+    np.savez_compressed(os.path.join(GOLD, "g8_nms.npz"), **out)
+    print("g8_nms.npz kept", {t: len(out[f"filter/{t}/score"]) for t in "abc"}, "of", len(kps_all), "direct", len(out["direct/keep_vis"]),
+          len(out["direct/keep_sig"]))
+
+
 def main():
     assert ref_import.available(), "needs /root/reference (build container only)"
     os.makedirs(GOLD, exist_ok=True)
@@ -302,6 +365,7 @@ def main():
     gen_se(ns)
     gen_next(ns)
     gen_train(ns)
+    gen_nms(ns)
     del hm
 
 

@@ -129,3 +129,35 @@ def normalize_crops(img_u8_bhwc_bgr, mean=(0.485, 0.456, 0.406)):
     """datasets/coco.py:136 + :137: (img[..., ::-1].astype(float32) / 255.0 - rgb_mean), HWC -> CHW."""
     x = img_u8_bhwc_bgr[..., ::-1].astype(np.float32) / np.float32(255.0) - np.asarray(mean, np.float32)
     return np.ascontiguousarray(x.transpose(0, 3, 1, 2))
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def pose_rescore(kps, box_score, in_vis_thre: float = 0.2) -> np.ndarray:
+    """eval.py:166-174: box_score * mean(visible key-point scores); kps [P,J,3] (x, y, score)."""
+    kps, box_score = _f64(kps), _f64(box_score)
+    P, J, _ = kps.shape
+    out = np.empty(P, np.float64)
+    lib().sp_oracle_pose_rescore(_p(kps), _p(box_score), P, J, ctypes.c_double(in_vis_thre), _p(out))
+    return out
+
+
+def oks_nms(kps, scores, areas, thresh, sigmas=None, in_vis_thresh=None):
+    """datasets/naive_data.py:153-173 on one image's persons -> list of kept indices in pick order."""
+    kps, scores, areas = _f64(kps), _f64(scores), _f64(areas)
+    N, J, _ = kps.shape
+    keep = np.empty(max(N, 1), np.int32)
+    sg = _f64(sigmas) if sigmas is not None else None
+    n = lib().sp_oracle_oks_nms(_p(kps), _p(scores), _p(areas), N, J, _p(sg) if sg is not None else None, ctypes.c_double(thresh),
+                                ctypes.c_double(-1.0 if in_vis_thresh is None else in_vis_thresh), _p(keep))
+    return keep[:n].tolist()
+
+
+def pose_score(max_val) -> np.ndarray:
+    """kps_to_dict_'s per-person score, metrics/pose_metrics.py:176: sc.mean() + sc.max(); max_val [B,J] or [B,J,1]."""
+    m = _f32(max_val).reshape(len(max_val), -1)
+    out = np.empty(m.shape[0], np.float32)
+    lib().sp_oracle_pose_score(_p(m), m.shape[0], m.shape[1], _p(out))
+    return out

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
+from ctypes import c_double, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
 
 from .build import LIB_PATH as _DEFAULT_LIB_PATH
 
@@ -20,7 +20,7 @@ SP_CONV_PIXEL_SHUFFLE = 0x4
 SP_CONV_BF16 = 0x8
 SP_CONV_OUT_F32 = 0x10
 CONV_TILES = ((128, 128), (64, 128), (128, 64), (64, 64), (256, 64), (128, 32))
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class HipLibraryError(RuntimeError):
@@ -72,6 +72,9 @@ SYMBOLS = {
     "sp_conv2d_wgrad": (c_int, [ctypes.POINTER(ConvDesc), _P, c_int, _P, c_int, c_int, c_int, c_int64, c_int64, _P, _P, c_int64, _P]),
     "sp_permute4_f32": (c_int, [_P, _P, c_int, ctypes.POINTER(c_int32), ctypes.POINTER(c_int64), ctypes.POINTER(c_int32), c_int64, c_int64, _P]),
     "sp_permute4_batched": (c_int, [_P, _P, c_int, c_int, _P]),
+    "sp_pose_score": (c_int, [_P, c_int, c_int, _P, _P]),
+    "sp_pose_rescore": (c_int, [_P, _P, c_int, c_int, c_double, _P, _P, _P]),
+    "sp_oks_nms": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_double, c_double, _P, _P, _P]),
     "sp_masked_mse": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
 }
 

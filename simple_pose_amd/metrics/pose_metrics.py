@@ -89,3 +89,16 @@ class HeatMapAcc(object):
         _lib.check(_lib.lib().sp_heat_map_acc(_lib.ptr(preds), _lib.ptr(labels), B, J, H, W, float(self.distance_thresh),
                                               float(self.norm_frac), _lib.ptr(acc), _lib.current_stream()), "sp_heat_map_acc")
         return acc
+
+
+def kps_to_dict_(predicts: torch.Tensor, scores: torch.Tensor, img_ids, set_in_list: list):
+    """`metrics/pose_metrics.py:172-179`: append one COCO result dict per person; `score = mean + max` of the per-joint maxima is
+    computed for the whole batch by one launch (the reference does B `.item()` syncs)."""
+    predicts = _lib.require_cuda_f32(predicts, "predicts")
+    scores = _lib.require_cuda_f32(scores, "scores")
+    B, J = predicts.shape[0], predicts.shape[1]
+    sc = torch.empty(B, dtype=torch.float32, device=predicts.device)
+    _lib.check(_lib.lib().sp_pose_score(_lib.ptr(scores), B, J, _lib.ptr(sc), _lib.current_stream()), "sp_pose_score")
+    flat = torch.cat([predicts, scores.reshape(B, J, 1)], dim=-1).reshape(B, -1).cpu().tolist()    # output formatting only
+    for kp, s, img_id in zip(flat, sc.cpu().tolist(), img_ids):
+        set_in_list.append({"image_id": img_id, "score": float(s), "category_id": 1, "keypoints": kp})

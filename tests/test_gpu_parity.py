@@ -456,3 +456,48 @@ def test_heat_map_acc_and_collate_normalisation_vs_reference_golden(golden):
         assert abs(val.item() - float(g[f"acc/{tag}/value"])) < 1e-6
     x = normalize_crops(_cuda(g["collate/img_u8"]))
     assert np.array_equal(x.cpu().numpy(), g["collate/input"])          # bit exact: x/255 - mean in fp32
+
+
+def test_oks_nms_and_result_scores_vs_reference_golden(golden):
+    """eval.py:153-197 + naive_data.py:120-173 + kps_to_dict_ on the GPU vs the real reference's outputs."""
+    from simple_pose_amd.datasets.naive_data import filter_poses, oks_nms
+    from simple_pose_amd.metrics.pose_metrics import kps_to_dict_
+    g = golden("g8_nms.npz")
+    for tag in "abc":
+        vis, thr = g[f"filter/{tag}/params"]
+        res = filter_poses(_cuda(g["kps"]), g["box_score"], g["area"], g["img_id"].tolist(), in_vis_thre=float(vis), oks_thre=float(thr))
+        assert [r["image_id"] for r in res] == g[f"filter/{tag}/image_id"].tolist()
+        np.testing.assert_array_equal(np.array([r["keypoints"] for r in res]), g[f"filter/{tag}/keypoints"])   # same persons, same order
+        np.testing.assert_allclose(np.array([r["score"] for r in res]), g[f"filter/{tag}/score"], rtol=1e-15)
+    k64, a64 = g["kps"][23:].astype(np.float64), g["area"][23:].astype(np.float64)
+    assert oks_nms(k64, g["direct/scores"], a64, 0.6, None, 0.3) == g["direct/keep_vis"].tolist()
+    assert oks_nms(k64, g["direct/scores"], a64, 0.8, g["direct/sigmas"], None) == g["direct/keep_sig"].tolist()
+    lst = []
+    kps_to_dict_(_cuda(g["kps"][:8, :, :2].copy()), _cuda(g["kps"][:8, :, 2:].copy()), g["dict/image_id"].tolist(), lst)
+    np.testing.assert_allclose([d["score"] for d in lst], g["dict/score"], rtol=2e-7)
+    np.testing.assert_array_equal(np.array([d["keypoints"] for d in lst]), g["dict/keypoints"])
+    assert [d["image_id"] for d in lst] == g["dict/image_id"].tolist()
+
+
+def test_oks_nms_large_batch_vs_oracle():
+    """256 images x up to 200 persons in one launch against the C oracle image by image; includes an image with equal scores."""
+    from simple_pose_amd.datasets.naive_data import oks_nms_batch
+    rng = np.random.default_rng(5)
+    sizes = rng.integers(1, 200, 256)
+    seg = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    Pn = int(seg[-1])
+    base = rng.random((Pn // 4 + 1, 17, 3)) * np.array([400.0, 600.0, 1.0])
+    kps = base[rng.integers(0, len(base), Pn)] + rng.normal(size=(Pn, 17, 3)) * np.array([3.0, 3.0, 0.03])
+    scores, areas = rng.random(Pn), rng.random(Pn) * 30000 + 800
+    scores[seg[3]:seg[4]] = 0.5
+    keep, cnt = oks_nms_batch(torch.from_numpy(kps).cuda(), torch.from_numpy(scores).cuda(), torch.from_numpy(areas).cuda(),
+                              torch.from_numpy(seg).cuda(), int(sizes.max()), 0.7)
+    keep, cnt = keep.cpu().numpy(), cnt.cpu().numpy()
+    n_kept = 0
+    for gi in range(256):
+        lo, hi = seg[gi], seg[gi + 1]
+        ref = pose_oracle.oks_nms(kps[lo:hi], scores[lo:hi], areas[lo:hi], 0.7)
+        assert (keep[lo:lo + cnt[gi]] - lo).tolist() == ref, gi
+        assert (keep[lo + cnt[gi]:hi] == -1).all()
+        n_kept += len(ref)
+    assert 0 < n_kept < Pn

@@ -152,3 +152,35 @@ def test_next_rows_oracle_matches_reference(golden):
         tgt, _ = pose_oracle.encode_refine(g[f"acc/{tag}/joints"], 2.0, (48, 64))
         assert abs(float(pose_oracle.heat_map_acc(g[f"acc/{tag}/pred"], tgt)) - float(g[f"acc/{tag}/value"])) < 1e-6
     assert np.array_equal(pose_oracle.normalize_crops(g["collate/img_u8"]), g["collate/input"])
+
+
+def _filter_like_eval(g, vis, thr, rescore, nms):
+    """eval.py:153-197 with the given rescoring / NMS functions; returns (image_id, score, keypoints) lists."""
+    kps, box, area, img = g["kps"].astype(np.float64), g["box_score"], g["area"].astype(np.float64), g["img_id"]
+    ids = list(dict.fromkeys(img.tolist()))
+    out_id, out_sc, out_kp = [], [], []
+    for iid in ids:
+        rows = np.nonzero(img == iid)[0]
+        sc = rescore(kps[rows], box[rows], vis)
+        for r in nms(kps[rows], sc, area[rows], thr):
+            out_id.append(iid); out_sc.append(sc[r]); out_kp.append(kps[rows][r].reshape(-1))
+    return np.array(out_id), np.array(out_sc), np.array(out_kp)
+
+
+def test_oks_nms_oracle_matches_reference(golden):
+    g = golden("g8_nms.npz")
+    for tag in "abc":
+        vis, thr = g[f"filter/{tag}/params"]
+        ids, sc, kp = _filter_like_eval(g, vis, thr, pose_oracle.pose_rescore, pose_oracle.oks_nms)
+        np.testing.assert_array_equal(ids, g[f"filter/{tag}/image_id"])
+        np.testing.assert_array_equal(sc, g[f"filter/{tag}/score"])              # float64, bit for bit
+        np.testing.assert_array_equal(kp, g[f"filter/{tag}/keypoints"])
+    k64 = g["kps"][23:].astype(np.float64)
+    a64 = g["area"][23:].astype(np.float64)
+    assert pose_oracle.oks_nms(k64, g["direct/scores"], a64, 0.6, None, 0.3) == g["direct/keep_vis"].tolist()
+    assert pose_oracle.oks_nms(k64, g["direct/scores"], a64, 0.8, g["direct/sigmas"], None) == g["direct/keep_sig"].tolist()
+    # equal scores: deterministic "higher index first" (the reference's order for ties is whatever numpy's argsort leaves)
+    same = np.zeros(5)
+    far = np.arange(5)[:, None, None] * 1000.0 + np.zeros((5, 17, 3))
+    assert pose_oracle.oks_nms(far, same, np.full(5, 1e3), 0.9) == [4, 3, 2, 1, 0]
+    np.testing.assert_allclose(pose_oracle.pose_score(g["kps"][:8, :, 2]), g["dict/score"], rtol=2e-7)
