@@ -191,6 +191,11 @@ class Program:
                 raise ValueError(op.kind)
         return out
 
+    def capture(self, x: torch.Tensor, decoder=None, trans_inv: Optional[torch.Tensor] = None, warmup: int = 2) -> "GraphedForward":
+        """Record the whole forward (and, when given, the key-point decode) of this batch shape into ONE hipGraph: the ~60 kernel
+        launches of a step become a single graph launch (what matters at small batch, where the step is launch-bound)."""
+        return GraphedForward(self, x, decoder, trans_inv, warmup)
+
     # -- per-layer tile autotuning -------------------------------------------------------------------------------
     def autotune(self, x: torch.Tensor, reps: int = 3, verbose: bool = False) -> Dict[str, Tuple[int, int]]:
         """Time every legal workgroup tile of every distinct conv shape once (HIP events on the launch stream, real
@@ -251,6 +256,47 @@ class Program:
     @property
     def flops_per_image(self) -> int:
         return sum(op.flops for op in self.ops)
+
+
+class GraphedForward:
+    """A Program (+ optional decoder) for one batch shape recorded as a hipGraph (torch.cuda.CUDAGraph is the recorder; every node
+    is one of this library's kernels).  `static_input` / `static_trans_inv` are the graph's fixed input buffers: fill them in place
+    (or pass tensors to __call__, which copies) and replay; the returned tensors are the graph's fixed outputs."""
+
+    def __init__(self, prog: "Program", x: torch.Tensor, decoder=None, trans_inv: Optional[torch.Tensor] = None, warmup: int = 2):
+        x = _lib.require_cuda_f32(x, "input")
+        if decoder is not None and trans_inv is None:
+            raise ValueError("capture with a decoder needs trans_inv")
+        self.prog, self.decoder = prog, decoder
+        self.static_input = x.clone()
+        self.static_trans_inv = _lib.require_cuda_f32(trans_inv, "trans_inv").clone() if trans_inv is not None else None
+        side = torch.cuda.Stream(device=x.device)
+        side.wait_stream(torch.cuda.current_stream(x.device))
+        with torch.cuda.stream(side):                       # warm-up outside the capture: buffer pools get allocated here
+            for _ in range(max(1, warmup)):
+                self._body()
+        torch.cuda.current_stream(x.device).wait_stream(side)
+        torch.cuda.synchronize(x.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.outputs = self._body()
+
+    def _body(self):
+        hm = self.prog.run(self.static_input)
+        if self.decoder is None:
+            return hm
+        kps, mv = self.decoder(hm, self.static_trans_inv)
+        return hm, kps, mv
+
+    def __call__(self, x: Optional[torch.Tensor] = None, trans_inv: Optional[torch.Tensor] = None):
+        if x is not None and x.data_ptr() != self.static_input.data_ptr():
+            if x.shape != self.static_input.shape:
+                raise ValueError(f"graph was captured for input {tuple(self.static_input.shape)}, got {tuple(x.shape)}")
+            self.static_input.copy_(_lib.require_cuda_f32(x, "input"))
+        if trans_inv is not None and self.static_trans_inv is not None and trans_inv.data_ptr() != self.static_trans_inv.data_ptr():
+            self.static_trans_inv.copy_(_lib.require_cuda_f32(trans_inv, "trans_inv"))
+        self.graph.replay()
+        return self.outputs
 
 
 class ProgramBuilder:

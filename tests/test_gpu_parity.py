@@ -501,3 +501,28 @@ def test_oks_nms_large_batch_vs_oracle():
         assert (keep[lo + cnt[gi]:hi] == -1).all()
         n_kept += len(ref)
     assert 0 < n_kept < Pn
+
+
+def test_captured_hip_graph_replays_forward_and_decode_bitwise(golden):
+    """Program.capture: forward + GaussTaylor decode of one batch shape as ONE hipGraph; replays must equal the stream launches
+    bit for bit, for inputs written into the graph's static buffers after capture."""
+    g = golden("g1_dconv_fwd.npz")
+    net = pose_resnet_dconv.resnet50(pretrained=False, num_classes=17)
+    sd = synth.conditioned_state_dict(nets_oracle.state_dict_shapes_resnet50("dconv"), int(g["seed"]))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net = net.cuda().eval()
+    dec = GaussTaylorKeyPointDecoder()
+    B = int(g["heat_maps"].shape[0])
+    x0 = _cuda(synth.input_images(B, int(g["seed"])))
+    x1 = _cuda(synth.input_images(B, 77))
+    tinv = _cuda(synth.trans_inv_batch(B))
+    prog = net.hip_program(x0)
+    graphed = prog.capture(x1, dec, tinv)                      # captured on OTHER data than what is replayed first
+    for x in (x0, x1, x0):
+        hm_e = prog.run(x)
+        kps_e, mv_e = dec(hm_e, tinv)
+        hm_g, kps_g, mv_g = graphed(x)
+        torch.cuda.synchronize()
+        assert torch.equal(hm_g, hm_e) and torch.equal(kps_g, kps_e) and torch.equal(mv_g, mv_e)
+    rel = np.abs(graphed(x0)[0].cpu().numpy() - g["heat_maps"]).max() / np.abs(g["heat_maps"]).max()
+    assert rel <= 1e-4, rel
