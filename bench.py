@@ -148,8 +148,8 @@ def main():
     x = torch.from_numpy(np.concatenate([base] * ((B + 7) // 8), 0)[:B]).to(dev)
     tinv = torch.from_numpy(synth.trans_inv_batch(B)).to(dev)
     if args.mode == "train":
-        if args.arch != "dconv":
-            raise SystemExit("--mode train lowers ResNet50-DConv (BASELINE config 4)")
+        if args.arch not in ("dconv", "duc"):
+            raise SystemExit("--mode train lowers the ResNet50 DConv / DUC nets")
         from simple_pose_amd.commons.transforms import RefineSimpleTransform
         from simple_pose_amd.train import PoseTrainer
         model.train()
@@ -218,7 +218,7 @@ def main():
     if rank == 0:
         name = ARCH_NAMES[args.arch]
         if args.mode == "train":
-            gflop = 3 * 10.8528   # train step ~ 3 x forward (fwd + dgrad + wgrad) = 32.56 GFLOP / image
+            gflop = 3 * (10.8528 if args.arch == "dconv" else 11.7517)   # train step ~ 3 x forward (fwd + dgrad + wgrad) = 32.56 GFLOP / image
             line = {
                 "metric": f"images/sec train step (fwd+bwd+Adam), {name} 256x192 bs={B}/GPU", "value": round(value, 1), "unit": "images/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),

@@ -27,7 +27,7 @@ extern "C" {
 #define SP_EINVAL (-1)   /* bad argument / unsupported shape (message in sp_last_error) */
 #define SP_ELAUNCH (-2)  /* HIP launch or runtime failure */
 
-#define SP_ABI_VERSION 6
+#define SP_ABI_VERSION 7
 
 /* epilogue / layout flags of sp_conv_desc.flags */
 #define SP_CONV_RELU 0x1u          /* y = max(y, 0) after scale/shift (+ residual) */
@@ -203,6 +203,8 @@ int sp_bn_train_bwd_reduce_nhwc(const void* dy, int bf16, const void* relu_src, 
 int sp_bn_train_bwd_apply_nhwc(const void* dy, int bf16, const void* relu_src, const void* z, const float* mean, const float* invstd,
                                const float* gamma, const float* sum_dgamma, const float* sum_dbeta, int64_t total_rows, int64_t rows,
                                int c, void* dz, void* dres, int dres_accumulate, void* stream);
+/* backward of nn.PixelShuffle(2) (DUC head, nets/commons.py:36-41): dy [B,2h,2w,c/4] fp32 -> dx [B,h,w,c] fp32 */
+int sp_pixel_unshuffle2_nhwc(const float* dy, float* dx, int batch, int h, int w, int c, void* stream);
 /* sum over rows of a [rows, c] tensor (conv bias gradient) */
 int sp_channel_sum_nhwc(const float* a, int64_t rows, int c, float* sum, void* workspace, void* stream);
 /* backward of nn.MaxPool2d(3,2,1) (first maximum of a window wins, as torch); x = the pool's input */

@@ -84,6 +84,23 @@ __global__ void pixel_shuffle2_kernel(const float* __restrict__ x, f32x4* __rest
     }
 }
 
+// backward of nn.PixelShuffle(2) (a permutation): one lane reads 16 B of dy (4 channels of one output pixel) and scatters them to
+// stride-4 channels of the source pixel
+__global__ void pixel_unshuffle2_kernel(const f32x4* __restrict__ dy, float* __restrict__ dx, int h, int w, int C, long long total) {
+    const int Co = C >> 2, Co4 = Co >> 2, W2 = 2 * w, H2 = 2 * h;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int k4 = (int)(i % Co4);
+        long long r = i / Co4;
+        const int X = (int)(r % W2); r /= W2;
+        const int Y = (int)(r % H2);
+        const long long b = r / H2;
+        const int sub = ((Y & 1) << 1) | (X & 1);
+        float* dst = dx + ((b * h + (Y >> 1)) * w + (X >> 1)) * C + (k4 << 4) + sub;
+        const f32x4 v = dy[i];
+        dst[0] = v.x; dst[4] = v.y; dst[8] = v.z; dst[12] = v.w;
+    }
+}
+
 // SELayer squeeze (nets/commons.py:8,15): y[b, c] = mean over the HW pixels of x[b, :, c].  One workgroup per (b, 256-channel
 // slab... up to 64 float4 lanes x 4 pixel stripes), double accumulation, fixed order.
 __global__ __launch_bounds__(256) void global_avg_pool_kernel(const f32x4* __restrict__ x, float* __restrict__ y, int HW, int C4) {
@@ -234,6 +251,16 @@ extern "C" int sp_pixel_shuffle2_nhwc(const float* x, float* y, int batch, int h
     hipLaunchKernelGGL(pixel_shuffle2_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
                        reinterpret_cast<f32x4*>(y), h, w, c, total);
     return sp_check_launch("pixel_shuffle2_kernel");
+}
+
+extern "C" int sp_pixel_unshuffle2_nhwc(const float* dy, float* dx, int batch, int h, int w, int c, void* stream) {
+    SP_REQUIRE(dy && dx, "sp_pixel_unshuffle2_nhwc: null pointer");
+    SP_REQUIRE(batch > 0 && h > 0 && w > 0 && c > 0 && c % 16 == 0, "sp_pixel_unshuffle2_nhwc: c=%d must be a multiple of 16", c);
+    const long long total = (long long)batch * h * w * c / 4;
+    SP_REQUIRE(total * 4 < (1ll << 31), "sp_pixel_unshuffle2_nhwc: tensor too large");
+    hipLaunchKernelGGL(pixel_unshuffle2_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const f32x4*>(dy), dx, h, w, c, total);
+    return sp_check_launch("pixel_unshuffle2_kernel");
 }
 
 extern "C" int sp_u8hwc_bgr_to_nchw_f32(const unsigned char* img, float* out, int batch, int h, int w, const float* mean_rgb_host, void* stream) {

@@ -13,9 +13,10 @@ from simple_pose_amd.train import PoseTrainer  # noqa: E402
 DEV = "cuda:0"
 
 
-def _model(seed):
-    m = pose_resnet_dconv.resnet50(pretrained=False, num_classes=17)
-    sd = synth.conditioned_state_dict(nets_oracle.state_dict_shapes_resnet50("dconv"), seed)
+def _model(seed, head="dconv"):
+    from simple_pose_amd.nets import pose_resnet_duc
+    m = (pose_resnet_dconv if head == "dconv" else pose_resnet_duc).resnet50(pretrained=False, num_classes=17)
+    sd = synth.conditioned_state_dict(nets_oracle.state_dict_shapes_resnet50(head), seed)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     return m.to(DEV).train(), {k: torch.from_numpy(v.copy()) for k, v in sd.items()}
 
@@ -32,28 +33,31 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / (np.sqrt((b * b).mean()) + 1e-30))
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (3, 96, 64)])
-def test_train_step_vs_oracle_small(B, H, W):
-    model, sd = _model(7)
+@pytest.mark.parametrize("B,H,W,head", [(2, 64, 64, "dconv"), (3, 96, 64, "dconv"), (2, 64, 64, "duc"), (3, 96, 64, "duc")])
+def test_train_step_vs_oracle_small(B, H, W, head):
+    model, sd = _model(7, head)
+    arch = "resnet50_" + head
     x, t, w = _batch(B, H, W, 7)
     tr = PoseTrainer(model, in_h=H, in_w=W, lr=1e-3)
     loss = tr.forward_backward(torch.from_numpy(x).to(DEV), torch.from_numpy(t).to(DEV), torch.from_numpy(w).to(DEV))
     torch.cuda.synchronize()
-    oloss, ograds, oheat = train_oracle.forward_backward(sd, torch.from_numpy(x), torch.from_numpy(t), torch.from_numpy(w))
+    oloss, ograds, oheat = train_oracle.forward_backward(sd, torch.from_numpy(x), torch.from_numpy(t), torch.from_numpy(w), arch=arch)
     assert _rel(tr.last_heat.cpu().numpy(), oheat.numpy()) < 1e-3
     assert abs(loss.item() - float(oloss)) <= 1e-4 * abs(float(oloss))
     named = dict(model.named_parameters())
     # Gradients of this deep BN net at a tiny batch are chaotic at the 0.3 % level: torch-fp32 differs from torch-fp64 (and
     # from itself at another thread count) by 3-4e-3 in relative L2.  The bar is therefore relative L2 against the fp64
     # oracle, a few times torch-fp32's own deviation; the better-conditioned first case also meets a max-abs bar.
-    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in _model(7)[1].items()}
-    _, g64, _ = train_oracle.forward_backward(sd64, torch.from_numpy(x).double(), torch.from_numpy(t).double(), torch.from_numpy(w).double())
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in _model(7, head)[1].items()}
+    _, g64, _ = train_oracle.forward_backward(sd64, torch.from_numpy(x).double(), torch.from_numpy(t).double(), torch.from_numpy(w).double(),
+                                              arch=arch)
     l2 = sorted(((float((named[k].grad.cpu().double() - g64[k]).norm() / (g64[k].norm() + 1e-30)), k) for k in g64), reverse=True)
     l2_torch = sorted((float((ograds[k].double() - g64[k]).norm() / (g64[k].norm() + 1e-30)) for k in g64), reverse=True)
     assert l2[0][0] < max(3e-2, 8 * l2_torch[0]), (l2[:6], l2_torch[:3])
     assert np.median([e for e, _ in l2]) < max(1e-2, 4 * np.median(l2_torch)), (np.median([e for e, _ in l2]), np.median(l2_torch))
     bufs = dict(model.named_buffers())
-    for k in ("bn1.running_mean", "bn1.running_var", "layer2.0.downsample.1.running_var", "deconv_layers.7.running_mean"):
+    for k in ("bn1.running_mean", "bn1.running_var", "layer2.0.downsample.1.running_var",
+              "deconv_layers.7.running_mean" if head == "dconv" else "duc_layers.2.bn.running_var"):
         assert _rel(bufs[k].cpu().numpy(), sd[k].numpy()) < 1e-4, k
     # Adam
     tr.optimizer_step(1.0)
