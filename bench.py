@@ -215,6 +215,17 @@ def main():
         roofline = kernel_roofline(prog, x, steps=max(3, min(args.steps, 10)), layers_out=args.layers_out,
                                    peak=FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else BF16_MATRIX_PEAK_TFLOPS)
 
+    step_split = None
+    if args.mode == "train":                                  # untimed extra steps with phase events (every rank: collectives inside)
+        trainer.profile = True
+        acc = {}
+        with torch.no_grad():
+            for _ in range(5):
+                step()
+                for k, v in trainer.phase_ms().items():
+                    acc[k] = acc.get(k, 0.0) + v / 5
+        trainer.profile = False
+        step_split = {k: round(v, 3) for k, v in acc.items()}
     if rank == 0:
         name = ARCH_NAMES[args.arch]
         if args.mode == "train":
@@ -229,7 +240,7 @@ def main():
                            "images_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
                 "gflop_per_image": round(gflop, 3), "network_tflops": round(value * gflop / 1e3, 2),
                 "network_frac_of_matrix_peak": round(value * gflop / 1e3 / ((FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else BF16_MATRIX_PEAK_TFLOPS) * world), 4),
-                "roofline": None, "cpu_baseline": None, "final_loss": float(out[0].item())}
+                "roofline": None, "cpu_baseline": None, "final_loss": float(out[0].item()), "step_split_ms": step_split}
         else:
             peak = FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else BF16_MATRIX_PEAK_TFLOPS
             line = {

@@ -27,7 +27,7 @@ extern "C" {
 #define SP_EINVAL (-1)   /* bad argument / unsupported shape (message in sp_last_error) */
 #define SP_ELAUNCH (-2)  /* HIP launch or runtime failure */
 
-#define SP_ABI_VERSION 7
+#define SP_ABI_VERSION 9
 
 /* epilogue / layout flags of sp_conv_desc.flags */
 #define SP_CONV_RELU 0x1u          /* y = max(y, 0) after scale/shift (+ residual) */
@@ -175,8 +175,9 @@ int sp_masked_mse(const float* pred, const float* target, const float* mask, int
  *      optimizer.step()) ---------------------------------------------------------------------------------------------
  * Activations NHWC; argument `bf16`: bit 0 = activations (z, relu_src, dz, pool input) are bf16, bit 1 = activation
  * gradients (dy, dres, pool dx/dy) are bf16; statistics and the gradients of the affine parameters are always fp32;
- * `rows` = B*H*W.  `workspace` of the reductions: >= SP_REDUCE_WORKSPACE_BYTES(c) bytes. */
-#define SP_REDUCE_WORKSPACE_BYTES(c) ((int64_t)256 * (c) * 2 * 8)
+ * `rows` = B*H*W.  `workspace` of the reductions: >= SP_REDUCE_WORKSPACE_BYTES(c) bytes (per-workgroup partial sums in fp64,
+ * folded in a fixed order by a second small kernel: deterministic, no float atomics); c <= 4096. */
+#define SP_REDUCE_WORKSPACE_BYTES(c) ((int64_t)4 << 20)
 
 /* nn.BatchNorm2d in train mode, statistics half: per-channel batch mean and 1/sqrt(biased var + eps) of z [rows, c];
  * running_mean/var (may both be NULL) are updated with `momentum` and the UNBIASED variance, as torch does. */
@@ -209,6 +210,10 @@ int sp_pixel_unshuffle2_nhwc(const float* dy, float* dx, int batch, int h, int w
 int sp_channel_sum_nhwc(const float* a, int64_t rows, int c, float* sum, void* workspace, void* stream);
 /* backward of nn.MaxPool2d(3,2,1) (first maximum of a window wins, as torch); x = the pool's input */
 int sp_maxpool3x3s2_bwd_nhwc(const void* x, int bf16, const void* dy, void* dx, int batch, int h, int w, int c, void* stream);
+/* the training pair: forward that also records the winning tap (ky*3+kx, one byte per output element, `idx` = [B,ho,wo,c] bytes),
+ * and the backward that gathers through it (<= 4 (index, dy) pairs per input pixel); same results as the function above */
+int sp_maxpool3x3s2_idx_nhwc(const void* x, int bf16, void* y, void* idx, int batch, int h, int w, int c, void* stream);
+int sp_maxpool3x3s2_bwd_idx_nhwc(const void* idx, const void* dy, int bf16, void* dx, int batch, int h, int w, int c, void* stream);
 /* torch.optim.Adam (amsgrad False, weight_decay 0) over flat buffers of n (multiple of 4) floats, `step` = 1,2,...;
  * grad is multiplied by grad_scale first (1/world_size after a SUM all-reduce) - ddp...:70-72,119 */
 int sp_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,

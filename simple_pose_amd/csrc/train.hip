@@ -5,7 +5,6 @@
 
 namespace {
 
-constexpr int RED_BLOCKS = 256;  // partial-sum workgroups per channel reduction
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -28,6 +27,16 @@ __device__ __forceinline__ void st4(void* p, long long i4, f32x4 v) {
     } else {
         reinterpret_cast<f32x4*>(p)[i4] = v;
     }
+}
+
+// partial-sum workgroups of a channel reduction: enough to fill the chip (>= 4 rows per thread), bounded by the 4 MB workspace
+// ([blocks][C][2] doubles)
+static int red_blocks(long long rows, int c) {
+    const int c4 = c / 4, lanes_c = c4 < 256 ? c4 : 256, rows_par = 256 / lanes_c;
+    long long n = (rows + (long long)rows_par * 4 - 1) / ((long long)rows_par * 4);
+    const long long cap = (262144 / c) < 1024 ? (262144 / c) : 1024;
+    if (n > cap) n = cap;
+    return (int)(n < 1 ? 1 : n);
 }
 
 inline int grid_for(long long total, int block) {
@@ -240,6 +249,63 @@ __global__ void maxpool3x3s2_bwd_kernel(const void* __restrict__ x, const void* 
     }
 }
 
+// Training-time nn.MaxPool2d(3,2,1): also records WHICH tap (ky*3+kx, first maximum in row-major scan as torch) produced each
+// output, one byte per element, so that backward is a gather of <= 4 (index, dy) pairs per input pixel instead of 36 compares.
+template <bool BF16>
+__global__ void maxpool3x3s2_idx_kernel(const void* __restrict__ x, void* __restrict__ y, unsigned int* __restrict__ idx, int H, int W, int C4,
+                                        int Ho, int Wo, long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long long r = i / C4;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho);
+        const long long b = r / Ho;
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        unsigned int tap[4] = {4u, 4u, 4u, 4u};                 // the centre tap is always inside the image
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yy = oy * 2 - 1 + ky;
+            if ((unsigned)yy >= (unsigned)H) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int xx = ox * 2 - 1 + kx;
+                if ((unsigned)xx >= (unsigned)W) continue;
+                const f32x4 v = ld4<BF16>(x, ((b * H + yy) * W + xx) * C4 + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; tap[e] = (unsigned)(ky * 3 + kx); }   // torch: (val > max) || isnan(val)
+            }
+        }
+        st4<BF16>(y, i, best);
+        idx[i] = tap[0] | (tap[1] << 8) | (tap[2] << 16) | (tap[3] << 24);
+    }
+}
+
+template <bool G16>
+__global__ void maxpool3x3s2_bwd_idx_kernel(const unsigned int* __restrict__ idx, const void* __restrict__ dy, void* __restrict__ dx, int H, int W,
+                                            int C4, int Ho, int Wo, long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long long r = i / C4;
+        const int ix = (int)(r % W); r /= W;
+        const int iy = (int)(r % H);
+        const long long b = r / H;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {        // windows oy with iy in [2oy-1, 2oy+1]
+            if (oy >= Ho) continue;
+            const unsigned ky = (unsigned)(iy - (2 * oy - 1));
+            for (int ox = ix / 2; ox <= (ix + 1) / 2; ++ox) {
+                if (ox >= Wo) continue;
+                const unsigned mine = ky * 3u + (unsigned)(ix - (2 * ox - 1));
+                const long long o = ((b * Ho + oy) * Wo + ox) * C4 + c;
+                const unsigned int t = idx[o];
+                const f32x4 g = ld4<G16>(dy, o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (((t >> (8 * e)) & 0xffu) == mine) acc[e] += g[e];
+            }
+        }
+        st4<G16>(dx, i, acc);
+    }
+}
+
 // torch.optim.Adam (no amsgrad, weight_decay 0) on flat buffers; g is multiplied by grad_scale first (1/world after a SUM all-reduce)
 __global__ void adam_kernel(f32x4* __restrict__ p, const f32x4* __restrict__ g, f32x4* __restrict__ m, f32x4* __restrict__ v, long long n4,
                             float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, float grad_scale) {
@@ -326,9 +392,9 @@ extern "C" int sp_bn_train_stats_nhwc(const void* z, int bf16, int64_t rows, int
     SP_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "sp_bn_train_stats_nhwc: running stats come in pairs");
     hipStream_t s = (hipStream_t)stream;
     double* part = reinterpret_cast<double*>(workspace);
-    if (bf16 & 1) hipLaunchKernelGGL((channel_reduce_kernel<0, true>), dim3(RED_BLOCKS), dim3(256), 0, s, z, nullptr, nullptr, nullptr, nullptr, (int)rows, c, part);
-    else hipLaunchKernelGGL((channel_reduce_kernel<0, false>), dim3(RED_BLOCKS), dim3(256), 0, s, z, nullptr, nullptr, nullptr, nullptr, (int)rows, c, part);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((c + 3) / 4), dim3(256), 0, s, part, RED_BLOCKS, c, (double)rows, eps, momentum, mean,
+    if (bf16 & 1) hipLaunchKernelGGL((channel_reduce_kernel<0, true>), dim3(red_blocks(rows, c)), dim3(256), 0, s, z, nullptr, nullptr, nullptr, nullptr, (int)rows, c, part);
+    else hipLaunchKernelGGL((channel_reduce_kernel<0, false>), dim3(red_blocks(rows, c)), dim3(256), 0, s, z, nullptr, nullptr, nullptr, nullptr, (int)rows, c, part);
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((c + 3) / 4), dim3(256), 0, s, part, red_blocks(rows, c), c, (double)rows, eps, momentum, mean,
                        invstd, running_mean, running_var);
     return sp_check_launch("bn_train_stats");
 }
@@ -338,9 +404,9 @@ extern "C" int sp_bn_train_partial_nhwc(const void* z, int bf16, int64_t rows, i
     SP_REQUIRE(rows > 0 && c > 0 && c % 4 == 0 && rows < (1ll << 31), "sp_bn_train_partial_nhwc: bad shape rows=%lld c=%d", (long long)rows, c);
     hipStream_t s = (hipStream_t)stream;
     double* part = reinterpret_cast<double*>(workspace);
-    if (bf16 & 1) hipLaunchKernelGGL((channel_reduce_kernel<0, true>), dim3(RED_BLOCKS), dim3(256), 0, s, z, nullptr, nullptr, nullptr, nullptr, (int)rows, c, part);
-    else hipLaunchKernelGGL((channel_reduce_kernel<0, false>), dim3(RED_BLOCKS), dim3(256), 0, s, z, nullptr, nullptr, nullptr, nullptr, (int)rows, c, part);
-    hipLaunchKernelGGL(pair_sum_final_f64_kernel, dim3((c + 3) / 4), dim3(256), 0, s, part, RED_BLOCKS, c, sums);
+    if (bf16 & 1) hipLaunchKernelGGL((channel_reduce_kernel<0, true>), dim3(red_blocks(rows, c)), dim3(256), 0, s, z, nullptr, nullptr, nullptr, nullptr, (int)rows, c, part);
+    else hipLaunchKernelGGL((channel_reduce_kernel<0, false>), dim3(red_blocks(rows, c)), dim3(256), 0, s, z, nullptr, nullptr, nullptr, nullptr, (int)rows, c, part);
+    hipLaunchKernelGGL(pair_sum_final_f64_kernel, dim3((c + 3) / 4), dim3(256), 0, s, part, red_blocks(rows, c), c, sums);
     return sp_check_launch("bn_train_partial");
 }
 
@@ -374,10 +440,10 @@ extern "C" int sp_bn_train_bwd_reduce_nhwc(const void* dy, int bf16, const void*
     double* part = reinterpret_cast<double*>(workspace);
     const bool a16 = bf16 & 1, g16 = bf16 & 2;
     SP_REQUIRE(a16 || !g16, "sp_bn_train_bwd_reduce_nhwc: bf16 gradients with fp32 activations is not a supported mix");
-    if (a16 && g16) hipLaunchKernelGGL((channel_reduce_kernel<1, true, true>), dim3(RED_BLOCKS), dim3(256), 0, s, dy, relu_src, z, mean, invstd, (int)rows, c, part);
-    else if (a16) hipLaunchKernelGGL((channel_reduce_kernel<1, true, false>), dim3(RED_BLOCKS), dim3(256), 0, s, dy, relu_src, z, mean, invstd, (int)rows, c, part);
-    else hipLaunchKernelGGL((channel_reduce_kernel<1, false, false>), dim3(RED_BLOCKS), dim3(256), 0, s, dy, relu_src, z, mean, invstd, (int)rows, c, part);
-    hipLaunchKernelGGL(pair_sum_final_kernel, dim3((c + 3) / 4), dim3(256), 0, s, part, RED_BLOCKS, c, dbeta, dgamma);
+    if (a16 && g16) hipLaunchKernelGGL((channel_reduce_kernel<1, true, true>), dim3(red_blocks(rows, c)), dim3(256), 0, s, dy, relu_src, z, mean, invstd, (int)rows, c, part);
+    else if (a16) hipLaunchKernelGGL((channel_reduce_kernel<1, true, false>), dim3(red_blocks(rows, c)), dim3(256), 0, s, dy, relu_src, z, mean, invstd, (int)rows, c, part);
+    else hipLaunchKernelGGL((channel_reduce_kernel<1, false, false>), dim3(red_blocks(rows, c)), dim3(256), 0, s, dy, relu_src, z, mean, invstd, (int)rows, c, part);
+    hipLaunchKernelGGL(pair_sum_final_kernel, dim3((c + 3) / 4), dim3(256), 0, s, part, red_blocks(rows, c), c, dbeta, dgamma);
     return sp_check_launch("bn_train_bwd_reduce");
 }
 
@@ -412,8 +478,8 @@ extern "C" int sp_channel_sum_nhwc(const float* a, int64_t rows, int c, float* s
     SP_REQUIRE(a && sum && workspace && rows > 0 && c > 0 && c % 4 == 0 && rows < (1ll << 31), "sp_channel_sum_nhwc: bad argument");
     hipStream_t s = (hipStream_t)stream;
     double* part = reinterpret_cast<double*>(workspace);
-    hipLaunchKernelGGL((channel_reduce_kernel<0, false>), dim3(RED_BLOCKS), dim3(256), 0, s, a, nullptr, nullptr, nullptr, nullptr, (int)rows, c, part);
-    hipLaunchKernelGGL(pair_sum_final_kernel, dim3((c + 3) / 4), dim3(256), 0, s, part, RED_BLOCKS, c, sum, nullptr);
+    hipLaunchKernelGGL((channel_reduce_kernel<0, false>), dim3(red_blocks(rows, c)), dim3(256), 0, s, a, nullptr, nullptr, nullptr, nullptr, (int)rows, c, part);
+    hipLaunchKernelGGL(pair_sum_final_kernel, dim3((c + 3) / 4), dim3(256), 0, s, part, red_blocks(rows, c), c, sum, nullptr);
     return sp_check_launch("channel_sum");
 }
 
@@ -431,6 +497,32 @@ extern "C" int sp_maxpool3x3s2_bwd_nhwc(const void* x, int bf16, const void* dy,
     else SP_POOL_BWD(false, false);
 #undef SP_POOL_BWD
     return sp_check_launch("maxpool3x3s2_bwd_kernel");
+}
+
+extern "C" int sp_maxpool3x3s2_idx_nhwc(const void* x, int bf16, void* y, void* idx, int batch, int h, int w, int c, void* stream) {
+    SP_REQUIRE(x && y && idx, "sp_maxpool3x3s2_idx_nhwc: null pointer");
+    SP_REQUIRE(batch > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "sp_maxpool3x3s2_idx_nhwc: bad shape");
+    const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+    const long long total = (long long)batch * ho * wo * (c / 4);
+    SP_REQUIRE((long long)batch * h * w * c < (1ll << 31), "sp_maxpool3x3s2_idx_nhwc: tensor too large");
+    if (bf16 & 1) hipLaunchKernelGGL(maxpool3x3s2_idx_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y,
+                                 reinterpret_cast<unsigned int*>(idx), h, w, c / 4, ho, wo, total);
+    else hipLaunchKernelGGL(maxpool3x3s2_idx_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y,
+                            reinterpret_cast<unsigned int*>(idx), h, w, c / 4, ho, wo, total);
+    return sp_check_launch("maxpool3x3s2_idx_kernel");
+}
+
+extern "C" int sp_maxpool3x3s2_bwd_idx_nhwc(const void* idx, const void* dy, int bf16, void* dx, int batch, int h, int w, int c, void* stream) {
+    SP_REQUIRE(idx && dy && dx, "sp_maxpool3x3s2_bwd_idx_nhwc: null pointer");
+    SP_REQUIRE(batch > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "sp_maxpool3x3s2_bwd_idx_nhwc: bad shape");
+    const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+    const long long total = (long long)batch * h * w * (c / 4);
+    SP_REQUIRE(total * 4 < (1ll << 31), "sp_maxpool3x3s2_bwd_idx_nhwc: tensor too large");
+    if (bf16 & 2) hipLaunchKernelGGL(maxpool3x3s2_bwd_idx_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                                 reinterpret_cast<const unsigned int*>(idx), dy, dx, h, w, c / 4, ho, wo, total);
+    else hipLaunchKernelGGL(maxpool3x3s2_bwd_idx_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                            reinterpret_cast<const unsigned int*>(idx), dy, dx, h, w, c / 4, ho, wo, total);
+    return sp_check_launch("maxpool3x3s2_bwd_idx_kernel");
 }
 
 extern "C" int sp_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,

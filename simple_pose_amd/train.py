@@ -303,7 +303,7 @@ class PoseTrainer:
         self.exp_avg = torch.zeros_like(self.flat.data)
         self.exp_avg_sq = torch.zeros_like(self.flat.data)
         self.step_count = 0
-        self.red_ws = torch.empty(256 * 2048 * 2, dtype=torch.float64, device=dev)        # SP_REDUCE_WORKSPACE_BYTES(2048)
+        self.red_ws = torch.empty(4 << 20, dtype=torch.uint8, device=dev)                  # SP_REDUCE_WORKSPACE_BYTES
         self.wgrad_ws = torch.empty(48 * 1024 * 1024, dtype=torch.float32, device=dev)    # 192 MB of split slabs
         self.loss_buf = torch.zeros(1, dtype=torch.float32, device=dev)
         self.mse_ws = torch.empty(4096, dtype=torch.uint8, device=dev)
@@ -388,23 +388,31 @@ class PoseTrainer:
 
     def repack(self):
         """Regenerate every packed weight copy from the (just updated) flat parameter buffer: one launch over a device-side
-        job table (141 jobs for ResNet50-DConv)."""
+        job table (141 pack jobs for ResNet50-DConv, cut into ~1,200 equal-sized slabs so that the grid is balanced)."""
         if getattr(self, "_pack_table", None) is None:
             import numpy as np
             rec = np.dtype([("d", "<i4", 4), ("s", "<i8", 4), ("lim", "<i4", 4), ("base", "<i8"), ("dst", "<i8"), ("total", "<i8"),
                             ("bf16", "<i4"), ("pad", "<i4")], align=True)
             jobs = [j for layer in self.layers.values() for j in layer.pack_jobs]
-            tab = np.zeros(len(jobs), dtype=rec)
-            for i, j in enumerate(jobs):
+            rows = []
+            for j in jobs:                                     # cut every job into slabs of <= ~64 K elements along its first axis
                 o, _ = self.flat.offsets[j.src_name]
                 es = 2 if j.dst.dtype == torch.bfloat16 else 4
-                tab[i]["d"], tab[i]["s"], tab[i]["lim"] = j.dims, j.strides, j.valid
-                tab[i]["base"], tab[i]["dst"] = o + j.base, j.dst.data_ptr() + j.dst_off * es
-                tab[i]["total"], tab[i]["bf16"] = int(np.prod(j.dims)), int(j.dst.dtype == torch.bfloat16)
+                inner = int(np.prod(j.dims[1:]))
+                step = max(1, 65536 // inner)
+                for r0 in range(0, j.dims[0], step):
+                    n0 = min(step, j.dims[0] - r0)
+                    rows.append(((n0,) + tuple(j.dims[1:]), j.strides, (max(0, min(n0, j.valid[0] - r0)),) + tuple(j.valid[1:]),
+                                 o + j.base + r0 * j.strides[0], j.dst.data_ptr() + (j.dst_off + r0 * inner) * es, n0 * inner,
+                                 int(j.dst.dtype == torch.bfloat16)))
+            tab = np.zeros(len(rows), dtype=rec)
+            for i, (d, st, lim, base, dst, total, b16) in enumerate(rows):
+                tab[i]["d"], tab[i]["s"], tab[i]["lim"] = d, st, lim
+                tab[i]["base"], tab[i]["dst"], tab[i]["total"], tab[i]["bf16"] = base, dst, total, b16
             assert rec.itemsize == 96, rec.itemsize
             self._pack_table = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(self.flat.data.device)
-            self._pack_n = len(jobs)
-        _lib.check(_lib.lib().sp_permute4_batched(P(self.flat.data), P(self._pack_table), self._pack_n, 32, _lib.current_stream()), "repack")
+            self._pack_n = len(rows)
+        _lib.check(_lib.lib().sp_permute4_batched(P(self.flat.data), P(self._pack_table), self._pack_n, 8, _lib.current_stream()), "repack")
 
     # ---- one step -----------------------------------------------------------------------------------------------------
     def forward_backward(self, x: torch.Tensor, targets: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
@@ -494,15 +502,15 @@ class PoseTrainer:
         _lib.check((lib.sp_nchw_to_nhwc8_bf16 if self.bf16 else lib.sp_nchw_to_nhwc4)(P(x), P(x4), B, 3, self.in_h, self.in_w, stream), "to_nhwc")
         a = conv_bn(Act(x4, self.in_h, self.in_w, cp, needs_grad=False), "conv1", "bn1", True)
         pooled = new((B, a.h // 2, a.w // 2, a.c))
-        _lib.check((lib.sp_maxpool3x3s2_nhwc_bf16 if self.bf16 else lib.sp_maxpool3x3s2_nhwc)(P(a.data), P(pooled), B, a.h, a.w, a.c, stream),
-                   "maxpool")
+        pool_idx = torch.empty(pooled.shape, dtype=torch.uint8, device=dev)       # winning tap per output element
+        _lib.check(lib.sp_maxpool3x3s2_idx_nhwc(P(a.data), bf, P(pooled), P(pool_idx), B, a.h, a.w, a.c, stream), "maxpool")
         pa = Act(pooled, a.h // 2, a.w // 2, a.c)
         stem_out = a
 
         def pool_bwd():
             stem_out.grad = newf(stem_out.data.shape)
-            _lib.check(lib.sp_maxpool3x3s2_bwd_nhwc(P(stem_out.data), bf, P(pa.grad), P(stem_out.grad), B, stem_out.h, stem_out.w, stem_out.c,
-                                                    stream), "maxpool.bwd")
+            _lib.check(lib.sp_maxpool3x3s2_bwd_idx_nhwc(P(pool_idx), P(pa.grad), 0, P(stem_out.grad), B, stem_out.h, stem_out.w, stem_out.c,
+                                                        stream), "maxpool.bwd")
             pa.grad = None
         tape.append(pool_bwd)
         a = pa
@@ -544,6 +552,7 @@ class PoseTrainer:
         dheat = newf((B, J, hh, ww))
         _lib.check(lib.sp_masked_mse(P(heat), P(targets), P(mask), B, J, hh * ww, P(self.loss_buf), P(dheat), P(self.mse_ws), stream), "mse")
         self.last_heat = heat
+        self._mark("forward_loss")
         # ---- backward ----
         Jb = fl.c_out_buf
         dh = torch.zeros((B, hh, ww, Jb), dtype=torch.float32, device=dev)
@@ -559,6 +568,7 @@ class PoseTrainer:
         for fn in reversed(tape):
             fn()
         torch._foreach_add_(nbt, 1)
+        self._mark("backward")
         return self.loss_buf
 
     def all_reduce_grads(self) -> float:
@@ -590,7 +600,28 @@ class PoseTrainer:
 
     def step(self, x, targets, mask) -> torch.Tensor:
         """optimizer.zero_grad(); loss = ...; loss.backward(); optimizer.step()  (ddp...:114-119)."""
+        self._mark("start")
         loss = self.forward_backward(x, targets, mask)
         scale = self.all_reduce_grads()
+        self._mark("allreduce_wait")
         self.optimizer_step(scale)
+        self._mark("adam_repack")
         return loss
+
+    # ---- step-time split (BASELINE config 4 asks for fwd / bwd / all-reduce / Adam) -------------------------------------
+    profile = False
+
+    def _mark(self, name: str):
+        if self.profile:
+            if name == "start":
+                self._marks = []
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._marks.append((name, ev))
+
+    def phase_ms(self) -> Dict[str, float]:
+        """Milliseconds of the last profiled step by phase (events on the compute stream; `allreduce_wait` is only the part of the
+        gradient exchange that backward did not hide)."""
+        torch.cuda.synchronize()
+        m = self._marks
+        return {m[i][0]: m[i - 1][1].elapsed_time(m[i][1]) for i in range(1, len(m))}

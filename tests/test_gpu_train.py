@@ -223,3 +223,33 @@ def _flat_init(seed):
     from simple_pose_amd.train import FlatParams
     m, _ = _model(seed)
     return FlatParams(m).data.cpu().numpy()
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_maxpool_index_pair_matches_gather_kernel_and_torch(bf16):
+    """nn.MaxPool2d(3,2,1) forward-with-index + index backward == the compare-based backward kernel == torch autograd, with many
+    exact ties (values quantised to 1/4) so that the first-maximum rule is exercised."""
+    from simple_pose_amd import _lib
+    P = _lib.ptr
+    B, H, W, C = 3, 18, 14, 8
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randint(-3, 6, (B, H, W, C), generator=g).float() / 4).clamp_min(0)          # post-ReLU like, many zeros and ties
+    dy = torch.randn(B, H // 2, W // 2, C, generator=g)
+    xt = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    yt = torch.nn.functional.max_pool2d(xt, 3, 2, 1)
+    yt.backward(dy.permute(0, 3, 1, 2))
+    ref_dx = xt.grad.permute(0, 2, 3, 1).contiguous()
+    xd = x.to(DEV).to(torch.bfloat16 if bf16 else torch.float32).contiguous()
+    dyd = dy.to(DEV).contiguous()
+    y = torch.empty((B, H // 2, W // 2, C), dtype=xd.dtype, device=DEV)
+    idx = torch.empty((B, H // 2, W // 2, C), dtype=torch.uint8, device=DEV)
+    dx_new = torch.empty((B, H, W, C), dtype=torch.float32, device=DEV)
+    dx_old = torch.empty_like(dx_new)
+    lib, st = _lib.lib(), _lib.current_stream()
+    _lib.check(lib.sp_maxpool3x3s2_idx_nhwc(P(xd), int(bf16), P(y), P(idx), B, H, W, C, st))
+    _lib.check(lib.sp_maxpool3x3s2_bwd_idx_nhwc(P(idx), P(dyd), 0, P(dx_new), B, H, W, C, st))
+    _lib.check(lib.sp_maxpool3x3s2_bwd_nhwc(P(xd), int(bf16), P(dyd), P(dx_old), B, H, W, C, st))
+    torch.cuda.synchronize()
+    assert torch.equal(y.float().cpu(), yt.detach().permute(0, 2, 3, 1))                   # quarter values are exact in bf16
+    assert torch.equal(dx_new, dx_old)
+    assert torch.equal(dx_new.cpu(), ref_dx)
