@@ -27,7 +27,7 @@ extern "C" {
 #define SP_EINVAL (-1)   /* bad argument / unsupported shape (message in sp_last_error) */
 #define SP_ELAUNCH (-2)  /* HIP launch or runtime failure */
 
-#define SP_ABI_VERSION 9
+#define SP_ABI_VERSION 10
 
 /* epilogue / layout flags of sp_conv_desc.flags */
 #define SP_CONV_RELU 0x1u          /* y = max(y, 0) after scale/shift (+ residual) */
@@ -128,8 +128,9 @@ int sp_decode_basic(const float* heat_nchw, const float* trans_inv, int batch, i
                     float* max_val, void* stream);
 
 /* HeatMapAcc.__call__ (:212-245) on the arg-max coordinates of predictions and targets (two sp_heat_map_to_axis calls):
- * acc_out = one device float, no host sync (the reference's .item() calls at :237 are gone) */
-int sp_heat_map_acc(const float* pred_coords, const float* label_coords, int batch, int joints, int h, int w,
+ * acc_out = one device float, no host sync (the reference's .item() calls at :237 are gone).  mask [B,J] (may be NULL): the
+ * solver evaluates maps multiplied by the joint mask (ddp...:130-131); a zero mask takes the joint out exactly as that does */
+int sp_heat_map_acc(const float* pred_coords, const float* label_coords, const float* mask, int batch, int joints, int h, int w,
                     float distance_thresh, float norm_frac, float* acc_out, void* stream);
 
 /* ---- input contract: datasets/coco.py:124-148 (collate_fn) -----------------------------------------

@@ -20,7 +20,7 @@ SP_CONV_PIXEL_SHUFFLE = 0x4
 SP_CONV_BF16 = 0x8
 SP_CONV_OUT_F32 = 0x10
 CONV_TILES = ((128, 128), (64, 128), (128, 64), (64, 64), (256, 64), (128, 32))
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class HipLibraryError(RuntimeError):
@@ -55,7 +55,7 @@ SYMBOLS = {
     "sp_heat_map_to_axis": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "sp_decode_gauss_taylor": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "sp_decode_basic": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
-    "sp_heat_map_acc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P]),
+    "sp_heat_map_acc": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P]),
     "sp_u8hwc_bgr_to_nchw_f32": (c_int, [_P, _P, c_int, c_int, c_int, ctypes.POINTER(c_float), _P]),
     "sp_encode_gauss_refine": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P]),
     "sp_encode_gauss_basic": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, c_int, _P, _P, _P]),

@@ -163,13 +163,16 @@ __global__ void u8hwc_bgr_to_nchw_kernel(const unsigned char* __restrict__ img, 
 
 // metrics/pose_metrics.py:212-245 HeatMapAcc on arg-max coordinates: per joint, share of valid samples (label x,y > 1) whose
 // normalised distance |pred - label| / (W/f, H/f) is below the threshold; mean over joints that have a valid sample.
-__global__ __launch_bounds__(256) void heat_map_acc_kernel(const float* __restrict__ pred, const float* __restrict__ label, int B, int J,
-                                                           float nx, float ny, float thresh, float* __restrict__ acc) {
+__global__ __launch_bounds__(256) void heat_map_acc_kernel(const float* __restrict__ pred, const float* __restrict__ label,
+                                                           const float* __restrict__ mask, int B, int J, float nx, float ny, float thresh,
+                                                           float* __restrict__ acc) {
     __shared__ float jacc[256];
     __shared__ int jok[256];
     for (int j = threadIdx.x; j < J; j += 256) {
         int valid = 0, hit = 0;
         for (int b = 0; b < B; ++b) {
+            // ddp...:130-131 feeds maps multiplied by the joint mask: a zero mask zeroes both maps -> both arg-max cells are (0,0)
+            if (mask && mask[b * J + j] == 0.f) continue;
             const float lx = label[(b * J + j) * 2], ly = label[(b * J + j) * 2 + 1];
             if (lx > 1.f && ly > 1.f) {
                 const float dx = pred[(b * J + j) * 2] / nx - lx / nx, dy = pred[(b * J + j) * 2 + 1] / ny - ly / ny;
@@ -272,11 +275,11 @@ extern "C" int sp_u8hwc_bgr_to_nchw_f32(const unsigned char* img, float* out, in
     return sp_check_launch("u8hwc_bgr_to_nchw_kernel");
 }
 
-extern "C" int sp_heat_map_acc(const float* pred_coords, const float* label_coords, int batch, int joints, int h, int w, float distance_thresh,
-                               float norm_frac, float* acc_out, void* stream) {
+extern "C" int sp_heat_map_acc(const float* pred_coords, const float* label_coords, const float* mask, int batch, int joints, int h, int w,
+                               float distance_thresh, float norm_frac, float* acc_out, void* stream) {
     SP_REQUIRE(pred_coords && label_coords && acc_out, "sp_heat_map_acc: null pointer");
     SP_REQUIRE(batch > 0 && joints > 0 && joints <= 256 && h > 0 && w > 0 && norm_frac > 0.f, "sp_heat_map_acc: bad argument (joints <= 256)");
-    hipLaunchKernelGGL(heat_map_acc_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pred_coords, label_coords, batch, joints,
+    hipLaunchKernelGGL(heat_map_acc_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pred_coords, label_coords, mask, batch, joints,
                        (float)w / norm_frac, (float)h / norm_frac, distance_thresh, acc_out);
     return sp_check_launch("heat_map_acc_kernel");
 }

@@ -81,12 +81,18 @@ class HeatMapAcc(object):
         self.norm_frac = norm_frac
 
     @torch.no_grad()
-    def __call__(self, predicts: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+    def __call__(self, predicts: torch.Tensor, targets: torch.Tensor, mask: torch.Tensor = None) -> torch.Tensor:
+        """`mask` [B,J] (optional): equivalent to passing `predicts.mul(mask[..., None, None])`, `targets.mul(...)` as the solver
+        does (ddp...:130-131) for masks of zeros and positive weights, without materialising the products."""
         preds, _ = BasicKeyPointDecoder.heat_map_to_axis(predicts)
         labels, _ = BasicKeyPointDecoder.heat_map_to_axis(targets)
         B, J, H, W = predicts.shape
+        if mask is not None:
+            mask = _lib.require_cuda_f32(mask, "mask")
+            if tuple(mask.shape) != (B, J):
+                raise ValueError(f"mask: expected [{B},{J}], got {tuple(mask.shape)}")
         acc = torch.empty((), dtype=torch.float32, device=predicts.device)
-        _lib.check(_lib.lib().sp_heat_map_acc(_lib.ptr(preds), _lib.ptr(labels), B, J, H, W, float(self.distance_thresh),
+        _lib.check(_lib.lib().sp_heat_map_acc(_lib.ptr(preds), _lib.ptr(labels), _lib.ptr(mask), B, J, H, W, float(self.distance_thresh),
                                               float(self.norm_frac), _lib.ptr(acc), _lib.current_stream()), "sp_heat_map_acc")
         return acc
 

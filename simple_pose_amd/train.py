@@ -597,6 +597,8 @@ class PoseTrainer:
                                            self.lr, self.betas[0], self.betas[1], self.eps, self.step_count, grad_scale,
                                            _lib.current_stream()), "adam")
         self.repack()
+        if getattr(self.model, "_program", None) is not None:
+            self.model._program = None        # the eval-mode program holds BN-folded copies of the weights the kernel just changed
 
     def step(self, x, targets, mask) -> torch.Tensor:
         """optimizer.zero_grad(); loss = ...; loss.backward(); optimizer.step()  (ddp...:114-119)."""

@@ -454,6 +454,14 @@ def test_heat_map_acc_and_collate_normalisation_vs_reference_golden(golden):
         val = acc(_cuda(g[f"acc/{tag}/pred"]), tgt)
         assert val.is_cuda and val.dim() == 0
         assert abs(val.item() - float(g[f"acc/{tag}/value"])) < 1e-6
+    # the solver's masked form (ddp...:130-131): a mask argument == multiplying both maps by the mask
+    pred, joints = _cuda(g["acc/a/pred"]), g["acc/a/joints"]
+    tgt, w = RefineSimpleTransform.get_heat_map(_cuda(joints), 2.0, (48, 64))
+    mask = w.clone()
+    mask[0, ::3] = 0.0
+    m4 = mask[..., None, None]
+    assert acc(pred, tgt, mask).item() == acc(pred * m4, tgt * m4).item()
+    assert acc(pred, tgt, mask).item() != acc(pred, tgt).item() or float(mask.min()) > 0
     x = normalize_crops(_cuda(g["collate/img_u8"]))
     assert np.array_equal(x.cpu().numpy(), g["collate/input"])          # bit exact: x/255 - mean in fp32
 

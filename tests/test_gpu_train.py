@@ -253,3 +253,28 @@ def test_maxpool_index_pair_matches_gather_kernel_and_torch(bf16):
     assert torch.equal(y.float().cpu(), yt.detach().permute(0, 2, 3, 1))                   # quarter values are exact in bf16
     assert torch.equal(dx_new, dx_old)
     assert torch.equal(dx_new.cpu(), ref_dx)
+
+
+def test_solver_counterpart_trains_validates_and_checkpoints(tmp_path):
+    """DDPProcessor (ddp...:20-212) on synthetic data, single process: two epochs with a MultiStepLR drop, loss goes down, val()
+    runs the eval-mode forward with the UPDATED weights, and the checkpoint has the reference's {"ema": state_dict, "epoch"} form."""
+    import yaml
+    from simple_pose_amd.processors.ddp_pose_resnet_solver import DDPProcessor
+    cfg = {"model_name": "t", "gpus": "0",
+           "data": {"synthetic": 8, "batch_size": 4, "num_workers": 0, "debug": False},
+           "model": {"type": "pose_resnet_duc", "name": "resnet50", "num_joints": 17, "pretrained": False},
+           "optim": {"lr": 1e-3, "amp": False, "sync_bn": True, "milestones": [1], "epochs": 2, "gamma": 0.1},
+           "val": {"interval": 1, "weight_path": str(tmp_path / "w")}}
+    path = tmp_path / "cfg.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    proc = DDPProcessor(str(path))
+    v0 = proc.val(-1)
+    proc.run()
+    assert [h["lr"] for h in proc.history] == [1e-3, 1e-4]
+    assert proc.history[1]["loss"] < proc.history[0]["loss"]
+    v1 = proc.val(1)
+    assert v1["loss"] != v0["loss"] and v1["results"] == 4 * len(proc.vloader)       # eval program was rebuilt from the new weights
+    ck = torch.load(tmp_path / "w" / "t_last.pth")
+    assert set(ck) == {"ema", "epoch"} and ck["epoch"] == 1
+    assert set(ck["ema"]) == {k for k, _, _ in nets_oracle.state_dict_shapes_resnet50("duc")}
+    assert float(ck["ema"]["bn1.num_batches_tracked"]) == 4.0                            # 2 epochs x 2 iterations

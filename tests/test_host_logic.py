@@ -187,3 +187,31 @@ def test_gradient_buckets_tile_the_flat_buffer_in_reverse_parameter_order():
     assert len(shim.buckets) >= 2
     shim.world = 1
     shim._grads_ready("3.bias")                                    # single rank: nothing to launch, no state needed
+
+
+def test_solver_schedule_and_config_schema_match_the_reference():
+    """simple_pose_amd.processors.ddp_pose_resnet_solver: MultiStepLR in closed form == torch's scheduler (ddp...:73-77), and the
+    shipped yaml carries every key the reference's solver reads (configs/ddp_fast_pose.yaml)."""
+    import os
+    import torch
+    import yaml
+    from simple_pose_amd.processors.ddp_pose_resnet_solver import AverageLogger, multi_step_lr
+
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=0.1)
+    sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[3, 5], gamma=0.1)
+    for epoch in range(8):
+        assert abs(opt.param_groups[0]["lr"] - multi_step_lr(0.1, [3, 5], 0.1, epoch)) < 1e-12
+        opt.step(); sch.step()
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(here, "simple_pose_amd", "configs", "ddp_fast_pose.yaml")) as fh:
+        cfg = yaml.safe_load(fh)
+    assert {"model_name", "data", "model", "optim", "val", "gpus"} <= set(cfg)
+    assert {"batch_size", "num_workers", "debug"} <= set(cfg["data"])
+    assert {"type", "name", "num_joints", "pretrained"} <= set(cfg["model"])
+    assert {"lr", "amp", "sync_bn", "milestones", "epochs", "gamma"} <= set(cfg["optim"])
+    assert {"interval", "weight_path"} <= set(cfg["val"])
+    lg = AverageLogger()
+    for v in (1.0, 2.0, 6.0):
+        lg.update(torch.tensor(v))
+    assert lg.avg() == 3.0
