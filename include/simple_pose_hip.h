@@ -27,7 +27,7 @@ extern "C" {
 #define SP_EINVAL (-1)   /* bad argument / unsupported shape (message in sp_last_error) */
 #define SP_ELAUNCH (-2)  /* HIP launch or runtime failure */
 
-#define SP_ABI_VERSION 10
+#define SP_ABI_VERSION 11
 
 /* epilogue / layout flags of sp_conv_desc.flags */
 #define SP_CONV_RELU 0x1u          /* y = max(y, 0) after scale/shift (+ residual) */
@@ -207,6 +207,9 @@ int sp_bn_train_bwd_apply_nhwc(const void* dy, int bf16, const void* relu_src, c
                                int c, void* dz, void* dres, int dres_accumulate, void* stream);
 /* backward of nn.PixelShuffle(2) (DUC head, nets/commons.py:36-41): dy [B,2h,2w,c/4] fp32 -> dx [B,h,w,c] fp32 */
 int sp_pixel_unshuffle2_nhwc(const float* dy, float* dx, int batch, int h, int w, int c, void* stream);
+/* x [B,channels,h,w] fp32 -> y [B,h,w,c_pad] (fp32, or bf16 when y_bf16), channels >= `channels` zero-filled: puts
+ * d loss / d heat-map (sp_masked_mse's grad) into the layout and K-tile padding the final layer's backward launches read */
+int sp_nchw_to_nhwc_pad(const float* x, void* y, int y_bf16, int batch, int channels, int h, int w, int c_pad, void* stream);
 /* sum over rows of a [rows, c] tensor (conv bias gradient) */
 int sp_channel_sum_nhwc(const float* a, int64_t rows, int c, float* sum, void* workspace, void* stream);
 /* backward of nn.MaxPool2d(3,2,1) (first maximum of a window wins, as torch); x = the pool's input */

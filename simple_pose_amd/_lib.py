@@ -20,7 +20,7 @@ SP_CONV_PIXEL_SHUFFLE = 0x4
 SP_CONV_BF16 = 0x8
 SP_CONV_OUT_F32 = 0x10
 CONV_TILES = ((128, 128), (64, 128), (128, 64), (64, 64), (256, 64), (128, 32))
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class HipLibraryError(RuntimeError):
@@ -78,6 +78,7 @@ SYMBOLS = {
     "sp_pixel_unshuffle2_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "sp_maxpool3x3s2_idx_nhwc": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "sp_maxpool3x3s2_bwd_idx_nhwc": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
+    "sp_nchw_to_nhwc_pad": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "sp_masked_mse": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
 }
 

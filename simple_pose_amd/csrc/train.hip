@@ -306,6 +306,25 @@ __global__ void maxpool3x3s2_bwd_idx_kernel(const unsigned int* __restrict__ idx
     }
 }
 
+// [B,C,H,W] fp32 -> [B,H,W,Cpad] (fp32 or bf16), channels >= C zero: the loss gradient d loss / d heat-map in the layout (and
+// K-tile padding) the final layer's dgrad / wgrad launches read.  One thread per (pixel, 4 output channels).
+template <bool BF16OUT>
+__global__ void nchw_to_nhwc_pad_kernel(const float* __restrict__ x, void* __restrict__ y, int C, int hw, int Cp4, long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % Cp4);
+        const long long r = i / Cp4;
+        const long long b = r / hw;
+        const int pix = (int)(r - b * hw);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = c4 * 4 + e;
+            if (c < C) v[e] = x[(b * C + c) * hw + pix];
+        }
+        st4<BF16OUT>(y, i, v);
+    }
+}
+
 // torch.optim.Adam (no amsgrad, weight_decay 0) on flat buffers; g is multiplied by grad_scale first (1/world after a SUM all-reduce)
 __global__ void adam_kernel(f32x4* __restrict__ p, const f32x4* __restrict__ g, f32x4* __restrict__ m, f32x4* __restrict__ v, long long n4,
                             float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, float grad_scale) {
@@ -523,6 +542,19 @@ extern "C" int sp_maxpool3x3s2_bwd_idx_nhwc(const void* idx, const void* dy, int
     else hipLaunchKernelGGL(maxpool3x3s2_bwd_idx_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
                             reinterpret_cast<const unsigned int*>(idx), dy, dx, h, w, c / 4, ho, wo, total);
     return sp_check_launch("maxpool3x3s2_bwd_idx_kernel");
+}
+
+extern "C" int sp_nchw_to_nhwc_pad(const float* x, void* y, int y_bf16, int batch, int channels, int h, int w, int c_pad, void* stream) {
+    SP_REQUIRE(x && y, "sp_nchw_to_nhwc_pad: null pointer");
+    SP_REQUIRE(batch > 0 && channels > 0 && h > 0 && w > 0 && c_pad >= channels && c_pad % 4 == 0, "sp_nchw_to_nhwc_pad: bad shape C=%d c_pad=%d",
+               channels, c_pad);
+    const long long total = (long long)batch * h * w * (c_pad / 4);
+    SP_REQUIRE(total * 4 < (1ll << 31), "sp_nchw_to_nhwc_pad: tensor too large");
+    if (y_bf16) hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, channels, h * w,
+                               c_pad / 4, total);
+    else hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, channels, h * w,
+                            c_pad / 4, total);
+    return sp_check_launch("nchw_to_nhwc_pad_kernel");
 }
 
 extern "C" int sp_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,

@@ -190,3 +190,11 @@ class DDPProcessor(object):
             self.train(epoch)
             if (epoch + 1) % self.val_cfg["interval"] == 0:
                 self.val(epoch)
+
+
+if __name__ == "__main__":                                    # main.py of the reference: DDPProcessor(cfg_path=...).run()
+    import sys
+    DDPProcessor(sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                      "configs", "ddp_fast_pose.yaml")).run()
+    if dist.is_initialized():
+        dist.destroy_process_group()

@@ -554,14 +554,15 @@ class PoseTrainer:
         self.last_heat = heat
         self._mark("forward_loss")
         # ---- backward ----
-        Jb = fl.c_out_buf
-        dh = torch.zeros((B, hh, ww, Jb), dtype=torch.float32, device=dev)
-        dh[..., :J] = dheat.permute(0, 2, 3, 1)           # tiny layout glue ([B,17,64,48] -> NHWC, channels padded to a K tile)
+        Jb = fl.c_out_buf                                  # heat-map channels padded to a K tile of the backward launches
+        dh = newf((B, hh, ww, Jb))
+        _lib.check(lib.sp_nchw_to_nhwc_pad(P(dheat), P(dh), 0, B, J, hh, ww, Jb, stream), "dheat.nhwc")
         bsum = newf(Jb)
         _lib.check(lib.sp_channel_sum_nhwc(P(dh), B * hh * ww, Jb, P(bsum), P(ws), stream), "final_layer.bias.grad")
-        self.flat.view("final_layer.bias", True).copy_(bsum[:J])
+        self.flat.view("final_layer.bias", True).copy_(bsum[:J])          # 17-float device copy into the flat gradient buffer
         if self.bf16:
-            dh = dh.to(torch.bfloat16)
+            dh = new((B, hh, ww, Jb))
+            _lib.check(lib.sp_nchw_to_nhwc_pad(P(dheat), P(dh), 1, B, J, hh, ww, Jb, stream), "dheat.nhwc16")
         fl.wgrad(a.data, dh, B)
         self._grads_ready("final_layer.bias", "final_layer.weight")
         a.grad = fl.dgrad(dh, B, None)
