@@ -27,7 +27,7 @@ extern "C" {
 #define SP_EINVAL (-1)   /* bad argument / unsupported shape (message in sp_last_error) */
 #define SP_ELAUNCH (-2)  /* HIP launch or runtime failure */
 
-#define SP_ABI_VERSION 11
+#define SP_ABI_VERSION 12
 
 /* epilogue / layout flags of sp_conv_desc.flags */
 #define SP_CONV_RELU 0x1u          /* y = max(y, 0) after scale/shift (+ residual) */
@@ -138,6 +138,12 @@ int sp_heat_map_acc(const float* pred_coords, const float* label_coords, const f
  * mean_rgb_host: 3 floats in HOST memory */
 int sp_u8hwc_bgr_to_nchw_f32(const unsigned char* img, float* out, int batch, int h, int w, const float* mean_rgb_host,
                              void* stream);
+
+/* person crops from the full image: dst[n] = cv.warpAffine(src, m_fwd[n], (out_w, out_h), flags=INTER_LINEAR) for
+ * `crops` forward (src -> dst) 2x3 float64 matrices (HOST memory; inverted on the host as OpenCV does) over one uint8 HxWx3 image; BORDER_CONSTANT 0; OpenCV's
+ * fixed-point bilinear arithmetic restated (not pinned against cv2: it is absent from the build image) - naive_data.py:50 */
+int sp_warp_affine_u8c3(const unsigned char* src, int src_h, int src_w, const double* m_fwd, int crops, unsigned char* dst, int out_h,
+                        int out_w, void* stream);
 
 /* ---- after decode: result scores and per-image OKS-NMS -----------------------------------
  * kps_to_dict_ (metrics/pose_metrics.py:172-179): score[b] = mean_j(max_val[b,j]) + max_j(max_val[b,j]) */

@@ -353,6 +353,30 @@ def gen_nms(ns):
           len(out["direct/keep_sig"]))
 
 
+def gen_crop(ns):
+    """g9_crop.npz: SURVEY 8(f)3 - the reference's BasicTransform.__call__ (datasets/naive_data.py:33-56: box -> centre/scale ->
+    get_affine_transform -> cv.warpAffine) on a synthetic image.  cv2 is absent here: its two primitives are the restatements of
+    oracle/pose_oracle.* plugged into the cv2 stub, so this fixture pins the reference's GLUE (conventions, float32 point
+    construction, which matrix goes where), not OpenCV's arithmetic."""
+    import importlib
+    from scipy import ndimage
+    nd = importlib.import_module("datasets.naive_data")
+    rng = np.random.default_rng(9)
+    img = ndimage.gaussian_filter(rng.random((240, 320, 3)) * 255, (2, 2, 0)).astype(np.uint8)
+    boxes = np.array([[40.3, 30.7, 140.9, 200.2], [-20.0, 10.0, 90.0, 120.0], [200.0, 100.0, 330.0, 250.0], [100.0, 50.0, 110.0, 230.0],
+                      [10.0, 10.0, 300.0, 60.0]], np.float32)
+    tf = nd.BasicTransform()
+    crops, tinv, centers, scales, areas = [], [], [], [], []
+    for b in boxes:
+        item = nd.KeyPointItem("x.jpg", b, 0.9)
+        item.img = img
+        item = tf(item)
+        crops.append(item.img); tinv.append(item.trans_inv); centers.append(item.center); scales.append(item.scale); areas.append(item.area)
+    np.savez_compressed(os.path.join(GOLD, "g9_crop.npz"), img=img, boxes=boxes, crops=np.stack(crops), trans_inv=np.stack(tinv),
+                        centers=np.stack(centers), scales=np.stack(scales), areas=np.array(areas))
+    print("g9_crop.npz", np.stack(crops).shape, "mean", np.stack(crops).mean())
+
+
 def main():
     assert ref_import.available(), "needs /root/reference (build container only)"
     os.makedirs(GOLD, exist_ok=True)
@@ -366,6 +390,7 @@ def main():
     gen_next(ns)
     gen_train(ns)
     gen_nms(ns)
+    gen_crop(ns)
     del hm
 
 

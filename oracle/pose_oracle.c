@@ -344,3 +344,48 @@ void sp_oracle_pose_score(const float* max_val /* [B,J] */, int B, int J, float*
         score[b] = (float)s / (float)J + m;
     }
 }
+
+/* ---- cv.warpAffine(img, M, (w,h), flags=INTER_LINEAR) as the reference calls it (commons/transforms.py:214,
+ * datasets/naive_data.py:50): 8-bit 3-channel, BORDER_CONSTANT 0, M = forward map src->dst (inverted here, as OpenCV does).
+ * THIRD-PARTY ARITHMETIC, RESTATED FROM THE PUBLISHED ALGORITHM (OpenCV 4.x imgproc/imgwarp.cpp: warpAffine -> WarpAffineInvoker
+ * -> remapBilinear with the fixed-point tables); opencv-python is not installed here and the reference pins no version, so
+ * this function is NOT pinned against cv2 itself ("parity unpinned" for the crop path).
+ *   coordinates: AB_BITS = 10 fixed point, rounded to 1/32 px (INTER_BITS = 5);
+ *   weights    : (1-fy)(1-fx), (1-fy)fx, fy(1-fx), fy*fx scaled by 2^15 as shorts (exact products of n/32 fractions; the one
+ *                saturating entry, fx=fy=0 -> 32767, gets OpenCV's +1 on the last weight), result = (sum + 2^14) >> 15. */
+static inline int cv_round(double v) { return (int)lrint(v); }      /* saturate_cast<int>(double): round half to even */
+static inline short sat_short(int v) { return (short)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+
+void sp_oracle_warp_affine_u8c3(const unsigned char* src, int H, int W, const double* Mfwd, unsigned char* dst, int oh, int ow) {
+    double M[6];
+    for (int i = 0; i < 6; ++i) M[i] = Mfwd[i];
+    double D = M[0] * M[4] - M[1] * M[3];
+    D = D != 0 ? 1. / D : 0;
+    const double A11 = M[4] * D, A22 = M[0] * D;
+    M[0] = A11; M[1] *= -D; M[3] *= -D; M[4] = A22;
+    const double b1 = -M[0] * M[2] - M[1] * M[5], b2 = -M[3] * M[2] - M[4] * M[5];
+    M[2] = b1; M[5] = b2;
+    const int AB_SCALE = 1 << 10, round_delta = AB_SCALE / 32 / 2;
+    for (int y = 0; y < oh; ++y) {
+        const int X0 = cv_round((M[1] * y + M[2]) * AB_SCALE) + round_delta;
+        const int Y0 = cv_round((M[4] * y + M[5]) * AB_SCALE) + round_delta;
+        for (int x = 0; x < ow; ++x) {
+            const int adelta = cv_round(M[0] * x * AB_SCALE), bdelta = cv_round(M[3] * x * AB_SCALE);
+            const int X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
+            const int sx = sat_short(X >> 5), sy = sat_short(Y >> 5), fx = X & 31, fy = Y & 31;
+            int w[4] = {(32 - fy) * (32 - fx) * 32, (32 - fy) * fx * 32, fy * (32 - fx) * 32, fy * fx * 32};
+            if (w[0] == 32768) { w[0] = 32767; w[3] = 1; }
+            unsigned char* d = dst + ((size_t)y * ow + x) * 3;
+            if (sx >= W || sx + 1 < 0 || sy >= H || sy + 1 < 0) { d[0] = d[1] = d[2] = 0; continue; }
+            for (int k = 0; k < 3; ++k) {
+                int v[4];
+                for (int t = 0; t < 4; ++t) {
+                    const int xx = sx + (t & 1), yy = sy + (t >> 1);
+                    v[t] = (xx >= 0 && yy >= 0 && xx < W && yy < H) ? src[((size_t)yy * W + xx) * 3 + k] : 0;
+                }
+                const int r = (v[0] * w[0] + v[1] * w[1] + v[2] * w[2] + v[3] * w[3] + (1 << 14)) >> 15;
+                d[k] = (unsigned char)(r < 0 ? 0 : (r > 255 ? 255 : r));
+            }
+        }
+    }
+}

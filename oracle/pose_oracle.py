@@ -161,3 +161,32 @@ def pose_score(max_val) -> np.ndarray:
     out = np.empty(m.shape[0], np.float32)
     lib().sp_oracle_pose_score(_p(m), m.shape[0], m.shape[1], _p(out))
     return out
+
+
+def warp_affine_u8c3(img, M, dsize):
+    """cv.warpAffine(img, M, dsize=(w, h), flags=cv.INTER_LINEAR) for uint8 HxWx3 (restated OpenCV arithmetic; see pose_oracle.c)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    H, W, C = img.shape
+    assert C == 3
+    M = np.ascontiguousarray(M, dtype=np.float64).reshape(6)
+    ow, oh = int(dsize[0]), int(dsize[1])
+    out = np.empty((oh, ow, 3), np.uint8)
+    lib().sp_oracle_warp_affine_u8c3(_p(img), H, W, _p(M), _p(out), oh, ow)
+    return out
+
+
+def get_affine_transform_3pt(src, dst):
+    """cv.getAffineTransform(src[3,2] float32, dst[3,2] float32) -> 2x3 float64.  OpenCV solves the 6x6 system by LU in float64;
+    here Cramer's rule in plain Python floats (IEEE double operations in a fixed order): the same map to ~1e-16 relative and,
+    unlike a LAPACK call, bit-reproducible on every machine (the GPU box's host CPU is not the build container's)."""
+    (x0, y0), (x1, y1), (x2, y2) = [(float(a), float(b)) for a, b in np.asarray(src, np.float64)]
+    d = np.asarray(dst, np.float64)
+    det = x0 * (y1 - y2) - y0 * (x1 - x2) + (x1 * y2 - x2 * y1)
+    rows = []
+    for k in range(2):
+        u0, u1, u2 = float(d[0, k]), float(d[1, k]), float(d[2, k])
+        a = (u0 * (y1 - y2) - y0 * (u1 - u2) + (u1 * y2 - u2 * y1)) / det
+        b = (x0 * (u1 - u2) - u0 * (x1 - x2) + (x1 * u2 - x2 * u1)) / det
+        c = (x0 * (y1 * u2 - y2 * u1) - y0 * (x1 * u2 - x2 * u1) + u0 * (x1 * y2 - x2 * y1)) / det
+        rows.append([a, b, c])
+    return np.array(rows, np.float64)

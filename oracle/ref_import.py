@@ -40,6 +40,10 @@ def _install_stubs():
         cv2.getGaussianKernel = _gaussian_kernel
         cv2.setNumThreads = lambda n: None
         cv2.INTER_LINEAR = 1
+        # restated OpenCV primitives (oracle/pose_oracle.*): let the reference's crop path run without opencv-python
+        from . import pose_oracle as _po
+        cv2.getAffineTransform = lambda src, dst: _po.get_affine_transform_3pt(src, dst)
+        cv2.warpAffine = lambda img, M, dsize, flags=1: _po.warp_affine_u8c3(img, M, dsize)
         cv2.COLOR_GRAY2BGR = 8
         sys.modules["cv2"] = cv2
     if "pycocotools" not in sys.modules:

@@ -20,7 +20,7 @@ SP_CONV_PIXEL_SHUFFLE = 0x4
 SP_CONV_BF16 = 0x8
 SP_CONV_OUT_F32 = 0x10
 CONV_TILES = ((128, 128), (64, 128), (128, 64), (64, 64), (256, 64), (128, 32))
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class HipLibraryError(RuntimeError):
@@ -79,6 +79,7 @@ SYMBOLS = {
     "sp_maxpool3x3s2_idx_nhwc": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "sp_maxpool3x3s2_bwd_idx_nhwc": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
     "sp_nchw_to_nhwc_pad": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "sp_warp_affine_u8c3": (c_int, [_P, c_int, c_int, _P, c_int, _P, c_int, c_int, _P]),
     "sp_masked_mse": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
 }
 

@@ -92,3 +92,28 @@ def filter_poses(kps: torch.Tensor, box_score, area, img_ids: Sequence, in_vis_t
         for r in keep_h[seg_h[g]: seg_h[g] + cnt_h[g]]:
             out.append({"image_id": iid, "score": float(score_h[r]), "category_id": 1, "keypoints": kps_h[r].reshape(-1).tolist()})
     return out
+
+
+def crop_boxes(img: torch.Tensor, boxes, input_shape=(192, 256), output_shape=(48, 64)):
+    """`BasicTransform.__call__` (datasets/naive_data.py:33-56) for every detected box of one image, on the GPU: uint8 BGR image
+    [H,W,3] (CUDA) + boxes [N,4] (x1,y1,x2,y2; host) -> (crops uint8 [N,h,w,3] ready for `datasets.coco.normalize_crops`,
+    trans_inv float32 [N,2,3] for the decoder, centers [N,2], scales [N,2], areas [N]).  One launch for all N warps."""
+    from ..commons.joint_utils import box_to_center_scale, get_affine_transform
+    if not (isinstance(img, torch.Tensor) and img.is_cuda and img.dtype == torch.uint8 and img.dim() == 3 and img.shape[-1] == 3):
+        raise _lib.HipLibraryError("crop_boxes: expected a CUDA uint8 image [H,W,3]")
+    img = img.contiguous()
+    boxes = np.asarray(boxes).reshape(-1, 4)        # dtype kept: the box arithmetic runs in the caller's precision, as the reference's does
+    n = boxes.shape[0]
+    w_h_ratio = input_shape[0] / input_shape[1]
+    m_fwd = np.empty((n, 2, 3), np.float64)
+    tinv = np.empty((n, 2, 3), np.float32)
+    centers, scales = np.empty((n, 2), np.float32), np.empty((n, 2), np.float32)
+    for i, (x1, y1, x2, y2) in enumerate(boxes):
+        center, scale = box_to_center_scale(x1, y1, x2 - x1, y2 - y1, w_h_ratio)
+        m_fwd[i], _ = get_affine_transform(center, scale, 0, input_shape)
+        _, tinv[i] = get_affine_transform(center, scale, 0, output_shape)
+        centers[i], scales[i] = center, scale
+    crops = torch.empty((n, input_shape[1], input_shape[0], 3), dtype=torch.uint8, device=img.device)
+    _lib.check(_lib.lib().sp_warp_affine_u8c3(P(img), img.shape[0], img.shape[1], m_fwd.ctypes.data, n, P(crops), input_shape[1], input_shape[0],
+                                              _lib.current_stream()), "sp_warp_affine_u8c3")
+    return crops, torch.from_numpy(tinv).to(img.device), centers, scales, scales[:, 0] * scales[:, 1]

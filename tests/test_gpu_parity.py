@@ -534,3 +534,31 @@ def test_captured_hip_graph_replays_forward_and_decode_bitwise(golden):
         assert torch.equal(hm_g, hm_e) and torch.equal(kps_g, kps_e) and torch.equal(mv_g, mv_e)
     rel = np.abs(graphed(x0)[0].cpu().numpy() - g["heat_maps"]).max() / np.abs(g["heat_maps"]).max()
     assert rel <= 1e-4, rel
+
+
+def test_gpu_person_crops_vs_reference_glue_golden(golden):
+    """crop_boxes (one launch for all boxes of an image) == the crops / trans_inv the reference's BasicTransform
+    produced through the restated OpenCV primitives, bit for bit; feeds normalize_crops -> model as eval.py's loader would."""
+    from simple_pose_amd.datasets.coco import normalize_crops
+    from simple_pose_amd.datasets.naive_data import crop_boxes
+    g = golden("g9_crop.npz")
+    crops, tinv, centers, scales, areas = crop_boxes(_cuda(g["img"]), g["boxes"])
+    np.testing.assert_array_equal(crops.cpu().numpy(), g["crops"])
+    np.testing.assert_array_equal(tinv.cpu().numpy(), g["trans_inv"].astype(np.float32))
+    np.testing.assert_array_equal(centers, g["centers"]); np.testing.assert_array_equal(scales, g["scales"])
+    np.testing.assert_array_equal(areas, g["areas"])
+    x = normalize_crops(crops)
+    assert x.shape == (5, 3, 256, 192) and x.dtype == torch.float32
+    # a large, rotated, partly outside warp against the C oracle
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    th = 0.4
+    M = np.array([[[1.3 * np.cos(th), -1.3 * np.sin(th), -80.5], [1.3 * np.sin(th), 1.3 * np.cos(th), -140.25]],
+                  [[0.31, 0.0, 10.0], [0.0, 0.29, -3.0]], [[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]], [[4.0, 0.0, -2000.0], [0.0, 4.0, 5.0]]])
+    out = torch.empty((4, 256, 192, 3), dtype=torch.uint8, device="cuda")
+    imd = torch.from_numpy(img).cuda()
+    M = np.ascontiguousarray(M)
+    _lib.check(_lib.lib().sp_warp_affine_u8c3(_lib.ptr(imd), 480, 640, M.ctypes.data, 4, _lib.ptr(out), 256, 192, _lib.current_stream()))
+    for i in range(4):
+        np.testing.assert_array_equal(out[i].cpu().numpy(), pose_oracle.warp_affine_u8c3(img, M[i], (192, 256)))
+    np.testing.assert_array_equal(out[2].cpu().numpy(), img[:256, :192])                 # identity map = plain copy

@@ -184,3 +184,28 @@ def test_oks_nms_oracle_matches_reference(golden):
     far = np.arange(5)[:, None, None] * 1000.0 + np.zeros((5, 17, 3))
     assert pose_oracle.oks_nms(far, same, np.full(5, 1e3), 0.9) == [4, 3, 2, 1, 0]
     np.testing.assert_allclose(pose_oracle.pose_score(g["kps"][:8, :, 2]), g["dict/score"], rtol=2e-7)
+
+
+def test_crop_geometry_and_warp_restatement(golden):
+    """SURVEY 8(f)3.  (1) the host-side geometry mirror reproduces the matrices the reference's BasicTransform produced; (2) the
+    restated cv.warpAffine reproduces the crops frozen through the reference's glue; (3) absent cv2, the restatement itself is only
+    sanity-bounded: within one grey level of exact (float64) bilinear interpolation on a smooth image ("parity unpinned")."""
+    from scipy import ndimage
+    from simple_pose_amd.commons.joint_utils import box_to_center_scale, get_affine_transform
+    g = golden("g9_crop.npz")
+    img = g["img"]
+    for i, (x1, y1, x2, y2) in enumerate(g["boxes"]):
+        c, s = box_to_center_scale(x1, y1, x2 - x1, y2 - y1, 192 / 256)
+        np.testing.assert_array_equal(c, g["centers"][i]); np.testing.assert_array_equal(s, g["scales"][i])
+        m, _ = get_affine_transform(c, s, 0, (192, 256))
+        _, tinv = get_affine_transform(c, s, 0, (48, 64))
+        np.testing.assert_array_equal(tinv, g["trans_inv"][i])
+        crop = pose_oracle.warp_affine_u8c3(img, m, (192, 256))
+        np.testing.assert_array_equal(crop, g["crops"][i])
+        mi = np.linalg.inv(np.vstack([m, [0, 0, 1]]))[:2]
+        ys, xs = np.mgrid[0:256, 0:192]
+        sx, sy = mi[0, 0] * xs + mi[0, 1] * ys + mi[0, 2], mi[1, 0] * xs + mi[1, 1] * ys + mi[1, 2]
+        ref = np.stack([ndimage.map_coordinates(img[..., k].astype(float), [sy, sx], order=1, mode="constant", cval=0) for k in range(3)], -1)
+        inside = (sx > 0) & (sx < img.shape[1] - 1) & (sy > 0) & (sy < img.shape[0] - 1)
+        assert np.abs(crop.astype(float) - ref)[inside].max() <= 1.0
+        assert (crop[(sx < -1) | (sy < -1) | (sx > img.shape[1]) | (sy > img.shape[0])] == 0).all()      # BORDER_CONSTANT 0
