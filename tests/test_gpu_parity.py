@@ -562,3 +562,61 @@ def test_gpu_person_crops_vs_reference_glue_golden(golden):
     for i in range(4):
         np.testing.assert_array_equal(out[i].cpu().numpy(), pose_oracle.warp_affine_u8c3(img, M[i], (192, 256)))
     np.testing.assert_array_equal(out[2].cpu().numpy(), img[:256, :192])                 # identity map = plain copy
+
+
+def _sweep_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    cases = []
+    while len(cases) < n:
+        k = int(rng.choice([1, 3]))
+        s = int(rng.choice([1, 1, 2]))
+        cin = int(rng.choice([32, 64, 96, 128, 160, 256]))
+        cout = int(rng.choice([17, 32, 48, 64, 100, 128, 192, 256, 320]))
+        B, H, W = int(rng.integers(1, 6)), int(rng.integers(3, 23)), int(rng.integers(3, 19))
+        p = int(rng.integers(0, 2)) if k == 3 else 0
+        if (H + 2 * p - k) // s + 1 < 1 or (W + 2 * p - k) // s + 1 < 1:
+            continue
+        cases.append((B, cin, H, W, cout, k, s, p))
+    return cases
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_conv_random_ragged_shapes_on_every_tile(dtype):
+    """20 random layer shapes (odd spatial sizes, M and N that are no multiple of any tile, channels that are no multiple of 64,
+    pad 0/1, stride 1/2) x every workgroup tile the launcher accepts for them: all tiles must agree bit for bit with each other
+    (same K order) and with an fp64 convolution to fp32 / bf16-operand accuracy."""
+    for ci, (B, Cin, H, W, Cout, k, s, p) in enumerate(_sweep_cases(20, 2024)):
+        tag = f"sweep{ci}"
+        if dtype == "bf16":
+            Cout = (Cout + 7) // 8 * 8                       # bf16 NHWC stores are 16-byte: c_out % 8 == 0 is part of the contract
+        w = torch.from_numpy(synth.tensor_normal(3, tag + "/w", (Cout, Cin, k, k), std=(2.0 / (Cin * k * k)) ** 0.5))
+        x = torch.from_numpy(synth.tensor_normal(3, tag + "/x", (B, Cin, H, W)))
+        shift = torch.from_numpy(synth.tensor_normal(3, tag + "/b", (Cout,), std=0.3))
+        if dtype == "bf16":
+            w, x = w.bfloat16().float(), x.bfloat16().float()          # exact operands for the reference
+        ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), stride=s, padding=p) + shift.double().view(1, -1, 1, 1))
+        b = engine.ProgramBuilder(H, W, dtype=dtype)
+        b.p.shapes["input"] = (H, W, Cin)
+        out = b.conv("input", w.to(DEV), stride=s, pad=p, shift=shift.to(DEV), relu=True, name="c")
+        prog = b.p
+        prog.out_name, prog.out_shape = out, prog.shapes[out]
+        op = [o for o in prog.ops if o.kind == "conv"][0]
+        tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+        xin = x.permute(0, 2, 3, 1).contiguous().to(DEV).to(tdt)
+        op.desc.batch = B
+        results = []
+        for tm, tn in _lib.CONV_TILES:
+            if op.desc.n_pad % tn:
+                continue
+            op.desc.tile_m, op.desc.tile_n = tm, tn
+            y = torch.full((B,) + tuple(prog.out_shape), float("nan"), dtype=tdt, device=DEV)      # every element must be written
+            _lib.check(_lib.lib().sp_conv2d_fwd(op.desc, _lib.ptr(xin), _lib.ptr(op.w), _lib.ptr(op.scale), _lib.ptr(op.shift), None,
+                                                _lib.ptr(y), _lib.current_stream()))
+            torch.cuda.synchronize()
+            results.append(((tm, tn), y.float().cpu()))
+        assert len(results) >= (2 if op.desc.n_pad >= 64 else 1), (Cout, op.desc.n_pad)
+        for tile, y in results[1:]:
+            assert torch.equal(y, results[0][1]), (ci, tile, (B, Cin, H, W, Cout, k, s, p))
+        got = results[0][1].permute(0, 3, 1, 2).double()
+        err = (got - ref).abs().max() / ref.abs().max()
+        assert err < (2e-6 if dtype == "fp32" else 6e-3), (ci, err, (B, Cin, H, W, Cout, k, s, p))
