@@ -270,7 +270,9 @@ def _variant_name(op):
     wr, wc = {(128, 128): (2, 2), (64, 128): (2, 2), (128, 64): (2, 2), (64, 64): (2, 2), (256, 64): (4, 1), (128, 32): (4, 1)}[(bm, bn)]
     bf16 = bool(d.flags & 0x8)
     uniform = (d.c_in % (64 if bf16 else 32) == 0) and d.taps_h * d.taps_w <= 32
-    return f"conv_igemm_kernel<{bm}, {bn}, {wr}, {wc}, {'true' if uniform else 'false'}, {'true' if bf16 else 'false'}>"
+    out16 = bf16 and not (d.flags & 0x10)             # template flag OUT16: bf16 operands without SP_CONV_OUT_F32
+    t = lambda v: "true" if v else "false"
+    return f"conv_igemm_kernel<{bm}, {bn}, {wr}, {wc}, {t(uniform)}, {t(bf16)}, {t(out16)}>"
 
 
 def kernel_roofline(prog, x, steps: int, layers_out=None, peak=FP32_MATRIX_PEAK_TFLOPS):

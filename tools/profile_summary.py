@@ -65,5 +65,31 @@ def main(src, dst):
                     fh.write("\nbench line of the profiled run (profiling perturbs clocks; see BENCH for the unprofiled number):\n\n```\n" + line.strip() + "\n```\n")
 
 
+def train_summary(src, dst):
+    """profiles/<tag>_train_bf16_kernel_stats.csv + a short table appended to the summary."""
+    found = glob.glob(os.path.join(src, "train_bf16", "**", "*_kernel_stats.csv"), recursive=True)
+    if not found:
+        return
+    shutil.copy(found[0], dst + "_train_bf16_kernel_stats.csv")
+    rows = list(csv.DictReader(open(found[0])))
+    with open(dst + "_summary.md", "a") as fh:
+        fh.write("\n## train step, bf16 compute, 32 images (python3 bench.py --mode train --dtype bf16 --batch 32 --steps 10 --warmup 3)\n\n")
+        fh.write("| kernel | calls | avg us | % GPU time |\n|---|---|---|---|\n")
+        for r in rows[:16]:
+            fh.write(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |\n")
+        for name in ("bench_train_bf16.json", "bench_train_f32.json"):
+            path = os.path.join(src, name)
+            if os.path.isfile(path):
+                for line in open(path):
+                    if line.startswith('{"metric"'):
+                        shutil.copy(path, dst + "_" + name)
+                        d = json.loads(line)
+                        fh.write(f"\n`{name}`: {d['value']} img/s, {d['ms_per_step']} ms/step, split {d.get('step_split_ms')}\n")
+
+
 if __name__ == "__main__":
     main(sys.argv[1], sys.argv[2])
+    train_summary(sys.argv[1], sys.argv[2])
+    for extra in ("bench_unprofiled.json",):
+        if os.path.isfile(os.path.join(sys.argv[1], extra)):
+            shutil.copy(os.path.join(sys.argv[1], extra), sys.argv[2] + "_" + extra)
