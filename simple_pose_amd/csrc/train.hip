@@ -104,8 +104,17 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(const void* __restr
 // partials in a fixed order, then a fixed-order butterfly - deterministic and ~3 us instead of a 256-deep serial chain.
 __device__ __forceinline__ void fold_partials(const double* __restrict__ part, int nblk, int C, int c, double& s0, double& s1) {
     const int lane = threadIdx.x & 63;
-    s0 = 0; s1 = 0;
-    for (int b = lane; b < nblk; b += 64) { s0 += part[((size_t)b * C + c) * 2]; s1 += part[((size_t)b * C + c) * 2 + 1]; }
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    const f64x2* p2 = reinterpret_cast<const f64x2*>(part);       // (s0, s1) pairs: one 16-byte load each
+    double a0 = 0, a1 = 0, b0 = 0, b1 = 0, c0 = 0, c1 = 0, d0 = 0, d1 = 0;
+    int b = lane;
+    for (; b + 192 < nblk; b += 256) {                             // four independent chains: four loads in flight per lane
+        const f64x2 v0 = p2[(size_t)b * C + c], v1 = p2[(size_t)(b + 64) * C + c], v2 = p2[(size_t)(b + 128) * C + c],
+                    v3 = p2[(size_t)(b + 192) * C + c];
+        a0 += v0.x; a1 += v0.y; b0 += v1.x; b1 += v1.y; c0 += v2.x; c1 += v2.y; d0 += v3.x; d1 += v3.y;
+    }
+    for (; b < nblk; b += 64) { const f64x2 v = p2[(size_t)b * C + c]; a0 += v.x; a1 += v.y; }
+    s0 = (a0 + b0) + (c0 + d0); s1 = (a1 + b1) + (c1 + d1);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off, SP_WAVE); s1 += __shfl_xor(s1, off, SP_WAVE); }
 }
