@@ -122,7 +122,6 @@ def main():
     torch.cuda.set_device(dev)
     red_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")   # where the measurement's scalar reductions live
 
-    from oracle import nets_oracle  # only for the reference state_dict LAYOUT (names/shapes) of the synthetic weights
     from simple_pose_amd import _lib, synth
     from simple_pose_amd.metrics import GaussTaylorKeyPointDecoder
     from simple_pose_amd.nets import pose_resnet_dconv, pose_resnet_duc
@@ -135,7 +134,9 @@ def main():
     else:
         mod = {"dconv": pose_resnet_dconv, "duc": pose_resnet_duc}[args.arch]
         model = mod.resnet50(pretrained=False, num_classes=17)
-        sd = synth.conditioned_state_dict(nets_oracle.state_dict_shapes_resnet50(args.arch), seed=0)
+        # names / shapes / dtypes come from the model itself (its state_dict layout is the reference's, tests/test_host_logic.py)
+        layout = [(k, tuple(v.shape), str(v.dtype)) for k, v in model.state_dict().items()]
+        sd = synth.conditioned_state_dict(layout, seed=0)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     model = model.to(dev).eval()
     if args.dtype == "bf16" and args.mode == "infer":
