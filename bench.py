@@ -40,6 +40,7 @@ def parse():
                     help="infer = forward + GaussTaylor decode (BASELINE metric, default); train = fwd+bwd+Adam step (config 4, fp32)")
     ap.add_argument("--no-sync-bn", action="store_true", help="train mode, N > 1: per-rank BN statistics (the reference's DDP solver syncs them)")
     ap.add_argument("--bucket-mb", type=float, default=32.0, help="train mode, N > 1: gradient all-reduce bucket size")
+    ap.add_argument("--single-stream", action="store_true", help="infer mode: issue independent branches (HRNet) on one stream")
     ap.add_argument("--graph", action="store_true", help="infer mode: replay the step (forward + decode) as one captured hipGraph")
     ap.add_argument("--tiles", default=None, help="JSON tile table: loaded if it exists (skips autotune), else written")
     ap.add_argument("--layers-out", default=None, help="write the per-layer timing table (JSON) here")
@@ -165,6 +166,7 @@ def main():
             return (loss,)
     else:
         prog = model.hip_program(x)
+        prog.multi_stream = not args.single_stream
         # untimed setup: pin the fastest workgroup tile per layer shape (or reuse a saved table: profiling runs do, so that
         # the trial launches of the tuner stay out of the per-kernel statistics)
         if args.tiles and os.path.isfile(args.tiles):

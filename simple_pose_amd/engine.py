@@ -13,6 +13,8 @@ Reference behaviour being lowered (file:line relative to liangheming/simple_pose
 """
 from __future__ import annotations
 
+import ctypes
+
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
@@ -112,6 +114,11 @@ class Op:
     args: tuple = ()
     flops: int = 0               # algorithmic FLOPs per image (2*MACs, real taps/channels only)
     name: str = ""
+    lane: int = 0                # HIP stream the op is issued on (0 = the caller's stream); independent branches get their own
+
+    def reads(self) -> Tuple[str, ...]:
+        extra = (self.args[2],) if self.kind == "se_gate" else ()
+        return tuple(n for n in (self.src, self.res) + extra if n)
 
 
 @dataclass
@@ -123,6 +130,10 @@ class Program:
     _pools: Dict[int, Dict[str, torch.Tensor]] = field(default_factory=dict)
     tuned_for_batch: int = 0
     dtype: str = "fp32"                                                     # activation / weight dtype: "fp32" | "bf16"
+    multi_stream: bool = True                                               # honour Op.lane (False: everything on the caller's stream)
+    _sync: Dict[Tuple[int, str], tuple] = field(default_factory=dict)       # per (batch, device): cross-lane wait / record plan
+    _streams: Dict[str, list] = field(default_factory=dict)
+    _events: Dict[str, dict] = field(default_factory=dict)
 
     # -- buffer planning: greedy reuse of dead activations (keeps the working set small for L2 / MALL) --
     def _alloc(self, batch: int, device) -> Dict[str, torch.Tensor]:
@@ -149,47 +160,115 @@ class Program:
         self._pools[key] = bufs
         return bufs
 
+    # -- cross-lane ordering: which earlier ops (on OTHER lanes) an op has to wait for -----------------------------------
+    def _plan_sync(self, batch: int, device) -> tuple:
+        """Ops of one lane are ordered by their stream.  Across lanes an op waits (HIP event) for: the producers of what it reads
+        (RAW), and every earlier reader / writer of the STORAGE it writes (WAR / WAW - the buffer planner hands dead storage to
+        later ops, and on another lane "later" is no longer implied).  Per (waiting lane, signalling lane) only the latest op is
+        kept.  Returns (waits per op, ops that record an event, last op per lane)."""
+        key = (batch, str(device))
+        if key in self._sync:
+            return self._sync[key]
+        bufs = self._alloc(batch, device)
+        store = lambda name: bufs[name].data_ptr() if name in bufs else ("@" + name)     # "input" / output: their own storage
+        last_writer: Dict[str, int] = {}
+        touched: Dict[object, List[int]] = {}
+        waits: List[List[int]] = []
+        for i, op in enumerate(self.ops):
+            need: Dict[int, int] = {}                       # signalling lane -> latest op index
+            cand = [last_writer[n] for n in op.reads() if n in last_writer] + touched.get(store(op.dst), [])
+            for j in cand:
+                lj = self.ops[j].lane
+                if lj != op.lane and need.get(lj, -1) < j:
+                    need[lj] = j
+            waits.append(sorted(need.values()))
+            last_writer[op.dst] = i
+            for n in op.reads() + (op.dst,):
+                touched.setdefault(store(n), []).append(i)
+        records = sorted({j for w in waits for j in w})
+        tails: Dict[int, int] = {}
+        for i, op in enumerate(self.ops):
+            tails[op.lane] = i
+        self._sync[key] = (waits, set(records), tails)
+        return self._sync[key]
+
+    def _lane_streams(self, device, n_lanes: int) -> list:
+        pool = self._streams.setdefault(str(device), [])
+        while len(pool) < n_lanes - 1:
+            pool.append(torch.cuda.Stream(device=device))
+        return pool
+
+    def _launch(self, lib, op: Op, bufs, B: int, stream) -> None:
+        P = _lib.ptr
+        if op.kind == "conv":
+            op.desc.batch = B
+            _lib.check(lib.sp_conv2d_fwd(op.desc, P(bufs[op.src]), P(op.w), P(op.scale), P(op.shift),
+                                         P(bufs[op.res]) if op.res else None, P(bufs[op.dst]), stream), op.name)
+        elif op.kind == "maxpool":
+            h, w, c = op.args
+            fn = lib.sp_maxpool3x3s2_nhwc_bf16 if self.dtype == "bf16" else lib.sp_maxpool3x3s2_nhwc
+            _lib.check(fn(P(bufs[op.src]), P(bufs[op.dst]), B, h, w, c, stream), op.name)
+        elif op.kind == "to_nhwc4":
+            c, h, w = op.args
+            fn = lib.sp_nchw_to_nhwc8_bf16 if self.dtype == "bf16" else lib.sp_nchw_to_nhwc4
+            _lib.check(fn(P(bufs[op.src]), P(bufs[op.dst]), B, c, h, w, stream), op.name)
+        elif op.kind == "pixel_shuffle":
+            h, w, c = op.args
+            fn = lib.sp_pixel_shuffle2_nhwc_bf16 if self.dtype == "bf16" else lib.sp_pixel_shuffle2_nhwc
+            _lib.check(fn(P(bufs[op.src]), P(bufs[op.dst]), B, h, w, c, stream), op.name)
+        elif op.kind == "gap":
+            hw, c = op.args
+            _lib.check(lib.sp_global_avg_pool_nhwc(P(bufs[op.src]), P(bufs[op.dst]), B, hw, c, stream), op.name)
+        elif op.kind == "se_gate":
+            hw, c, gate = op.args
+            _lib.check(lib.sp_se_gate_add_relu_nhwc(P(bufs[op.src]), P(bufs[gate]), P(bufs[op.res]), P(bufs[op.dst]), B, hw, c,
+                                                    stream), op.name)
+        elif op.kind == "upsample_add":
+            h, w, c, f, relu = op.args
+            fn = lib.sp_upsample_add_nhwc_bf16 if self.dtype == "bf16" else lib.sp_upsample_add_nhwc
+            _lib.check(fn(P(bufs[op.src]), P(bufs[op.res]), P(bufs[op.dst]), B, h, w, c, f, relu, stream), op.name)
+        else:
+            raise ValueError(op.kind)
+
     def run(self, x: torch.Tensor) -> torch.Tensor:
-        """x: fp32 NCHW [B,3,H,W] on the GPU -> heat maps fp32 NCHW [B,J,H/4,W/4]."""
+        """x: fp32 NCHW [B,3,H,W] on the GPU -> heat maps fp32 NCHW [B,J,H/4,W/4].  Ops are issued in program order; ops of
+        different lanes (independent HRNet branches) go to different HIP streams and overlap on the GPU, ordered by events."""
         lib = _lib.lib()
         B = x.shape[0]
         bufs = dict(self._alloc(B, x.device))
         bufs["input"] = x
         out = torch.empty((B,) + tuple(self.out_shape), dtype=torch.float32, device=x.device)
         bufs[self.out_name] = out
-        stream = _lib.current_stream()
-        P = _lib.ptr
-        for op in self.ops:
-            if op.kind == "conv":
-                op.desc.batch = B
-                _lib.check(lib.sp_conv2d_fwd(op.desc, P(bufs[op.src]), P(op.w), P(op.scale), P(op.shift),
-                                             P(bufs[op.res]) if op.res else None, P(bufs[op.dst]), stream), op.name)
-            elif op.kind == "maxpool":
-                h, w, c = op.args
-                fn = lib.sp_maxpool3x3s2_nhwc_bf16 if self.dtype == "bf16" else lib.sp_maxpool3x3s2_nhwc
-                _lib.check(fn(P(bufs[op.src]), P(bufs[op.dst]), B, h, w, c, stream), op.name)
-            elif op.kind == "to_nhwc4":
-                c, h, w = op.args
-                fn = lib.sp_nchw_to_nhwc8_bf16 if self.dtype == "bf16" else lib.sp_nchw_to_nhwc4
-                _lib.check(fn(P(bufs[op.src]), P(bufs[op.dst]), B, c, h, w, stream), op.name)
-            elif op.kind == "pixel_shuffle":
-                h, w, c = op.args
-                fn = lib.sp_pixel_shuffle2_nhwc_bf16 if self.dtype == "bf16" else lib.sp_pixel_shuffle2_nhwc
-                _lib.check(fn(P(bufs[op.src]), P(bufs[op.dst]), B, h, w, c, stream), op.name)
-            elif op.kind == "gap":
-                hw, c = op.args
-                _lib.check(lib.sp_global_avg_pool_nhwc(P(bufs[op.src]), P(bufs[op.dst]), B, hw, c, stream), op.name)
-            elif op.kind == "se_gate":
-                hw, c, gate = op.args
-                _lib.check(lib.sp_se_gate_add_relu_nhwc(P(bufs[op.src]), P(bufs[gate]), P(bufs[op.res]), P(bufs[op.dst]), B, hw, c,
-                                                        stream), op.name)
-            elif op.kind == "upsample_add":
-                h, w, c, f, relu = op.args
-                fn = lib.sp_upsample_add_nhwc_bf16 if self.dtype == "bf16" else lib.sp_upsample_add_nhwc
-                _lib.check(fn(P(bufs[op.src]), P(bufs[op.res]), P(bufs[op.dst]), B, h, w, c, f, relu, stream), op.name)
-            else:
-                raise ValueError(op.kind)
-        return out
+        n_lanes = 1 + max((op.lane for op in self.ops), default=0) if self.multi_stream else 1
+        if n_lanes == 1:
+            stream = _lib.current_stream()
+            for op in self.ops:
+                self._launch(lib, op, bufs, B, stream)
+            return out
+        waits, records, tails = self._plan_sync(B, x.device)
+        main = torch.cuda.current_stream(x.device)
+        side = self._lane_streams(x.device, n_lanes)
+        streams = [main] + side[: n_lanes - 1]
+        fork = torch.cuda.Event()
+        fork.record(main)                                   # inputs are ready / the previous run has drained (it joined on `main`)
+        for st in streams[1:]:
+            st.wait_event(fork)
+        handles = [ctypes.c_void_p(st.cuda_stream) for st in streams]
+        events = self._events.setdefault(str(x.device), {})
+        for i, op in enumerate(self.ops):
+            st = streams[op.lane]
+            for j in waits[i]:
+                st.wait_event(events[j])
+            self._launch(lib, op, bufs, B, handles[op.lane])
+            if i in records or (op.lane != 0 and tails[op.lane] == i):
+                ev = events.get(i)
+                if ev is None:
+                    ev = events[i] = torch.cuda.Event()
+                ev.record(st)
+        for lane, i in tails.items():                       # join: the caller's stream owns the result and every buffer again
+            if lane != 0:
+                main.wait_event(events[i])
+        return out                                          # (activation storage belongs to the program's pool: nothing to hand back)
 
     def capture(self, x: torch.Tensor, decoder=None, trans_inv: Optional[torch.Tensor] = None, warmup: int = 2) -> "GraphedForward":
         """Record the whole forward (and, when given, the key-point decode) of this batch shape into ONE hipGraph: the ~60 kernel
@@ -282,7 +361,12 @@ class GraphedForward:
             self.outputs = self._body()
 
     def _body(self):
-        hm = self.prog.run(self.static_input)
+        # one stream inside the capture: hipStreamEndCapture of ROCm 7.2 crashed on the forked multi-stream HRNet schedule
+        keep, self.prog.multi_stream = self.prog.multi_stream, False
+        try:
+            hm = self.prog.run(self.static_input)
+        finally:
+            self.prog.multi_stream = keep
         if self.decoder is None:
             return hm
         kps, mv = self.decoder(hm, self.static_trans_inv)
@@ -310,6 +394,11 @@ class ProgramBuilder:
         self.cpad = 8 if self.bf16 else 4           # channels per 16-byte chunk
         self.p.shapes["input"] = (in_h, in_w, 3)
         self._n = 0
+        self.lane = 0                               # ops appended from now on are issued on this lane (HIP stream)
+
+    def _add(self, op: Op) -> None:
+        op.lane = self.lane
+        self.p.ops.append(op)
 
     def _fresh(self, stem: str) -> str:
         self._n += 1
@@ -319,14 +408,14 @@ class ProgramBuilder:
         h, w, c = self.p.shapes[src]
         dst = self._fresh("x4")
         self.p.shapes[dst] = (h, w, self.cpad)
-        self.p.ops.append(Op("to_nhwc4", src, dst, args=(c, h, w), name="to_nhwc4"))
+        self._add(Op("to_nhwc4", src, dst, args=(c, h, w), name="to_nhwc4"))
         return dst
 
     def maxpool(self, src: str) -> str:
         h, w, c = self.p.shapes[src]
         dst = self._fresh("pool")
         self.p.shapes[dst] = ((h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1, c)
-        self.p.ops.append(Op("maxpool", src, dst, args=(h, w, c), name="maxpool"))
+        self._add(Op("maxpool", src, dst, args=(h, w, c), name="maxpool"))
         return dst
 
     def conv(self, src: str, weight: torch.Tensor, *, stride: int = 1, pad: int = 0, scale=None, shift=None,
@@ -370,7 +459,7 @@ class ProgramBuilder:
         d.flags = flags
         dst = dst or self._fresh(name)
         self.p.shapes[dst] = (d.out_h, d.out_w, d.out_c)
-        self.p.ops.append(Op("conv", src, dst, res=res, desc=d, w=packed, scale=scale, shift=shift, name=name,
+        self._add(Op("conv", src, dst, res=res, desc=d, w=packed, scale=scale, shift=shift, name=name,
                              flops=2 * gh * gw * O * I * kh * kw))
         return dst
 
@@ -393,7 +482,7 @@ class ProgramBuilder:
             packed = packed.to(torch.bfloat16)
         dst = self._fresh(name)
         self.p.shapes[dst] = (2 * h, 2 * w, O)
-        self.p.ops.append(Op("conv", src, dst, desc=d, w=packed.reshape(4 * n_pad, 4 * I), scale=scale, shift=shift,
+        self._add(Op("conv", src, dst, desc=d, w=packed.reshape(4 * n_pad, 4 * I), scale=scale, shift=shift,
                              name=name, flops=2 * h * w * I * O * 16))
         return dst
 
@@ -401,7 +490,7 @@ class ProgramBuilder:
         h, w, c = self.p.shapes[src]
         dst = self._fresh("pshuf")
         self.p.shapes[dst] = (2 * h, 2 * w, c // 4)
-        self.p.ops.append(Op("pixel_shuffle", src, dst, args=(h, w, c), name="pixel_shuffle"))
+        self._add(Op("pixel_shuffle", src, dst, args=(h, w, c), name="pixel_shuffle"))
         return dst
 
     def gap(self, src: str) -> str:
@@ -410,14 +499,14 @@ class ProgramBuilder:
         h, w, c = self.p.shapes[src]
         dst = self._fresh("gap")
         self.p.shapes[dst] = (1, 1, c)
-        self.p.ops.append(Op("gap", src, dst, args=(h * w, c), name="se.avg_pool"))
+        self._add(Op("gap", src, dst, args=(h * w, c), name="se.avg_pool"))
         return dst
 
     def se_gate(self, x: str, gate_logits: str, identity: str) -> str:
         h, w, c = self.p.shapes[x]
         dst = self._fresh("se")
         self.p.shapes[dst] = (h, w, c)
-        self.p.ops.append(Op("se_gate", x, dst, res=identity, args=(h * w, c, gate_logits), name="se.gate_add_relu"))
+        self._add(Op("se_gate", x, dst, res=identity, args=(h * w, c, gate_logits), name="se.gate_add_relu"))
         return dst
 
     def upsample_add(self, src: str, base: str, factor: int, relu: bool = False) -> str:
@@ -426,7 +515,7 @@ class ProgramBuilder:
         assert self.p.shapes[base] == (h * factor, w * factor, c), (self.p.shapes[base], (h, w, c), factor)
         dst = self._fresh("fuse")
         self.p.shapes[dst] = self.p.shapes[base]
-        self.p.ops.append(Op("upsample_add", src, dst, res=base, args=(h, w, c, factor, int(relu)), name="upsample_add"))
+        self._add(Op("upsample_add", src, dst, res=base, args=(h, w, c, factor, int(relu)), name="upsample_add"))
         return dst
 
 
@@ -445,6 +534,8 @@ def _bottleneck(b: ProgramBuilder, sd, x: str, p: str, stride: int) -> str:
     idn = x
     if (p + ".downsample.0.weight") in sd:
         sdn, hdn = _bn(sd, p + ".downsample.1")
+        # (stays on the main path's stream: giving the shortcut its own stream measured -1 % fp32 / -4 % bf16 at bs=128 - these
+        # launches fill the chip on their own, unlike HRNet's low-resolution branches)
         idn = b.conv(x, sd[p + ".downsample.0.weight"], stride=stride, scale=sdn, shift=hdn, name=p + ".downsample")
     s3, h3 = _bn(sd, p + ".bn3")
     if (p + ".se.fc.0.weight") in sd:
@@ -508,10 +599,12 @@ def _hr_module(b: ProgramBuilder, sd, xs: List[str], base: str, num_blocks: List
     nb = len(xs)
     xs = list(xs)
     for i in range(nb):
+        b.lane = i                                         # the branches of a module are independent: one HIP stream each
         for k in range(num_blocks[i]):
             xs[i] = _basic_block(b, sd, xs[i], f"{base}.branches.{i}.{k}")
     outs = []
     for i in range(nb if multi else 1):
+        b.lane = i                                         # output i of the fuse stage is assembled on branch i's stream
         y: Optional[str] = None
         for j in range(nb):
             last = (j == nb - 1)
@@ -536,6 +629,7 @@ def _hr_module(b: ProgramBuilder, sd, xs: List[str], base: str, num_blocks: List
                                relu=(last if fin else True), res=(y if fin else None), name=f"{f}.{k}")
                 y = t
         outs.append(y)
+    b.lane = 0
     return outs
 
 
@@ -558,6 +652,7 @@ def hrnet_program(sd: Dict[str, torch.Tensor], cfg: dict, in_h: int = 256, in_w:
         t = f"transition{si + 1}"
         xs: List[str] = []
         for i in range(nb):                              # :427-432 / :436-441 / :445-450
+            b.lane = i
             if i < pre_n:
                 if (f"{t}.{i}.0.weight") in sd:
                     s_, h_ = _bn(sd, f"{t}.{i}.1")
@@ -570,6 +665,7 @@ def hrnet_program(sd: Dict[str, torch.Tensor], cfg: dict, in_h: int = 256, in_w:
                     s_, h_ = _bn(sd, f"{t}.{i}.{j}.1")
                     v = b.conv(v, sd[f"{t}.{i}.{j}.0.weight"], stride=2, pad=1, scale=s_, shift=h_, relu=True, name=f"{t}.{i}.{j}")
                 xs.append(v)
+        b.lane = 0
         for m in range(sc["NUM_MODULES"]):
             multi = not (st == 4 and m == sc["NUM_MODULES"] - 1)
             xs = _hr_module(b, sd, xs, f"stage{st}.{m}", list(sc["NUM_BLOCKS"]), multi)

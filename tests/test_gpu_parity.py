@@ -620,3 +620,29 @@ def test_conv_random_ragged_shapes_on_every_tile(dtype):
         got = results[0][1].permute(0, 3, 1, 2).double()
         err = (got - ref).abs().max() / ref.abs().max()
         assert err < (2e-6 if dtype == "fp32" else 6e-3), (ci, err, (B, Cin, H, W, Cout, k, s, p))
+
+
+def test_hrnet_branches_on_separate_streams_match_single_stream(golden):
+    """engine.Program lanes: the independent branches of every HRNet module run on their own HIP stream, ordered by events
+    (RAW on activations, WAR/WAW on the planner's recycled storage).  The result must equal the one-stream schedule bit for bit,
+    run after run (a missing dependency shows up as a difference); a captured hipGraph keeps to one stream and agrees too."""
+    from simple_pose_amd.nets.pose_hrnet import get_pose_net, hrnet_state_dict_shapes
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    net = get_pose_net(os.path.join(root, "simple_pose_amd", "nets", "hrnet_w32.yaml"), pretrained=None, joint_num=17)
+    sd = synth.conditioned_state_dict(hrnet_state_dict_shapes(net.cfg, 17), seed=0)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    net = net.cuda().eval()
+    x = _cuda(synth.input_images(6, 3))
+    prog = net.hip_program(x)
+    assert max(op.lane for op in prog.ops) == 3
+    prog.multi_stream = False
+    ref = prog.run(x).clone()
+    prog.multi_stream = True
+    for _ in range(8):
+        assert torch.equal(prog.run(x), ref)
+    waits, records, tails = prog._plan_sync(6, x.device)
+    assert sum(len(w) for w in waits) > 50 and set(tails) == {0, 1, 2, 3}
+    graphed = prog.capture(x)
+    for _ in range(3):
+        assert torch.equal(graphed(x), ref)
