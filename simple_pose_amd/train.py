@@ -254,7 +254,7 @@ class ConvT:
             _lib.check(lib.sp_conv2d_fwd(d, P(dz), P(w), None, None, P(res), P(acc_t), _lib.current_stream()), self.name + ".dgrad")
         return acc_t
 
-    def wgrad(self, x: torch.Tensor, dz: torch.Tensor, B: int):
+    def wgrad(self, x: torch.Tensor, dz: torch.Tensor, B: int, stream=None):
         lib, tr = _lib.lib(), self.tr
         d = self.d_wgrad
         d.batch = B
@@ -262,7 +262,7 @@ class ConvT:
         gc = g.shape[-1]
         _lib.check(lib.sp_conv2d_wgrad(d, P(g), gc, P(a), self.wg["n_valid"], self.wg["c_valid"], self.wg["kw_valid"], self.wg["s_n"],
                                        self.wg["s_c"], P(tr.flat.view(self.wname, grad=True)), P(tr.wgrad_ws), tr.wgrad_ws.numel() * 4,
-                                       _lib.current_stream()), self.name + ".wgrad")
+                                       stream if stream is not None else _lib.current_stream()), self.name + ".wgrad")
 
 
 class PoseTrainer:
@@ -271,7 +271,7 @@ class PoseTrainer:
 
     def __init__(self, model, in_h: int = 256, in_w: int = 192, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  process_group=None, dtype: str = "fp32", sync_bn: Optional[bool] = None, bucket_mb: float = 32.0,
-                 broadcast_init: bool = True):
+                 broadcast_init: bool = True, overlap_wgrad: bool = True):
         """dtype "bf16": bf16 activations and packed weights (v_mfma_f32_32x32x16_bf16 for forward, dgrad and wgrad); the
         gradient w.r.t. a block output stays fp32 until the BatchNorm backward has subtracted its per-channel mean (rounding
         it to bf16 first costs 10-50 % gradient error in this net: the useful part is a small difference of large terms), the
@@ -295,6 +295,8 @@ class PoseTrainer:
         self.head = model.HEAD
         self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
         self.pg = process_group
+        self.overlap_wgrad = overlap_wgrad
+        self._wgrad_stream = None
         import torch.distributed as dist
         self.world = dist.get_world_size(self.pg) if (dist.is_available() and dist.is_initialized()) else 1
         self.sync_bn = (self.world > 1) if sync_bn is None else (bool(sync_bn) and self.world > 1)
@@ -350,6 +352,8 @@ class PoseTrainer:
             self._pending[i].discard(n)
             if not self._pending[i] and self._works[i] is None:
                 b = self.buckets[i]
+                if self._wgrad_tail is not None:           # the bucket's weight gradients come from the wgrad stream
+                    torch.cuda.current_stream().wait_event(self._wgrad_tail)
                 self._works[i] = dist.all_reduce(self.flat.grad[b["lo"]:b["hi"]], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
     # ---- static structure -------------------------------------------------------------------------------------------
@@ -429,6 +433,32 @@ class PoseTrainer:
         ws = self.red_ws
 
         bf = int(self.bf16)
+        self._wgrad_tail = None
+        side = side_h = None
+        if self.overlap_wgrad:
+            # weight gradients only feed the optimizer: they run on a second HIP stream beside the dgrad / BN-backward chain, which
+            # at 32 images per GPU is a string of small launches that leave most CUs idle
+            if self._wgrad_stream is None:
+                self._wgrad_stream = torch.cuda.Stream(device=dev)
+                self._wgrad_events = {}
+            side = self._wgrad_stream
+            side_h = _lib.c_void_p(side.cuda_stream)
+            main = torch.cuda.current_stream(dev)
+
+        def wgrad_async(layer, xin: torch.Tensor, dzt: torch.Tensor):
+            if side is None:
+                layer.wgrad(xin, dzt, B)
+                return
+            ev = self._wgrad_events.get(layer.name)
+            if ev is None:
+                ev = self._wgrad_events[layer.name] = (torch.cuda.Event(), torch.cuda.Event())
+            ev[0].record(main)                              # dz (and everything before it) is ready
+            side.wait_event(ev[0])
+            layer.wgrad(xin, dzt, B, stream=side_h)
+            dzt.record_stream(side)                         # dz is released by the tape right after: the allocator must wait for `side`
+            ev[1].record(side)
+            self._wgrad_tail = ev[1]
+
         self._pending = [set(b["names"]) for b in self.buckets]
         self._works: List[Optional[object]] = [None] * len(self.buckets)
         sync = self.sync_bn
@@ -489,7 +519,7 @@ class PoseTrainer:
                     _lib.check(lib.sp_bn_train_bwd_nhwc(P(ya.grad), bf, rs, P(z), P(mean), P(invstd), P(gamma), rows, C, P(dz), P(dgamma), P(dbeta),
                                                         P(dres), acc, P(ws), stream), bname + ".bwd")
                 ya.grad = None
-                layer.wgrad(xa.data, dz, B)
+                wgrad_async(layer, xa.data, dz)
                 self._grads_ready(bname + ".weight", bname + ".bias", cname + ".weight")
                 if xa.needs_grad and layer.need_dgrad:
                     xa.grad = layer.dgrad(dz, B, xa.grad)
@@ -563,12 +593,14 @@ class PoseTrainer:
         if self.bf16:
             dh = new((B, hh, ww, Jb))
             _lib.check(lib.sp_nchw_to_nhwc_pad(P(dheat), P(dh), 1, B, J, hh, ww, Jb, stream), "dheat.nhwc16")
-        fl.wgrad(a.data, dh, B)
+        wgrad_async(fl, a.data, dh)
         self._grads_ready("final_layer.bias", "final_layer.weight")
         a.grad = fl.dgrad(dh, B, None)
         for fn in reversed(tape):
             fn()
         torch._foreach_add_(nbt, 1)
+        if self._wgrad_tail is not None:
+            torch.cuda.current_stream(dev).wait_event(self._wgrad_tail)      # join: the optimizer reads every weight gradient
         self._mark("backward")
         return self.loss_buf
 
