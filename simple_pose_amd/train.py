@@ -297,6 +297,8 @@ class PoseTrainer:
         self.pg = process_group
         self.overlap_wgrad = overlap_wgrad
         self._wgrad_stream = None
+        self._opt_stream = None
+        self._opt_in_backward = False
         import torch.distributed as dist
         self.world = dist.get_world_size(self.pg) if (dist.is_available() and dist.is_initialized()) else 1
         self.sync_bn = (self.world > 1) if sync_bn is None else (bool(sync_bn) and self.world > 1)
@@ -343,18 +345,48 @@ class PoseTrainer:
         self._bucket_of = {n: i for i, b in enumerate(self.buckets) for n in b["names"]}
 
     def _grads_ready(self, *names: str):
-        """Called by the backward tape when the gradients of `names` have been enqueued on the compute stream."""
-        if self.world == 1:
+        """Called by the backward tape when the gradients of `names` have been enqueued AND the layer's dgrad launches (the last
+        readers of its packed weights) are on the compute stream.  A bucket whose last gradient arrived goes out:
+          * plain mode: its all-reduce is launched (async) - `all_reduce_grads()` waits, `optimizer_step()` follows;
+          * `step()` mode (optimizer in backward): on a third stream the bucket is all-reduced, Adam updates its slice of the flat
+            buffers and its packed weight copies are regenerated, all while backward continues with earlier layers."""
+        fused = self._opt_in_backward
+        if self.world == 1 and not fused:
             return
         import torch.distributed as dist
         for n in names:
             i = self._bucket_of[n]
             self._pending[i].discard(n)
-            if not self._pending[i] and self._works[i] is None:
-                b = self.buckets[i]
+            if self._pending[i] or self._works[i] is not None:
+                continue
+            b = self.buckets[i]
+            main = torch.cuda.current_stream()
+            if not fused:
                 if self._wgrad_tail is not None:           # the bucket's weight gradients come from the wgrad stream
-                    torch.cuda.current_stream().wait_event(self._wgrad_tail)
+                    main.wait_event(self._wgrad_tail)
                 self._works[i] = dist.all_reduce(self.flat.grad[b["lo"]:b["hi"]], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                continue
+            if self._opt_stream is None:
+                self._opt_stream = torch.cuda.Stream(device=self.flat.data.device)
+                self._opt_events = {}
+            opt = self._opt_stream
+            ev = self._opt_events.get(i)
+            if ev is None:
+                ev = self._opt_events[i] = (torch.cuda.Event(), torch.cuda.Event())
+            ev[0].record(main)                              # dgrads of the bucket's layers are behind this point
+            opt.wait_event(ev[0])
+            if self._wgrad_tail is not None:
+                opt.wait_event(self._wgrad_tail)
+            with torch.cuda.stream(opt):
+                if self.world > 1:
+                    dist.all_reduce(self.flat.grad[b["lo"]:b["hi"]], op=dist.ReduceOp.SUM, group=self.pg)
+                sl = slice(b["lo"], b["hi"])
+                _lib.check(_lib.lib().sp_adam_step(P(self.flat.data[sl]), P(self.flat.grad[sl]), P(self.exp_avg[sl]), P(self.exp_avg_sq[sl]),
+                                                   b["hi"] - b["lo"], self.lr, self.betas[0], self.betas[1], self.eps, self.step_count,
+                                                   1.0 / self.world, _lib.c_void_p(opt.cuda_stream)), "adam")
+                self.repack(self._pack_rows_of_bucket[i], _lib.c_void_p(opt.cuda_stream))
+            ev[1].record(opt)
+            self._works[i] = ev[1]
 
     # ---- static structure -------------------------------------------------------------------------------------------
     def _conv(self, name, h, w, **kw) -> ConvT:
@@ -390,7 +422,7 @@ class PoseTrainer:
             self._conv("final_layer", h, w, pad=1, bias_name="final_layer.bias", out_nchw=True)
         self.heat_hw = (h, w)
 
-    def repack(self):
+    def repack(self, rows_range=None, stream=None):
         """Regenerate every packed weight copy from the (just updated) flat parameter buffer: one launch over a device-side
         job table (141 pack jobs for ResNet50-DConv, cut into ~1,200 equal-sized slabs so that the grid is balanced)."""
         if getattr(self, "_pack_table", None) is None:
@@ -416,7 +448,18 @@ class PoseTrainer:
             assert rec.itemsize == 96, rec.itemsize
             self._pack_table = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(self.flat.data.device)
             self._pack_n = len(rows)
-        _lib.check(_lib.lib().sp_permute4_batched(P(self.flat.data), P(self._pack_table), self._pack_n, 8, _lib.current_stream()), "repack")
+            # rows are in parameter order: the rows that read from a gradient bucket's slice of the flat buffer are one range
+            self._pack_rows_of_bucket = []
+            src_off = [int(r[3]) for r in rows]
+            for b in self.buckets:
+                idx = [i for i, o in enumerate(src_off) if b["lo"] <= o < b["hi"]]
+                assert not idx or idx == list(range(idx[0], idx[-1] + 1)), "pack rows of a bucket must be contiguous"
+                self._pack_rows_of_bucket.append((idx[0], idx[-1] + 1) if idx else (0, 0))
+        lo, hi = (0, self._pack_n) if rows_range is None else rows_range
+        if hi > lo:
+            tab = _lib.c_void_p(self._pack_table.data_ptr() + 96 * lo)
+            _lib.check(_lib.lib().sp_permute4_batched(P(self.flat.data), tab, hi - lo, 8, stream if stream is not None else _lib.current_stream()),
+                       "repack")
 
     # ---- one step -----------------------------------------------------------------------------------------------------
     def forward_backward(self, x: torch.Tensor, targets: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
@@ -520,9 +563,9 @@ class PoseTrainer:
                                                         P(dres), acc, P(ws), stream), bname + ".bwd")
                 ya.grad = None
                 wgrad_async(layer, xa.data, dz)
-                self._grads_ready(bname + ".weight", bname + ".bias", cname + ".weight")
                 if xa.needs_grad and layer.need_dgrad:
                     xa.grad = layer.dgrad(dz, B, xa.grad)
+                self._grads_ready(bname + ".weight", bname + ".bias", cname + ".weight")
             tape.append(bwd)
             return ya
 
@@ -594,13 +637,18 @@ class PoseTrainer:
             dh = new((B, hh, ww, Jb))
             _lib.check(lib.sp_nchw_to_nhwc_pad(P(dheat), P(dh), 1, B, J, hh, ww, Jb, stream), "dheat.nhwc16")
         wgrad_async(fl, a.data, dh)
-        self._grads_ready("final_layer.bias", "final_layer.weight")
         a.grad = fl.dgrad(dh, B, None)
+        self._grads_ready("final_layer.bias", "final_layer.weight")
         for fn in reversed(tape):
             fn()
         torch._foreach_add_(nbt, 1)
         if self._wgrad_tail is not None:
             torch.cuda.current_stream(dev).wait_event(self._wgrad_tail)      # join: the optimizer reads every weight gradient
+        if self._opt_in_backward:
+            assert all(w is not None for w in self._works), "a gradient bucket never completed"
+            for w in self._works:
+                torch.cuda.current_stream(dev).wait_event(w)                 # join: parameters and packed copies are updated
+            self._works = None
         self._mark("backward")
         return self.loss_buf
 
@@ -634,14 +682,29 @@ class PoseTrainer:
             self.model._program = None        # the eval-mode program holds BN-folded copies of the weights the kernel just changed
 
     def step(self, x, targets, mask) -> torch.Tensor:
-        """optimizer.zero_grad(); loss = ...; loss.backward(); optimizer.step()  (ddp...:114-119)."""
+        """optimizer.zero_grad(); loss = ...; loss.backward(); optimizer.step()  (ddp...:114-119).  The optimizer runs inside
+        backward, bucket by bucket (see `_grads_ready`); `fuse_optimizer = False` gives the three separate phases."""
         self._mark("start")
-        loss = self.forward_backward(x, targets, mask)
-        scale = self.all_reduce_grads()
+        if not self.fuse_optimizer:
+            loss = self.forward_backward(x, targets, mask)
+            scale = self.all_reduce_grads()
+            self._mark("allreduce_wait")
+            self.optimizer_step(scale)
+            self._mark("adam_repack")
+            return loss
+        self.step_count += 1
+        self._opt_in_backward = True
+        try:
+            loss = self.forward_backward(x, targets, mask)
+        finally:
+            self._opt_in_backward = False
         self._mark("allreduce_wait")
-        self.optimizer_step(scale)
+        if getattr(self.model, "_program", None) is not None:
+            self.model._program = None
         self._mark("adam_repack")
         return loss
+
+    fuse_optimizer = True
 
     # ---- step-time split (BASELINE config 4 asks for fwd / bwd / all-reduce / Adam) -------------------------------------
     profile = False

@@ -158,7 +158,7 @@ def test_bf16_training_is_deterministic_and_decreases_loss():
 
 
 # ---- N > 1: two ranks sharing the one GPU of the box (gloo carries the collectives) ---------------------------------------
-def _ddp_worker(rank, world, port, sync_bn, bucket_mb, out_dir):
+def _ddp_worker(rank, world, port, sync_bn, bucket_mb, out_dir, fused=False):
     import os
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -170,11 +170,16 @@ def _ddp_worker(rank, world, port, sync_bn, bucket_mb, out_dir):
         idx = rank_indices(4, rank, world)
         xs, ts, ws = (torch.from_numpy(v[idx]).to(DEV) for v in (x, t, w))
         tr = PoseTrainer(model, in_h=64, in_w=64, lr=1e-3, sync_bn=sync_bn, bucket_mb=bucket_mb)
-        loss = tr.forward_backward(xs, ts, ws).item()
-        n_launched = sum(wk is not None for wk in tr._works)
-        scale = tr.all_reduce_grads()
-        grad = (tr.flat.grad * scale).cpu().numpy()
-        tr.optimizer_step(scale)
+        if fused:                                    # step(): all-reduce + Adam + re-pack per bucket on the optimizer stream
+            loss = tr.step(xs, ts, ws).item()
+            n_launched, scale = len(tr.buckets), 1.0 / world
+            grad = (tr.flat.grad * scale).cpu().numpy()
+        else:
+            loss = tr.forward_backward(xs, ts, ws).item()
+            n_launched = sum(wk is not None for wk in tr._works)
+            scale = tr.all_reduce_grads()
+            grad = (tr.flat.grad * scale).cpu().numpy()
+            tr.optimizer_step(scale)
         torch.cuda.synchronize()
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), loss=loss, grad=grad, param=tr.flat.data.cpu().numpy(),
                  rm=tr.buffers["layer4.2.bn3.running_mean"].cpu().numpy(), rv=tr.buffers["bn1.running_var"].cpu().numpy(),
@@ -188,14 +193,14 @@ def _l2(a, b):
     return float(np.sqrt(((a - b) ** 2).sum()) / (np.sqrt((b * b).sum()) + 1e-30))
 
 
-@pytest.mark.parametrize("sync_bn", [True, False])
-def test_two_rank_step_matches_single_rank(sync_bn, tmp_path):
+@pytest.mark.parametrize("sync_bn,fused", [(True, False), (False, False), (True, True)])
+def test_two_rank_step_matches_single_rank(sync_bn, fused, tmp_path):
     """DDP + SyncBatchNorm semantics (ddp...:89-93): 2 ranks x 2 images == 1 rank x 4 images when BN statistics are synced;
     without SyncBN both ranks still end with identical parameters (same averaged gradient, same Adam)."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_ddp_worker, args=(2, port, sync_bn, 8.0, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_ddp_worker, args=(2, port, sync_bn, 8.0, str(tmp_path), fused), nprocs=2, join=True)
     r0, r1 = (np.load(tmp_path / f"rank{r}.npz") for r in (0, 1))
     assert int(r0["n_buckets"]) > 4 and int(r0["n_launched"]) >= int(r0["n_buckets"]) - 1      # buckets went out during backward
     np.testing.assert_array_equal(r0["grad"], r1["grad"])
@@ -278,3 +283,25 @@ def test_solver_counterpart_trains_validates_and_checkpoints(tmp_path):
     assert set(ck) == {"ema", "epoch"} and ck["epoch"] == 1
     assert set(ck["ema"]) == {k for k, _, _ in nets_oracle.state_dict_shapes_resnet50("duc")}
     assert float(ck["ema"]["bn1.num_batches_tracked"]) == 4.0                            # 2 epochs x 2 iterations
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_streamed_schedule_equals_plain_schedule(dtype):
+    """step() runs weight gradients on a second stream and the optimizer (Adam + re-packing, bucket by bucket) on a third while
+    backward continues; the plain schedule does everything in order on one stream.  Same kernels, same operands: parameters,
+    optimizer state, BN buffers and losses must be bit-identical after several steps (a missing dependency would show here)."""
+    x, t, w = _batch(4, 128, 96, 3)
+    xs, ts, ws = (torch.from_numpy(v).to(DEV) for v in (x, t, w))
+    out = []
+    for streamed in (True, False):
+        model, _ = _model(3)
+        tr = PoseTrainer(model, in_h=128, in_w=96, lr=1e-3, dtype=dtype, overlap_wgrad=streamed, bucket_mb=8.0)
+        tr.fuse_optimizer = streamed
+        losses = [tr.step(xs, ts, ws).item() for _ in range(4)]
+        torch.cuda.synchronize()
+        out.append((losses, tr.flat.data.clone(), tr.exp_avg_sq.clone(), model.bn1.running_var.clone(),
+                    [l.w_fwd.clone() for l in tr.layers.values()]))
+    (l0, p0, v0, r0, w0), (l1, p1, v1, r1, w1) = out
+    assert l0 == l1 and l0[-1] < l0[0]
+    assert torch.equal(p0, p1) and torch.equal(v0, v1) and torch.equal(r0, r1)
+    assert all(torch.equal(a, b) for a, b in zip(w0, w1))
