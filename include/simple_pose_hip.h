@@ -27,7 +27,7 @@ extern "C" {
 #define SP_EINVAL (-1)   /* bad argument / unsupported shape (message in sp_last_error) */
 #define SP_ELAUNCH (-2)  /* HIP launch or runtime failure */
 
-#define SP_ABI_VERSION 12
+#define SP_ABI_VERSION 13
 
 /* epilogue / layout flags of sp_conv_desc.flags */
 #define SP_CONV_RELU 0x1u          /* y = max(y, 0) after scale/shift (+ residual) */
@@ -190,6 +190,16 @@ int sp_masked_mse(const float* pred, const float* target, const float* mask, int
  * running_mean/var (may both be NULL) are updated with `momentum` and the UNBIASED variance, as torch does. */
 int sp_bn_train_stats_nhwc(const void* z, int bf16, int64_t rows, int c, float eps, float momentum, float* mean, float* invstd,
                            float* running_mean, float* running_var, void* workspace, void* stream);
+/* The same statistics without a pass over z: sp_conv2d_fwd_bn_stats is sp_conv2d_fwd (no scale/shift/residual/ReLU, NHWC store in
+ * the conv's dtype) whose epilogue also writes, per (phase, M tile, wave row) of the launch, the per-channel sum and sum of squares
+ * of the values it stores ([partial_rows][n_pad] fp32 each; sp_conv2d_bn_stats_rows gives partial_rows for the tile the launch
+ * will use); sp_bn_train_stats_from_conv folds them in index order in fp64 and finishes like sp_bn_train_stats_nhwc. */
+int sp_conv2d_bn_stats_rows(const sp_conv_desc* desc, int* partial_rows);
+int sp_conv2d_fwd_bn_stats(const sp_conv_desc* desc, const void* x, const void* w_packed, void* y, float* stats_sum,
+                           float* stats_sumsq, int stats_rows_capacity, void* stream);
+int sp_bn_train_stats_from_conv(const float* stats_sum, const float* stats_sumsq, int partial_rows, int stride, int64_t rows, int c,
+                                float eps, float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
+                                void* stream);
 /* y = [relu]((z - mean) * invstd * gamma + beta [+ residual])   (Bottleneck.forward tail, pose_resnet_dconv.py:124-131) */
 int sp_bn_apply_nhwc(const void* z, int bf16, const float* mean, const float* invstd, const float* gamma, const float* beta,
                      const void* residual, void* y, int64_t rows, int c, int relu, void* stream);

@@ -76,6 +76,10 @@ struct ConvArgs {
     unsigned flags;
     int tiles_m, tiles_n;
     int x_bytes, w_bytes, y_bytes;  // buffer-descriptor extents (w: one phase slab)
+    // STATS instantiations (train-mode BatchNorm): per (phase, M tile, wave row) partial sums of the stored values, per channel
+    float* stats_s;      // [rows][stats_stride] sum
+    float* stats_q;      // [rows][stats_stride] sum of squares
+    int stats_stride;
 };
 
 constexpr int BK = 32;  // floats per K tile (8 chunks of 16 B)
@@ -84,7 +88,7 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * BK + ((chu
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int BM, int BN, int WR, int WC, bool UNIFORM_TAP, bool BF16, bool OUT16>
+template <int BM, int BN, int WR, int WC, bool UNIFORM_TAP, bool BF16, bool OUT16, bool STATS = false>
 __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm_kernel(const ConvArgs p) {
     constexpr int ES = BF16 ? 2 : 4;     // element size of activations / weights
     constexpr int EPC = 16 / ES;         // elements per 16-byte chunk
@@ -433,6 +437,11 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
             const int ro = rowtab[(wr * WM + it * RPI + rsub) * 4 + 3];
             off[it] = (col_ok && ro >= 0) ? (unsigned)((ro + col_off) * ESO) : OOB;
         }
+        float st_s[STATS ? CPL : 1], st_q[STATS ? CPL : 1];   // STATS: column sums of what this lane stores
+        if constexpr (STATS) {
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) { st_s[e] = 0.f; st_q[e] = 0.f; }
+        }
         u32x4 rv[NIT];
         if (p.res) {  // every residual load of the tile in flight before the first use
 #pragma unroll
@@ -469,11 +478,42 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o8[e] = (__bf16)v[e];
                 o = __builtin_bit_cast(u32x4, o8);
+                if constexpr (STATS) {                    // BatchNorm sees the ROUNDED tensor (as torch does on a bf16 activation)
+                    if (off[it] != OOB) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { const float z = (float)o8[e]; st_s[e] += z; st_q[e] += z * z; }
+                    }
+                }
             } else {
                 const f32x4 o4 = {v[0], v[1], v[2], v[3]};
                 o = __builtin_bit_cast(u32x4, o4);
+                if constexpr (STATS) {
+                    if (off[it] != OOB) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { st_s[e] += v[e]; st_q[e] += v[e] * v[e]; }
+                    }
+                }
             }
             __builtin_amdgcn_raw_buffer_store_b128(o, yr, off[it], 0, 0);
+        }
+        if constexpr (STATS) {
+            // lanes chunk, chunk + CPR, ... hold the same channels for different rows: fixed butterfly, then one partial row per
+            // (phase, M tile, wave row); the host-side fold adds the rows in index order -> deterministic statistics
+#pragma unroll
+            for (int o = CPR; o < 64; o <<= 1) {
+#pragma unroll
+                for (int e = 0; e < CPL; ++e) { st_s[e] += __shfl_xor(st_s[e], o, 64); st_q[e] += __shfl_xor(st_q[e], o, 64); }
+            }
+            if (rsub == 0 && col_ok) {
+                const size_t base = ((size_t)(phase * p.tiles_m + tm) * WR + wr) * p.stats_stride + col;
+#pragma unroll
+                for (int e4 = 0; e4 < CPL / 4; ++e4) {
+                    const f32x4 a4 = {st_s[4 * e4], st_s[4 * e4 + 1], st_s[4 * e4 + 2], st_s[4 * e4 + 3]};
+                    const f32x4 b4 = {st_q[4 * e4], st_q[4 * e4 + 1], st_q[4 * e4 + 2], st_q[4 * e4 + 3]};
+                    *reinterpret_cast<f32x4*>(p.stats_s + base + 4 * e4) = a4;
+                    *reinterpret_cast<f32x4*>(p.stats_q + base + 4 * e4) = b4;
+                }
+            }
         }
     } else {
         const bool vec4 = nchw && (hw_out & 3) == 0 && !p.res;  // rows 4g..4g+3 = 4 consecutive pixels of one image
@@ -537,7 +577,7 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
 #endif
 }
 
-template <int BM, int BN, int WR, int WC, bool BF16, bool OUT16>
+template <int BM, int BN, int WR, int WC, bool BF16, bool OUT16, bool STATS>
 int launch_t(const ConvArgs& a, int phases, bool uniform, hipStream_t stream) {
     ConvArgs p = a;
     p.tiles_m = (a.M + BM - 1) / BM;
@@ -545,36 +585,42 @@ int launch_t(const ConvArgs& a, int phases, bool uniform, hipStream_t stream) {
     const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float) + (size_t)BM * 4 * sizeof(int);
     dim3 grid(p.tiles_m * p.tiles_n, phases, 1), block(256, 1, 1);
     // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel instantiation
-    static const hipError_t attr_u = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, true, BF16, OUT16>),
+    static const hipError_t attr_u = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, true, BF16, OUT16, STATS>),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    static const hipError_t attr_c = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, false, BF16, OUT16>),
+    static const hipError_t attr_c = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, false, BF16, OUT16, STATS>),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr_u != hipSuccess || attr_c != hipSuccess) {
         sp_set_error("conv_igemm: hipFuncSetAttribute(max dynamic LDS = %zu) failed", lds);
         return SP_ELAUNCH;
     }
     if (uniform)
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, true, BF16, OUT16>), grid, block, lds, stream, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, true, BF16, OUT16, STATS>), grid, block, lds, stream, p);
     else
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, false, BF16, OUT16>), grid, block, lds, stream, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, false, BF16, OUT16, STATS>), grid, block, lds, stream, p);
     return sp_check_launch("conv_igemm_kernel");
 }
 
 template <int BM, int BN, int WR, int WC>
 int launch(const ConvArgs& a, int phases, bool uniform, hipStream_t stream) {
-    if (a.flags & SP_CONV_BF16) {
-        if (a.flags & SP_CONV_OUT_F32) return launch_t<BM, BN, WR, WC, true, false>(a, phases, uniform, stream);
-        return launch_t<BM, BN, WR, WC, true, true>(a, phases, uniform, stream);
+    if (a.stats_s) {                                   // train-mode forward: plain NHWC store of the conv's own dtype
+        if (a.flags & SP_CONV_BF16) return launch_t<BM, BN, WR, WC, true, true, true>(a, phases, uniform, stream);
+        return launch_t<BM, BN, WR, WC, false, false, true>(a, phases, uniform, stream);
     }
-    return launch_t<BM, BN, WR, WC, false, false>(a, phases, uniform, stream);
+    if (a.flags & SP_CONV_BF16) {
+        if (a.flags & SP_CONV_OUT_F32) return launch_t<BM, BN, WR, WC, true, false, false>(a, phases, uniform, stream);
+        return launch_t<BM, BN, WR, WC, true, true, false>(a, phases, uniform, stream);
+    }
+    return launch_t<BM, BN, WR, WC, false, false, false>(a, phases, uniform, stream);
 }
 
 }  // namespace
 
 extern "C" int sp_conv2d_default_tile(const sp_conv_desc* d, int* tile_m, int* tile_n);
 
-extern "C" int sp_conv2d_fwd(const sp_conv_desc* d, const void* x, const void* w_packed, const float* scale,
-                             const float* shift, const void* residual, void* y, void* stream) {
+static int tile_rows_per_block(int bm, int bn) { return (bm == 256 && bn == 64) || (bm == 128 && bn == 32) ? 4 : 2; }   // WR of the tile
+
+static int conv_fwd_impl(const sp_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift,
+                         const void* residual, void* y, float* stats_s, float* stats_q, int stats_rows_capacity, void* stream) {
     SP_REQUIRE(d && x && w_packed && y, "sp_conv2d_fwd: null pointer");
     SP_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->grid_h > 0 && d->grid_w > 0 && d->c_out > 0,
                "sp_conv2d_fwd: non-positive dimension");
@@ -630,6 +676,7 @@ extern "C" int sp_conv2d_fwd(const sp_conv_desc* d, const void* x, const void* w
     a.phases_x = d->phases_x; a.flags = d->flags; a.tiles_m = a.tiles_n = 0;
     a.x_bytes = (int)(in_elems * es); a.w_bytes = (int)(w_elems * es);
     a.y_bytes = (int)(out_elems * (((d->flags & SP_CONV_OUT_NCHW) || !out16) ? 4 : 2));
+    a.stats_s = stats_s; a.stats_q = stats_q; a.stats_stride = d->n_pad;
     const int phases = d->phases_y * d->phases_x;
     hipStream_t s = (hipStream_t)stream;
 
@@ -638,6 +685,13 @@ extern "C" int sp_conv2d_fwd(const sp_conv_desc* d, const void* x, const void* w
     const int np = d->n_pad;
     if (bm == 0 && bn == 0) sp_conv2d_default_tile(d, &bm, &bn);
     SP_REQUIRE(bn > 0 && np % bn == 0, "sp_conv2d_fwd: tile_n=%d must divide n_pad=%d", bn, np);
+    if (stats_s) {
+        SP_REQUIRE(stats_q, "sp_conv2d_fwd_bn_stats: null statistics pointer");
+        SP_REQUIRE(!(d->flags & (SP_CONV_OUT_NCHW | SP_CONV_PIXEL_SHUFFLE | SP_CONV_OUT_F32)) && d->c_out % (bf16 ? 8 : 4) == 0,
+                   "sp_conv2d_fwd_bn_stats: needs a plain NHWC store in the conv's own dtype (c_out %% %d == 0)", bf16 ? 8 : 4);
+        const long long rows = (long long)phases * ((M + bm - 1) / bm) * tile_rows_per_block(bm, bn);
+        SP_REQUIRE(rows <= stats_rows_capacity, "sp_conv2d_fwd_bn_stats: %lld partial rows needed, capacity %d", rows, stats_rows_capacity);
+    }
 #define SP_TILE(BM_, BN_, WR_, WC_) \
     if (bm == BM_ && bn == BN_) return launch<BM_, BN_, WR_, WC_>(a, phases, uniform, s);
     SP_TILE(128, 128, 2, 2)
@@ -649,6 +703,27 @@ extern "C" int sp_conv2d_fwd(const sp_conv_desc* d, const void* x, const void* w
 #undef SP_TILE
     sp_set_error("sp_conv2d_fwd: unsupported tile %dx%d (supported: 128x128 64x128 128x64 64x64 256x64 128x32)", bm, bn);
     return SP_EINVAL;
+}
+
+extern "C" int sp_conv2d_fwd(const sp_conv_desc* d, const void* x, const void* w_packed, const float* scale,
+                             const float* shift, const void* residual, void* y, void* stream) {
+    return conv_fwd_impl(d, x, w_packed, scale, shift, residual, y, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int sp_conv2d_bn_stats_rows(const sp_conv_desc* d, int* rows) {
+    if (!d || !rows) { sp_set_error("sp_conv2d_bn_stats_rows: null pointer"); return SP_EINVAL; }
+    int bm = d->tile_m, bn = d->tile_n;
+    if (bm == 0 && bn == 0) sp_conv2d_default_tile(d, &bm, &bn);
+    SP_REQUIRE(bm > 0 && bn > 0, "sp_conv2d_bn_stats_rows: bad tile");
+    const long long M = (long long)d->batch * d->grid_h * d->grid_w;
+    *rows = (int)((long long)d->phases_y * d->phases_x * ((M + bm - 1) / bm) * tile_rows_per_block(bm, bn));
+    return SP_OK;
+}
+
+extern "C" int sp_conv2d_fwd_bn_stats(const sp_conv_desc* d, const void* x, const void* w_packed, void* y, float* stats_sum,
+                                      float* stats_sumsq, int stats_rows_capacity, void* stream) {
+    SP_REQUIRE(stats_sum && stats_sumsq, "sp_conv2d_fwd_bn_stats: null statistics pointer");
+    return conv_fwd_impl(d, x, w_packed, nullptr, nullptr, nullptr, y, stats_sum, stats_sumsq, stats_rows_capacity, stream);
 }
 
 // Built-in tile heuristic (measured on MI355X, bs=128 ResNet-50 shapes): 128x128 when the launch is many rounds deep,

@@ -150,6 +150,37 @@ __global__ void pair_sum_final_kernel(const double* __restrict__ part, int nblk,
     if (o1) o1[c] = (float)s1;
 }
 
+// BN forward statistics from the per-(phase, M tile, wave row) partial sums the STATS conv epilogue wrote (fp32 sums of <= 64 values
+// each): one wave per channel adds them in index order in fp64, then the same finalisation as above.
+__global__ void bn_stats_from_conv_kernel(const float* __restrict__ ps, const float* __restrict__ pq, int nrows, int stride, int C, double M,
+                                          float eps, float momentum, float* __restrict__ mean, float* __restrict__ invstd,
+                                          float* __restrict__ run_mean, float* __restrict__ run_var) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    const int lane = threadIdx.x & 63;
+    double a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+    int r = lane;
+    for (; r + 64 < nrows; r += 128) {
+        a0 += (double)ps[(size_t)r * stride + c]; a1 += (double)pq[(size_t)r * stride + c];
+        b0 += (double)ps[(size_t)(r + 64) * stride + c]; b1 += (double)pq[(size_t)(r + 64) * stride + c];
+    }
+    for (; r < nrows; r += 64) { a0 += (double)ps[(size_t)r * stride + c]; a1 += (double)pq[(size_t)r * stride + c]; }
+    double s0 = a0 + b0, s1 = a1 + b1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off, SP_WAVE); s1 += __shfl_xor(s1, off, SP_WAVE); }
+    if (lane != 0) return;
+    const double mu = s0 / M;
+    double var = s1 / M - mu * mu;
+    if (var < 0) var = 0;
+    mean[c] = (float)mu;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (run_mean) {
+        const double unb = M > 1 ? var * M / (M - 1) : var;
+        run_mean[c] = (float)((1.0 - momentum) * (double)run_mean[c] + (double)momentum * mu);
+        run_var[c] = (float)((1.0 - momentum) * (double)run_var[c] + (double)momentum * unb);
+    }
+}
+
 // SyncBatchNorm halves: per-rank (sum, sum of squares) kept in fp64 so that the cross-rank SUM is order-insensitive to ~1e-16
 __global__ void pair_sum_final_f64_kernel(const double* __restrict__ part, int nblk, int C, double* __restrict__ sums) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -446,6 +477,17 @@ extern "C" int sp_bn_train_finalize(const double* sums, int64_t total_rows, int 
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3((c + 3) / 4), dim3(256), 0, (hipStream_t)stream, sums, 1, c, (double)total_rows, eps, momentum,
                        mean, invstd, running_mean, running_var);
     return sp_check_launch("bn_train_finalize");
+}
+
+extern "C" int sp_bn_train_stats_from_conv(const float* stats_sum, const float* stats_sumsq, int partial_rows, int stride, int64_t rows, int c,
+                                           float eps, float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
+                                           void* stream) {
+    SP_REQUIRE(stats_sum && stats_sumsq && mean && invstd, "sp_bn_train_stats_from_conv: null pointer");
+    SP_REQUIRE(partial_rows > 0 && stride >= c && c > 0 && rows > 0, "sp_bn_train_stats_from_conv: bad shape");
+    SP_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "sp_bn_train_stats_from_conv: running stats come in pairs");
+    hipLaunchKernelGGL(bn_stats_from_conv_kernel, dim3((c + 3) / 4), dim3(256), 0, (hipStream_t)stream, stats_sum, stats_sumsq, partial_rows, stride,
+                       c, (double)rows, eps, momentum, mean, invstd, running_mean, running_var);
+    return sp_check_launch("bn_stats_from_conv_kernel");
 }
 
 extern "C" int sp_bn_apply_nhwc(const void* z, int bf16, const float* mean, const float* invstd, const float* gamma, const float* beta,

@@ -238,6 +238,19 @@ class ConvT:
         _lib.check(lib.sp_conv2d_fwd(d, P(x), P(self.w_fwd), None, P(shift), None, P(out), _lib.current_stream()), self.name)
         return out
 
+    def forward_bn_stats(self, x: torch.Tensor, B: int):
+        """Forward launch whose epilogue also leaves the per-channel partial sums BatchNorm needs (no extra pass over z).
+        Returns (z, partial sums [rows, n_pad], partial sums of squares, rows)."""
+        lib, d = _lib.lib(), self.d_fwd
+        d.batch = B
+        rows = ctypes.c_int(0)
+        _lib.check(lib.sp_conv2d_bn_stats_rows(d, ctypes.byref(rows)), self.name)
+        part = torch.empty((2, rows.value, d.n_pad), dtype=torch.float32, device=x.device)
+        out = torch.empty((B, d.out_h, d.out_w, d.out_c), dtype=self._wdt, device=x.device)
+        _lib.check(lib.sp_conv2d_fwd_bn_stats(d, P(x), P(self.w_fwd), P(out), P(part[0]), P(part[1]), rows.value, _lib.current_stream()),
+                   self.name)
+        return out, part, rows.value
+
     def dgrad(self, dz: torch.Tensor, B: int, acc: Optional[torch.Tensor]) -> torch.Tensor:
         """dx (+= into `acc` when given)."""
         lib = _lib.lib()
@@ -517,11 +530,19 @@ class PoseTrainer:
 
         def conv_bn(xa: Act, cname: str, bname: str, relu: bool, res: Optional[Act] = None) -> Act:
             layer = L[cname]
-            z = layer.forward(xa.data, B)
+            fused_stats = self.fuse_bn_stats and not sync
+            if fused_stats:
+                z, part, prow = layer.forward_bn_stats(xa.data, B)
+            else:
+                z = layer.forward(xa.data, B)
             rows, C = z.shape[0] * z.shape[1] * z.shape[2], z.shape[3]
             mean, invstd = newf(C), newf(C)
             gamma, beta = self.sd[bname + ".weight"], self.sd[bname + ".bias"]
-            if sync:
+            if fused_stats:
+                _lib.check(lib.sp_bn_train_stats_from_conv(P(part[0]), P(part[1]), prow, part.shape[2], rows, C, BN_EPS, BN_MOMENTUM, P(mean),
+                                                           P(invstd), P(self.buffers[bname + ".running_mean"]),
+                                                           P(self.buffers[bname + ".running_var"]), stream), bname)
+            elif sync:
                 sums = torch.empty(2 * C, dtype=torch.float64, device=dev)
                 _lib.check(lib.sp_bn_train_partial_nhwc(P(z), bf, rows, C, P(sums), P(ws), stream), bname)
                 dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.pg)
@@ -705,6 +726,7 @@ class PoseTrainer:
         return loss
 
     fuse_optimizer = True
+    fuse_bn_stats = True       # BN batch statistics from the conv epilogue (sp_conv2d_fwd_bn_stats); SyncBN keeps the two-pass form
 
     # ---- step-time split (BASELINE config 4 asks for fwd / bwd / all-reduce / Adam) -------------------------------------
     profile = False
