@@ -726,6 +726,10 @@ class PoseTrainer:
         return loss
 
     fuse_optimizer = True
+    _opt_in_backward = False   # class-level defaults: also valid for partially constructed instances (host-logic tests)
+    _opt_stream = None
+    _wgrad_stream = None
+    _wgrad_tail = None
     fuse_bn_stats = True       # BN batch statistics from the conv epilogue (sp_conv2d_fwd_bn_stats); SyncBN keeps the two-pass form
 
     # ---- step-time split (BASELINE config 4 asks for fwd / bwd / all-reduce / Adam) -------------------------------------
