@@ -646,3 +646,66 @@ def test_hrnet_branches_on_separate_streams_match_single_stream(golden):
     graphed = prog.capture(x)
     for _ in range(3):
         assert torch.equal(graphed(x), ref)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_full_size_layers_sampled_reference_and_exact_linearity(dtype):
+    """BASELINE size (bs=128) on the three largest layer shapes of ResNet50-DConv - too big for a dense CPU reference, so:
+    (1) 300 randomly sampled output elements per layer against float64 dot products computed on the host (catches addressing
+    errors that only exist at full size: byte offsets here reach 4e8); (2) size-independent exact properties: y(2x) == 2*y(x)
+    bit for bit (power-of-two scaling commutes with every rounding) and every workgroup tile gives the same bits."""
+    B = 128
+    rng = np.random.default_rng(11)
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    shapes = [("layer1.conv2", 64, 64, 48, 64, 3, 1, 1, "conv"), ("layer2.conv3", 128, 32, 24, 512, 1, 1, 0, "conv"),
+              ("deconv6", 256, 32, 24, 256, 4, 2, 1, "deconv")]
+    for name, cin, H, W, cout, k, s, p, kind in shapes:
+        x = torch.from_numpy(synth.tensor_normal(5, name + "/x", (B, H, W, cin))).to(tdt)          # NHWC
+        if kind == "conv":
+            w = torch.from_numpy(synth.tensor_normal(5, name + "/w", (cout, cin, k, k), std=(2.0 / (cin * k * k)) ** 0.5))
+        else:
+            w = torch.from_numpy(synth.tensor_normal(5, name + "/w", (cin, cout, 4, 4), std=(8.0 / (cin * 16)) ** 0.5))
+        w = w.to(tdt).float()
+        b = engine.ProgramBuilder(H, W, dtype=dtype)
+        b.p.shapes["input"] = (H, W, cin)
+        out = b.conv("input", w.to(DEV), stride=s, pad=p, name="c") if kind == "conv" else b.deconv_k4s2p1("input", w.to(DEV), name="c")
+        prog = b.p
+        op = [o for o in prog.ops if o.kind == "conv"][0]
+        oh, ow, oc = prog.shapes[out]
+        op.desc.batch = B
+        xd = x.to(DEV)
+
+        def run(inp):
+            y = torch.full((B, oh, ow, oc), float("nan"), dtype=tdt, device=DEV)
+            _lib.check(_lib.lib().sp_conv2d_fwd(op.desc, _lib.ptr(inp), _lib.ptr(op.w), None, None, None, _lib.ptr(y), _lib.current_stream()))
+            torch.cuda.synchronize()
+            return y
+
+        y = run(xd)
+        assert torch.isfinite(y.float()).all()
+        assert torch.equal(run(xd * 2), y * 2)                                               # exact linearity
+        tiles = [t for t in _lib.CONV_TILES if op.desc.n_pad % t[1] == 0]
+        keep = (op.desc.tile_m, op.desc.tile_n)
+        for tm, tn in tiles[:3]:
+            op.desc.tile_m, op.desc.tile_n = tm, tn
+            assert torch.equal(run(xd), y), (name, tm, tn)
+        op.desc.tile_m, op.desc.tile_n = keep
+        yh, xh, wh = y.float().cpu().numpy(), x.float().numpy().astype(np.float64), w.numpy().astype(np.float64)
+        worst = 0.0
+        for _ in range(300):
+            bi, oy, ox, co = (int(rng.integers(0, n)) for n in (B, oh, ow, oc))
+            acc = 0.0
+            if kind == "conv":
+                for ky in range(k):
+                    for kx in range(k):
+                        iy, ix = oy * s - p + ky, ox * s - p + kx
+                        if 0 <= iy < H and 0 <= ix < W:
+                            acc += float(xh[bi, iy, ix] @ wh[co, :, ky, kx])
+            else:                                            # ConvTranspose2d(4,2,1): oy = 2*iy - 1 + ky
+                for ky in range(4):
+                    for kx in range(4):
+                        ty, tx = oy + 1 - ky, ox + 1 - kx
+                        if ty % 2 == 0 and tx % 2 == 0 and 0 <= ty // 2 < H and 0 <= tx // 2 < W:
+                            acc += float(xh[bi, ty // 2, tx // 2] @ wh[:, co, ky, kx])
+            worst = max(worst, abs(float(yh[bi, oy, ox, co]) - acc) / (abs(acc) + 1.0))
+        assert worst < (2e-6 if dtype == "fp32" else 8e-3), (name, worst)

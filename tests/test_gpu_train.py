@@ -305,3 +305,29 @@ def test_streamed_schedule_equals_plain_schedule(dtype):
     assert l0 == l1 and l0[-1] < l0[0]
     assert torch.equal(p0, p1) and torch.equal(v0, v1) and torch.equal(r0, r1)
     assert all(torch.equal(a, b) for a, b in zip(w0, w1))
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 2e-5), ("bf16", 5e-3)])
+def test_full_size_step_properties(dtype, tol):
+    """BASELINE config 4 size (32 images of 256x192 per GPU), where the oracle is too slow to be the checker: size-independent
+    properties instead.  (1) the step is bit-reproducible; (2) train-mode BN makes the loss and the BN statistics a function of
+    the batch as a SET: permuting the 32 samples changes only summation orders; (3) Adam's first step moves every parameter by
+    at most lr."""
+    B = 32
+    x, t, w = _batch(B, 256, 192, 21)
+    perm = np.random.default_rng(0).permutation(B)
+    runs = {}
+    for tag, idx in (("a", np.arange(B)), ("a2", np.arange(B)), ("perm", perm)):
+        model, _ = _model(5)
+        tr = PoseTrainer(model, lr=1e-3, dtype=dtype)
+        p0 = tr.flat.data.clone()
+        xs, ts, ws = (torch.from_numpy(v[idx]).to(DEV) for v in (x, t, w))
+        loss = tr.step(xs, ts, ws).item()
+        torch.cuda.synchronize()
+        runs[tag] = (loss, tr.flat.data.clone(), model.layer3[2].bn2.running_var.clone(), (tr.flat.data - p0).abs().max().item())
+    assert runs["a"][0] == runs["a2"][0] and torch.equal(runs["a"][1], runs["a2"][1])            # (1)
+    assert abs(runs["perm"][0] - runs["a"][0]) <= tol * abs(runs["a"][0])                         # (2)
+    rel = ((runs["perm"][2] - runs["a"][2]).abs().max() / runs["a"][2].abs().max()).item()
+    assert rel <= max(tol, 1e-4), rel
+    assert 0 < runs["a"][3] <= 1e-3 * (1 + 2e-4)           # (3): lr * |g| / (|g| + eps) <= lr, plus the rounding of p itself
+    assert np.isfinite(runs["a"][0]) and runs["a"][0] > 0
