@@ -88,7 +88,7 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * BK + ((chu
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int BM, int BN, int WR, int WC, bool UNIFORM_TAP, bool BF16, bool OUT16, bool STATS = false>
+template <int BM, int BN, int WR, int WC, bool UNIFORM_TAP, bool BF16, bool OUT16, bool STATS = false, bool DEEP = false>
 __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm_kernel(const ConvArgs p) {
     constexpr int ES = BF16 ? 2 : 4;     // element size of activations / weights
     constexpr int EPC = 16 / ES;         // elements per 16-byte chunk
@@ -195,7 +195,13 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
     const unsigned b_voff = (unsigned)((srow * p.k_pad + kc * EPC) * ES);
     const unsigned b_soff0 = (unsigned)n0 * p.k_pad * ES;
 
-    u32x4 sa[A_CH], sb[B_CH];
+    // Staging registers.  fp32: one set (a K tile is ~3,000 cycles of MFMA, enough to cover a load).  bf16: a K tile is only
+    // 130-500 cycles; the DEEP instantiation of the 64x64 tile (chosen by the launcher for K >= 12 tiles: the long-K,
+    // few-workgroup layers and most of the 32-image train step) keeps PF tiles in flight in a ring of register sets (tile j lives in set j % PF) - the loads of tile kt+PF are issued during tile kt and are
+    // only needed (ds_write) at the end of tile kt+PF-1.
+    static_assert(!DEEP || BF16, "the register ring is a bf16 feature");
+    constexpr int PF = DEEP ? (BM * BN <= 64 * 64 ? 4 : 2) : 1;   // larger bf16 tiles: the ring's registers cost more occupancy than the depth wins (measured)
+    u32x4 sa[PF][A_CH], sb[PF][B_CH];
     const int cin_chunks = p.c_in / EPC;
 
     // tap decode of K tile kt (scalar when UNIFORM_TAP), then the loads as A_CH + B_CH independent pieces that the main
@@ -220,7 +226,9 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
             t_ddy = ty * p.dy_step; t_ddx = tx * p.dx_step;
         }
     };
-    auto load_a = [&](int i) {
+    using I0 = std::integral_constant<int, 0>;
+    auto load_a = [&](int i, auto s_tag) {
+        constexpr int S = decltype(s_tag)::value;
         unsigned off;
         if (UNIFORM_TAP) {
             off = (a_mask[i] & t_bit) ? (unsigned)(a_off0[i] + t_shift) : OOB;
@@ -229,22 +237,16 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
             const bool ok = t_ok && (unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w;
             off = ok ? (unsigned)(a_off0[i] + ((t_ddy * p.in_w + t_ddx) * p.c_in + t_coff) * ES - kc * 16) : OOB;
         }
-        sa[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
+        sa[S][i] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
     };
-    auto load_b = [&](int i) {
-        sb[i] = __builtin_amdgcn_raw_buffer_load_b128(wr_, b_voff + (unsigned)(32 * i * p.k_pad * ES), b_soff0 + (unsigned)(t_k0 * ES), 0);
+    auto load_b = [&](int i, auto s_tag) {
+        constexpr int S = decltype(s_tag)::value;
+        sb[S][i] = __builtin_amdgcn_raw_buffer_load_b128(wr_, b_voff + (unsigned)(32 * i * p.k_pad * ES), b_soff0 + (unsigned)(t_k0 * ES), 0);
     };
-    auto store_piece = [&](int buf, int o) {  // o in [0, A_CH + B_CH)
-        if (o < A_CH) *reinterpret_cast<u32x4*>(As + buf * BM * BK + swz(srow + 32 * o, kc)) = sa[o];
-        else *reinterpret_cast<u32x4*>(Bs + buf * BN * BK + swz(srow + 32 * (o - A_CH), kc)) = sb[o - A_CH];
-    };
-    auto store_tile = [&](int buf) {
-        float* a = As + buf * BM * BK;
-        float* b = Bs + buf * BN * BK;
-#pragma unroll
-        for (int i = 0; i < A_CH; ++i) *reinterpret_cast<u32x4*>(a + swz(srow + 32 * i, kc)) = sa[i];
-#pragma unroll
-        for (int i = 0; i < B_CH; ++i) *reinterpret_cast<u32x4*>(b + swz(srow + 32 * i, kc)) = sb[i];
+    auto store_piece = [&](int buf, int o, auto s_tag) {  // o in [0, A_CH + B_CH)
+        constexpr int S = decltype(s_tag)::value;
+        if (o < A_CH) *reinterpret_cast<u32x4*>(As + buf * BM * BK + swz(srow + 32 * o, kc)) = sa[S][o];
+        else *reinterpret_cast<u32x4*>(Bs + buf * BN * BK + swz(srow + 32 * (o - A_CH), kc)) = sb[S][o - A_CH];
     };
 
     f32x16 acc[TM][TN];
@@ -279,14 +281,28 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
     };
 #define SP_SB() __builtin_amdgcn_sched_barrier(0)
 
-    // prologue: tile 0 -> LDS, first fragments -> registers
+    // prologue: tile 0 -> LDS, first fragments -> registers (bf16: tiles 1 .. PF-1 are already requested behind tile 0)
     tile_taps(0);
 #pragma unroll
-    for (int i = 0; i < A_CH; ++i) load_a(i);
+    for (int i = 0; i < A_CH; ++i) load_a(i, I0{});
 #pragma unroll
-    for (int i = 0; i < B_CH; ++i) load_b(i);
+    for (int i = 0; i < B_CH; ++i) load_b(i, I0{});
+    if constexpr (PF > 1) {
+        auto request = [&](auto j_tag) {
+            constexpr int J = decltype(j_tag)::value;
+            if (J < nk) {
+                tile_taps(J);
 #pragma unroll
-    for (int o = 0; o < NOPS; ++o) store_piece(0, o);
+                for (int i = 0; i < A_CH; ++i) load_a(i, j_tag);
+#pragma unroll
+                for (int i = 0; i < B_CH; ++i) load_b(i, j_tag);
+            }
+        };
+        request(std::integral_constant<int, 1>{});
+        if constexpr (PF == 4) { request(std::integral_constant<int, 2>{}); request(std::integral_constant<int, 3>{}); }
+    }
+#pragma unroll
+    for (int o = 0; o < NOPS; ++o) store_piece(0, o, I0{});
     __syncthreads();
     read_frags(As + (wr * WM) * BK, Bs + (wc * WN) * BK, 0, 0);
 
@@ -320,7 +336,7 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
             if (MORE) {
 #pragma unroll
                 for (int o = (q * NOPS) / NM; o < ((q + 1) * NOPS) / NM; ++o) {
-                    if (o < A_CH) load_a(o); else load_b(o - A_CH);
+                    if (o < A_CH) load_a(o, I0{}); else load_b(o - A_CH, I0{});
                 }
             }
             SP_SB();
@@ -344,7 +360,7 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
         if constexpr (H3 == 0) {
             if (MORE) {
 #pragma unroll
-                for (int o = 0; o < NOPS; ++o) store_piece(cur ^ 1, o);
+                for (int o = 0; o < NOPS; ++o) store_piece(cur ^ 1, o, I0{});
             }
         } else {
 #pragma unroll
@@ -352,7 +368,7 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
                 mfma_q(1, q);
                 if (MORE) {
 #pragma unroll
-                    for (int o = (q * NOPS) / H3; o < ((q + 1) * NOPS) / H3; ++o) store_piece(cur ^ 1, o);
+                    for (int o = (q * NOPS) / H3; o < ((q + 1) * NOPS) / H3; ++o) store_piece(cur ^ 1, o, I0{});
                 }
                 SP_SB();
             }
@@ -377,8 +393,92 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
 #ifdef SP_DIAG
     SP_STAMP_ALWAYS(t_loop0)
 #endif
-    for (int kt = 0; kt + 1 < nk; ++kt) k_tile(kt, std::true_type{});
-    k_tile(nk - 1, std::false_type{});
+    if constexpr (PF == 1) {
+        for (int kt = 0; kt + 1 < nk; ++kt) k_tile(kt, std::true_type{});
+        k_tile(nk - 1, std::false_type{});
+    } else {
+        // bf16: the same tile body with a ring of PF register sets.  S = kt % PF is a compile-time constant (the loop advances PF
+        // tiles per trip), LOAD = tile kt+PF exists, STORE = tile kt+1 exists.
+        auto k_tile_pf = [&](int kt, auto slot_tag, auto load_tag, auto store_tag) {
+            constexpr int S = decltype(slot_tag)::value, SN = (S + 1) % PF;
+            constexpr bool LOAD = decltype(load_tag)::value, STORE = decltype(store_tag)::value;
+            const int cur = kt & 1;
+            const float* a = As + cur * BM * BK + (wr * WM) * BK;
+            const float* b = Bs + cur * BN * BK + (wc * WN) * BK;
+            const float* an = As + (cur ^ 1) * BM * BK + (wr * WM) * BK;
+            const float* bn = Bs + (cur ^ 1) * BN * BK + (wc * WN) * BK;
+            // step 0: MFMAs of k-step 0 with the global loads of tile kt+PF dropped between them
+            read_frags(a, b, 1, 1);
+            if (LOAD) tile_taps(kt + PF);
+            SP_SB();
+#pragma unroll
+            for (int q = 0; q < NM; ++q) {
+                mfma_q(0, q);
+                if (LOAD) {
+#pragma unroll
+                    for (int o = (q * NOPS) / NM; o < ((q + 1) * NOPS) / NM; ++o) {
+                        if (o < A_CH) load_a(o, slot_tag); else load_b(o - A_CH, slot_tag);
+                    }
+                }
+                SP_SB();
+            }
+            read_frags(a, b, 2, 0);
+#pragma unroll
+            for (int q = 0; q < NM; ++q) mfma_q(1, q);
+            SP_SB();
+            read_frags(a, b, 3, 1);
+#pragma unroll
+            for (int q = 0; q < NM; ++q) mfma_q(0, q);
+            SP_SB();
+            // step 3: ds_writes of tile kt+1 (requested PF-1 tiles ago), barrier, first fragments of the next tile
+            constexpr int H3 = NM / 2;
+            if constexpr (H3 == 0) {
+                if (STORE) {
+#pragma unroll
+                    for (int o = 0; o < NOPS; ++o) store_piece(cur ^ 1, o, std::integral_constant<int, SN>{});
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < H3; ++q) {
+                    mfma_q(1, q);
+                    if (STORE) {
+#pragma unroll
+                        for (int o = (q * NOPS) / H3; o < ((q + 1) * NOPS) / H3; ++o) store_piece(cur ^ 1, o, std::integral_constant<int, SN>{});
+                    }
+                    SP_SB();
+                }
+            }
+            if (STORE) {
+                __syncthreads();
+                read_frags(an, bn, 0, 0);
+                SP_SB();
+            }
+#pragma unroll
+            for (int q = NM / 2; q < NM; ++q) mfma_q(1, q);
+            SP_SB();
+        };
+        // nk is a multiple of PF (the launcher only picks DEEP then): whole trips of PF tiles, no data-dependent tail - the
+        // register allocator needs ~60 VGPRs more as soon as the ring's sets are conditionally defined.
+        int kt = 0;
+        for (; kt + PF < nk; kt += PF) {                   // every tile of the trip requests tile kt+PF and stores tile kt+1
+            k_tile_pf(kt, std::integral_constant<int, 0>{}, std::true_type{}, std::true_type{});
+            k_tile_pf(kt + 1, std::integral_constant<int, 1 % PF>{}, std::true_type{}, std::true_type{});
+            if constexpr (PF == 4) {
+                k_tile_pf(kt + 2, std::integral_constant<int, 2 % PF>{}, std::true_type{}, std::true_type{});
+                k_tile_pf(kt + 3, std::integral_constant<int, 3 % PF>{}, std::true_type{}, std::true_type{});
+            }
+        }
+        // last trip: nothing left to request; the very last tile has nothing to store
+        if constexpr (PF == 2) {
+            k_tile_pf(kt, std::integral_constant<int, 0>{}, std::false_type{}, std::true_type{});
+            k_tile_pf(kt + 1, std::integral_constant<int, 1 % PF>{}, std::false_type{}, std::false_type{});
+        } else {
+            k_tile_pf(kt, std::integral_constant<int, 0>{}, std::false_type{}, std::true_type{});
+            k_tile_pf(kt + 1, std::integral_constant<int, 1 % PF>{}, std::false_type{}, std::true_type{});
+            k_tile_pf(kt + 2, std::integral_constant<int, 2 % PF>{}, std::false_type{}, std::true_type{});
+            k_tile_pf(kt + 3, std::integral_constant<int, 3 % PF>{}, std::false_type{}, std::false_type{});
+        }
+    }
 #ifdef SP_DIAG
     SP_STAMP_ALWAYS(t_loop1)
 #endif
@@ -577,26 +677,35 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
 #endif
 }
 
-template <int BM, int BN, int WR, int WC, bool BF16, bool OUT16, bool STATS>
+template <int BM, int BN, int WR, int WC, bool BF16, bool OUT16, bool STATS, bool DEEP = false>
 int launch_t(const ConvArgs& a, int phases, bool uniform, hipStream_t stream) {
+    if constexpr (!DEEP && BF16) {
+        // deep-prefetch variant once the K loop is long enough to pay for its registers (64x64 tile: +17 % at K = 72 tiles, -10 %
+        // at 4; thresholds 12 / 32 K tiles measured on HRNet-W32 and the ResNets); whole trips only: the K-tile count must be a
+        // multiple of the ring depth
+        constexpr int pf = BM * BN <= 64 * 64 ? 4 : 2;
+        const int nk = a.k_pad / 64;
+        if (nk % pf == 0 && nk >= (BM * BN <= 64 * 64 ? 12 : 32))
+            return launch_t<BM, BN, WR, WC, BF16, OUT16, STATS, true>(a, phases, uniform, stream);
+    }
     ConvArgs p = a;
     p.tiles_m = (a.M + BM - 1) / BM;
     p.tiles_n = a.n_pad / BN;
     const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float) + (size_t)BM * 4 * sizeof(int);
     dim3 grid(p.tiles_m * p.tiles_n, phases, 1), block(256, 1, 1);
     // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel instantiation
-    static const hipError_t attr_u = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, true, BF16, OUT16, STATS>),
+    static const hipError_t attr_u = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, true, BF16, OUT16, STATS, DEEP>),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    static const hipError_t attr_c = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, false, BF16, OUT16, STATS>),
+    static const hipError_t attr_c = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, false, BF16, OUT16, STATS, DEEP>),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr_u != hipSuccess || attr_c != hipSuccess) {
         sp_set_error("conv_igemm: hipFuncSetAttribute(max dynamic LDS = %zu) failed", lds);
         return SP_ELAUNCH;
     }
     if (uniform)
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, true, BF16, OUT16, STATS>), grid, block, lds, stream, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, true, BF16, OUT16, STATS, DEEP>), grid, block, lds, stream, p);
     else
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, false, BF16, OUT16, STATS>), grid, block, lds, stream, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, false, BF16, OUT16, STATS, DEEP>), grid, block, lds, stream, p);
     return sp_check_launch("conv_igemm_kernel");
 }
 
