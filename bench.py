@@ -275,7 +275,10 @@ def _variant_name(op):
     uniform = (d.c_in % (64 if bf16 else 32) == 0) and d.taps_h * d.taps_w <= 32
     out16 = bf16 and not (d.flags & 0x10)             # template flag OUT16: bf16 operands without SP_CONV_OUT_F32
     t = lambda v: "true" if v else "false"
-    return f"conv_igemm_kernel<{bm}, {bn}, {wr}, {wc}, {t(uniform)}, {t(bf16)}, {t(out16)}>"
+    small = bm * bn <= 64 * 64
+    nk = d.k_pad // 64
+    deep = bf16 and nk % (4 if small else 2) == 0 and nk >= (12 if small else 32)      # the launcher's rule (conv_igemm.hip launch_t)
+    return f"conv_igemm_kernel<{bm}, {bn}, {wr}, {wc}, {t(uniform)}, {t(bf16)}, {t(out16)}, false, {t(deep)}>"
 
 
 def kernel_roofline(prog, x, steps: int, layers_out=None, peak=FP32_MATRIX_PEAK_TFLOPS):
