@@ -27,7 +27,7 @@ extern "C" {
 #define SP_EINVAL (-1)   /* bad argument / unsupported shape (message in sp_last_error) */
 #define SP_ELAUNCH (-2)  /* HIP launch or runtime failure */
 
-#define SP_ABI_VERSION 13
+#define SP_ABI_VERSION 14
 
 /* epilogue / layout flags of sp_conv_desc.flags */
 #define SP_CONV_RELU 0x1u          /* y = max(y, 0) after scale/shift (+ residual) */
@@ -200,6 +200,16 @@ int sp_conv2d_fwd_bn_stats(const sp_conv_desc* desc, const void* x, const void* 
 int sp_bn_train_stats_from_conv(const float* stats_sum, const float* stats_sumsq, int partial_rows, int stride, int64_t rows, int c,
                                 float eps, float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
                                 void* stream);
+/* Backward counterpart: a dgrad launch (sp_conv2d_fwd on the dgrad packing, fp32 NHWC store, optional in-place accumulate) whose
+ * output IS dy of a BatchNorm+ReLU layer.  Given that layer's saved output bn_y (ReLU mask), input bn_z and statistics, the
+ * epilogue also writes the partial sums of g = dy*(bn_y > 0) and g*xhat, one row per (phase, M tile, wave row) as above;
+ * several launches that together cover dy (the phases of a stride-2 dgrad) fill consecutive row ranges of the same buffers.
+ * sp_bn_bwd_sums_from_conv folds them (index order, fp64) into dbeta / dgamma; sp_bn_train_bwd_apply_nhwc finishes the layer. */
+int sp_conv2d_dgrad_bn_bwd_stats(const sp_conv_desc* desc, const void* dz, const void* w_packed, const void* accumulate, void* dx,
+                                 const void* bn_y, const void* bn_z, const float* bn_mean, const float* bn_invstd, float* sum_g,
+                                 float* sum_g_xhat, int stats_rows_capacity, void* stream);
+int sp_bn_bwd_sums_from_conv(const float* sum_g, const float* sum_g_xhat, int partial_rows, int stride, int c, float* dgamma,
+                             float* dbeta, void* stream);
 /* y = [relu]((z - mean) * invstd * gamma + beta [+ residual])   (Bottleneck.forward tail, pose_resnet_dconv.py:124-131) */
 int sp_bn_apply_nhwc(const void* z, int bf16, const float* mean, const float* invstd, const float* gamma, const float* beta,
                      const void* residual, void* y, int64_t rows, int c, int relu, void* stream);

@@ -80,6 +80,14 @@ struct ConvArgs {
     float* stats_s;      // [rows][stats_stride] sum
     float* stats_q;      // [rows][stats_stride] sum of squares
     int stats_stride;
+    // BSTATS instantiations (dgrad launches): the tensor this launch writes is dy of a BatchNorm+ReLU; with that layer's saved
+    // output by (ReLU mask), input bz and statistics, the epilogue also leaves the partial sums of g = dy*(by > 0) (-> stats_s)
+    // and g * xhat (-> stats_q): the BN backward reduction without its own pass over dy / y / z
+    const void* by;
+    const void* bz;
+    const float* bmean;
+    const float* binvstd;
+    int bz_bytes;
 };
 
 constexpr int BK = 32;  // floats per K tile (8 chunks of 16 B)
@@ -88,7 +96,7 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * BK + ((chu
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int BM, int BN, int WR, int WC, bool UNIFORM_TAP, bool BF16, bool OUT16, bool STATS = false, bool DEEP = false>
+template <int BM, int BN, int WR, int WC, bool UNIFORM_TAP, bool BF16, bool OUT16, bool STATS = false, bool DEEP = false, bool BSTATS = false>
 __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm_kernel(const ConvArgs p) {
     constexpr int ES = BF16 ? 2 : 4;     // element size of activations / weights
     constexpr int EPC = 16 / ES;         // elements per 16-byte chunk
@@ -537,11 +545,24 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
             const int ro = rowtab[(wr * WM + it * RPI + rsub) * 4 + 3];
             off[it] = (col_ok && ro >= 0) ? (unsigned)((ro + col_off) * ESO) : OOB;
         }
-        float st_s[STATS ? CPL : 1], st_q[STATS ? CPL : 1];   // STATS: column sums of what this lane stores
-        if constexpr (STATS) {
+        static_assert(!(STATS && BSTATS) && (!BSTATS || !OUT16), "BSTATS: an fp32 gradient store");
+        float st_s[(STATS || BSTATS) ? CPL : 1], st_q[(STATS || BSTATS) ? CPL : 1];   // column sums over this lane's rows
+        float b_mu[BSTATS ? CPL : 1], b_is[BSTATS ? CPL : 1];
+        if constexpr (STATS || BSTATS) {
 #pragma unroll
             for (int e = 0; e < CPL; ++e) { st_s[e] = 0.f; st_q[e] = 0.f; }
         }
+        if constexpr (BSTATS) {
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) { b_mu[e] = 0.f; b_is[e] = 0.f; }
+            if (col_ok) {
+                const f32x4 m4 = *reinterpret_cast<const f32x4*>(p.bmean + col), i4 = *reinterpret_cast<const f32x4*>(p.binvstd + col);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { b_mu[e] = m4[e]; b_is[e] = i4[e]; }
+            }
+        }
+        const __amdgpu_buffer_rsrc_t byr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(BSTATS ? p.by : p.y), (short)0, BSTATS ? p.bz_bytes : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t bzr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(BSTATS ? p.bz : p.y), (short)0, BSTATS ? p.bz_bytes : 0, 0x00020000);
         u32x4 rv[NIT];
         if (p.res) {  // every residual load of the tile in flight before the first use
 #pragma unroll
@@ -593,10 +614,33 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
                         for (int e = 0; e < 4; ++e) { st_s[e] += v[e]; st_q[e] += v[e] * v[e]; }
                     }
                 }
+                if constexpr (BSTATS) {       // v = dy (complete: the residual input carried the other contributions)
+                    f32x4 yy, zz;
+                    if constexpr (BF16) {     // activations are bf16: 8 bytes per 4 channels at half the fp32 byte offset
+                        const unsigned ho = off[it] == OOB ? OOB : off[it] >> 1;
+                        typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+                        typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
+                        const bf16x4_ y4 = __builtin_bit_cast(bf16x4_, __builtin_amdgcn_raw_buffer_load_b64(byr, ho, 0, 0));
+                        const bf16x4_ z4 = __builtin_bit_cast(bf16x4_, __builtin_amdgcn_raw_buffer_load_b64(bzr, ho, 0, 0));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { yy[e] = (float)y4[e]; zz[e] = (float)z4[e]; }
+                    } else {
+                        yy = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(byr, off[it], 0, 0));
+                        zz = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bzr, off[it], 0, 0));
+                    }
+                    if (off[it] != OOB) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float g = yy[e] > 0.f ? v[e] : 0.f;
+                            st_s[e] += g;
+                            st_q[e] += g * ((zz[e] - b_mu[e]) * b_is[e]);
+                        }
+                    }
+                }
             }
             __builtin_amdgcn_raw_buffer_store_b128(o, yr, off[it], 0, 0);
         }
-        if constexpr (STATS) {
+        if constexpr (STATS || BSTATS) {
             // lanes chunk, chunk + CPR, ... hold the same channels for different rows: fixed butterfly, then one partial row per
             // (phase, M tile, wave row); the host-side fold adds the rows in index order -> deterministic statistics
 #pragma unroll
@@ -677,7 +721,7 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
 #endif
 }
 
-template <int BM, int BN, int WR, int WC, bool BF16, bool OUT16, bool STATS, bool DEEP = false>
+template <int BM, int BN, int WR, int WC, bool BF16, bool OUT16, bool STATS, bool DEEP = false, bool BSTATS = false>
 int launch_t(const ConvArgs& a, int phases, bool uniform, hipStream_t stream) {
     if constexpr (!DEEP && BF16) {
         // deep-prefetch variant once the K loop is long enough to pay for its registers (64x64 tile: +17 % at K = 72 tiles, -10 %
@@ -686,7 +730,7 @@ int launch_t(const ConvArgs& a, int phases, bool uniform, hipStream_t stream) {
         constexpr int pf = BM * BN <= 64 * 64 ? 4 : 2;
         const int nk = a.k_pad / 64;
         if (nk % pf == 0 && nk >= (BM * BN <= 64 * 64 ? 12 : 32))
-            return launch_t<BM, BN, WR, WC, BF16, OUT16, STATS, true>(a, phases, uniform, stream);
+            return launch_t<BM, BN, WR, WC, BF16, OUT16, STATS, true, BSTATS>(a, phases, uniform, stream);
     }
     ConvArgs p = a;
     p.tiles_m = (a.M + BM - 1) / BM;
@@ -694,23 +738,27 @@ int launch_t(const ConvArgs& a, int phases, bool uniform, hipStream_t stream) {
     const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float) + (size_t)BM * 4 * sizeof(int);
     dim3 grid(p.tiles_m * p.tiles_n, phases, 1), block(256, 1, 1);
     // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel instantiation
-    static const hipError_t attr_u = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, true, BF16, OUT16, STATS, DEEP>),
+    static const hipError_t attr_u = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, true, BF16, OUT16, STATS, DEEP, BSTATS>),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    static const hipError_t attr_c = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, false, BF16, OUT16, STATS, DEEP>),
+    static const hipError_t attr_c = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, false, BF16, OUT16, STATS, DEEP, BSTATS>),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr_u != hipSuccess || attr_c != hipSuccess) {
         sp_set_error("conv_igemm: hipFuncSetAttribute(max dynamic LDS = %zu) failed", lds);
         return SP_ELAUNCH;
     }
     if (uniform)
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, true, BF16, OUT16, STATS, DEEP>), grid, block, lds, stream, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, true, BF16, OUT16, STATS, DEEP, BSTATS>), grid, block, lds, stream, p);
     else
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, false, BF16, OUT16, STATS, DEEP>), grid, block, lds, stream, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, false, BF16, OUT16, STATS, DEEP, BSTATS>), grid, block, lds, stream, p);
     return sp_check_launch("conv_igemm_kernel");
 }
 
 template <int BM, int BN, int WR, int WC>
 int launch(const ConvArgs& a, int phases, bool uniform, hipStream_t stream) {
+    if (a.bz) {                                        // dgrad launch that also reduces the BN backward sums of the tensor it writes
+        if (a.flags & SP_CONV_BF16) return launch_t<BM, BN, WR, WC, true, false, false, false, true>(a, phases, uniform, stream);
+        return launch_t<BM, BN, WR, WC, false, false, false, false, true>(a, phases, uniform, stream);
+    }
     if (a.stats_s) {                                   // train-mode forward: plain NHWC store of the conv's own dtype
         if (a.flags & SP_CONV_BF16) return launch_t<BM, BN, WR, WC, true, true, true>(a, phases, uniform, stream);
         return launch_t<BM, BN, WR, WC, false, false, true>(a, phases, uniform, stream);
@@ -728,8 +776,11 @@ extern "C" int sp_conv2d_default_tile(const sp_conv_desc* d, int* tile_m, int* t
 
 static int tile_rows_per_block(int bm, int bn) { return (bm == 256 && bn == 64) || (bm == 128 && bn == 32) ? 4 : 2; }   // WR of the tile
 
+struct BnBwdSrc { const void* y; const void* z; const float* mean; const float* invstd; };
+
 static int conv_fwd_impl(const sp_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift,
-                         const void* residual, void* y, float* stats_s, float* stats_q, int stats_rows_capacity, void* stream) {
+                         const void* residual, void* y, float* stats_s, float* stats_q, int stats_rows_capacity, void* stream,
+                         const BnBwdSrc* bsrc = nullptr) {
     SP_REQUIRE(d && x && w_packed && y, "sp_conv2d_fwd: null pointer");
     SP_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->grid_h > 0 && d->grid_w > 0 && d->c_out > 0,
                "sp_conv2d_fwd: non-positive dimension");
@@ -786,6 +837,8 @@ static int conv_fwd_impl(const sp_conv_desc* d, const void* x, const void* w_pac
     a.x_bytes = (int)(in_elems * es); a.w_bytes = (int)(w_elems * es);
     a.y_bytes = (int)(out_elems * (((d->flags & SP_CONV_OUT_NCHW) || !out16) ? 4 : 2));
     a.stats_s = stats_s; a.stats_q = stats_q; a.stats_stride = d->n_pad;
+    a.by = bsrc ? bsrc->y : nullptr; a.bz = bsrc ? bsrc->z : nullptr; a.bmean = bsrc ? bsrc->mean : nullptr; a.binvstd = bsrc ? bsrc->invstd : nullptr;
+    a.bz_bytes = (int)(out_elems * es);
     const int phases = d->phases_y * d->phases_x;
     hipStream_t s = (hipStream_t)stream;
 
@@ -794,7 +847,14 @@ static int conv_fwd_impl(const sp_conv_desc* d, const void* x, const void* w_pac
     const int np = d->n_pad;
     if (bm == 0 && bn == 0) sp_conv2d_default_tile(d, &bm, &bn);
     SP_REQUIRE(bn > 0 && np % bn == 0, "sp_conv2d_fwd: tile_n=%d must divide n_pad=%d", bn, np);
-    if (stats_s) {
+    if (bsrc) {
+        SP_REQUIRE(stats_s && stats_q && bsrc->y && bsrc->z && bsrc->mean && bsrc->invstd, "sp_conv2d_dgrad_bn_bwd_stats: null pointer");
+        SP_REQUIRE(!(d->flags & (SP_CONV_OUT_NCHW | SP_CONV_PIXEL_SHUFFLE | SP_CONV_RELU)) && (!bf16 || (d->flags & SP_CONV_OUT_F32)) &&
+                       d->c_out % 4 == 0 && !scale && !shift,
+                   "sp_conv2d_dgrad_bn_bwd_stats: needs a plain fp32 NHWC gradient store (SP_CONV_OUT_F32 with bf16 operands)");
+        const long long rows = (long long)phases * ((M + bm - 1) / bm) * tile_rows_per_block(bm, bn);
+        SP_REQUIRE(rows <= stats_rows_capacity, "sp_conv2d_dgrad_bn_bwd_stats: %lld partial rows needed, capacity %d", rows, stats_rows_capacity);
+    } else if (stats_s) {
         SP_REQUIRE(stats_q, "sp_conv2d_fwd_bn_stats: null statistics pointer");
         SP_REQUIRE(!(d->flags & (SP_CONV_OUT_NCHW | SP_CONV_PIXEL_SHUFFLE | SP_CONV_OUT_F32)) && d->c_out % (bf16 ? 8 : 4) == 0,
                    "sp_conv2d_fwd_bn_stats: needs a plain NHWC store in the conv's own dtype (c_out %% %d == 0)", bf16 ? 8 : 4);
@@ -833,6 +893,13 @@ extern "C" int sp_conv2d_fwd_bn_stats(const sp_conv_desc* d, const void* x, cons
                                       float* stats_sumsq, int stats_rows_capacity, void* stream) {
     SP_REQUIRE(stats_sum && stats_sumsq, "sp_conv2d_fwd_bn_stats: null statistics pointer");
     return conv_fwd_impl(d, x, w_packed, nullptr, nullptr, nullptr, y, stats_sum, stats_sumsq, stats_rows_capacity, stream);
+}
+
+extern "C" int sp_conv2d_dgrad_bn_bwd_stats(const sp_conv_desc* d, const void* dz, const void* w_packed, const void* accumulate, void* dx,
+                                           const void* bn_y, const void* bn_z, const float* bn_mean, const float* bn_invstd,
+                                           float* sum_g, float* sum_g_xhat, int stats_rows_capacity, void* stream) {
+    const BnBwdSrc src = {bn_y, bn_z, bn_mean, bn_invstd};
+    return conv_fwd_impl(d, dz, w_packed, nullptr, nullptr, accumulate, dx, sum_g, sum_g_xhat, stats_rows_capacity, stream, &src);
 }
 
 // Built-in tile heuristic (measured on MI355X, bs=128 ResNet-50 shapes): 128x128 when the launch is many rounds deep,

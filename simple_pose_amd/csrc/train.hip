@@ -181,6 +181,25 @@ __global__ void bn_stats_from_conv_kernel(const float* __restrict__ ps, const fl
     }
 }
 
+// dbeta = sum g, dgamma = sum g*xhat from the partial rows a BSTATS dgrad launch (or several: one per output phase) left
+__global__ void bn_bwd_sums_from_conv_kernel(const float* __restrict__ ps, const float* __restrict__ pq, int nrows, int stride, int C,
+                                             float* __restrict__ dbeta, float* __restrict__ dgamma) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    const int lane = threadIdx.x & 63;
+    double a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+    int r = lane;
+    for (; r + 64 < nrows; r += 128) {
+        a0 += (double)ps[(size_t)r * stride + c]; a1 += (double)pq[(size_t)r * stride + c];
+        b0 += (double)ps[(size_t)(r + 64) * stride + c]; b1 += (double)pq[(size_t)(r + 64) * stride + c];
+    }
+    for (; r < nrows; r += 64) { a0 += (double)ps[(size_t)r * stride + c]; a1 += (double)pq[(size_t)r * stride + c]; }
+    double s0 = a0 + b0, s1 = a1 + b1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off, SP_WAVE); s1 += __shfl_xor(s1, off, SP_WAVE); }
+    if (lane == 0) { dbeta[c] = (float)s0; dgamma[c] = (float)s1; }
+}
+
 // SyncBatchNorm halves: per-rank (sum, sum of squares) kept in fp64 so that the cross-rank SUM is order-insensitive to ~1e-16
 __global__ void pair_sum_final_f64_kernel(const double* __restrict__ part, int nblk, int C, double* __restrict__ sums) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -488,6 +507,14 @@ extern "C" int sp_bn_train_stats_from_conv(const float* stats_sum, const float* 
     hipLaunchKernelGGL(bn_stats_from_conv_kernel, dim3((c + 3) / 4), dim3(256), 0, (hipStream_t)stream, stats_sum, stats_sumsq, partial_rows, stride,
                        c, (double)rows, eps, momentum, mean, invstd, running_mean, running_var);
     return sp_check_launch("bn_stats_from_conv_kernel");
+}
+
+extern "C" int sp_bn_bwd_sums_from_conv(const float* sum_g, const float* sum_g_xhat, int partial_rows, int stride, int c, float* dgamma,
+                                        float* dbeta, void* stream) {
+    SP_REQUIRE(sum_g && sum_g_xhat && dgamma && dbeta && partial_rows > 0 && stride >= c && c > 0, "sp_bn_bwd_sums_from_conv: bad argument");
+    hipLaunchKernelGGL(bn_bwd_sums_from_conv_kernel, dim3((c + 3) / 4), dim3(256), 0, (hipStream_t)stream, sum_g, sum_g_xhat, partial_rows, stride,
+                       c, dbeta, dgamma);
+    return sp_check_launch("bn_bwd_sums_from_conv_kernel");
 }
 
 extern "C" int sp_bn_apply_nhwc(const void* z, int bf16, const float* mean, const float* invstd, const float* gamma, const float* beta,

@@ -70,6 +70,9 @@ class Act:
     c: int
     grad: Optional[torch.Tensor] = None
     needs_grad: bool = True
+    consumers: int = 0                 # forward ops that read this activation
+    bn: Optional[tuple] = None         # produced by BatchNorm+ReLU (no residual): (z, mean, invstd) of that layer
+    bstats: Optional[tuple] = None     # backward: (partial sums [2, rows, stride], rows) left by the dgrad launch that wrote .grad
 
 
 @dataclass
@@ -251,9 +254,32 @@ class ConvT:
                    self.name)
         return out, part, rows.value
 
-    def dgrad(self, dz: torch.Tensor, B: int, acc: Optional[torch.Tensor]) -> torch.Tensor:
-        """dx (+= into `acc` when given)."""
+    def dgrad(self, dz: torch.Tensor, B: int, acc: Optional[torch.Tensor], bn_src: Optional["Act"] = None) -> torch.Tensor:
+        """dx (+= into `acc` when given).  `bn_src`: the activation dx is the gradient of, when it came out of a BatchNorm+ReLU and
+        this launch family is its only consumer: the epilogue then also reduces that layer's backward sums (bn_src.bstats)."""
         lib = _lib.lib()
+        if bn_src is not None:
+            assert acc is None
+            d0 = self.d_dgrad[0]
+            dx = torch.zeros((B, d0.out_h, d0.out_w, d0.out_c), dtype=torch.float32, device=dz.device) if not self.dgrad_full_cover else \
+                torch.empty((B, d0.out_h, d0.out_w, d0.out_c), dtype=torch.float32, device=dz.device)
+            need = []
+            for d in self.d_dgrad:
+                d.batch = B
+                r = ctypes.c_int(0)
+                _lib.check(lib.sp_conv2d_bn_stats_rows(d, ctypes.byref(r)), self.name + ".dgrad")
+                need.append(r.value)
+            total, stride = sum(need), self.d_dgrad[0].n_pad
+            part = torch.empty((2, total, stride), dtype=torch.float32, device=dz.device)
+            z, mean, invstd = bn_src.bn
+            row0 = 0
+            for d, w, n in zip(self.d_dgrad, self.w_dgrad, need):
+                _lib.check(lib.sp_conv2d_dgrad_bn_bwd_stats(d, P(dz), P(w), None, P(dx), P(bn_src.data), P(z), P(mean), P(invstd),
+                                                            P(part[0, row0:]), P(part[1, row0:]), n, _lib.current_stream()),
+                           self.name + ".dgrad")
+                row0 += n
+            bn_src.bstats = (part, total)
+            return dx
         if acc is None:
             d0 = self.d_dgrad[0]
             shape = (B, d0.out_h, d0.out_w, d0.out_c)
@@ -530,6 +556,7 @@ class PoseTrainer:
 
         def conv_bn(xa: Act, cname: str, bname: str, relu: bool, res: Optional[Act] = None) -> Act:
             layer = L[cname]
+            xa.consumers += 1
             fused_stats = self.fuse_bn_stats and not sync
             if fused_stats:
                 z, part, prow = layer.forward_bn_stats(xa.data, B)
@@ -558,6 +585,8 @@ class PoseTrainer:
             _lib.check(lib.sp_bn_apply_nhwc(P(z), bf, P(mean), P(invstd), P(gamma), P(beta), P(res.data) if res else None, P(y), rows, C,
                                             int(relu), stream), bname)
             ya = Act(y, z.shape[1], z.shape[2], C)
+            if relu and res is None:
+                ya.bn = (z, mean, invstd)
 
             def bwd():
                 dz = new(z.shape)                      # MFMA operand of dgrad / wgrad: activation dtype
@@ -571,7 +600,20 @@ class PoseTrainer:
                     dres = res.grad
                 dgamma, dbeta = self.flat.view(bname + ".weight", True), self.flat.view(bname + ".bias", True)
                 rs = P(y) if relu else None
-                if sync:
+                if ya.bstats is not None:
+                    # the dgrad launch that produced ya.grad already reduced sum g and sum g*xhat (sp_conv2d_dgrad_bn_bwd_stats)
+                    part, prow = ya.bstats
+                    ya.bstats = None
+                    _lib.check(lib.sp_bn_bwd_sums_from_conv(P(part[0]), P(part[1]), prow, part.shape[2], C, P(dgamma), P(dbeta), stream),
+                               bname + ".bwd")
+                    sg, sb, tot = dgamma, dbeta, rows
+                    if sync:
+                        both = torch.cat([dgamma, dbeta])
+                        dist.all_reduce(both, op=dist.ReduceOp.SUM, group=self.pg)
+                        sg, sb, tot = both[:C], both[C:], rows * W
+                    _lib.check(lib.sp_bn_train_bwd_apply_nhwc(P(ya.grad), bf, rs, P(z), P(mean), P(invstd), P(gamma), P(sg), P(sb), tot, rows, C,
+                                                              P(dz), P(dres), acc, stream), bname + ".bwd")
+                elif sync:
                     # local sums are this rank's parameter gradients (DDP averages them later); dz needs the global ones
                     _lib.check(lib.sp_bn_train_bwd_reduce_nhwc(P(ya.grad), bf, rs, P(z), P(mean), P(invstd), rows, C, P(dgamma), P(dbeta), P(ws),
                                                                stream), bname + ".bwd")
@@ -585,7 +627,8 @@ class PoseTrainer:
                 ya.grad = None
                 wgrad_async(layer, xa.data, dz)
                 if xa.needs_grad and layer.need_dgrad:
-                    xa.grad = layer.dgrad(dz, B, xa.grad)
+                    fuse = self.fuse_bn_bwd and xa.bn is not None and xa.consumers == 1 and xa.grad is None
+                    xa.grad = layer.dgrad(dz, B, xa.grad, bn_src=xa if fuse else None)
                 self._grads_ready(bname + ".weight", bname + ".bias", cname + ".weight")
             tape.append(bwd)
             return ya
@@ -617,6 +660,7 @@ class PoseTrainer:
                 a = conv_bn(t, p + ".conv3", p + ".bn3", True, res=idn)
         def shuffle(xa: Act) -> Act:
             """nn.PixelShuffle(2) and, on the tape, its inverse permutation for the gradient."""
+            xa.consumers += 1
             y = new((B, 2 * xa.h, 2 * xa.w, xa.c // 4))
             _lib.check((lib.sp_pixel_shuffle2_nhwc_bf16 if self.bf16 else lib.sp_pixel_shuffle2_nhwc)(P(xa.data), P(y), B, xa.h, xa.w, xa.c,
                                                                                                        stream), "pixel_shuffle")
@@ -641,6 +685,7 @@ class PoseTrainer:
         J = fl.O
         hh, ww = self.heat_hw
         heat = torch.empty((B, J, hh, ww), dtype=torch.float32, device=dev)
+        a.consumers += 1
         fl.forward(a.data, B, out=heat, shift=self.sd["final_layer.bias"])
         # ---- loss + d loss / d heat ----
         dheat = newf((B, J, hh, ww))
@@ -658,7 +703,7 @@ class PoseTrainer:
             dh = new((B, hh, ww, Jb))
             _lib.check(lib.sp_nchw_to_nhwc_pad(P(dheat), P(dh), 1, B, J, hh, ww, Jb, stream), "dheat.nhwc16")
         wgrad_async(fl, a.data, dh)
-        a.grad = fl.dgrad(dh, B, None)
+        a.grad = fl.dgrad(dh, B, None, bn_src=a if (self.fuse_bn_bwd and a.bn is not None and a.consumers == 1) else None)
         self._grads_ready("final_layer.bias", "final_layer.weight")
         for fn in reversed(tape):
             fn()
@@ -730,6 +775,7 @@ class PoseTrainer:
     _opt_stream = None
     _wgrad_stream = None
     _wgrad_tail = None
+    fuse_bn_bwd = True         # BN backward sums from the epilogue of the dgrad launch that produces dy (single-consumer BN+ReLU outputs)
     fuse_bn_stats = True       # BN batch statistics from the conv epilogue (sp_conv2d_fwd_bn_stats); SyncBN keeps the two-pass form
 
     # ---- step-time split (BASELINE config 4 asks for fwd / bwd / all-reduce / Adam) -------------------------------------
