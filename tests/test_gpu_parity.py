@@ -709,3 +709,28 @@ def test_full_size_layers_sampled_reference_and_exact_linearity(dtype):
                             acc += float(xh[bi, ty // 2, tx // 2] @ wh[:, co, ky, kx])
             worst = max(worst, abs(float(yh[bi, oy, ox, co]) - acc) / (abs(acc) + 1.0))
         assert worst < (2e-6 if dtype == "fp32" else 8e-3), (name, worst)
+
+
+def test_hrnet_w48_at_384x288_vs_oracle():
+    """The reference's other HRNet configuration (nets/hrnet_w48.yaml, 48/96/192/384 channels) at its usual 384x288 input: no golden
+    fixture of it is committed, so the checker is the forward oracle (the torch-CPU restatement that is pinned on W32)."""
+    import os
+    import yaml
+    from simple_pose_amd.nets.pose_hrnet import get_pose_net, hrnet_state_dict_shapes
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "simple_pose_amd", "nets", "hrnet_w48.yaml")
+    m = get_pose_net(path, pretrained=None, joint_num=17)
+    sd = synth.conditioned_state_dict(hrnet_state_dict_shapes(m.cfg, 17), 9)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m = m.to(DEV).eval()
+    x = synth.input_images(2, 9, h=384, w=288)
+    with torch.no_grad():
+        hm = m(_cuda(x))
+    assert hm.shape == (2, 17, 96, 72)
+    with open(path) as fh:
+        cfg = yaml.safe_load(fh)
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        ref = nets_oracle.hrnet_forward({k: torch.from_numpy(v) for k, v in sd.items()}, torch.from_numpy(x), cfg).numpy()
+    rel = np.abs(hm.cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert rel <= 1e-4, rel
