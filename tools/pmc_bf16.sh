@@ -1,4 +1,5 @@
 #!/bin/bash
+# SQ occupancy / stall counters of the bf16 conv kernels (three --pmc passes, no trace domains): the evidence behind DESIGN.md 3.1b
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_bf16
 mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
