@@ -27,7 +27,7 @@ extern "C" {
 #define SP_EINVAL (-1)   /* bad argument / unsupported shape (message in sp_last_error) */
 #define SP_ELAUNCH (-2)  /* HIP launch or runtime failure */
 
-#define SP_ABI_VERSION 14
+#define SP_ABI_VERSION 15
 
 /* epilogue / layout flags of sp_conv_desc.flags */
 #define SP_CONV_RELU 0x1u          /* y = max(y, 0) after scale/shift (+ residual) */
@@ -161,6 +161,12 @@ int sp_pose_rescore(const float* kps, const double* box_score, int persons, int 
 int sp_oks_nms(const double* kps, const double* scores, const double* areas, const int32_t* seg, int groups, int max_group,
                int joints, const double* sigmas_host, double thresh, double vis_thresh, int32_t* keep, int32_t* keep_count,
                void* stream);
+
+/* the same normalisation written directly in the network's input layout (the stem's loader format): NHWC4 fp32 [B,h,w,4] or,
+ * out_bf16 != 0, NHWC8 bf16 [B,h,w,8]; pad channels are zero.  Replaces sp_u8hwc_bgr_to_nchw_f32 + sp_nchw_to_nhwc4 when the crops
+ * arrive as uint8 (1 byte per value over PCIe, one pass on the GPU). */
+int sp_u8hwc_bgr_to_nhwc(const unsigned char* img, void* out, int out_bf16, int batch, int h, int w, const float* mean_rgb_host,
+                         void* stream);
 
 /* ---- encoders: commons/transforms.py ----------------------------------------------------------- */
 

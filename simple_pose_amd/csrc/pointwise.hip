@@ -161,6 +161,25 @@ __global__ void u8hwc_bgr_to_nchw_kernel(const unsigned char* __restrict__ img, 
     }
 }
 
+// The same normalisation straight into the network's input layout: BGR u8 HWC -> RGB NHWC4 fp32 / NHWC8 bf16 (pad channels 0).
+// One pass instead of normalise (NCHW fp32) + layout change: 3 B read, 16 B written per pixel.
+template <bool BF16OUT>
+__global__ void u8hwc_bgr_to_nhwc_kernel(const unsigned char* __restrict__ img, u32x4* __restrict__ out, float m0, float m1, float m2,
+                                         long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const unsigned char* p = img + i * 3;
+        const float r = (float)p[2] / 255.0f - m0, g = (float)p[1] / 255.0f - m1, b = (float)p[0] / 255.0f - m2;
+        if constexpr (BF16OUT) {
+            typedef __bf16 bf16x8_ __attribute__((ext_vector_type(8)));
+            bf16x8_ v = {(__bf16)r, (__bf16)g, (__bf16)b, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+            out[i] = __builtin_bit_cast(u32x4, v);
+        } else {
+            const f32x4 v = {r, g, b, 0.f};
+            out[i] = __builtin_bit_cast(u32x4, v);
+        }
+    }
+}
+
 // metrics/pose_metrics.py:212-245 HeatMapAcc on arg-max coordinates: per joint, share of valid samples (label x,y > 1) whose
 // normalised distance |pred - label| / (W/f, H/f) is below the threshold; mean over joints that have a valid sample.
 __global__ __launch_bounds__(256) void heat_map_acc_kernel(const float* __restrict__ pred, const float* __restrict__ label,
@@ -273,6 +292,19 @@ extern "C" int sp_u8hwc_bgr_to_nchw_f32(const unsigned char* img, float* out, in
     hipLaunchKernelGGL(u8hwc_bgr_to_nchw_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, img, out, h * w,
                        mean_rgb_host[0], mean_rgb_host[1], mean_rgb_host[2], total);
     return sp_check_launch("u8hwc_bgr_to_nchw_kernel");
+}
+
+extern "C" int sp_u8hwc_bgr_to_nhwc(const unsigned char* img, void* out, int out_bf16, int batch, int h, int w, const float* mean_rgb_host,
+                                    void* stream) {
+    SP_REQUIRE(img && out && mean_rgb_host, "sp_u8hwc_bgr_to_nhwc: null pointer");
+    SP_REQUIRE(batch > 0 && h > 0 && w > 0, "sp_u8hwc_bgr_to_nhwc: bad shape");
+    const long long total = (long long)batch * h * w;
+    SP_REQUIRE(total * 16 < (1ll << 31), "sp_u8hwc_bgr_to_nhwc: tensor too large");
+    if (out_bf16) hipLaunchKernelGGL(u8hwc_bgr_to_nhwc_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, img,
+                                 reinterpret_cast<u32x4*>(out), mean_rgb_host[0], mean_rgb_host[1], mean_rgb_host[2], total);
+    else hipLaunchKernelGGL(u8hwc_bgr_to_nhwc_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, img,
+                            reinterpret_cast<u32x4*>(out), mean_rgb_host[0], mean_rgb_host[1], mean_rgb_host[2], total);
+    return sp_check_launch("u8hwc_bgr_to_nhwc_kernel");
 }
 
 extern "C" int sp_heat_map_acc(const float* pred_coords, const float* label_coords, const float* mask, int batch, int joints, int h, int w,

@@ -210,8 +210,13 @@ class Program:
             _lib.check(fn(P(bufs[op.src]), P(bufs[op.dst]), B, h, w, c, stream), op.name)
         elif op.kind == "to_nhwc4":
             c, h, w = op.args
-            fn = lib.sp_nchw_to_nhwc8_bf16 if self.dtype == "bf16" else lib.sp_nchw_to_nhwc4
-            _lib.check(fn(P(bufs[op.src]), P(bufs[op.dst]), B, c, h, w, stream), op.name)
+            src = bufs[op.src]
+            if src.dtype == torch.uint8:           # BGR crops [B,h,w,3]: normalise (coco.py:136) and lay out in one pass
+                mean = (ctypes.c_float * 3)(0.485, 0.456, 0.406)
+                _lib.check(lib.sp_u8hwc_bgr_to_nhwc(P(src), P(bufs[op.dst]), int(self.dtype == "bf16"), B, h, w, mean, stream), op.name)
+            else:
+                fn = lib.sp_nchw_to_nhwc8_bf16 if self.dtype == "bf16" else lib.sp_nchw_to_nhwc4
+                _lib.check(fn(P(src), P(bufs[op.dst]), B, c, h, w, stream), op.name)
         elif op.kind == "pixel_shuffle":
             h, w, c = op.args
             fn = lib.sp_pixel_shuffle2_nhwc_bf16 if self.dtype == "bf16" else lib.sp_pixel_shuffle2_nhwc
@@ -231,7 +236,8 @@ class Program:
             raise ValueError(op.kind)
 
     def run(self, x: torch.Tensor) -> torch.Tensor:
-        """x: fp32 NCHW [B,3,H,W] on the GPU -> heat maps fp32 NCHW [B,J,H/4,W/4].  Ops are issued in program order; ops of
+        """x: fp32 NCHW [B,3,H,W] on the GPU (or uint8 BGR crops [B,H,W,3], normalised on the fly as datasets/coco.py:136 does) ->
+        heat maps fp32 NCHW [B,J,H/4,W/4].  Ops are issued in program order; ops of
         different lanes (independent HRNet branches) go to different HIP streams and overlap on the GPU, ordered by events."""
         lib = _lib.lib()
         B = x.shape[0]

@@ -104,12 +104,33 @@ class PoseResNetBase(nn.Module):
         if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] % 32 or x.shape[3] % 32:
             raise ValueError(f"expected [B,3,H,W] with H,W multiples of 32, got {tuple(x.shape)}")
         if self.training:
-            raise NotImplementedError(
-                "train-mode forward/backward (batch-stat BN, dgrad/wgrad) is not lowered to HIP yet; call .eval()")
+            raise NotImplementedError("model(x) is the eval-mode path; the train step (batch-stat BN, backward, Adam) is "
+                                      "simple_pose_amd.train.PoseTrainer(model).step(x, targets, mask)")
         prog = self.hip_program(x)
         if self.autotune and x.shape[0] >= 16 and prog.tuned_for_batch != x.shape[0]:
             prog.autotune(x)  # once per (weights, input shape): pins the fastest tile per layer; results unchanged
         return prog.run(x)
+
+    def forward_crops(self, crops: torch.Tensor) -> torch.Tensor:
+        return forward_uint8_crops(self, crops)
+
+
+def forward_uint8_crops(model, crops: torch.Tensor) -> torch.Tensor:
+    """uint8 BGR crops [B,H,W,3] on the GPU (what `cv.warpAffine` / `datasets.naive_data.crop_boxes` produce) -> heat maps.  The
+    collate normalisation of datasets/coco.py:136 (`x/255 - mean`, BGR -> RGB) happens inside the first launch, which writes the
+    network's NHWC input directly; bit-identical to `model(normalize_crops(crops))`."""
+    if not (isinstance(crops, torch.Tensor) and crops.is_cuda and crops.dtype == torch.uint8 and crops.dim() == 4 and crops.shape[-1] == 3):
+        raise HipLibraryError("forward_crops: expected a CUDA uint8 tensor [B,H,W,3]")
+    B, H, W, _ = crops.shape
+    if H % 32 or W % 32:
+        raise ValueError(f"expected H,W multiples of 32, got {H}x{W}")
+    if model.training:
+        raise NotImplementedError("forward_crops is the eval-mode path; training goes through simple_pose_amd.train.PoseTrainer")
+    prog = model.hip_program(torch.empty((0, 3, H, W), device=crops.device))
+    crops = crops.contiguous()
+    if model.autotune and B >= 16 and prog.tuned_for_batch != B:
+        prog.autotune(crops)
+    return prog.run(crops)
 
 
 def load_pretrained_like_reference(model: nn.Module, arch: str):

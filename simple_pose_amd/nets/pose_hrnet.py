@@ -133,6 +133,10 @@ class PoseHighResolutionNet(ParamTree):
             prog.autotune(x)
         return prog.run(x)
 
+    def forward_crops(self, crops: torch.Tensor) -> torch.Tensor:
+        from ._resnet_base import forward_uint8_crops
+        return forward_uint8_crops(self, crops)
+
 
 def load_cfg(cfg_path: str) -> dict:
     with open(cfg_path, "r") as fh:

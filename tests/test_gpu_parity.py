@@ -734,3 +734,22 @@ def test_hrnet_w48_at_384x288_vs_oracle():
         ref = nets_oracle.hrnet_forward({k: torch.from_numpy(v) for k, v in sd.items()}, torch.from_numpy(x), cfg).numpy()
     rel = np.abs(hm.cpu().numpy() - ref).max() / np.abs(ref).max()
     assert rel <= 1e-4, rel
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_uint8_crops_straight_into_the_network(dtype, golden):
+    """model.forward_crops(uint8 BGR crops) == model(normalize_crops(crops)) bit for bit: the collate normalisation and the NHWC
+    layout change are one launch (sp_u8hwc_bgr_to_nhwc), for the crops crop_boxes makes."""
+    from simple_pose_amd.datasets.coco import normalize_crops
+    from simple_pose_amd.datasets.naive_data import crop_boxes
+    g = golden("g9_crop.npz")
+    crops, *_ = crop_boxes(_cuda(g["img"]), g["boxes"])
+    net = pose_resnet_dconv.resnet50(pretrained=False, num_classes=17)
+    sd = synth.conditioned_state_dict(nets_oracle.state_dict_shapes_resnet50("dconv"), 4)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net = net.cuda().eval()
+    net.compute_dtype = dtype
+    with torch.no_grad():
+        a = net.forward_crops(crops)
+        b = net(normalize_crops(crops))
+    assert a.shape == (5, 17, 64, 48) and torch.equal(a, b)
