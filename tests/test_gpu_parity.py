@@ -753,3 +753,34 @@ def test_uint8_crops_straight_into_the_network(dtype, golden):
         a = net.forward_crops(crops)
         b = net(normalize_crops(crops))
     assert a.shape == (5, 17, 64, 48) and torch.equal(a, b)
+
+
+def test_detector_driven_pipeline_composes_end_to_end(golden):
+    """eval.py's inference path with every stage on the GPU and nothing but the final dict list crossing to the host: image + boxes
+    -> crop_boxes -> forward_crops -> GaussTaylor decode (trans_inv from the crop geometry) -> filter_poses (rescoring + OKS-NMS).
+    Stage by stage the pieces are pinned elsewhere; here the chain is checked against the oracle chain fed with the same crops."""
+    from simple_pose_amd.datasets.naive_data import crop_boxes, filter_poses
+    g = golden("g9_crop.npz")
+    boxes = np.concatenate([g["boxes"], g["boxes"][:3] + np.float32(1.5)])            # 3 near-duplicate detections
+    crops, tinv, centers, scales, areas = crop_boxes(_cuda(g["img"]), boxes)
+    net = pose_resnet_dconv.resnet50(pretrained=False, num_classes=17)
+    sd = synth.conditioned_state_dict(nets_oracle.state_dict_shapes_resnet50("dconv"), 4)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net = net.cuda().eval()
+    with torch.no_grad():
+        hm = net.forward_crops(crops)
+    kps, mv = GaussTaylorKeyPointDecoder()(hm, tinv)
+    det_score = np.linspace(0.9, 0.5, len(boxes))
+    res = filter_poses(torch.cat([kps, mv], dim=-1), det_score, areas, [7] * len(boxes), in_vis_thre=0.0, oks_thre=0.9)
+    # oracle chain on the same crops
+    x = pose_oracle.normalize_crops(crops.cpu().numpy())
+    with torch.no_grad():
+        ohm = nets_oracle.resnet_dconv_forward({k: torch.from_numpy(v) for k, v in sd.items()}, torch.from_numpy(x)).numpy()
+    assert np.abs(hm.cpu().numpy() - ohm).max() / np.abs(ohm).max() <= 1e-4
+    okps, omv = pose_oracle.decode_gauss_taylor(hm.cpu().numpy(), tinv.cpu().numpy())     # decoder on the SAME maps
+    assert np.abs(kps.cpu().numpy() - okps).max() <= 1e-3 and np.array_equal(mv.cpu().numpy(), omv)
+    k3 = np.concatenate([kps.cpu().numpy(), mv.cpu().numpy()], -1).astype(np.float64)
+    osc = pose_oracle.pose_rescore(k3, det_score, 0.0)
+    keep = pose_oracle.oks_nms(k3, osc, areas.astype(np.float64), 0.9)
+    assert [r["keypoints"] for r in res] == [k3[i].reshape(-1).tolist() for i in keep]
+    assert 1 <= len(res) <= len(boxes) and all(r["image_id"] == 7 for r in res)
