@@ -296,35 +296,20 @@ def kernel_roofline(prog, x, steps: int, layers_out=None, peak=FP32_MATRIX_PEAK_
     bufs = dict(prog._alloc(B, x.device))
     bufs["input"] = x
     bufs[prog.out_name] = torch.empty((B,) + tuple(prog.out_shape), dtype=torch.float32, device=x.device)
-    P = _lib.ptr
-    bf = prog.dtype == "bf16"
     conv_ops = [op for op in prog.ops if op.kind == "conv"]
     ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in conv_ops]
           for _ in range(steps)]
     stream = _lib.current_stream()
     for s in range(steps):
         ci = 0
-        for op in prog.ops:
+        for op in prog.ops:                      # the program's own dispatcher (one stream), events around the conv launches
             if op.kind == "conv":
-                op.desc.batch = B
                 ev[s][ci][0].record()
-                _lib.check(lib.sp_conv2d_fwd(op.desc, P(bufs[op.src]), P(op.w), P(op.scale), P(op.shift),
-                                             P(bufs[op.res]) if op.res else None, P(bufs[op.dst]), stream), op.name)
+                prog._launch(lib, op, bufs, B, stream)
                 ev[s][ci][1].record()
                 ci += 1
-            elif op.kind == "maxpool":
-                h, w, c = op.args
-                (lib.sp_maxpool3x3s2_nhwc_bf16 if bf else lib.sp_maxpool3x3s2_nhwc)(P(bufs[op.src]), P(bufs[op.dst]), B, h, w, c, stream)
-            elif op.kind == "to_nhwc4":
-                c, h, w = op.args
-                (lib.sp_nchw_to_nhwc8_bf16 if bf else lib.sp_nchw_to_nhwc4)(P(bufs[op.src]), P(bufs[op.dst]), B, c, h, w, stream)
-            elif op.kind == "pixel_shuffle":
-                h, w, c = op.args
-                (lib.sp_pixel_shuffle2_nhwc_bf16 if bf else lib.sp_pixel_shuffle2_nhwc)(P(bufs[op.src]), P(bufs[op.dst]), B, h, w, c, stream)
-            elif op.kind == "upsample_add":
-                h, w, c, f, relu = op.args
-                (lib.sp_upsample_add_nhwc_bf16 if bf else lib.sp_upsample_add_nhwc)(P(bufs[op.src]), P(bufs[op.res]), P(bufs[op.dst]), B, h, w, c,
-                                                                                      f, relu, stream)
+            else:
+                prog._launch(lib, op, bufs, B, stream)
     torch.cuda.synchronize()
     per_layer = []
     for ci, op in enumerate(conv_ops):

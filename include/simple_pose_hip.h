@@ -27,7 +27,7 @@ extern "C" {
 #define SP_EINVAL (-1)   /* bad argument / unsupported shape (message in sp_last_error) */
 #define SP_ELAUNCH (-2)  /* HIP launch or runtime failure */
 
-#define SP_ABI_VERSION 15
+#define SP_ABI_VERSION 16
 
 /* epilogue / layout flags of sp_conv_desc.flags */
 #define SP_CONV_RELU 0x1u          /* y = max(y, 0) after scale/shift (+ residual) */
@@ -65,6 +65,9 @@ typedef struct sp_conv_desc {
     uint32_t flags;
     int32_t tile_m, tile_n;          /* workgroup tile (rows x columns); 0,0 = sp_conv2d_default_tile().  Results do not
                                         depend on the tile: every output's K reduction order is the same for all shapes. */
+    int32_t stride_x;                /* 0: same as `stride`.  Otherwise the x stride where it differs from the y stride (`stride`):
+                                        the bf16 stem reads the 4-channel image as x-PAIRS of 8 values, where a stride of two
+                                        pixels is a stride of one pair */
 } sp_conv_desc;
 
 /* ---- library ---------------------------------------------------------------------------------- */
@@ -163,10 +166,13 @@ int sp_oks_nms(const double* kps, const double* scores, const double* areas, con
                void* stream);
 
 /* the same normalisation written directly in the network's input layout (the stem's loader format): NHWC4 fp32 [B,h,w,4] or,
- * out_bf16 != 0, NHWC8 bf16 [B,h,w,8]; pad channels are zero.  Replaces sp_u8hwc_bgr_to_nchw_f32 + sp_nchw_to_nhwc4 when the crops
+ * out_bf16 == 1: NHWC8 bf16 [B,h,w,8]; out_bf16 == 2: NHWC4 bf16 [B,h,w,4] (what the bf16 inference stem reads); pad channels are zero.  Replaces sp_u8hwc_bgr_to_nchw_f32 + sp_nchw_to_nhwc4 when the crops
  * arrive as uint8 (1 byte per value over PCIe, one pass on the GPU). */
 int sp_u8hwc_bgr_to_nhwc(const unsigned char* img, void* out, int out_bf16, int batch, int h, int w, const float* mean_rgb_host,
                          void* stream);
+
+/* NCHW fp32 [B,C<=4,h,w] -> NHWC4 bf16 [B,h,w,4] (8 bytes per pixel; w even: the stem conv reads pixel pairs as 8 channels) */
+int sp_nchw_to_nhwc4_bf16(const float* x, void* y, int batch, int channels, int h, int w, void* stream);
 
 /* ---- encoders: commons/transforms.py ----------------------------------------------------------- */
 

@@ -20,7 +20,7 @@ SP_CONV_PIXEL_SHUFFLE = 0x4
 SP_CONV_BF16 = 0x8
 SP_CONV_OUT_F32 = 0x10
 CONV_TILES = ((128, 128), (64, 128), (128, 64), (64, 64), (256, 64), (128, 32))
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class HipLibraryError(RuntimeError):
@@ -32,7 +32,7 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [(n, c_int32) for n in (
         "batch", "in_h", "in_w", "c_in", "grid_h", "grid_w", "c_out", "n_pad", "taps_h", "taps_w", "k_pad", "stride",
         "dy0", "dy_step", "dx0", "dx_step", "out_h", "out_w", "out_c", "oy_mul", "oy_add", "ox_mul", "ox_add",
-        "phases_y", "phases_x")] + [("flags", c_uint32), ("tile_m", c_int32), ("tile_n", c_int32)]
+        "phases_y", "phases_x")] + [("flags", c_uint32), ("tile_m", c_int32), ("tile_n", c_int32), ("stride_x", c_int32)]
 
 
 # every symbol include/simple_pose_hip.h declares: name -> (restype, argtypes)
@@ -86,6 +86,7 @@ SYMBOLS = {
     "sp_conv2d_dgrad_bn_bwd_stats": (c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "sp_bn_bwd_sums_from_conv": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "sp_u8hwc_bgr_to_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "sp_nchw_to_nhwc4_bf16": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "sp_masked_mse": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
 }
 

@@ -69,7 +69,7 @@ struct ConvArgs {
     int grid_h, grid_w;
     int c_out, n_pad, k_pad;
     int taps_h, taps_w;
-    int stride, dy0, dy_step, dx0, dx_step;
+    int stride, stride_x, dy0, dy_step, dx0, dx_step;   // stride: y (and x unless the descriptor says otherwise)
     int out_h, out_w, out_c;
     int oy_mul, oy_add, ox_mul, ox_add;
     int phases_x;  // 1 or 2
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
             const int gw = p.grid_w, ghw = p.grid_h * gw;
             const int b = m / ghw, rem = m - b * ghw;
             const int gy = rem / gw, gx = rem - gy * gw;
-            const int iy0 = gy * p.stride + dy0, ix0 = gx * p.stride + dx0;
+            const int iy0 = gy * p.stride + dy0, ix0 = gx * p.stride_x + dx0;
             e.x = ((b * p.in_h + iy0) * p.in_w + ix0) * p.c_in * ES;
             unsigned msk = 0;
             if (UNIFORM_TAP) {
@@ -787,7 +787,7 @@ static int conv_fwd_impl(const sp_conv_desc* d, const void* x, const void* w_pac
     const bool bf16 = d->flags & SP_CONV_BF16;
     const int es = bf16 ? 2 : 4, epc = 16 / es, bke = 128 / es;
     SP_REQUIRE(d->c_in > 0 && d->c_in % epc == 0, "sp_conv2d_fwd: c_in=%d must be a positive multiple of %d", d->c_in, epc);
-    SP_REQUIRE(d->taps_h > 0 && d->taps_w > 0 && d->stride > 0, "sp_conv2d_fwd: bad taps/stride");
+    SP_REQUIRE(d->taps_h > 0 && d->taps_w > 0 && d->stride > 0 && d->stride_x >= 0, "sp_conv2d_fwd: bad taps/stride");
     SP_REQUIRE(d->k_pad % bke == 0 && d->k_pad >= d->taps_h * d->taps_w * d->c_in,
                "sp_conv2d_fwd: k_pad=%d must be a multiple of %d and >= taps*c_in=%d", d->k_pad, bke,
                d->taps_h * d->taps_w * d->c_in);
@@ -830,7 +830,7 @@ static int conv_fwd_impl(const sp_conv_desc* d, const void* x, const void* w_pac
     a.grid_h = d->grid_h; a.grid_w = d->grid_w;
     a.c_out = d->c_out; a.n_pad = d->n_pad; a.k_pad = d->k_pad;
     a.taps_h = d->taps_h; a.taps_w = d->taps_w;
-    a.stride = d->stride; a.dy0 = d->dy0; a.dy_step = d->dy_step; a.dx0 = d->dx0; a.dx_step = d->dx_step;
+    a.stride = d->stride; a.stride_x = d->stride_x > 0 ? d->stride_x : d->stride; a.dy0 = d->dy0; a.dy_step = d->dy_step; a.dx0 = d->dx0; a.dx_step = d->dx_step;
     a.out_h = d->out_h; a.out_w = d->out_w; a.out_c = d->out_c;
     a.oy_mul = d->oy_mul; a.oy_add = d->oy_add; a.ox_mul = d->ox_mul; a.ox_add = d->ox_add;
     a.phases_x = d->phases_x; a.flags = d->flags; a.tiles_m = a.tiles_n = 0;

@@ -273,6 +273,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, 
 extern "C" int sp_conv2d_wgrad(const sp_conv_desc* d, const void* g, int g_channels, const void* a, int n_valid, int c_valid, int kw_valid,
                                int64_t dst_stride_n, int64_t dst_stride_c, float* dw, void* workspace, int64_t workspace_bytes,
                                void* stream) {
+    SP_REQUIRE(d && (d->stride_x == 0 || d->stride_x == d->stride), "sp_conv2d_wgrad: separate x / y strides are a forward-only feature");
     SP_REQUIRE(d && g && a && dw && workspace, "sp_conv2d_wgrad: null pointer");
     const bool bf16 = d->flags & SP_CONV_BF16;
     const int es = bf16 ? 2 : 4, epc = 16 / es;

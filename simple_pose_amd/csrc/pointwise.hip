@@ -163,13 +163,17 @@ __global__ void u8hwc_bgr_to_nchw_kernel(const unsigned char* __restrict__ img, 
 
 // The same normalisation straight into the network's input layout: BGR u8 HWC -> RGB NHWC4 fp32 / NHWC8 bf16 (pad channels 0).
 // One pass instead of normalise (NCHW fp32) + layout change: 3 B read, 16 B written per pixel.
-template <bool BF16OUT>
+template <int BF16OUT>   // 0: NHWC4 fp32, 1: NHWC8 bf16, 2: NHWC4 bf16
 __global__ void u8hwc_bgr_to_nhwc_kernel(const unsigned char* __restrict__ img, u32x4* __restrict__ out, float m0, float m1, float m2,
                                          long long total) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const unsigned char* p = img + i * 3;
         const float r = (float)p[2] / 255.0f - m0, g = (float)p[1] / 255.0f - m1, b = (float)p[0] / 255.0f - m2;
-        if constexpr (BF16OUT) {
+        if constexpr (BF16OUT == 2) {
+            typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
+            const bf16x4_ v = {(__bf16)r, (__bf16)g, (__bf16)b, (__bf16)0.f};
+            reinterpret_cast<unsigned long long*>(out)[i] = __builtin_bit_cast(unsigned long long, v);
+        } else if constexpr (BF16OUT == 1) {
             typedef __bf16 bf16x8_ __attribute__((ext_vector_type(8)));
             bf16x8_ v = {(__bf16)r, (__bf16)g, (__bf16)b, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
             out[i] = __builtin_bit_cast(u32x4, v);
@@ -300,10 +304,13 @@ extern "C" int sp_u8hwc_bgr_to_nhwc(const unsigned char* img, void* out, int out
     SP_REQUIRE(batch > 0 && h > 0 && w > 0, "sp_u8hwc_bgr_to_nhwc: bad shape");
     const long long total = (long long)batch * h * w;
     SP_REQUIRE(total * 16 < (1ll << 31), "sp_u8hwc_bgr_to_nhwc: tensor too large");
-    if (out_bf16) hipLaunchKernelGGL(u8hwc_bgr_to_nhwc_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, img,
-                                 reinterpret_cast<u32x4*>(out), mean_rgb_host[0], mean_rgb_host[1], mean_rgb_host[2], total);
-    else hipLaunchKernelGGL(u8hwc_bgr_to_nhwc_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, img,
-                            reinterpret_cast<u32x4*>(out), mean_rgb_host[0], mean_rgb_host[1], mean_rgb_host[2], total);
+    SP_REQUIRE(out_bf16 >= 0 && out_bf16 <= 2 && (out_bf16 != 2 || w % 2 == 0), "sp_u8hwc_bgr_to_nhwc: out_bf16 must be 0, 1 or 2 (2: w even)");
+#define SP_U8_LAUNCH(MODE) hipLaunchKernelGGL(u8hwc_bgr_to_nhwc_kernel<MODE>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, img, \
+                                              reinterpret_cast<u32x4*>(out), mean_rgb_host[0], mean_rgb_host[1], mean_rgb_host[2], total)
+    if (out_bf16 == 2) SP_U8_LAUNCH(2);
+    else if (out_bf16 == 1) SP_U8_LAUNCH(1);
+    else SP_U8_LAUNCH(0);
+#undef SP_U8_LAUNCH
     return sp_check_launch("u8hwc_bgr_to_nhwc_kernel");
 }
 

@@ -23,6 +23,20 @@ __global__ void nchw_to_nhwc8_bf16_kernel(const float* __restrict__ x, u32x4* __
     }
 }
 
+// [B,C<=4,H,W] fp32 -> [B,H,W,4] bf16: the bf16 stem reads two neighbouring pixels as one 8-channel "pair pixel"
+__global__ void nchw_to_nhwc4_bf16_kernel(const float* __restrict__ x, unsigned long long* __restrict__ y, int C, int hw, long long total) {
+    typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / hw;
+        const int pix = (int)(i - b * hw);
+        const float* src = x + b * C * hw + pix;
+        bf16x4_ v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = (__bf16)(c < C ? src[(long long)c * hw] : 0.f);
+        y[i] = __builtin_bit_cast(unsigned long long, v);
+    }
+}
+
 __device__ __forceinline__ float pmax(float m, float v) { return (v > m || v != v) ? v : m; }
 
 __global__ void maxpool3x3s2_bf16_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ y, int H, int W, int C8, int Ho, int Wo,
@@ -106,6 +120,17 @@ extern "C" int sp_nchw_to_nhwc8_bf16(const float* x, void* y, int batch, int cha
     hipLaunchKernelGGL(nchw_to_nhwc8_bf16_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, reinterpret_cast<u32x4*>(y),
                        channels, h * w, total);
     return sp_check_launch("nchw_to_nhwc8_bf16_kernel");
+}
+
+extern "C" int sp_nchw_to_nhwc4_bf16(const float* x, void* y, int batch, int channels, int h, int w, void* stream) {
+    SP_REQUIRE(x && y, "sp_nchw_to_nhwc4_bf16: null pointer");
+    SP_REQUIRE(batch > 0 && h > 0 && w > 0 && w % 2 == 0 && channels >= 1 && channels <= 4, "sp_nchw_to_nhwc4_bf16: bad shape B=%d C=%d H=%d W=%d (W even)",
+               batch, channels, h, w);
+    const long long total = (long long)batch * h * w;
+    SP_REQUIRE(total * 8 < (1ll << 31), "sp_nchw_to_nhwc4_bf16: tensor too large");
+    hipLaunchKernelGGL(nchw_to_nhwc4_bf16_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       reinterpret_cast<unsigned long long*>(y), channels, h * w, total);
+    return sp_check_launch("nchw_to_nhwc4_bf16_kernel");
 }
 
 extern "C" int sp_maxpool3x3s2_nhwc_bf16(const void* x, void* y, int batch, int h, int w, int c, void* stream) {

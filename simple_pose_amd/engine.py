@@ -213,9 +213,9 @@ class Program:
             src = bufs[op.src]
             if src.dtype == torch.uint8:           # BGR crops [B,h,w,3]: normalise (coco.py:136) and lay out in one pass
                 mean = (ctypes.c_float * 3)(0.485, 0.456, 0.406)
-                _lib.check(lib.sp_u8hwc_bgr_to_nhwc(P(src), P(bufs[op.dst]), int(self.dtype == "bf16"), B, h, w, mean, stream), op.name)
+                _lib.check(lib.sp_u8hwc_bgr_to_nhwc(P(src), P(bufs[op.dst]), 2 if self.dtype == "bf16" else 0, B, h, w, mean, stream), op.name)
             else:
-                fn = lib.sp_nchw_to_nhwc8_bf16 if self.dtype == "bf16" else lib.sp_nchw_to_nhwc4
+                fn = lib.sp_nchw_to_nhwc4_bf16 if self.dtype == "bf16" else lib.sp_nchw_to_nhwc4
                 _lib.check(fn(P(src), P(bufs[op.dst]), B, c, h, w, stream), op.name)
         elif op.kind == "pixel_shuffle":
             h, w, c = op.args
@@ -413,7 +413,9 @@ class ProgramBuilder:
     def to_nhwc4(self, src: str) -> str:
         h, w, c = self.p.shapes[src]
         dst = self._fresh("x4")
-        self.p.shapes[dst] = (h, w, self.cpad)
+        # fp32: NHWC4 (one 16-byte chunk per pixel).  bf16: NHWC4 as well (8 bytes per pixel) - the stem then reads x-PAIRS of pixels
+        # as 8-channel chunks (conv(): `paired`), which halves its K compared with padding every pixel to 8 channels
+        self.p.shapes[dst] = (h, w, 4)
         self._add(Op("to_nhwc4", src, dst, args=(c, h, w), name="to_nhwc4"))
         return dst
 
@@ -430,7 +432,22 @@ class ProgramBuilder:
         h, w, c_buf = self.p.shapes[src]
         O, I, kh, kw = weight.shape
         k_mult = 64 if self.bf16 else 32
-        if c_buf == self.cpad and I < self.cpad:   # stem on NHWC4 / NHWC8: pad channels to one chunk and the tap row to 8 / 4
+        paired = False
+        if self.bf16 and c_buf == 4 and I < 4:
+            # bf16 stem on the NHWC4 image read as pixel pairs [h, w/2, 8]: pixel 2*ox - pad + kx = pair (ox - ceil(pad/2)) + pt, half
+            # `sub`, with kx + s0 = 2*pt + sub.  A stride of 2 pixels is a stride of ONE pair: separate x / y strides (stride_x).
+            if stride != 2 or w % 2:
+                raise NotImplementedError("bf16 stem: stride-2 convolution on an even-width image expected")
+            paired = True
+            half = (pad + 1) // 2
+            s0 = 2 * half - pad
+            tpw = (kw - 1 + s0) // 2 + 1
+            w2 = torch.zeros((O, 8, kh, tpw), dtype=weight.dtype, device=weight.device)
+            for kx in range(kw):
+                pt, sub = (kx + s0) // 2, (kx + s0) % 2
+                w2[:, sub * 4: sub * 4 + I, :, pt] = weight[:, :, :, kx]
+            packed, th, tw, ci, k_pad = pack_conv(w2, k_mult=k_mult)
+        elif c_buf == self.cpad and I < self.cpad:   # fp32 stem on NHWC4: pad channels to one chunk and the tap row to 8 / 4
             taps_w_pad = _round_up(kw, 8) if kw > 4 else 4
             packed, th, tw, ci, k_pad = pack_conv(weight, c_in_pad=self.cpad, taps_w_pad=taps_w_pad, k_mult=k_mult)
         else:
@@ -446,6 +463,8 @@ class ProgramBuilder:
         d.grid_h, d.grid_w, d.c_out, d.n_pad = gh, gw, O, packed.shape[0]
         d.taps_h, d.taps_w, d.k_pad, d.stride = th, tw, k_pad, stride
         d.dy0, d.dy_step, d.dx0, d.dx_step = -pad, 1, -pad, 1
+        if paired:
+            d.in_w, d.stride_x, d.dx0 = w // 2, 1, -half
         d.phases_y = d.phases_x = 1
         flags = SP_CONV_RELU if relu else 0
         if pixel_shuffle:

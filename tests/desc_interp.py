@@ -12,6 +12,7 @@ from simple_pose_amd._lib import SP_CONV_BF16, SP_CONV_OUT_NCHW, SP_CONV_PIXEL_S
 def conv_desc_cpu(d, x, w, scale, shift, res, y, B):
     """x: [B,in_h,in_w,c_in]; w: [phases*n_pad, k_pad]; y: NHWC [B,out_h,out_w,out_c] or NCHW if flagged (in place)."""
     phases = d.phases_y * d.phases_x
+    x = x.reshape(B, d.in_h, d.in_w, d.c_in)      # the bf16 stem reads the [h, w, 4] image as pixel pairs [h, w/2, 8]
     wp = w.reshape(phases, d.n_pad, d.k_pad)
     gy = torch.arange(d.grid_h).view(-1, 1)
     gx = torch.arange(d.grid_w).view(1, -1)
@@ -21,7 +22,7 @@ def conv_desc_cpu(d, x, w, scale, shift, res, y, B):
         for ty in range(d.taps_h):
             for tx in range(d.taps_w):
                 iy = gy * d.stride + d.dy0 + py + ty * d.dy_step
-                ix = gx * d.stride + d.dx0 + px + tx * d.dx_step
+                ix = gx * (d.stride_x or d.stride) + d.dx0 + px + tx * d.dx_step
                 ok = ((iy >= 0) & (iy < d.in_h) & (ix >= 0) & (ix < d.in_w))
                 iyc, ixc = iy.clamp(0, d.in_h - 1).expand(d.grid_h, d.grid_w), ix.clamp(0, d.in_w - 1).expand(d.grid_h, d.grid_w)
                 g = x[:, iyc, ixc, :].float() * ok.expand(d.grid_h, d.grid_w)[None, :, :, None]
