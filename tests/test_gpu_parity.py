@@ -784,3 +784,30 @@ def test_detector_driven_pipeline_composes_end_to_end(golden):
     keep = pose_oracle.oks_nms(k3, osc, areas.astype(np.float64), 0.9)
     assert [r["keypoints"] for r in res] == [k3[i].reshape(-1).tolist() for i in keep]
     assert 1 <= len(res) <= len(boxes) and all(r["image_id"] == 7 for r in res)
+
+
+@pytest.mark.parametrize("k,pad,H,W", [(7, 3, 64, 96), (3, 1, 34, 20), (5, 2, 32, 64)])
+def test_bf16_stem_on_pixel_pairs_vs_fp64(k, pad, H, W):
+    """The bf16 stem reads the NHWC4 image as x-pairs (sp_conv_desc.stride_x = 1 for a pixel stride of 2; odd and even paddings shift
+    the pair grid differently).  Reference: fp64 stride-2 convolution of the same bf16-rounded image and weights."""
+    B = 3
+    x = torch.from_numpy(synth.input_images(B, seed=8, h=H, w=W)).bfloat16().float()
+    w = torch.from_numpy(synth.tensor_normal(6, f"stem{k}/w", (32, 3, k, k), std=(2.0 / (3 * k * k)) ** 0.5)).bfloat16().float()
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), stride=2, padding=pad))
+    b = engine.ProgramBuilder(H, W, dtype="bf16")
+    x4 = b.to_nhwc4("input")
+    out = b.conv(x4, w.to(DEV), stride=2, pad=pad, relu=True, name="conv1")
+    op = b.p.ops[-1]
+    assert op.desc.stride_x == 1 and op.desc.in_w == W // 2 and op.desc.c_in == 8 and op.desc.k_pad < k * 8 * 8
+    oh, ow, oc = b.p.shapes[out]
+    xin = torch.empty((B, H, W, 4), dtype=torch.bfloat16, device=DEV)
+    _lib.check(_lib.lib().sp_nchw_to_nhwc4_bf16(_lib.ptr(x.to(DEV)), _lib.ptr(xin), B, 3, H, W, _lib.current_stream()))
+    y = torch.full((B, oh, ow, oc), float("nan"), dtype=torch.bfloat16, device=DEV)
+    op.desc.batch = B
+    _lib.check(_lib.lib().sp_conv2d_fwd(op.desc, _lib.ptr(xin), _lib.ptr(op.w), None, None, None, _lib.ptr(y), _lib.current_stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(xin[..., :3].float().cpu(), x.permute(0, 2, 3, 1)) and (xin[..., 3] == 0).all()
+    got = y.float().cpu().permute(0, 3, 1, 2).double()
+    assert got.shape == ref.shape
+    err = (got - ref).abs().max() / ref.abs().max()
+    assert err < 6e-3, err
