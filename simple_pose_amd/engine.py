@@ -282,7 +282,7 @@ class Program:
         return GraphedForward(self, x, decoder, trans_inv, warmup)
 
     # -- per-layer tile autotuning -------------------------------------------------------------------------------
-    def autotune(self, x: torch.Tensor, reps: int = 3, verbose: bool = False) -> Dict[str, Tuple[int, int]]:
+    def autotune(self, x: torch.Tensor, reps: int = 5, verbose: bool = False) -> Dict[str, Tuple[int, int]]:
         """Time every legal workgroup tile of every distinct conv shape once (HIP events on the launch stream, real
         activations of a warm-up pass as operands) and pin the fastest in the launch descriptors.  Results are
         bit-identical for every tile (same K reduction order), so this only moves speed.  ~0.2 s for ResNet-50."""
