@@ -269,6 +269,8 @@ def main():
 def _variant_name(op):
     """Kernel instantiation a conv launch resolves to (the name rocprofv3 reports)."""
     d = op.desc
+    if getattr(op, "direct", False):
+        return "conv3x3_c32_direct_kernel"
     bm, bn = d.tile_m, d.tile_n
     wr, wc = {(128, 128): (2, 2), (64, 128): (2, 2), (128, 64): (2, 2), (64, 64): (2, 2), (256, 64): (4, 1), (128, 32): (4, 1)}[(bm, bn)]
     bf16 = bool(d.flags & 0x8)

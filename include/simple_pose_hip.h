@@ -27,7 +27,7 @@ extern "C" {
 #define SP_EINVAL (-1)   /* bad argument / unsupported shape (message in sp_last_error) */
 #define SP_ELAUNCH (-2)  /* HIP launch or runtime failure */
 
-#define SP_ABI_VERSION 16
+#define SP_ABI_VERSION 17
 
 /* epilogue / layout flags of sp_conv_desc.flags */
 #define SP_CONV_RELU 0x1u          /* y = max(y, 0) after scale/shift (+ residual) */
@@ -86,6 +86,13 @@ int sp_nchw_to_nhwc4(const float* x_nchw, float* y_nhwc4, int batch, int channel
  * scale/shift: [c_out] or NULL (scale NULL -> 1, shift NULL -> 0); residual: same layout as y or NULL. */
 int sp_conv2d_fwd(const sp_conv_desc* desc, const void* x, const void* w_packed, const float* scale,
                   const float* shift, const void* residual, void* y, void* stream);
+
+/* Direct (non-im2col) 3x3 stride-1 pad-1 convolution for 32 -> 32 channels in bf16 (HRNet's high-resolution branch): the halo tile of
+ * an 8x16 output tile goes through LDS once instead of once per tap.  Same arguments and bit-identical results as sp_conv2d_fwd for
+ * the descriptors sp_conv3x3_direct_ok accepts (returns 1 / 0); tile fields are ignored. */
+int sp_conv3x3_direct_ok(const sp_conv_desc* desc);
+int sp_conv3x3_direct(const sp_conv_desc* desc, const void* x, const void* w_packed, const float* scale, const float* shift,
+                      const void* residual, void* y, void* stream);
 
 /* The tile sp_conv2d_fwd picks when desc->tile_m == tile_n == 0; legal tiles: 128x128 64x128 128x64 64x64 256x64 128x32
  * (tile_n must divide n_pad).  Host code may time the legal tiles once per layer shape and pin the fastest. */

@@ -20,7 +20,7 @@ SP_CONV_PIXEL_SHUFFLE = 0x4
 SP_CONV_BF16 = 0x8
 SP_CONV_OUT_F32 = 0x10
 CONV_TILES = ((128, 128), (64, 128), (128, 64), (64, 64), (256, 64), (128, 32))
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 class HipLibraryError(RuntimeError):
@@ -87,6 +87,8 @@ SYMBOLS = {
     "sp_bn_bwd_sums_from_conv": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "sp_u8hwc_bgr_to_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "sp_nchw_to_nhwc4_bf16": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "sp_conv3x3_direct_ok": (c_int, [ctypes.POINTER(ConvDesc)]),
+    "sp_conv3x3_direct": (c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
     "sp_masked_mse": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
 }
 

@@ -115,6 +115,7 @@ class Op:
     flops: int = 0               # algorithmic FLOPs per image (2*MACs, real taps/channels only)
     name: str = ""
     lane: int = 0                # HIP stream the op is issued on (0 = the caller's stream); independent branches get their own
+    direct: bool = False         # conv: use sp_conv3x3_direct (bf16 3x3, 32 -> 32 channels) instead of the implicit GEMM; same bits
 
     def reads(self) -> Tuple[str, ...]:
         extra = (self.args[2],) if self.kind == "se_gate" else ()
@@ -202,8 +203,9 @@ class Program:
         P = _lib.ptr
         if op.kind == "conv":
             op.desc.batch = B
-            _lib.check(lib.sp_conv2d_fwd(op.desc, P(bufs[op.src]), P(op.w), P(op.scale), P(op.shift),
-                                         P(bufs[op.res]) if op.res else None, P(bufs[op.dst]), stream), op.name)
+            fn = lib.sp_conv3x3_direct if op.direct else lib.sp_conv2d_fwd
+            _lib.check(fn(op.desc, P(bufs[op.src]), P(op.w), P(op.scale), P(op.shift),
+                          P(bufs[op.res]) if op.res else None, P(bufs[op.dst]), stream), op.name)
         elif op.kind == "maxpool":
             h, w, c = op.args
             fn = lib.sp_maxpool3x3s2_nhwc_bf16 if self.dtype == "bf16" else lib.sp_maxpool3x3s2_nhwc
@@ -322,20 +324,39 @@ class Program:
                         print(f"  {op.name:28s} {bm:3d}x{bn:<3d} {t * 1e3:8.1f} us")
                     if best is None or t < best[0]:
                         best = (t, bm, bn)
+                if lib.sp_conv3x3_direct_ok(d):           # the direct kernel competes with the best GEMM tile; (-1, -1) = direct
+                    args = (d, P(bufs[op.src]), P(op.w), P(op.scale), P(op.shift), P(bufs[op.res]) if op.res else None, P(bufs[op.dst]), stream)
+                    _lib.check(lib.sp_conv3x3_direct(*args), op.name)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(reps):
+                        lib.sp_conv3x3_direct(*args)
+                    e1.record()
+                    e1.synchronize()
+                    t = e0.elapsed_time(e1) / reps
+                    if verbose:
+                        print(f"  {op.name:28s} direct  {t * 1e3:8.1f} us")
+                    if t < best[0]:
+                        best = (t, -1, -1)
                 chosen[key] = (best[1], best[2])
-            d.tile_m, d.tile_n = chosen[key]
+            op.direct = chosen[key][0] < 0
+            if not op.direct:
+                d.tile_m, d.tile_n = chosen[key]
             report[op.name] = chosen[key]
         self.tuned_for_batch = B
         return report
 
     def tiles(self) -> Dict[str, Tuple[int, int]]:
-        return {op.name: (op.desc.tile_m, op.desc.tile_n) for op in self.ops if op.kind == "conv"}
+        return {op.name: ((-1, -1) if op.direct else (op.desc.tile_m, op.desc.tile_n)) for op in self.ops if op.kind == "conv"}
 
     def set_tiles(self, tiles: Dict[str, Tuple[int, int]], batch: int) -> None:
         """Re-apply a tile table produced by autotune() (e.g. loaded from a file) instead of re-timing."""
         for op in self.ops:
             if op.kind == "conv" and op.name in tiles:
-                op.desc.tile_m, op.desc.tile_n = (int(v) for v in tiles[op.name])
+                tm, tn = (int(v) for v in tiles[op.name])
+                op.direct = tm < 0
+                if not op.direct:
+                    op.desc.tile_m, op.desc.tile_n = tm, tn
         self.tuned_for_batch = batch
 
     @property
@@ -484,8 +505,10 @@ class ProgramBuilder:
         d.flags = flags
         dst = dst or self._fresh(name)
         self.p.shapes[dst] = (d.out_h, d.out_w, d.out_c)
-        self._add(Op("conv", src, dst, res=res, desc=d, w=packed, scale=scale, shift=shift, name=name,
-                             flops=2 * gh * gw * O * I * kh * kw))
+        op = Op("conv", src, dst, res=res, desc=d, w=packed, scale=scale, shift=shift, name=name, flops=2 * gh * gw * O * I * kh * kw)
+        # small-channel 3x3 layers (HRNet's 32-channel branch): the direct kernel is the default, the tuner may still pick a GEMM tile
+        op.direct = bool(self.bf16 and _lib.lib().sp_conv3x3_direct_ok(d))
+        self._add(op)
         return dst
 
     def deconv_k4s2p1(self, src: str, weight: torch.Tensor, *, scale=None, shift=None, relu: bool = False,
