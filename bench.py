@@ -4,9 +4,11 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 128] [--arch dconv|duc] [--no-cpu-baseline]
 
 One "step" = one pass of the hot path (network forward + key-point decode) over one batch of synthetic images that
-are already resident in HBM.  N > 1: launched by torch.distributed.run, one process per GPU; the path shards by image
-(independent replicas, no data-path collective) -> weak scaling; barrier + device sync on both sides of the timed
-region, MAX over ranks, rank 0 prints ONE JSON line.
+are already resident in HBM.  N > 1: one process per GPU - either started by `python -m torch.distributed.run` (RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) or, when invoked plainly as `python bench.py --gpus N`, by this
+file itself: the parent starts N fresh child interpreters BEFORE importing torch or touching the GPU and forwards rank
+0's line.  The path shards by image (independent replicas, no data-path collective) -> weak scaling; barrier + device
+sync on both sides of the timed region, MAX over ranks, rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -97,28 +99,104 @@ def cpu_baseline(arch: str):
                       f"best of thread counts <= {threads} on {os.cpu_count()} logical CPUs"}
 
 
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: this process is only a launcher.  It has
+    touched neither torch nor the GPU (a process that has initialised HIP must never be replaced or forked into ranks); it starts
+    N fresh interpreters of this same file, one per GPU, with the env:// rendezvous variables the reference's DDP solver reads
+    (processors/ddp_pose_resnet_solver.py:36,85-93: rank doubles as the device index), forwards rank 0's single JSON line and
+    returns non-zero if any rank fails."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:                      # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ)
+    base.update({"WORLD_SIZE": str(args.gpus), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": base.get("MASTER_PORT", str(port)),
+                 "LOCAL_WORLD_SIZE": str(args.gpus), "SP_BENCH_CHILD": "1"})
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    base.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    procs = []
+    for r in range(args.gpus):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
+    rc = 0
+    out0 = ""
+    try:
+        # rank 0's stdout is small (one line); drain it while polling every child so that one dead rank ends the job
+        import selectors
+        sel = selectors.DefaultSelector()
+        sel.register(procs[0].stdout, selectors.EVENT_READ)
+        open0 = True
+        while True:
+            if open0:
+                for _ in sel.select(timeout=0.5):
+                    chunk = procs[0].stdout.readline()
+                    if chunk == "":
+                        open0 = False
+                        sel.unregister(procs[0].stdout)
+                    else:
+                        out0 += chunk
+            else:
+                time.sleep(0.2)
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:
+                rc = bad[0]
+                break
+            if all(c == 0 for c in codes):
+                break
+    finally:
+        for p in procs:                              # exact PIDs of the children this launcher started
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except Exception:
+                p.kill()
+    if procs[0].stdout and not procs[0].stdout.closed:
+        out0 += procs[0].stdout.read() or ""
+    lines = [ln for ln in out0.splitlines() if ln.lstrip().startswith("{")]
+    for ln in out0.splitlines():
+        if ln not in lines:
+            print(ln, file=sys.stderr)
+    if rc == 0 and len(lines) != 1:
+        print(f"bench.py launcher: expected ONE JSON line from rank 0, got {len(lines)}", file=sys.stderr)
+        rc = 1
+    if lines:
+        print(lines[-1], flush=True)
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))        # before torch is imported or the GPU is touched
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this host driver: before the first HIP call
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     n_dev = torch.cuda.device_count()
-    dev_index = local_rank % max(n_dev, 1)
+    if n_dev == 0:
+        raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU path")
+    if world > n_dev and args.dist_backend == "nccl":
+        raise SystemExit(f"--gpus {world} on a node with {n_dev} GPU(s): RCCL needs one device per rank "
+                         "(--dist-backend gloo shares devices, for exercising the N > 1 path only)")
+    dev_index = local_rank % n_dev
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(dev_index)
         if args.dist_backend == "nccl":
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-    elif args.gpus > 1:
-        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
     red_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")   # where the measurement's scalar reductions live
@@ -240,7 +318,8 @@ def main():
                 "config": {"workload": f"{name} 256x192 train step, bs={B} per GPU, {'fp32' if args.dtype == 'f32' else 'bf16 compute + fp32 master weights/Adam'}, train-mode BN (batch statistics), Adam lr 1e-3, "
                                        "targets from the HIP encoder; N > 1: SyncBatchNorm " + ("off" if args.no_sync_bn else "on") +
                                        f", gradients all-reduced in {args.bucket_mb:g} MB buckets overlapped with backward (RCCL)",
-                           "images_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
+                           "images_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                           "collectives": ("RCCL (nccl backend)" if args.dist_backend == "nccl" else "gloo") if world > 1 else "none"},
                 "gflop_per_image": round(gflop, 3), "network_tflops": round(value * gflop / 1e3, 2),
                 "network_frac_of_matrix_peak": round(value * gflop / 1e3 / ((FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else BF16_MATRIX_PEAK_TFLOPS) * world), 4),
                 "roofline": None, "cpu_baseline": None, "final_loss": float(out[0].item()), "step_split_ms": step_split}
@@ -254,12 +333,13 @@ def main():
                 "config": {"workload": f"{name} 256x192 bs={B} per GPU, {'fp32' if args.dtype == 'f32' else 'bf16 (fp32 accumulate)'} forward "
                                        "(NCHW in -> heat maps) + GaussTaylor decode, eval-mode BN, conditioned random weights",
                            "images_per_gpu": B, "global_batch": B * world, "parallelism": f"replicas x{world} (no collective)",
+                           "ranks": f"{world} process(es), one per GPU" + (f", {args.dist_backend} for the barrier / MAX only" if world > 1 else ""),
                            "launch": "one hipGraph per step" if args.graph else "stream launches"},
                 "gflop_per_image": round(prog.flops_per_image / 1e9, 4),
                 "network_tflops": round(value * prog.flops_per_image / 1e12, 2),
                 "network_frac_of_matrix_peak": round(value * prog.flops_per_image / 1e12 / (peak * world), 4),
                 "roofline": roofline,
-                "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(args.arch),
+                "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args.arch),   # rank 0 at N = 1 only
             }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -842,3 +842,32 @@ def test_direct_3x3_c32_kernel_is_bit_identical_to_the_implicit_gemm(B, H, W, re
     # and what it refuses
     d.c_out = 64
     assert lib.sp_conv3x3_direct_ok(d) == 0 and lib.sp_conv3x3_direct(d, P(x), P(op.w), None, None, None, P(y1), st) != 0
+
+
+# ---------------------------------------------------------------------------------------------- bench.py --gpus N as the driver invokes it
+@pytest.mark.parametrize("mode", ["infer", "train"])
+def test_bench_self_launches_two_ranks(mode):
+    """`python bench.py --gpus 2` (no torchrun, no WORLD_SIZE): the parent spawns the ranks before touching the GPU and forwards
+    rank 0's ONE line.  On a 1-GPU box the two ranks share the device and gloo carries the barrier / reductions."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8",
+           "--dist-backend", backend, "--no-cpu-baseline", "--no-kernel-events", "--mode", mode]
+    if mode == "train":
+        cmd += ["--dtype", "bf16"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1
+    assert line["config"]["global_batch"] == 16 and line["config"]["images_per_gpu"] == 8
+    assert line["value"] > 0 and line["scaling"] == "weak" and line["cpu_baseline"] is None
+    # whole-job throughput = units of all ranks / MAX time: consistent with ms_per_step
+    assert abs(line["value"] - 16 / (line["ms_per_step"] * 1e-3)) / line["value"] < 0.02

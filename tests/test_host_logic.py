@@ -215,3 +215,22 @@ def test_solver_schedule_and_config_schema_match_the_reference():
     for v in (1.0, 2.0, 6.0):
         lg.update(torch.tensor(v))
     assert lg.avg() == 3.0
+
+
+def test_bench_self_launch_fails_loudly_without_a_gpu():
+    """`python bench.py --gpus 2` is its own launcher (no torch.distributed.run needed): the parent starts 2 fresh ranks before it
+    imports torch.  On a machine without a GPU every rank exits with the "no CPU path" message and the launcher returns non-zero
+    instead of hanging or printing a line."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    if torch.cuda.is_available():
+        pytest.skip("covered by the gpu test on a GPU box")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert r.stdout.strip() == ""
+    assert r.stderr.count("no CPU path") == 2          # both ranks started, both refused
