@@ -347,20 +347,10 @@ def main():
 
 
 def _variant_name(op):
-    """Kernel instantiation a conv launch resolves to (the name rocprofv3 reports)."""
-    d = op.desc
-    if getattr(op, "direct", False):
-        return "conv3x3_c32_direct_kernel"
-    bm, bn = d.tile_m, d.tile_n
-    wr, wc = {(128, 128): (2, 2), (64, 128): (2, 2), (128, 64): (2, 2), (64, 64): (2, 2), (256, 64): (4, 1), (128, 32): (4, 1)}[(bm, bn)]
-    bf16 = bool(d.flags & 0x8)
-    uniform = (d.c_in % (64 if bf16 else 32) == 0) and d.taps_h * d.taps_w <= 32
-    out16 = bf16 and not (d.flags & 0x10)             # template flag OUT16: bf16 operands without SP_CONV_OUT_F32
-    t = lambda v: "true" if v else "false"
-    small = bm * bn <= 64 * 64
-    nk = d.k_pad // 64
-    deep = bf16 and nk % (4 if small else 2) == 0 and nk >= (12 if small else 32)      # the launcher's rule (conv_igemm.hip launch_t)
-    return f"conv_igemm_kernel<{bm}, {bn}, {wr}, {wc}, {t(uniform)}, {t(bf16)}, {t(out16)}, false, {t(deep)}>"
+    """Kernel instantiation a conv launch resolves to (the name rocprofv3 reports): asked of the library's own dispatch
+    (sp_conv2d_kernel_name), so it cannot drift from what is launched."""
+    from simple_pose_amd import _lib
+    return _lib.conv_kernel_name(op.desc, op.res is not None, 3 if getattr(op, "direct", False) else 0)
 
 
 def kernel_roofline(prog, x, steps: int, layers_out=None, peak=FP32_MATRIX_PEAK_TFLOPS):

@@ -27,7 +27,7 @@ extern "C" {
 #define SP_EINVAL (-1)   /* bad argument / unsupported shape (message in sp_last_error) */
 #define SP_ELAUNCH (-2)  /* HIP launch or runtime failure */
 
-#define SP_ABI_VERSION 17
+#define SP_ABI_VERSION 18
 
 /* epilogue / layout flags of sp_conv_desc.flags */
 #define SP_CONV_RELU 0x1u          /* y = max(y, 0) after scale/shift (+ residual) */
@@ -68,7 +68,14 @@ typedef struct sp_conv_desc {
     int32_t stride_x;                /* 0: same as `stride`.  Otherwise the x stride where it differs from the y stride (`stride`):
                                         the bf16 stem reads the 4-channel image as x-PAIRS of 8 values, where a stride of two
                                         pixels is a stride of one pair */
+    int32_t kernel;                  /* SP_CONV_KERNEL_IGEMM (0, default) or SP_CONV_KERNEL_RING: which kernel structure runs the
+                                        launch; same results bit for bit (same K order, same MFMA chain per output) */
 } sp_conv_desc;
+
+/* sp_conv_desc.kernel */
+#define SP_CONV_KERNEL_IGEMM 0 /* 4-wave workgroups, register-staged double buffer: every dtype / flag / tile listed at sp_conv2d_default_tile */
+#define SP_CONV_KERNEL_RING 1  /* bf16 only: persistent 8-wave workgroups fed by an LDS-DMA ring (buffer_load ... lds, counted vmcnt);
+                                  tiles 256x256 256x128 128x256 256x64 128x128; needs sp_conv2d_ring_ok(desc) == 1 */
 
 /* ---- library ---------------------------------------------------------------------------------- */
 int sp_abi_version(void);
@@ -93,6 +100,16 @@ int sp_conv2d_fwd(const sp_conv_desc* desc, const void* x, const void* w_packed,
 int sp_conv3x3_direct_ok(const sp_conv_desc* desc);
 int sp_conv3x3_direct(const sp_conv_desc* desc, const void* x, const void* w_packed, const float* scale, const float* shift,
                       const void* residual, void* y, void* stream);
+
+/* 1 when `desc` (flags, shapes, tile_m x tile_n) can run with kernel = SP_CONV_KERNEL_RING: bf16 NHWC in and out (ReLU, residual and
+ * fused PixelShuffle allowed; no NCHW / fp32 output), c_in % 64 == 0, taps <= 32, k_pad / 64 >= the tile's ring depth, tile_n | n_pad. */
+int sp_conv2d_ring_ok(const sp_conv_desc* desc);
+
+/* Name of the kernel instantiation a launch of `desc` resolves to, as rocprofv3's kernel trace reports it (without the
+ * "void (anonymous namespace)::" prefix and the argument list).  variant 0 = sp_conv2d_fwd, 1 = sp_conv2d_fwd_bn_stats,
+ * 2 = sp_conv2d_dgrad_bn_bwd_stats, 3 = sp_conv3x3_direct.  Produced by the launch dispatch itself (nothing is launched), so
+ * profiles and bench.py's roofline line key on exactly what ran. */
+int sp_conv2d_kernel_name(const sp_conv_desc* desc, int has_residual, int variant, char* buf, int cap);
 
 /* The tile sp_conv2d_fwd picks when desc->tile_m == tile_n == 0; legal tiles: 128x128 64x128 128x64 64x64 256x64 128x32
  * (tile_n must divide n_pad).  Host code may time the legal tiles once per layer shape and pin the fastest. */

@@ -20,7 +20,9 @@ SP_CONV_PIXEL_SHUFFLE = 0x4
 SP_CONV_BF16 = 0x8
 SP_CONV_OUT_F32 = 0x10
 CONV_TILES = ((128, 128), (64, 128), (128, 64), (64, 64), (256, 64), (128, 32))
-ABI_VERSION = 17
+ABI_VERSION = 18
+SP_CONV_KERNEL_IGEMM, SP_CONV_KERNEL_RING = 0, 1
+RING_TILES = ((256, 256), (256, 128), (128, 256), (256, 64), (128, 128))   # kernel = SP_CONV_KERNEL_RING (bf16)
 
 
 class HipLibraryError(RuntimeError):
@@ -32,7 +34,7 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [(n, c_int32) for n in (
         "batch", "in_h", "in_w", "c_in", "grid_h", "grid_w", "c_out", "n_pad", "taps_h", "taps_w", "k_pad", "stride",
         "dy0", "dy_step", "dx0", "dx_step", "out_h", "out_w", "out_c", "oy_mul", "oy_add", "ox_mul", "ox_add",
-        "phases_y", "phases_x")] + [("flags", c_uint32), ("tile_m", c_int32), ("tile_n", c_int32), ("stride_x", c_int32)]
+        "phases_y", "phases_x")] + [("flags", c_uint32), ("tile_m", c_int32), ("tile_n", c_int32), ("stride_x", c_int32), ("kernel", c_int32)]
 
 
 # every symbol include/simple_pose_hip.h declares: name -> (restype, argtypes)
@@ -42,6 +44,8 @@ SYMBOLS = {
     "sp_last_error": (ctypes.c_char_p, []),
     "sp_nchw_to_nhwc4": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "sp_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
+    "sp_conv2d_ring_ok": (c_int, [ctypes.POINTER(ConvDesc)]),
+    "sp_conv2d_kernel_name": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_int, ctypes.c_char_p, c_int]),
     "sp_conv2d_default_tile": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "sp_maxpool3x3s2_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "sp_pixel_shuffle2_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
@@ -117,6 +121,13 @@ def lib():
             raise HipLibraryError(f"ABI mismatch: library {handle.sp_abi_version()} vs binding {ABI_VERSION}")
         _lib = handle
     return _lib
+
+
+def conv_kernel_name(desc, has_residual: bool = False, variant: int = 0) -> str:
+    """Kernel instantiation a launch of `desc` resolves to (sp_conv2d_kernel_name: the library's own dispatch names it)."""
+    buf = ctypes.create_string_buffer(256)
+    check(lib().sp_conv2d_kernel_name(desc, int(has_residual), variant, buf, 256), "sp_conv2d_kernel_name")
+    return buf.value.decode()
 
 
 def check(rc: int, what: str = ""):

@@ -732,6 +732,11 @@ int launch_t(const ConvArgs& a, int phases, bool uniform, hipStream_t stream) {
         if (nk % pf == 0 && nk >= (BM * BN <= 64 * 64 ? 12 : 32))
             return launch_t<BM, BN, WR, WC, BF16, OUT16, STATS, true, BSTATS>(a, phases, uniform, stream);
     }
+    if (sp_name_query_active()) {
+        auto t = [](bool v) { return v ? "true" : "false"; };
+        sp_name_query_set("conv_igemm_kernel<%d, %d, %d, %d, %s, %s, %s, %s, %s, %s>", BM, BN, WR, WC, t(uniform), t(BF16), t(OUT16), t(STATS), t(DEEP), t(BSTATS));
+        return SP_OK;
+    }
     ConvArgs p = a;
     p.tiles_m = (a.M + BM - 1) / BM;
     p.tiles_n = a.n_pad / BN;
@@ -773,6 +778,8 @@ int launch(const ConvArgs& a, int phases, bool uniform, hipStream_t stream) {
 }  // namespace
 
 extern "C" int sp_conv2d_default_tile(const sp_conv_desc* d, int* tile_m, int* tile_n);
+int sp_conv_ring_launch(const sp_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift,
+                        const void* residual, void* y, void* stream);   // conv_ring.hip
 
 static int tile_rows_per_block(int bm, int bn) { return (bm == 256 && bn == 64) || (bm == 128 && bn == 32) ? 4 : 2; }   // WR of the tile
 
@@ -842,6 +849,11 @@ static int conv_fwd_impl(const sp_conv_desc* d, const void* x, const void* w_pac
     const int phases = d->phases_y * d->phases_x;
     hipStream_t s = (hipStream_t)stream;
 
+    SP_REQUIRE(d->kernel == SP_CONV_KERNEL_IGEMM || d->kernel == SP_CONV_KERNEL_RING, "sp_conv2d_fwd: unknown kernel id %d", d->kernel);
+    if (d->kernel == SP_CONV_KERNEL_RING) {
+        SP_REQUIRE(!stats_s && !bsrc, "sp_conv2d_fwd: the LDS-DMA ring kernel has no statistics epilogue");
+        return sp_conv_ring_launch(d, x, w_packed, scale, shift, residual, y, stream);
+    }
     // ---- tile shape: caller's choice (autotuned by the host, sp_conv_desc.tile_m/tile_n) or the built-in heuristic ----
     int bm = d->tile_m, bn = d->tile_n;
     const int np = d->n_pad;
@@ -877,6 +889,28 @@ static int conv_fwd_impl(const sp_conv_desc* d, const void* x, const void* w_pac
 extern "C" int sp_conv2d_fwd(const sp_conv_desc* d, const void* x, const void* w_packed, const float* scale,
                              const float* shift, const void* residual, void* y, void* stream) {
     return conv_fwd_impl(d, x, w_packed, scale, shift, residual, y, nullptr, nullptr, 0, stream);
+}
+
+// Name of the kernel instantiation a launch of `d` resolves to (what rocprofv3's kernel trace calls it, minus the
+// "void (anonymous namespace)::" / "(...Args)" decoration).  variant: 0 = sp_conv2d_fwd, 1 = sp_conv2d_fwd_bn_stats, 2 =
+// sp_conv2d_dgrad_bn_bwd_stats, 3 = sp_conv3x3_direct.  Nothing is launched; `d` is validated exactly as a launch would.
+extern "C" int sp_conv2d_kernel_name(const sp_conv_desc* d, int has_residual, int variant, char* buf, int cap) {
+    SP_REQUIRE(d && buf && cap > 0, "sp_conv2d_kernel_name: null pointer");
+    SP_REQUIRE(variant >= 0 && variant <= 3, "sp_conv2d_kernel_name: variant %d", variant);
+    if (variant == 3) {
+        snprintf(buf, (size_t)cap, "conv3x3_c32_direct_kernel");
+        return SP_OK;
+    }
+    void* const dummy = reinterpret_cast<void*>(16);        // never dereferenced: the launch functions return before launching
+    float* const fdummy = reinterpret_cast<float*>(16);
+    const BnBwdSrc src = {dummy, dummy, fdummy, fdummy};
+    sp_name_query_begin();
+    const int rc = conv_fwd_impl(d, dummy, dummy, nullptr, nullptr, has_residual ? dummy : nullptr, dummy, variant ? fdummy : nullptr,
+                                 variant ? fdummy : nullptr, 1 << 30, nullptr, variant == 2 ? &src : nullptr);
+    const char* name = sp_name_query_end();
+    if (rc != SP_OK) return rc;
+    snprintf(buf, (size_t)cap, "%s", name);
+    return SP_OK;
 }
 
 extern "C" int sp_conv2d_bn_stats_rows(const sp_conv_desc* d, int* rows) {

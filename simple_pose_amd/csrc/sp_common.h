@@ -16,6 +16,14 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 void sp_set_error(const char* fmt, ...);
 int sp_check_launch(const char* what);
 
+// ---- kernel-name query (sp_conv2d_kernel_name): while a query is active on the calling thread, a launch function records the name
+// of the kernel instantiation it WOULD launch (as rocprofv3 reports it, without the namespace / argument decoration) and returns
+// SP_OK without launching - the name comes out of the dispatch code itself, so it cannot drift from it
+bool sp_name_query_active();
+void sp_name_query_begin();
+const char* sp_name_query_end();
+void sp_name_query_set(const char* fmt, ...);
+
 #define SP_REQUIRE(cond, ...)        \
     do {                             \
         if (!(cond)) {               \

@@ -107,7 +107,7 @@ class PoseResNetBase(nn.Module):
             raise NotImplementedError("model(x) is the eval-mode path; the train step (batch-stat BN, backward, Adam) is "
                                       "simple_pose_amd.train.PoseTrainer(model).step(x, targets, mask)")
         prog = self.hip_program(x)
-        if self.autotune and x.shape[0] >= 16 and prog.tuned_for_batch != x.shape[0]:
+        if self.autotune and x.shape[0] >= 16 and x.shape[0] >= 4 * prog.tuned_for_batch:
             prog.autotune(x)  # once per (weights, input shape): pins the fastest tile per layer; results unchanged
         return prog.run(x)
 
@@ -128,7 +128,7 @@ def forward_uint8_crops(model, crops: torch.Tensor) -> torch.Tensor:
         raise NotImplementedError("forward_crops is the eval-mode path; training goes through simple_pose_amd.train.PoseTrainer")
     prog = model.hip_program(torch.empty((0, 3, H, W), device=crops.device))
     crops = crops.contiguous()
-    if model.autotune and B >= 16 and prog.tuned_for_batch != B:
+    if model.autotune and B >= 16 and B >= 4 * prog.tuned_for_batch:
         prog.autotune(crops)
     return prog.run(crops)
 

@@ -129,7 +129,7 @@ class PoseHighResolutionNet(ParamTree):
         if self.training:
             raise NotImplementedError("train-mode HRNet is not lowered to HIP yet; call .eval()")
         prog = self.hip_program(x)
-        if self.autotune and x.shape[0] >= 16 and prog.tuned_for_batch != x.shape[0]:
+        if self.autotune and x.shape[0] >= 16 and x.shape[0] >= 4 * prog.tuned_for_batch:
             prog.autotune(x)
         return prog.run(x)
 

@@ -20,7 +20,7 @@ import sys
 
 
 def short(name):
-    m = re.search(r"(conv_igemm_kernel<[^>]*>|\w+_kernel(?:<\d+>)?)", name)
+    m = re.search(r"(conv_\w+_kernel<[^>]*>|\w+_kernel(?:<\d+>)?)", name)
     return m.group(1) if m else name[:60]
 
 
