@@ -622,6 +622,79 @@ def test_conv_random_ragged_shapes_on_every_tile(dtype):
         assert err < (2e-6 if dtype == "fp32" else 6e-3), (ci, err, (B, Cin, H, W, Cout, k, s, p))
 
 
+def test_ring_kernel_matches_igemm_on_ragged_shapes():
+    """conv_ring.hip (persistent 8-wave workgroups, LDS-DMA ring; sp_conv_desc.kernel = SP_CONV_KERNEL_RING) against the register-staged
+    implicit GEMM on shapes that stress what is new in it: M that is no multiple of any tile and smaller than one tile (rows beyond M,
+    fewer tiles than CUs), several output tiles per workgroup (the K-tile stream crossing tile boundaries), K of exactly the ring
+    depth, stride 2, residual + ReLU, the fused PixelShuffle store and the 4 phases of the transposed conv.  Every ring tile the
+    library accepts must give the igemm kernel's bits, and both the fp64 convolution of the same bf16 operands."""
+    lib = _lib.lib()
+    cases = [  # (B, Cin, H, W, Cout, k, stride, pad, residual, kind)
+        (3, 64, 13, 11, 64, 3, 1, 1, False, "conv"),
+        (2, 128, 9, 7, 256, 1, 1, 0, True, "conv"),          # K = 2 tiles < every ring depth: no ring tile may accept it
+        (5, 192, 17, 9, 128, 3, 2, 1, False, "conv"),
+        (2, 256, 31, 23, 512, 1, 1, 0, True, "conv"),        # K = 4 tiles: the ring wraps inside every output tile
+        (40, 64, 16, 12, 256, 3, 1, 1, True, "conv"),        # 7,680 rows x 256 columns: several tiles per workgroup on small tiles
+        (2, 128, 12, 10, 512, 3, 1, 1, False, "pshuf"),
+        (3, 256, 7, 5, 256, 4, 2, 1, False, "deconv"),
+        (70, 512, 8, 6, 256, 4, 2, 1, False, "deconv"),      # 4 phases x 3,360 rows
+    ]
+    ran = 0
+    for ci, (B, Cin, H, W, Cout, k, s, p, with_res, kind) in enumerate(cases):
+        tag = f"ring{ci}"
+        wshape = (Cin, Cout, 4, 4) if kind == "deconv" else (Cout, Cin, k, k)
+        w = torch.from_numpy(synth.tensor_normal(5, tag + "/w", wshape, std=(2.0 / (Cin * k * k)) ** 0.5)).bfloat16().float()
+        x = torch.from_numpy(synth.tensor_normal(5, tag + "/x", (B, Cin, H, W))).bfloat16().float()
+        scale = torch.from_numpy(synth.tensor_uniform(5, tag + "/s", (Cout,), 0.5, 1.5)).float()
+        shift = torch.from_numpy(synth.tensor_normal(5, tag + "/b", (Cout,), std=0.3))
+        b = engine.ProgramBuilder(H, W, dtype="bf16")
+        b.p.shapes["input"] = (H, W, Cin)
+        res_name = None
+        if kind == "deconv":
+            out = b.deconv_k4s2p1("input", w.to(DEV), scale=scale.to(DEV), shift=shift.to(DEV), relu=True, name="c")
+            ref = torch.nn.functional.conv_transpose2d(x.double(), w.double(), stride=2, padding=1)
+        else:
+            ref = torch.nn.functional.conv2d(x.double(), w.double(), stride=s, padding=p)
+            if with_res:
+                b.p.shapes["res"] = (ref.shape[2], ref.shape[3], Cout)
+                res_name = "res"
+            out = b.conv("input", w.to(DEV), stride=s, pad=p, scale=scale.to(DEV), shift=shift.to(DEV), relu=True, res=res_name,
+                         pixel_shuffle=(kind == "pshuf"), name="c")
+        ref = ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+        r = None
+        if with_res:
+            r = torch.from_numpy(synth.tensor_normal(5, tag + "/r", tuple(ref.shape))).bfloat16()
+            ref = ref + r.double()
+        ref = torch.relu(ref)
+        if kind == "pshuf":
+            ref = torch.nn.functional.pixel_shuffle(ref, 2)
+        prog = b.p
+        op = [o for o in prog.ops if o.kind == "conv"][0]
+        xin = x.permute(0, 2, 3, 1).contiguous().to(DEV).bfloat16()
+        rin = r.permute(0, 2, 3, 1).contiguous().to(DEV) if r is not None else None
+        op.desc.batch = B
+        results = []
+        for cand in prog._candidates(lib, op):
+            if cand[0] < 0:
+                continue
+            op.desc.tile_m, op.desc.tile_n, op.desc.kernel = cand
+            y = torch.full((B,) + tuple(prog.shapes[out]), float("nan"), dtype=torch.bfloat16, device=DEV)
+            _lib.check(lib.sp_conv2d_fwd(op.desc, _lib.ptr(xin), _lib.ptr(op.w), _lib.ptr(op.scale), _lib.ptr(op.shift), _lib.ptr(rin), _lib.ptr(y),
+                                         _lib.current_stream()), f"{tag} {cand}")
+            torch.cuda.synchronize()
+            results.append((cand, y.view(torch.int16).cpu(), y.float().cpu()))
+        ring = [c for c, _, _ in results if c[2] == _lib.SP_CONV_KERNEL_RING]
+        ran += len(ring)
+        for cand, bits, _ in results[1:]:
+            assert torch.equal(bits, results[0][1]), (tag, cand, int((bits != results[0][1]).sum()))
+        got = results[0][2].permute(0, 3, 1, 2).double()
+        assert not torch.isnan(got).any(), tag                  # every output element was written
+        err = (got - ref).abs().max() / ref.abs().max()
+        assert err < 6e-3, (tag, err)
+    assert ran >= 20, ran                                      # the ring kernel really took part
+    print(f"ring-vs-igemm: {ran} ring launches bit-identical to the implicit GEMM")
+
+
 def test_hrnet_branches_on_separate_streams_match_single_stream(golden):
     """engine.Program lanes: the independent branches of every HRNet module run on their own HIP stream, ordered by events
     (RAW on activations, WAR/WAW on the planner's recycled storage).  The result must equal the one-stream schedule bit for bit,

@@ -234,3 +234,24 @@ def test_bench_self_launch_fails_loudly_without_a_gpu():
     assert r.returncode != 0
     assert r.stdout.strip() == ""
     assert r.stderr.count("no CPU path") == 2          # both ranks started, both refused
+
+
+def test_conv_kernel_name_query_matches_dispatch():
+    """sp_conv2d_kernel_name (used by bench.py's roofline object and the profile summaries) names what the dispatch launches."""
+    d = _lib.ConvDesc()
+    d.batch, d.in_h, d.in_w, d.c_in = 8, 16, 12, 256
+    d.grid_h, d.grid_w, d.c_out, d.n_pad = 16, 12, 256, 256
+    d.taps_h, d.taps_w, d.k_pad, d.stride = 3, 3, 2304, 1
+    d.dy0, d.dy_step, d.dx0, d.dx_step = -1, 1, -1, 1
+    d.out_h, d.out_w, d.out_c = 16, 12, 256
+    d.oy_mul = d.ox_mul = 1
+    d.phases_y = d.phases_x = 1
+    d.flags = _lib.SP_CONV_BF16 | _lib.SP_CONV_RELU
+    d.tile_m, d.tile_n, d.kernel = 128, 128, _lib.SP_CONV_KERNEL_IGEMM
+    assert _lib.conv_kernel_name(d, True) == "conv_igemm_kernel<128, 128, 2, 2, true, true, true, false, true, false>"   # 36 K tiles: deep ring
+    d.tile_m, d.tile_n, d.kernel = 128, 256, _lib.SP_CONV_KERNEL_RING
+    assert _lib.conv_kernel_name(d, False) == "conv_ring_kernel<128, 256, 2, 4, 3, false>"
+    d.flags = _lib.SP_CONV_RELU
+    d.tile_m, d.tile_n, d.kernel = 64, 128, _lib.SP_CONV_KERNEL_IGEMM
+    d.c_in, d.k_pad = 256, 2304
+    assert _lib.conv_kernel_name(d, False).startswith("conv_igemm_kernel<64, 128, 2, 2, true, false, false")

@@ -61,7 +61,7 @@ def main():
     rows, seen = [], {}
     bad = 0
     for op in prog.ops:
-        if op.kind != "conv" or (args.only and args.only not in op.name):
+        if op.kind != "conv" or (args.only and not any(t in op.name for t in args.only.split(","))):
             continue
         d = op.desc
         d.batch = B
