@@ -104,15 +104,52 @@ class PoseResNetBase(nn.Module):
         if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] % 32 or x.shape[3] % 32:
             raise ValueError(f"expected [B,3,H,W] with H,W multiples of 32, got {tuple(x.shape)}")
         if self.training:
-            raise NotImplementedError("model(x) is the eval-mode path; the train step (batch-stat BN, backward, Adam) is "
-                                      "simple_pose_amd.train.PoseTrainer(model).step(x, targets, mask)")
+            return self._forward_train(x)
         prog = self.hip_program(x)
         if self.autotune and x.shape[0] >= 16 and x.shape[0] >= 4 * prog.tuned_for_batch:
             prog.autotune(x)  # once per (weights, input shape): pins the fastest tile per layer; results unchanged
         return prog.run(x)
 
+    # -- train mode: the reference loop `predicts = model(x); loss = ...; loss.backward(); optimizer.step()` (ddp...:114-119) ------
+    def _forward_train(self, x: torch.Tensor) -> torch.Tensor:
+        """Train-mode forward as one autograd node: the HIP train-mode forward (batch-statistics BatchNorm, running statistics
+        updated) records its tape; `loss.backward()` runs the HIP backward (dgrad / wgrad / BN backward) and hands every parameter
+        gradient to autograd, so `.grad`, gradient hooks (DistributedDataParallel) and any torch optimizer work as in the reference.
+        `simple_pose_amd.train.PoseTrainer.step` stays the faster fused path (loss, Adam and repack as kernels of the same tape)."""
+        if self.reduction:
+            raise NotImplementedError("training with SELayer (reduction=True) is not lowered; eval-mode forward is")
+        from ..train import PoseTrainer
+        key = (x.shape[2], x.shape[3], str(x.device), self.compute_dtype)
+        tr = getattr(self, "_trainer", None)
+        if tr is None or self._trainer_key != key or not tr.still_owns_parameters():
+            tr = PoseTrainer(self, in_h=x.shape[2], in_w=x.shape[3], dtype="bf16" if self.compute_dtype == "bf16" else "fp32",
+                             collectives=False)
+            self._trainer, self._trainer_key = tr, key
+        if not torch.is_grad_enabled():
+            return tr.forward_tape(x)[0]
+        return _TrainForward.apply(x, tr, *tr.sd.values())
+
     def forward_crops(self, crops: torch.Tensor) -> torch.Tensor:
         return forward_uint8_crops(self, crops)
+
+
+class _TrainForward(torch.autograd.Function):
+    """heat = f(x; parameters) with the HIP train step's tape as the backward (simple_pose_amd.train.PoseTrainer.forward_tape)."""
+
+    @staticmethod
+    def forward(ctx, x, trainer, *params):
+        heat, backward = trainer.forward_tape(x)
+        ctx.trainer, ctx.run_backward, ctx.params = trainer, backward, params
+        return heat
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dheat):
+        if ctx.run_backward is None:
+            raise RuntimeError("the HIP tape of this forward has already been consumed (backward twice)")
+        run, ctx.run_backward = ctx.run_backward, None
+        grads = ctx.trainer.autograd_backward(run, dheat.contiguous(), ctx.params)
+        return (None, None) + grads          # no gradient w.r.t. the input image (the stem's dgrad is not computed, as in the solver)
 
 
 def forward_uint8_crops(model, crops: torch.Tensor) -> torch.Tensor:

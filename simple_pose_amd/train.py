@@ -40,7 +40,7 @@ def _i64(*v):
 class FlatParams:
     """All parameters of `model` as views into one flat fp32 buffer (+ a flat gradient buffer of the same layout)."""
 
-    def __init__(self, model: torch.nn.Module):
+    def __init__(self, model: torch.nn.Module, attach_grads: bool = True):
         params = [(n, p) for n, p in model.named_parameters()]
         dev = params[0][1].device
         self.offsets: Dict[str, Tuple[int, int]] = {}
@@ -55,7 +55,8 @@ class FlatParams:
             o, k = self.offsets[n]
             self.data[o:o + k].copy_(p.detach().reshape(-1))
             p.data = self.data[o:o + k].view(p.shape)
-            p.grad = self.grad[o:o + k].view(p.shape)
+            if attach_grads:                            # (the autograd surface leaves .grad to autograd: None until the first backward)
+                p.grad = self.grad[o:o + k].view(p.shape)
 
     def view(self, name: str, grad: bool = False) -> torch.Tensor:
         o, k = self.offsets[name]
@@ -310,7 +311,7 @@ class PoseTrainer:
 
     def __init__(self, model, in_h: int = 256, in_w: int = 192, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  process_group=None, dtype: str = "fp32", sync_bn: Optional[bool] = None, bucket_mb: float = 32.0,
-                 broadcast_init: bool = True, overlap_wgrad: bool = True):
+                 broadcast_init: bool = True, overlap_wgrad: bool = True, collectives: bool = True):
         """dtype "bf16": bf16 activations and packed weights (v_mfma_f32_32x32x16_bf16 for forward, dgrad and wgrad); the
         gradient w.r.t. a block output stays fp32 until the BatchNorm backward has subtracted its per-channel mean (rounding
         it to bf16 first costs 10-50 % gradient error in this net: the useful part is a small difference of large terms), the
@@ -339,9 +340,11 @@ class PoseTrainer:
         self._opt_stream = None
         self._opt_in_backward = False
         import torch.distributed as dist
-        self.world = dist.get_world_size(self.pg) if (dist.is_available() and dist.is_initialized()) else 1
+        # collectives=False: a trainer that only computes local gradients (the autograd surface `model(x)` of nets.*: there the
+        # caller - e.g. torch's DistributedDataParallel wrapper, as in ddp...:91-93 - owns the gradient exchange)
+        self.world = dist.get_world_size(self.pg) if (collectives and dist.is_available() and dist.is_initialized()) else 1
         self.sync_bn = (self.world > 1) if sync_bn is None else (bool(sync_bn) and self.world > 1)
-        self.flat = FlatParams(model)
+        self.flat = FlatParams(model, attach_grads=collectives)
         dev = self.flat.data.device
         self.exp_avg = torch.zeros_like(self.flat.data)
         self.exp_avg_sq = torch.zeros_like(self.flat.data)
@@ -495,20 +498,77 @@ class PoseTrainer:
                 assert not idx or idx == list(range(idx[0], idx[-1] + 1)), "pack rows of a bucket must be contiguous"
                 self._pack_rows_of_bucket.append((idx[0], idx[-1] + 1) if idx else (0, 0))
         lo, hi = (0, self._pack_n) if rows_range is None else rows_range
+        if rows_range is None:
+            self._packed_version = self._param_version()
         if hi > lo:
             tab = _lib.c_void_p(self._pack_table.data_ptr() + 96 * lo)
             _lib.check(_lib.lib().sp_permute4_batched(P(self.flat.data), tab, hi - lo, 8, stream if stream is not None else _lib.current_stream()),
                        "repack")
+
+    # ---- keeping the packed copies in step with the parameters -------------------------------------------------------------
+    def _param_version(self) -> int:
+        return sum(p._version for p in self.sd.values())
+
+    def refresh_packed_weights(self) -> None:
+        """Repack if a parameter changed behind the trainer's back (a torch optimizer's step, load_state_dict: in-place writes that
+        bump the tensors' version counters).  The trainer's own Adam kernel + repack do not, and keep the copies current themselves."""
+        if self._param_version() != getattr(self, "_packed_version", None):
+            self.repack()
+
+    def still_owns_parameters(self) -> bool:
+        """False once the module's parameters no longer live in this trainer's flat buffer (model.to(...), a re-assigned .data)."""
+        base, n = self.flat.data.data_ptr(), self.flat.numel * 4
+        return all(base <= p.data_ptr() < base + n for p in self.sd.values())
+
+    # ---- autograd surface (nets.*.forward in train mode) -----------------------------------------------------------------------
+    def autograd_backward(self, backward, dheat: torch.Tensor, params) -> tuple:
+        """Run the recorded tape and hand the parameter gradients to autograd as views of the flat gradient buffer (autograd then
+        sets / accumulates `p.grad`, fires hooks - DDP's reducer included).  The kernels OVERWRITE their gradient buffer, so when
+        live `.grad` tensors still alias it (zero_grad(set_to_none=False), gradient accumulation) the tape writes into a second
+        flat buffer and autograd's `p.grad += returned` is then the correct accumulation."""
+        def aliased(buf):
+            lo, hi = buf.data_ptr(), buf.data_ptr() + buf.numel() * 4
+            return any(p.grad is not None and lo <= p.grad.data_ptr() < hi for p in params)
+        clone = False
+        if aliased(self.flat.grad):
+            if getattr(self, "_grad_alt", None) is None:
+                self._grad_alt = torch.zeros_like(self.flat.grad)
+            self.flat.grad, self._grad_alt = self._grad_alt, self.flat.grad
+            clone = aliased(self.flat.grad)            # both buffers referenced by live gradients: return copies
+        backward(dheat)
+        out = []
+        for name, p in self.sd.items():
+            g = self.flat.view(name, grad=True).view(p.shape)
+            out.append(g.clone() if clone else g)
+        return tuple(out)
 
     # ---- one step -----------------------------------------------------------------------------------------------------
     def forward_backward(self, x: torch.Tensor, targets: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
         """x [B,3,H,W], targets [B,J,H/4,W/4], mask [B,J] on the GPU -> loss (device scalar); gradients land in the flat
         gradient buffer (every element is overwritten, no zero_grad needed)."""
         lib, stream = _lib.lib(), _lib.current_stream()
-        x = _lib.require_cuda_f32(x, "input")
         targets = _lib.require_cuda_f32(targets, "targets")
         mask = _lib.require_cuda_f32(mask, "mask")
+        heat, backward = self.forward_tape(x)
+        B, J, hh, ww = heat.shape
+        # ---- loss + d loss / d heat ----
+        dheat = torch.empty_like(heat)
+        _lib.check(lib.sp_masked_mse(P(heat), P(targets), P(mask), B, J, hh * ww, P(self.loss_buf), P(dheat), P(self.mse_ws), stream), "mse")
+        self._mark("forward_loss")
+        backward(dheat)
+        return self.loss_buf
+
+    def forward_tape(self, x: torch.Tensor):
+        """Train-mode forward (batch-statistics BatchNorm, running statistics updated): x [B,3,H,W] -> (heat maps [B,J,H/4,W/4],
+        backward) where `backward(dheat)` runs the recorded tape - dgrad / wgrad / BN backward - and leaves every parameter gradient
+        in the flat gradient buffer `self.flat.grad` (overwritten, not accumulated).  `forward_backward` = this + the masked-MSE
+        kernel; `nets.*.forward` in train mode = this behind a torch.autograd.Function (reference loop ddp...:114-119)."""
+        lib, stream = _lib.lib(), _lib.current_stream()
+        x = _lib.require_cuda_f32(x, "input")
         B, dev = x.shape[0], x.device
+        self.refresh_packed_weights()
+        if getattr(self.model, "_program", None) is not None:
+            self.model._program = None        # running statistics change below: the eval-mode program folds them into its weights
         tape: List[Callable[[], None]] = []
         nbt: List[torch.Tensor] = []
         L = self.layers
@@ -687,36 +747,41 @@ class PoseTrainer:
         heat = torch.empty((B, J, hh, ww), dtype=torch.float32, device=dev)
         a.consumers += 1
         fl.forward(a.data, B, out=heat, shift=self.sd["final_layer.bias"])
-        # ---- loss + d loss / d heat ----
-        dheat = newf((B, J, hh, ww))
-        _lib.check(lib.sp_masked_mse(P(heat), P(targets), P(mask), B, J, hh * ww, P(self.loss_buf), P(dheat), P(self.mse_ws), stream), "mse")
         self.last_heat = heat
-        self._mark("forward_loss")
-        # ---- backward ----
-        Jb = fl.c_out_buf                                  # heat-map channels padded to a K tile of the backward launches
-        dh = newf((B, hh, ww, Jb))
-        _lib.check(lib.sp_nchw_to_nhwc_pad(P(dheat), P(dh), 0, B, J, hh, ww, Jb, stream), "dheat.nhwc")
-        bsum = newf(Jb)
-        _lib.check(lib.sp_channel_sum_nhwc(P(dh), B * hh * ww, Jb, P(bsum), P(ws), stream), "final_layer.bias.grad")
-        self.flat.view("final_layer.bias", True).copy_(bsum[:J])          # 17-float device copy into the flat gradient buffer
-        if self.bf16:
-            dh = new((B, hh, ww, Jb))
-            _lib.check(lib.sp_nchw_to_nhwc_pad(P(dheat), P(dh), 1, B, J, hh, ww, Jb, stream), "dheat.nhwc16")
-        wgrad_async(fl, a.data, dh)
-        a.grad = fl.dgrad(dh, B, None, bn_src=a if (self.fuse_bn_bwd and a.bn is not None and a.consumers == 1) else None)
-        self._grads_ready("final_layer.bias", "final_layer.weight")
-        for fn in reversed(tape):
-            fn()
-        torch._foreach_add_(nbt, 1)
-        if self._wgrad_tail is not None:
-            torch.cuda.current_stream(dev).wait_event(self._wgrad_tail)      # join: the optimizer reads every weight gradient
-        if self._opt_in_backward:
-            assert all(w is not None for w in self._works), "a gradient bucket never completed"
-            for w in self._works:
-                torch.cuda.current_stream(dev).wait_event(w)                 # join: parameters and packed copies are updated
-            self._works = None
+        torch._foreach_add_(nbt, 1)                        # num_batches_tracked of every BatchNorm (train-mode forward)
+        last = a
+
+        def backward(dheat: torch.Tensor) -> None:
+            self._backward_tape(tape, last, fl, dheat, B, J, hh, ww, wgrad_async, new, newf)
+        return heat, backward
+
+    def _backward_tape(self, tape, a, fl, dheat, B, J, hh, ww, wgrad_async, new, newf) -> None:
+        lib, stream = _lib.lib(), _lib.current_stream()
+        dheat = _lib.require_cuda_f32(dheat, "d loss / d heat maps")
+        dev, ws = dheat.device, self.red_ws
+        if True:   # (block kept for a minimal diff of the tape below)
+            Jb = fl.c_out_buf                              # heat-map channels padded to a K tile of the backward launches
+            dh = newf((B, hh, ww, Jb))
+            _lib.check(lib.sp_nchw_to_nhwc_pad(P(dheat), P(dh), 0, B, J, hh, ww, Jb, stream), "dheat.nhwc")
+            bsum = newf(Jb)
+            _lib.check(lib.sp_channel_sum_nhwc(P(dh), B * hh * ww, Jb, P(bsum), P(ws), stream), "final_layer.bias.grad")
+            self.flat.view("final_layer.bias", True).copy_(bsum[:J])          # 17-float device copy into the flat gradient buffer
+            if self.bf16:
+                dh = new((B, hh, ww, Jb))
+                _lib.check(lib.sp_nchw_to_nhwc_pad(P(dheat), P(dh), 1, B, J, hh, ww, Jb, stream), "dheat.nhwc16")
+            wgrad_async(fl, a.data, dh)
+            a.grad = fl.dgrad(dh, B, None, bn_src=a if (self.fuse_bn_bwd and a.bn is not None and a.consumers == 1) else None)
+            self._grads_ready("final_layer.bias", "final_layer.weight")
+            for fn in reversed(tape):
+                fn()
+            if self._wgrad_tail is not None:
+                torch.cuda.current_stream(dev).wait_event(self._wgrad_tail)      # join: the optimizer reads every weight gradient
+            if self._opt_in_backward:
+                assert all(w is not None for w in self._works), "a gradient bucket never completed"
+                for w in self._works:
+                    torch.cuda.current_stream(dev).wait_event(w)                 # join: parameters and packed copies are updated
+                self._works = None
         self._mark("backward")
-        return self.loss_buf
 
     def all_reduce_grads(self) -> float:
         """DDP semantics: gradients are averaged over ranks.  SUM all-reduces of the flat buffer's buckets (RCCL over xGMI) were

@@ -331,3 +331,107 @@ def test_full_size_step_properties(dtype, tol):
     assert rel <= max(tol, 1e-4), rel
     assert 0 < runs["a"][3] <= 1e-3 * (1 + 2e-4)           # (3): lr * |g| / (|g| + eps) <= lr, plus the rounding of p itself
     assert np.isfinite(runs["a"][0]) and runs["a"][0] > 0
+
+
+# ---------------------------------------------------------------------------------------------- the reference's own loop, through autograd
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_reference_training_loop_through_autograd(dtype):
+    """`model.train(); optimizer.zero_grad(); predicts = model(x); loss = 0.5 * MSE(predicts * m, targets * m); loss.backward();
+    optimizer.step()` - the body of DDPProcessor.train (ddp...:114-119) verbatim, with torch.optim.Adam - runs on the HIP tape through
+    one autograd node.  Gradients equal the fused trainer's (same kernels; only d loss / d heat comes from torch instead of
+    sp_masked_mse), three steps track PoseTrainer.step (the library's Adam kernel against torch's), BatchNorm running statistics and
+    num_batches_tracked advance as in torch, and `.grad` accumulates like autograd's when it is not reset."""
+    B, H, W = 4, 64, 64
+    x, t, w = _batch(B, H, W, 11)
+    xd, td, wd = (torch.from_numpy(a).to(DEV) for a in (x, t, w))
+    ma, _ = _model(11)
+    mb, _ = _model(11)
+    if dtype == "bf16":
+        ma.compute_dtype = "bf16"
+    opt = torch.optim.Adam(ma.parameters(), lr=1e-3)
+    crit = torch.nn.MSELoss()
+    trb = PoseTrainer(mb, in_h=H, in_w=W, lr=1e-3, dtype=dtype)
+    pa, pb = dict(ma.named_parameters()), dict(mb.named_parameters())
+    for step in range(3):
+        opt.zero_grad()
+        predicts = ma(xd)
+        assert predicts.requires_grad and predicts.shape == (B, 17, H // 4, W // 4)
+        if step == 0:
+            predicts.retain_grad()
+        loss = 0.5 * crit(predicts * wd[..., None, None], td * wd[..., None, None])
+        loss.backward()
+        if step == 0:
+            # (1) same tape, same d loss / d heat -> the same bits as the trainer's own forward_tape / backward
+            mc, _ = _model(11)
+            trc = PoseTrainer(mc, in_h=H, in_w=W, lr=1e-3, dtype=dtype)
+            heat_c, bwd_c = trc.forward_tape(xd)
+            assert torch.equal(heat_c, predicts.detach())
+            bwd_c(predicts.grad)
+            torch.cuda.synchronize()
+            for k in pa:
+                assert torch.equal(pa[k].grad, trc.flat.view(k, grad=True).view(pa[k].shape)), k
+            # (2) against the fused step, whose d loss / d heat comes from sp_masked_mse instead of torch's MSELoss backward (1 ulp
+            # apart): measured 3.0e-6 worst per-tensor deviation (a BatchNorm bias gradient: a sum with cancellation)
+            lb = trb.forward_backward(xd, td, wd)
+            torch.cuda.synchronize()
+            assert abs(loss.item() - lb.item()) <= 1e-6 * abs(lb.item())
+            worst = max((float((pa[k].grad - trb.flat.view(k, grad=True).view(pa[k].shape)).abs().max() /
+                               (trb.flat.view(k, grad=True).abs().max() + 1e-30)), k) for k in pa)
+            print(f"autograd vs fused trainer, {dtype}: worst per-tensor gradient deviation {worst[0]:.2e} ({worst[1]})")
+            assert worst[0] < (1e-5 if dtype == "fp32" else 2e-3), worst
+            trb.optimizer_step()                              # (completes mb's first step: forward_backward + Adam + repack)
+        else:
+            trb.step(xd, td, wd)
+        opt.step()
+        if step == 0:                                         # one Adam step: torch.optim.Adam here, sp_adam_step there
+            torch.cuda.synchronize()
+            d1 = max(float((pa[k] - pb[k]).abs().max()) for k in pa)
+            f1 = np.mean([float(((pa[k] - pb[k]).abs() <= 1e-6).float().mean()) for k in pa])
+            print(f"after 1 step, {dtype}: max parameter deviation {d1:.2e}, {100 * f1:.4f} % within 1e-6")
+            assert f1 > (0.999 if dtype == "fp32" else 0.98) and d1 <= 2.1e-3   # (a sign flip of a ~0 gradient moves a weight by 2 lr)
+    torch.cuda.synchronize()
+    # Three steps of this deep BatchNorm net at 4 images are chaotic: the 3e-6 gradient difference of step 1 grows (measured fp32:
+    # 95.2 % of the weights within 2e-5 after 3 steps, max 2.9e-3 = 3 lr) - the two runs track each other, they are not equal.
+    dev = max(float((pa[k] - pb[k]).abs().max()) for k in pa)
+    frac = np.mean([float(((pa[k] - pb[k]).abs() <= 2e-5).float().mean()) for k in pa])
+    print(f"3 reference-loop steps vs 3 PoseTrainer steps, {dtype}: max parameter deviation {dev:.2e}, {100 * frac:.3f} % within 2e-5")
+    frac_lr = np.mean([float(((pa[k] - pb[k]).abs() <= 1e-3).float().mean()) for k in pa])
+    print(f"    ... {100 * frac_lr:.3f} % within one learning rate (1e-3)")
+    # bf16: a 1e-7 weight difference can flip the bf16 rounding of an operand, so the runs part faster (measured 29 % within 2e-5)
+    assert (frac > 0.90 if dtype == "fp32" else frac_lr > 0.90) and dev <= 6.1e-3
+    ba = dict(ma.named_buffers())
+    for k in ba:
+        if k.endswith("num_batches_tracked"):
+            assert int(ba[k]) == 3, k
+    # eval mode after training: the inference program is rebuilt from the updated parameters and running statistics - the same heat
+    # maps, bit for bit, as a fresh model that loads this state_dict (no stale packed weight anywhere)
+    ma.eval()
+    fresh = pose_resnet_dconv.resnet50(pretrained=False, num_classes=17)
+    fresh.load_state_dict({k: v.detach().cpu().clone() for k, v in ma.state_dict().items()}, strict=True)
+    fresh = fresh.to(DEV).eval()
+    fresh.compute_dtype = ma.compute_dtype
+    with torch.no_grad():
+        assert torch.equal(ma(xd), fresh(xd))
+    # ... and in train mode too: the tape's packed copies were refreshed after the torch optimizer's in-place updates
+    ma.train(); fresh.train()
+    with torch.no_grad():
+        assert torch.equal(ma(xd), fresh(xd))
+    # accumulation semantics: a second backward without zero_grad adds to .grad (the kernels overwrite their buffer, the surface
+    # switches buffers when live gradients alias it)
+    opt.zero_grad()
+    l1 = 0.5 * crit(ma(xd) * wd[..., None, None], td * wd[..., None, None]); l1.backward()
+    g1 = {k: v.grad.clone() for k, v in pa.items()}
+    l2 = 0.5 * crit(ma(xd) * wd[..., None, None], td * wd[..., None, None]); l2.backward()
+    k = "layer3.2.conv2.weight"
+    # (the second forward saw BN running statistics one step further, but batch statistics - and so the gradients - are the same)
+    assert torch.allclose(pa[k].grad, 2 * g1[k], rtol=1e-5, atol=1e-12)
+    opt.zero_grad(set_to_none=False)
+    l3 = 0.5 * crit(ma(xd) * wd[..., None, None], td * wd[..., None, None]); l3.backward()
+    assert torch.allclose(pa[k].grad, g1[k], rtol=1e-5, atol=1e-12)
+
+
+def test_train_mode_forward_needs_no_trainer_object_and_refuses_what_is_not_lowered():
+    from simple_pose_amd.nets import pose_resnet_dconv as prd
+    m = prd.resnet50(pretrained=False, num_classes=17, reduction=True).to(DEV).train()
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(2, 3, 64, 64, device=DEV))
