@@ -27,7 +27,7 @@ extern "C" {
 #define SP_EINVAL (-1)   /* bad argument / unsupported shape (message in sp_last_error) */
 #define SP_ELAUNCH (-2)  /* HIP launch or runtime failure */
 
-#define SP_ABI_VERSION 18
+#define SP_ABI_VERSION 19
 
 /* epilogue / layout flags of sp_conv_desc.flags */
 #define SP_CONV_RELU 0x1u          /* y = max(y, 0) after scale/shift (+ residual) */
@@ -301,6 +301,30 @@ int sp_permute4_f32(const float* src, void* dst, int dst_bf16, const int32_t* ds
  *   { int32 dst_dims[4]; int64 src_strides[4]; int32 valid[4]; int64 src_base; int64 dst_address; int64 total; int32 dst_bf16; int32 pad; }
  * (dst_address = device pointer of the destination incl. its offset), blocks_per_job workgroups grid-stride over a job */
 int sp_permute4_batched(const float* src, const void* jobs_device, int n_jobs, int blocks_per_job, void* stream);
+
+/* ---- parameter packing: the reference's tensors -> what the launches above read ------------------------------------------
+ * (all pointers are device memory; every call fills its whole destination, padding included)
+ *
+ * sp_conv_packed_dims: rows / depth of a packed weight matrix: n_pad = c_out rounded up to the widest tile that fits (128, 64 or
+ * 32), k_pad = k rounded up to one K tile (32 fp32 / 64 bf16 elements = 128 bytes). */
+int sp_conv_packed_dims(int c_out, int k, int bf16, int* n_pad, int* k_pad);
+/* nn.Conv2d weight [c_out, c_in, kh, kw] fp32 (nets/pose_resnet_dconv.py:19-27) -> w_packed [n_pad][k_pad] (fp32, or bf16 when
+ * dst_bf16), K ordered (ty, tx, c) with c_in_packed >= c_in channels per tap and taps_w_packed >= kw taps per row (the stem's
+ * 3-channel 7x7 filter on the NHWC4 image: c_in_packed 4, taps_w_packed 8).  pixel_shuffle: rows in sub-pixel-major order
+ * n' = sub*(c_out/4) + c <- channel 4*c + sub, what SP_CONV_PIXEL_SHUFFLE expects (nets/commons.py:36-41).  pair_s0 >= 0: the bf16
+ * stem's x-paired form (sp_conv_desc.stride_x): packed channel = sub*4 + c of pixel pair tx, i.e. kx = 2*tx + sub - pair_s0,
+ * c_in_packed = 8; pair_s0 = -1: plain. */
+int sp_pack_conv_weights(const float* w, int c_out, int c_in, int kh, int kw, int c_in_packed, int taps_w_packed, int pixel_shuffle,
+                         int pair_s0, int n_pad, int k_pad, void* dst, int dst_bf16, void* stream);
+/* nn.ConvTranspose2d(k=4, s=2, p=1) weight [c_in, c_out, 4, 4] (nets/pose_resnet_dconv.py:236-244) -> [4 phases][n_pad][4*c_in]:
+ * phase (py,px) holds the 2x2 taps W[:, :, 2ty+1-py, 2tx+1-px] that reach output pixels (2y+py, 2x+px) - no multiply is spent
+ * on the zeros a transposed conv inserts */
+int sp_pack_deconv_k4s2p1(const float* w, int c_in, int c_out, int n_pad, void* dst, int dst_bf16, void* stream);
+/* eval-mode nn.BatchNorm2d as the conv epilogue's (scale, shift): scale = weight / sqrt(running_var + eps),
+ * shift = bias - running_mean * scale (each operation rounded on its own, as the torch expressions); weight / bias NULL = 1 / 0;
+ * pixel_shuffle: outputs in the packed row order of sp_pack_conv_weights */
+int sp_fold_bn(const float* weight, const float* bias, const float* running_mean, const float* running_var, int c, float eps,
+               int pixel_shuffle, float* scale, float* shift, void* stream);
 
 #ifdef __cplusplus
 }

@@ -27,7 +27,7 @@ BN_EPS = 1e-5
 
 
 # ------------------------------------------------------------------------------------------------
-# weight packing (pure torch; runs on whatever device the weights live on; unit-tested on CPU)
+# weight packing: device kernels behind the C ABI (csrc/pack.hip)
 # ------------------------------------------------------------------------------------------------
 def _round_up(v: int, m: int) -> int:
     return (v + m - 1) // m * m
@@ -42,60 +42,54 @@ def n_pad_for(c_out: int) -> int:
     return 32
 
 
-def fold_bn(weight, bias, running_mean, running_var, eps: float = BN_EPS):
-    """Eval-mode BatchNorm2d as y = x*scale + shift (same factoring as ATen's CPU kernel: alpha = w/sqrt(var+eps),
-    beta = b - mean*alpha)."""
-    invstd = 1.0 / torch.sqrt(running_var.float() + eps)
-    scale = weight.float() * invstd
-    shift = bias.float() - running_mean.float() * scale
-    return scale.contiguous(), shift.contiguous()
+class HipPacker:
+    """Reference-layout parameters -> kernel layouts ON THE GPU through the C ABI (sp_pack_conv_weights, sp_pack_deconv_k4s2p1,
+    sp_fold_bn, sp_conv_packed_dims): the same entry points a maintainer binding include/simple_pose_hip.h would call.  Tensors must
+    live on the GPU; there is no host path (tests/desc_interp.TorchPacker restates the layouts in torch for the CPU-only host-logic
+    tests and is never imported by the package)."""
 
+    @staticmethod
+    def _dims(c_out: int, k: int, bf16: bool) -> Tuple[int, int]:
+        n_pad, k_pad = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(_lib.lib().sp_conv_packed_dims(c_out, k, int(bf16), ctypes.byref(n_pad), ctypes.byref(k_pad)), "sp_conv_packed_dims")
+        return n_pad.value, k_pad.value
 
-def pack_conv(w: torch.Tensor, c_in_pad: Optional[int] = None, taps_w_pad: Optional[int] = None,
-              row_perm: Optional[torch.Tensor] = None, k_mult: int = 32) -> Tuple[torch.Tensor, int, int, int, int]:
-    """Conv2d weight [O,I,kh,kw] -> packed [n_pad, k_pad] with K ordered (ky, kx, c), c fastest.
-    Returns (packed, taps_h, taps_w, c_in_packed, k_pad)."""
-    O, I, kh, kw = w.shape
-    ci = c_in_pad or I
-    tw = taps_w_pad or kw
-    assert ci >= I and ci % 4 == 0 and tw >= kw
-    p = torch.zeros((O, kh, tw, ci), dtype=torch.float32, device=w.device)
-    p[:, :, :kw, :I] = w.float().permute(0, 2, 3, 1)
-    p = p.reshape(O, kh * tw * ci)
-    if row_perm is not None:
-        p = p[row_perm]
-    k = kh * tw * ci
-    k_pad = _round_up(k, k_mult)   # one K tile = 128 bytes: 32 fp32 / 64 bf16
-    n_pad = n_pad_for(O)
-    out = torch.zeros((n_pad, k_pad), dtype=torch.float32, device=w.device)
-    out[:O, :k] = p
-    return out.contiguous(), kh, tw, ci, k_pad
+    def conv(self, w: torch.Tensor, *, c_in_pad: Optional[int] = None, taps_w_pad: Optional[int] = None, pixel_shuffle: bool = False,
+             pair_s0: int = -1, bf16: bool = False) -> Tuple[torch.Tensor, int, int, int, int]:
+        """Conv2d weight [O,I,kh,kw] -> packed [n_pad, k_pad] with K ordered (ky, kx, c), c fastest.
+        Returns (packed, taps_h, taps_w, c_in_packed, k_pad)."""
+        w = _lib.require_cuda_f32(w.detach(), "conv weight")
+        O, I, kh, kw = w.shape
+        ci, tw = c_in_pad or I, taps_w_pad or kw
+        n_pad, k_pad = self._dims(O, kh * tw * ci, bf16)
+        out = torch.empty((n_pad, k_pad), dtype=torch.bfloat16 if bf16 else torch.float32, device=w.device)
+        _lib.check(_lib.lib().sp_pack_conv_weights(_lib.ptr(w), O, I, kh, kw, ci, tw, int(pixel_shuffle), pair_s0, n_pad, k_pad, _lib.ptr(out),
+                                                   int(bf16), _lib.current_stream()), "sp_pack_conv_weights")
+        return out, kh, tw, ci, k_pad
 
+    def deconv(self, w: torch.Tensor, *, bf16: bool = False) -> Tuple[torch.Tensor, int]:
+        """ConvTranspose2d(k=4, s=2, p=1) weight [I,O,4,4] -> ([4 * n_pad, 4*I], n_pad): one 2x2-tap slab per output phase."""
+        w = _lib.require_cuda_f32(w.detach(), "deconv weight")
+        I, O, kh, kw = w.shape
+        assert (kh, kw) == (4, 4) and I % 32 == 0
+        n_pad = n_pad_for(O)
+        out = torch.empty((4 * n_pad, 4 * I), dtype=torch.bfloat16 if bf16 else torch.float32, device=w.device)
+        _lib.check(_lib.lib().sp_pack_deconv_k4s2p1(_lib.ptr(w), I, O, n_pad, _lib.ptr(out), int(bf16), _lib.current_stream()),
+                   "sp_pack_deconv_k4s2p1")
+        return out, n_pad
 
-def pack_deconv_k4s2p1(w: torch.Tensor) -> Tuple[torch.Tensor, int]:
-    """ConvTranspose2d(k=4, s=2, p=1) weight [I,O,4,4] -> [4 phases, n_pad, 4*I].
-    Output pixel (2y+py, 2x+px) = sum over 2x2 taps (ty,tx) of x[y+py-ty, x+px-tx] * W[:, :, 2ty+1-py, 2tx+1-px]."""
-    I, O, kh, kw = w.shape
-    assert (kh, kw) == (4, 4) and I % 32 == 0
-    n_pad = n_pad_for(O)
-    out = torch.zeros((4, n_pad, 4 * I), dtype=torch.float32, device=w.device)
-    wf = w.float()
-    for py in range(2):
-        for px in range(2):
-            for ty in range(2):
-                for tx in range(2):
-                    ky, kx = 2 * ty + 1 - py, 2 * tx + 1 - px
-                    t = ty * 2 + tx
-                    out[py * 2 + px, :O, t * I:(t + 1) * I] = wf[:, :, ky, kx].t()
-    return out.contiguous(), n_pad
+    def fold_bn(self, weight, bias, running_mean, running_var, eps: float = BN_EPS, pixel_shuffle: bool = False):
+        """Eval-mode BatchNorm2d as y = x*scale + shift (ATen's factoring: alpha = w/sqrt(var+eps), beta = b - mean*alpha)."""
+        f = lambda t, n: _lib.require_cuda_f32(t.detach(), n)
+        mean, var = f(running_mean, "running_mean"), f(running_var, "running_var")
+        C = mean.numel()
+        scale, shift = torch.empty(C, dtype=torch.float32, device=mean.device), torch.empty(C, dtype=torch.float32, device=mean.device)
+        _lib.check(_lib.lib().sp_fold_bn(_lib.ptr(f(weight, "bn weight")), _lib.ptr(f(bias, "bn bias")), _lib.ptr(mean), _lib.ptr(var), C, eps,
+                                         int(pixel_shuffle), _lib.ptr(scale), _lib.ptr(shift), _lib.current_stream()), "sp_fold_bn")
+        return scale, shift
 
-
-def pixel_shuffle_row_perm(c_out: int, device) -> torch.Tensor:
-    """Packed column n' = sub*(C/4) + c holds original channel c*4 + sub (sub = i*2 + j of nn.PixelShuffle(2)),
-    so that a wave's 32 consecutive columns store 32 consecutive output channels of one pixel."""
-    c4 = c_out // 4
-    n = torch.arange(c_out, device=device)
-    return (n % c4) * 4 + (n // c4)
+    def bias(self, b: torch.Tensor) -> torch.Tensor:
+        return _lib.require_cuda_f32(b.detach(), "bias")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -445,9 +439,10 @@ class GraphedForward:
 class ProgramBuilder:
     """Appends launches to a Program while tracking NHWC buffer shapes."""
 
-    def __init__(self, in_h: int, in_w: int, dtype: str = "fp32"):
+    def __init__(self, in_h: int, in_w: int, dtype: str = "fp32", packer=None):
         if dtype not in ("fp32", "bf16"):
             raise ValueError(dtype)
+        self.packer = packer or HipPacker()         # parameters -> kernel layouts (device kernels behind the C ABI)
         self.p = Program(dtype=dtype)
         self.bf16 = dtype == "bf16"
         self.cpad = 8 if self.bf16 else 4           # channels per 16-byte chunk
@@ -484,8 +479,8 @@ class ProgramBuilder:
              dst: Optional[str] = None, name: str = "conv") -> str:
         h, w, c_buf = self.p.shapes[src]
         O, I, kh, kw = weight.shape
-        k_mult = 64 if self.bf16 else 32
         paired = False
+        pk = self.packer
         if self.bf16 and c_buf == 4 and I < 4:
             # bf16 stem on the NHWC4 image read as pixel pairs [h, w/2, 8]: pixel 2*ox - pad + kx = pair (ox - ceil(pad/2)) + pt, half
             # `sub`, with kx + s0 = 2*pt + sub.  A stride of 2 pixels is a stride of ONE pair: separate x / y strides (stride_x).
@@ -495,21 +490,14 @@ class ProgramBuilder:
             half = (pad + 1) // 2
             s0 = 2 * half - pad
             tpw = (kw - 1 + s0) // 2 + 1
-            w2 = torch.zeros((O, 8, kh, tpw), dtype=weight.dtype, device=weight.device)
-            for kx in range(kw):
-                pt, sub = (kx + s0) // 2, (kx + s0) % 2
-                w2[:, sub * 4: sub * 4 + I, :, pt] = weight[:, :, :, kx]
-            packed, th, tw, ci, k_pad = pack_conv(w2, k_mult=k_mult)
+            packed, th, tw, ci, k_pad = pk.conv(weight, c_in_pad=8, taps_w_pad=tpw, pair_s0=s0, bf16=True)
         elif c_buf == self.cpad and I < self.cpad:   # fp32 stem on NHWC4: pad channels to one chunk and the tap row to 8 / 4
             taps_w_pad = _round_up(kw, 8) if kw > 4 else 4
-            packed, th, tw, ci, k_pad = pack_conv(weight, c_in_pad=self.cpad, taps_w_pad=taps_w_pad, k_mult=k_mult)
+            packed, th, tw, ci, k_pad = pk.conv(weight, c_in_pad=self.cpad, taps_w_pad=taps_w_pad, bf16=self.bf16)
         else:
             assert I == c_buf, (name, I, c_buf)
-            perm = pixel_shuffle_row_perm(O, weight.device) if pixel_shuffle else None
-            packed, th, tw, ci, k_pad = pack_conv(weight, row_perm=perm, k_mult=k_mult)
-            if pixel_shuffle:
-                scale = scale[perm].contiguous() if scale is not None else None
-                shift = shift[perm].contiguous() if shift is not None else None
+            # pixel_shuffle: rows sub-pixel-major; `scale` / `shift` must come in the same order (fold_bn(..., pixel_shuffle=True))
+            packed, th, tw, ci, k_pad = pk.conv(weight, pixel_shuffle=pixel_shuffle, bf16=self.bf16)
         gh, gw = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
         d = ConvDesc()
         d.batch, d.in_h, d.in_w, d.c_in = 1, h, w, ci
@@ -533,7 +521,6 @@ class ProgramBuilder:
             flags |= SP_CONV_OUT_NCHW
         if self.bf16:
             flags |= SP_CONV_BF16
-            packed = packed.to(torch.bfloat16)
         d.flags = flags
         dst = dst or self._fresh(name)
         self.p.shapes[dst] = (d.out_h, d.out_w, d.out_c)
@@ -548,7 +535,7 @@ class ProgramBuilder:
         h, w, c = self.p.shapes[src]
         I, O = weight.shape[:2]
         assert I == c
-        packed, n_pad = pack_deconv_k4s2p1(weight)
+        packed, n_pad = self.packer.deconv(weight, bf16=self.bf16)
         d = ConvDesc()
         d.batch, d.in_h, d.in_w, d.c_in = 1, h, w, I
         d.grid_h, d.grid_w, d.c_out, d.n_pad = h, w, O, n_pad
@@ -558,11 +545,9 @@ class ProgramBuilder:
         d.oy_mul, d.oy_add, d.ox_mul, d.ox_add = 2, 0, 2, 0    # + phase
         d.phases_y = d.phases_x = 2
         d.flags = (SP_CONV_RELU if relu else 0) | (SP_CONV_BF16 if self.bf16 else 0)
-        if self.bf16:
-            packed = packed.to(torch.bfloat16)
         dst = self._fresh(name)
         self.p.shapes[dst] = (2 * h, 2 * w, O)
-        self._add(Op("conv", src, dst, desc=d, w=packed.reshape(4 * n_pad, 4 * I), scale=scale, shift=shift,
+        self._add(Op("conv", src, dst, desc=d, w=packed, scale=scale, shift=shift,
                              name=name, flops=2 * h * w * I * O * 16))
         return dst
 
@@ -602,39 +587,40 @@ class ProgramBuilder:
 # ------------------------------------------------------------------------------------------------
 # ResNet-50 (+ DConv / DUC head)
 # ------------------------------------------------------------------------------------------------
-def _bn(sd, prefix):
-    return fold_bn(sd[prefix + ".weight"], sd[prefix + ".bias"], sd[prefix + ".running_mean"], sd[prefix + ".running_var"])
+def _bn(b: "ProgramBuilder", sd, prefix, pixel_shuffle: bool = False):
+    return b.packer.fold_bn(sd[prefix + ".weight"], sd[prefix + ".bias"], sd[prefix + ".running_mean"], sd[prefix + ".running_var"],
+                            pixel_shuffle=pixel_shuffle)
 
 
 def _bottleneck(b: ProgramBuilder, sd, x: str, p: str, stride: int) -> str:
-    s1, h1 = _bn(sd, p + ".bn1")
+    s1, h1 = _bn(b, sd, p + ".bn1")
     t = b.conv(x, sd[p + ".conv1.weight"], scale=s1, shift=h1, relu=True, name=p + ".conv1")
-    s2, h2 = _bn(sd, p + ".bn2")
+    s2, h2 = _bn(b, sd, p + ".bn2")
     t = b.conv(t, sd[p + ".conv2.weight"], stride=stride, pad=1, scale=s2, shift=h2, relu=True, name=p + ".conv2")
     idn = x
     if (p + ".downsample.0.weight") in sd:
-        sdn, hdn = _bn(sd, p + ".downsample.1")
+        sdn, hdn = _bn(b, sd, p + ".downsample.1")
         # (stays on the main path's stream: giving the shortcut its own stream measured -1 % fp32 / -4 % bf16 at bs=128 - these
         # launches fill the chip on their own, unlike HRNet's low-resolution branches)
         idn = b.conv(x, sd[p + ".downsample.0.weight"], stride=stride, scale=sdn, shift=hdn, name=p + ".downsample")
-    s3, h3 = _bn(sd, p + ".bn3")
+    s3, h3 = _bn(b, sd, p + ".bn3")
     if (p + ".se.fc.0.weight") in sd:
         # SE variant (reduction=True): out = relu(se(bn3(conv3(t))) + identity), pose_resnet_dconv.py:124-131
         z = b.conv(t, sd[p + ".conv3.weight"], scale=s3, shift=h3, name=p + ".conv3")
         g = b.gap(z)
-        g = b.conv(g, sd[p + ".se.fc.0.weight"], shift=sd[p + ".se.fc.0.bias"].float().contiguous(), relu=True, name=p + ".se.fc.0")
-        g = b.conv(g, sd[p + ".se.fc.2.weight"], shift=sd[p + ".se.fc.2.bias"].float().contiguous(), name=p + ".se.fc.2")
+        g = b.conv(g, sd[p + ".se.fc.0.weight"], shift=b.packer.bias(sd[p + ".se.fc.0.bias"]), relu=True, name=p + ".se.fc.0")
+        g = b.conv(g, sd[p + ".se.fc.2.weight"], shift=b.packer.bias(sd[p + ".se.fc.2.bias"]), name=p + ".se.fc.2")
         return b.se_gate(z, g, idn)
     # bn3 + residual add + relu fused in conv3's epilogue (pose_resnet_dconv.py:124-131)
     return b.conv(t, sd[p + ".conv3.weight"], scale=s3, shift=h3, relu=True, res=idn, name=p + ".conv3")
 
 
 def resnet_program(sd: Dict[str, torch.Tensor], head: str, in_h: int = 256, in_w: int = 192,
-                   blocks=(3, 4, 6, 3), dtype: str = "fp32") -> Program:
+                   blocks=(3, 4, 6, 3), dtype: str = "fp32", packer=None) -> Program:
     """Lower a reference-layout state_dict into a Program.  `sd` tensors must be on the GPU."""
-    b = ProgramBuilder(in_h, in_w, dtype)
+    b = ProgramBuilder(in_h, in_w, dtype, packer)
     x = b.to_nhwc4("input")
-    s, h = _bn(sd, "bn1")
+    s, h = _bn(b, sd, "bn1")
     x = b.conv(x, sd["conv1.weight"], stride=2, pad=3, scale=s, shift=h, relu=True, name="conv1")
     x = b.maxpool(x)
     for li, n in enumerate(blocks, start=1):
@@ -643,18 +629,18 @@ def resnet_program(sd: Dict[str, torch.Tensor], head: str, in_h: int = 256, in_w
     J = sd["final_layer.weight"].shape[0]
     if head == "dconv":
         for idx in (0, 3, 6):
-            s, h = _bn(sd, f"deconv_layers.{idx + 1}")
+            s, h = _bn(b, sd, f"deconv_layers.{idx + 1}")
             x = b.deconv_k4s2p1(x, sd[f"deconv_layers.{idx}.weight"], scale=s, shift=h, relu=True,
                                 name=f"deconv_layers.{idx}")
-        b.conv(x, sd["final_layer.weight"], shift=sd["final_layer.bias"].float().contiguous(), out_nchw=True,
+        b.conv(x, sd["final_layer.weight"], shift=b.packer.bias(sd["final_layer.bias"]), out_nchw=True,
                dst="heat", name="final_layer")
     elif head == "duc":
         x = b.pixel_shuffle(x)
         for idx in (1, 2):
-            s, h = _bn(sd, f"duc_layers.{idx}.bn")
+            s, h = _bn(b, sd, f"duc_layers.{idx}.bn", pixel_shuffle=True)    # in the packed (sub-pixel-major) column order
             x = b.conv(x, sd[f"duc_layers.{idx}.conv.weight"], pad=1, scale=s, shift=h, relu=True, pixel_shuffle=True,
                        name=f"duc_layers.{idx}")
-        b.conv(x, sd["final_layer.weight"], pad=1, shift=sd["final_layer.bias"].float().contiguous(), out_nchw=True,
+        b.conv(x, sd["final_layer.weight"], pad=1, shift=b.packer.bias(sd["final_layer.bias"]), out_nchw=True,
                dst="heat", name="final_layer")
     else:
         raise ValueError(head)
@@ -668,9 +654,9 @@ def resnet_program(sd: Dict[str, torch.Tensor], head: str, in_h: int = 256, in_w
 # ------------------------------------------------------------------------------------------------
 def _basic_block(b: ProgramBuilder, sd, x: str, p: str) -> str:
     """BasicBlock.forward (pose_hrnet.py:34-51): conv3x3-bn-relu, conv3x3-bn, + x, relu (stride 1, no downsample)."""
-    s1, h1 = _bn(sd, p + ".bn1")
+    s1, h1 = _bn(b, sd, p + ".bn1")
     t = b.conv(x, sd[p + ".conv1.weight"], pad=1, scale=s1, shift=h1, relu=True, name=p + ".conv1")
-    s2, h2 = _bn(sd, p + ".bn2")
+    s2, h2 = _bn(b, sd, p + ".bn2")
     return b.conv(t, sd[p + ".conv2.weight"], pad=1, scale=s2, shift=h2, relu=True, res=x, name=p + ".conv2")
 
 
@@ -697,13 +683,13 @@ def _hr_module(b: ProgramBuilder, sd, xs: List[str], base: str, num_blocks: List
                 else:
                     y = b.upsample_add(xs[i], y, 1, relu=last)
             elif j > i:            # 1x1 conv + bn at the low resolution, nearest upsample, add (:192-202)
-                s, h = _bn(sd, f + ".1")
+                s, h = _bn(b, sd, f + ".1")
                 t = b.conv(xs[j], sd[f + ".0.weight"], scale=s, shift=h, name=f)
                 y = b.upsample_add(t, y, 2 ** (j - i), relu=last)
             else:                  # chain of 3x3 stride-2 convs (+bn, +relu except the last) (:205-233)
                 t = xs[j]
                 for k in range(i - j):
-                    s, h = _bn(sd, f"{f}.{k}.1")
+                    s, h = _bn(b, sd, f"{f}.{k}.1")
                     fin = (k == i - j - 1)
                     t = b.conv(t, sd[f"{f}.{k}.0.weight"], stride=2, pad=1, scale=s, shift=h,
                                relu=(last if fin else True), res=(y if fin else None), name=f"{f}.{k}")
@@ -713,14 +699,14 @@ def _hr_module(b: ProgramBuilder, sd, xs: List[str], base: str, num_blocks: List
     return outs
 
 
-def hrnet_program(sd: Dict[str, torch.Tensor], cfg: dict, in_h: int = 256, in_w: int = 192, dtype: str = "fp32") -> Program:
+def hrnet_program(sd: Dict[str, torch.Tensor], cfg: dict, in_h: int = 256, in_w: int = 192, dtype: str = "fp32", packer=None) -> Program:
     """Lower a reference-layout HRNet state_dict into a Program (PoseHighResolutionNet.forward, pose_hrnet.py:419-454)."""
     extra = cfg["MODEL"]["EXTRA"]
-    b = ProgramBuilder(in_h, in_w, dtype)
+    b = ProgramBuilder(in_h, in_w, dtype, packer)
     x = b.to_nhwc4("input")
-    s, h = _bn(sd, "bn1")
+    s, h = _bn(b, sd, "bn1")
     x = b.conv(x, sd["conv1.weight"], stride=2, pad=1, scale=s, shift=h, relu=True, name="conv1")
-    s, h = _bn(sd, "bn2")
+    s, h = _bn(b, sd, "bn2")
     x = b.conv(x, sd["conv2.weight"], stride=2, pad=1, scale=s, shift=h, relu=True, name="conv2")
     for k in range(4):
         x = _bottleneck(b, sd, x, f"layer1.{k}", 1)
@@ -735,14 +721,14 @@ def hrnet_program(sd: Dict[str, torch.Tensor], cfg: dict, in_h: int = 256, in_w:
             b.lane = i
             if i < pre_n:
                 if (f"{t}.{i}.0.weight") in sd:
-                    s_, h_ = _bn(sd, f"{t}.{i}.1")
+                    s_, h_ = _bn(b, sd, f"{t}.{i}.1")
                     xs.append(b.conv(ys[i], sd[f"{t}.{i}.0.weight"], pad=1, scale=s_, shift=h_, relu=True, name=f"{t}.{i}"))
                 else:
                     xs.append(ys[i])
             else:
                 v = ys[-1]
                 for j in range(i + 1 - pre_n):
-                    s_, h_ = _bn(sd, f"{t}.{i}.{j}.1")
+                    s_, h_ = _bn(b, sd, f"{t}.{i}.{j}.1")
                     v = b.conv(v, sd[f"{t}.{i}.{j}.0.weight"], stride=2, pad=1, scale=s_, shift=h_, relu=True, name=f"{t}.{i}.{j}")
                 xs.append(v)
         b.lane = 0
@@ -752,7 +738,7 @@ def hrnet_program(sd: Dict[str, torch.Tensor], cfg: dict, in_h: int = 256, in_w:
         ys = xs
         pre_n = nb
     kf = extra["FINAL_CONV_KERNEL"]
-    b.conv(ys[0], sd["final_layer.weight"], pad=1 if kf == 3 else 0, shift=sd["final_layer.bias"].float().contiguous(),
+    b.conv(ys[0], sd["final_layer.weight"], pad=1 if kf == 3 else 0, shift=b.packer.bias(sd["final_layer.bias"]),
            out_nchw=True, dst="heat", name="final_layer")
     hh, ww, _ = b.p.shapes["heat"]
     b.p.out_shape = (sd["final_layer.weight"].shape[0], hh, ww)

@@ -98,3 +98,79 @@ def run_program_cpu(prog, x):
         else:
             raise ValueError(op.kind)
     return bufs[prog.out_name], bufs
+
+
+class TorchPacker:
+    """TEST HELPER: the packed layouts of include/simple_pose_hip.h (sp_pack_conv_weights, sp_pack_deconv_k4s2p1, sp_fold_bn) restated
+    in plain torch, so that the CPU-only host-logic tests can lower a network without a GPU, and so that the GPU tests have an
+    independent statement of the layouts to hold the device kernels against.  Same interface as simple_pose_amd.engine.HipPacker."""
+
+    @staticmethod
+    def _round_up(v, m):
+        return (v + m - 1) // m * m
+
+    @classmethod
+    def n_pad_for(cls, c_out):
+        return cls._round_up(c_out, 128) if c_out >= 128 else (cls._round_up(c_out, 64) if c_out > 32 else 32)
+
+    def conv(self, w, *, c_in_pad=None, taps_w_pad=None, pixel_shuffle=False, pair_s0=-1, bf16=False):
+        w = w.detach().float()
+        O, I, kh, kw = w.shape
+        if pair_s0 >= 0:                      # x-paired stem: channel sub*4 + c of pair pt holds pixel tap kx = 2*pt + sub - s0
+            w2 = torch.zeros((O, 8, kh, taps_w_pad), dtype=torch.float32, device=w.device)
+            for kx in range(kw):
+                pt, sub = (kx + pair_s0) // 2, (kx + pair_s0) % 2
+                w2[:, sub * 4: sub * 4 + I, :, pt] = w[:, :, :, kx]
+            w, I, kw = w2, 8, taps_w_pad
+        ci, tw = c_in_pad or I, taps_w_pad or kw
+        p = torch.zeros((O, kh, tw, ci), dtype=torch.float32, device=w.device)
+        p[:, :, :kw, :I] = w.permute(0, 2, 3, 1)
+        p = p.reshape(O, kh * tw * ci)
+        if pixel_shuffle:
+            p = p[self.row_perm(O, w.device)]
+        k = kh * tw * ci
+        k_pad, n_pad = self._round_up(k, 64 if bf16 else 32), self.n_pad_for(O)
+        out = torch.zeros((n_pad, k_pad), dtype=torch.float32, device=w.device)
+        out[:O, :k] = p
+        return (out.to(torch.bfloat16) if bf16 else out).contiguous(), kh, tw, ci, k_pad
+
+    def deconv(self, w, *, bf16=False):
+        wf = w.detach().float()
+        I, O = wf.shape[:2]
+        n_pad = self.n_pad_for(O)
+        out = torch.zeros((4, n_pad, 4 * I), dtype=torch.float32, device=w.device)
+        for py in range(2):
+            for px in range(2):
+                for ty in range(2):
+                    for tx in range(2):
+                        ky, kx = 2 * ty + 1 - py, 2 * tx + 1 - px
+                        t = ty * 2 + tx
+                        out[py * 2 + px, :O, t * I:(t + 1) * I] = wf[:, :, ky, kx].t()
+        out = out.reshape(4 * n_pad, 4 * I)
+        return (out.to(torch.bfloat16) if bf16 else out).contiguous(), n_pad
+
+    @staticmethod
+    def row_perm(c_out, device):
+        """packed row n' = sub*(C/4) + c holds original channel c*4 + sub (sub = i*2 + j of nn.PixelShuffle(2))"""
+        c4 = c_out // 4
+        n = torch.arange(c_out, device=device)
+        return (n % c4) * 4 + (n // c4)
+
+    def fold_bn(self, weight, bias, running_mean, running_var, eps=1e-5, pixel_shuffle=False):
+        """scale = w / sqrt(var + eps), shift = b - mean * scale, every operation an IEEE fp32 operation of its own (numpy: the
+        vectorised torch-CPU expression 1.0 / torch.sqrt(x) is NOT correctly rounded on every host - it differed by 1 ulp on the GPU
+        box's AVX-512 cores - so it cannot be the bit-exact checker of sp_fold_bn)."""
+        import numpy as np
+        f = lambda t: t.detach().float().cpu().numpy()
+        w, b, m, v = f(weight), f(bias), f(running_mean), f(running_var)
+        root = np.sqrt((v + np.float32(eps)).astype(np.float32).astype(np.float64)).astype(np.float32)   # correctly rounded fp32 root
+        scale = (w * (np.float32(1.0) / root).astype(np.float32)).astype(np.float32)
+        shift = (b - (m * scale).astype(np.float32)).astype(np.float32)
+        scale, shift = torch.from_numpy(scale), torch.from_numpy(shift)
+        if pixel_shuffle:
+            perm = self.row_perm(scale.numel(), "cpu")
+            scale, shift = scale[perm], shift[perm]
+        return scale.contiguous().to(weight.device), shift.contiguous().to(weight.device)
+
+    def bias(self, b):
+        return b.detach().float().contiguous()

@@ -12,6 +12,7 @@ from simple_pose_amd import _lib, engine, synth  # noqa: E402
 from simple_pose_amd.commons.transforms import BasicSimpleTransform, RefineSimpleTransform  # noqa: E402
 from simple_pose_amd.metrics import BasicKeyPointDecoder, GaussTaylorKeyPointDecoder  # noqa: E402
 from simple_pose_amd.nets import pose_resnet_dconv, pose_resnet_duc  # noqa: E402
+from tests.desc_interp import TorchPacker  # noqa: E402  (the packed layouts restated in torch: the checker of the pack kernels)
 
 DEV = "cuda:0"
 
@@ -242,7 +243,8 @@ def test_duc_conv_with_fused_pixel_shuffle_and_final_nchw():
     ref = torch.nn.functional.conv2d(x.double(), wt.double(), padding=1)
     ref = torch.relu(ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))
     ref = torch.nn.functional.pixel_shuffle(ref, 2)
-    y = _run_conv(x, lambda b, src: b.conv(src, wt.to(DEV), pad=1, scale=scale.to(DEV), shift=shift.to(DEV), relu=True,
+    perm = TorchPacker.row_perm(256, "cpu")      # scale / shift go in the packed (sub-pixel-major) column order
+    y = _run_conv(x, lambda b, src: b.conv(src, wt.to(DEV), pad=1, scale=scale[perm].to(DEV), shift=shift[perm].to(DEV), relu=True,
                                            pixel_shuffle=True))
     assert y.shape == (B, 2 * h, 2 * w, 64)
     assert (y.permute(0, 3, 1, 2).double() - ref).abs().max() / ref.abs().max() < 2e-6
@@ -261,6 +263,80 @@ def test_duc_conv_with_fused_pixel_shuffle_and_final_nchw():
     bld.p.out_shape = (17, 16, 12)
     yf = bld.p.run(xf.permute(0, 2, 3, 1).contiguous().to(DEV)).cpu()
     assert (yf.double() - reff).abs().max() / reff.abs().max() < 2e-6
+
+
+
+
+def test_c_abi_packing_matches_the_layout_spec_bit_for_bit():
+    """sp_pack_conv_weights / sp_pack_deconv_k4s2p1 / sp_fold_bn (csrc/pack.hip, what engine.HipPacker calls) against the torch
+    restatement of the layouts (tests/desc_interp.TorchPacker): plain, padded-stem, x-paired bf16 stem, PixelShuffle row order,
+    transposed-conv phases, fp32 and bf16 destinations - identical bits, padding included."""
+    hp, tp = engine.HipPacker(), TorchPacker()
+    cases = [((64, 32, 3, 3), {}), ((256, 64, 1, 1), {}), ((17, 256, 1, 1), {}), ((17, 128, 3, 3), {}),
+             ((64, 3, 7, 7), dict(c_in_pad=4, taps_w_pad=8)), ((64, 3, 3, 3), dict(c_in_pad=4, taps_w_pad=4)),
+             ((64, 3, 7, 7), dict(c_in_pad=8, taps_w_pad=4, pair_s0=1, bf16=True)), ((64, 3, 3, 3), dict(c_in_pad=8, taps_w_pad=2, pair_s0=1, bf16=True)),
+             ((64, 3, 5, 5), dict(c_in_pad=8, taps_w_pad=3, pair_s0=0, bf16=True)),
+             ((1024, 512, 3, 3), dict(pixel_shuffle=True)), ((512, 256, 3, 3), dict(pixel_shuffle=True, bf16=True)), ((96, 40, 3, 3), dict(bf16=False))]
+    for i, (shape, kw) in enumerate(cases):
+        w = torch.from_numpy(synth.tensor_normal(21, f"pack/{i}", shape))
+        for bf in ({kw.get("bf16", False)} | ({True} if "pair_s0" not in kw and shape[1] % 8 == 0 else set())):
+            k2 = dict(kw, bf16=bf)
+            got, want = hp.conv(w.to(DEV), **k2), tp.conv(w, **k2)
+            assert got[1:] == want[1:], (shape, k2, got[1:], want[1:])
+            assert got[0].dtype == want[0].dtype and torch.equal(got[0].cpu(), want[0]), (shape, k2)
+    for cin, cout in ((64, 256), (2048, 256), (256, 17)):
+        w = torch.from_numpy(synth.tensor_normal(21, f"packd/{cin}", (cin, cout, 4, 4)))
+        for bf in (False, True):
+            got, want = hp.deconv(w.to(DEV), bf16=bf), tp.deconv(w, bf16=bf)
+            assert got[1] == want[1] and torch.equal(got[0].cpu(), want[0]), (cin, cout, bf)
+    for C, ps in ((64, False), (1024, True), (17, False)):
+        g, b_ = (torch.from_numpy(synth.tensor_uniform(21, f"bn/{C}/{n}", (C,), 0.5, 1.5)) for n in "gb")
+        m = torch.from_numpy(synth.tensor_normal(21, f"bn/{C}/m", (C,), std=0.3))
+        v = torch.from_numpy(synth.tensor_uniform(21, f"bn/{C}/v", (C,), 1e-3, 4.0))
+        got, want = hp.fold_bn(g.to(DEV), b_.to(DEV), m.to(DEV), v.to(DEV), pixel_shuffle=ps), tp.fold_bn(g, b_, m, v, pixel_shuffle=ps)
+        assert torch.equal(got[0].cpu(), want[0]) and torch.equal(got[1].cpu(), want[1]), C
+
+
+def test_ctypes_only_pack_and_run_one_conv():
+    """What a maintainer binding only include/simple_pose_hip.h does: no simple_pose_amd.engine, just the
+    C entry points - sp_conv_packed_dims + sp_pack_conv_weights + sp_fold_bn + a hand-filled sp_conv_desc + sp_conv2d_fwd -
+    reproduce conv3x3 + eval-mode BatchNorm + ReLU of the reference block (pose_resnet_dconv.py:112-120) in fp64."""
+    import ctypes
+    lib = _lib.lib()
+    B, Cin, H, W, Cout = 3, 64, 16, 12, 128
+    w = torch.from_numpy(synth.tensor_normal(22, "c/w", (Cout, Cin, 3, 3), std=(2.0 / (Cin * 9)) ** 0.5))
+    x = torch.from_numpy(synth.tensor_normal(22, "c/x", (B, Cin, H, W)))
+    g, b_ = (torch.from_numpy(synth.tensor_uniform(22, f"c/{n}", (Cout,), 0.5, 1.5)) for n in "gb")
+    m = torch.from_numpy(synth.tensor_normal(22, "c/m", (Cout,), std=0.3))
+    v = torch.from_numpy(synth.tensor_uniform(22, "c/v", (Cout,), 0.2, 2.0))
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    ref = torch.relu(torch.nn.functional.batch_norm(ref, m.double(), v.double(), g.double(), b_.double(), False, 0.0, 1e-5))
+    n_pad, k_pad = ctypes.c_int(0), ctypes.c_int(0)
+    assert lib.sp_conv_packed_dims(Cout, 9 * Cin, 0, ctypes.byref(n_pad), ctypes.byref(k_pad)) == 0
+    st = _lib.current_stream()
+    dw = w.to(DEV)
+    packed = torch.empty((n_pad.value, k_pad.value), dtype=torch.float32, device=DEV)
+    _lib.check(lib.sp_pack_conv_weights(_lib.ptr(dw), Cout, Cin, 3, 3, Cin, 3, 0, -1, n_pad.value, k_pad.value, _lib.ptr(packed), 0, st))
+    scale, shift = torch.empty(Cout, device=DEV), torch.empty(Cout, device=DEV)
+    dg, db, dm, dv = (t.to(DEV) for t in (g, b_, m, v))
+    _lib.check(lib.sp_fold_bn(_lib.ptr(dg), _lib.ptr(db), _lib.ptr(dm), _lib.ptr(dv), Cout, 1e-5, 0, _lib.ptr(scale), _lib.ptr(shift), st))
+    d = _lib.ConvDesc()
+    d.batch, d.in_h, d.in_w, d.c_in = B, H, W, Cin
+    d.grid_h, d.grid_w, d.c_out, d.n_pad = H, W, Cout, n_pad.value
+    d.taps_h, d.taps_w, d.k_pad, d.stride = 3, 3, k_pad.value, 1
+    d.dy0, d.dy_step, d.dx0, d.dx_step = -1, 1, -1, 1
+    d.out_h, d.out_w, d.out_c = H, W, Cout
+    d.oy_mul = d.ox_mul = d.phases_y = d.phases_x = 1
+    d.flags = _lib.SP_CONV_RELU
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=DEV)
+    _lib.check(lib.sp_conv2d_fwd(d, _lib.ptr(xn), _lib.ptr(packed), _lib.ptr(scale), _lib.ptr(shift), None, _lib.ptr(y), st))
+    torch.cuda.synchronize()
+    err = (y.cpu().permute(0, 3, 1, 2).double() - ref).abs().max() / ref.abs().max()
+    assert err < 2e-6, err
+    # argument validation up front: a destination too small for the padded matrix is refused with a message, nothing is launched
+    assert lib.sp_pack_conv_weights(_lib.ptr(dw), Cout, Cin, 3, 3, Cin, 3, 0, -1, n_pad.value, 9 * Cin - 32, _lib.ptr(packed), 0, st) == -1
+    assert b"k_pad" in lib.sp_last_error()
 
 
 # ---------------------------------------------------------------------------------------------- networks
@@ -658,7 +734,8 @@ def test_ring_kernel_matches_igemm_on_ragged_shapes():
             if with_res:
                 b.p.shapes["res"] = (ref.shape[2], ref.shape[3], Cout)
                 res_name = "res"
-            out = b.conv("input", w.to(DEV), stride=s, pad=p, scale=scale.to(DEV), shift=shift.to(DEV), relu=True, res=res_name,
+            perm = TorchPacker.row_perm(Cout, "cpu") if kind == "pshuf" else torch.arange(Cout)
+            out = b.conv("input", w.to(DEV), stride=s, pad=p, scale=scale[perm].to(DEV), shift=shift[perm].to(DEV), relu=True, res=res_name,
                          pixel_shuffle=(kind == "pshuf"), name="c")
         ref = ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
         r = None

@@ -12,7 +12,7 @@ from oracle import nets_oracle
 from simple_pose_amd import _lib, engine, synth
 from simple_pose_amd.build import LIB_PATH
 from simple_pose_amd.nets import pose_resnet_dconv, pose_resnet_duc
-from tests.desc_interp import run_program_cpu
+from tests.desc_interp import TorchPacker, run_program_cpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -36,7 +36,7 @@ def test_packing_and_descriptors_reproduce_oracle_forward(head):
     shapes = nets_oracle.state_dict_shapes_resnet50(head)
     sd = {k: torch.from_numpy(v) for k, v in synth.conditioned_state_dict(shapes, seed=3).items()}
     x = torch.from_numpy(synth.input_images(2, seed=3, h=64, w=64))
-    prog = engine.resnet_program(sd, head, in_h=64, in_w=64)
+    prog = engine.resnet_program(sd, head, in_h=64, in_w=64, packer=TorchPacker())
     with torch.no_grad():
         ref = nets_oracle.FORWARDS["resnet50_" + head](sd, x)
         got, _ = run_program_cpu(prog, x)
@@ -44,7 +44,7 @@ def test_packing_and_descriptors_reproduce_oracle_forward(head):
     rel = (got - ref).abs().max() / ref.abs().max()
     assert rel < 1e-5, rel
     # algorithmic FLOPs bookkeeping: per-image conv MACs scale with the image area
-    full = engine.resnet_program(sd, head, in_h=256, in_w=192)
+    full = engine.resnet_program(sd, head, in_h=256, in_w=192, packer=TorchPacker())
     expect = {"dconv": 10.8528e9, "duc": 11.7517e9}[head]
     assert abs(full.flops_per_image - expect) / expect < 1e-4, full.flops_per_image
 
@@ -52,7 +52,7 @@ def test_packing_and_descriptors_reproduce_oracle_forward(head):
 def test_buffer_plan_never_aliases_live_tensors():
     shapes = nets_oracle.state_dict_shapes_resnet50("dconv")
     sd = {k: torch.from_numpy(v) for k, v in synth.conditioned_state_dict(shapes, seed=1).items()}
-    prog = engine.resnet_program(sd, "dconv", in_h=64, in_w=64)
+    prog = engine.resnet_program(sd, "dconv", in_h=64, in_w=64, packer=TorchPacker())
     bufs = prog._alloc(1, torch.device("cpu"))
     live = {}
     last = {}
@@ -121,13 +121,13 @@ def test_hrnet_module_layout_and_lowering_reproduce_oracle(golden):
     sd = {k: torch.from_numpy(v) for k, v in synth.conditioned_state_dict(shapes, seed=2).items()}
     m.load_state_dict(sd, strict=True)
     x = torch.from_numpy(synth.input_images(1, seed=2, h=64, w=64))
-    prog = engine.hrnet_program(sd, m.cfg, in_h=64, in_w=64)
+    prog = engine.hrnet_program(sd, m.cfg, in_h=64, in_w=64, packer=TorchPacker())
     with torch.no_grad():
         ref = nets_oracle.hrnet_forward(sd, x, m.cfg)
         got, _ = run_program_cpu(prog, x)
     assert got.shape == ref.shape == (1, 17, 16, 16)
     assert (got - ref).abs().max() / ref.abs().max() < 1e-5
-    full = engine.hrnet_program(sd, m.cfg, in_h=256, in_w=192)
+    full = engine.hrnet_program(sd, m.cfg, in_h=256, in_w=192, packer=TorchPacker())
     assert abs(full.flops_per_image - 15.29e9) / 15.29e9 < 1e-3     # 15.2900 GFLOP / image
     with pytest.raises(_lib.HipLibraryError):
         m.eval()(torch.zeros(1, 3, 256, 192))
@@ -141,7 +141,7 @@ def test_se_variant_module_layout_and_lowering(golden):
     shapes = nets_oracle.state_dict_shapes_resnet50("dconv", se=True)
     sd = {k: torch.from_numpy(v) for k, v in synth.conditioned_state_dict(shapes, seed=4).items()}
     x = torch.from_numpy(synth.input_images(2, seed=4, h=64, w=64))
-    prog = engine.resnet_program(sd, "dconv", in_h=64, in_w=64)
+    prog = engine.resnet_program(sd, "dconv", in_h=64, in_w=64, packer=TorchPacker())
     with torch.no_grad():
         ref = nets_oracle.resnet_dconv_forward(sd, x)
         got, _ = run_program_cpu(prog, x)
@@ -154,7 +154,7 @@ def test_bf16_lowering_tracks_fp32_oracle(head):
     shapes = nets_oracle.state_dict_shapes_resnet50(head)
     sd = {k: torch.from_numpy(v) for k, v in synth.conditioned_state_dict(shapes, seed=3).items()}
     x = torch.from_numpy(synth.input_images(1, seed=3, h=64, w=64))
-    prog = engine.resnet_program(sd, head, in_h=64, in_w=64, dtype="bf16")
+    prog = engine.resnet_program(sd, head, in_h=64, in_w=64, dtype="bf16", packer=TorchPacker())
     assert all(op.w.dtype == torch.bfloat16 for op in prog.ops if op.kind == "conv")
     with torch.no_grad():
         ref = nets_oracle.FORWARDS["resnet50_" + head](sd, x)
