@@ -294,7 +294,8 @@ def main():
     roofline = None
     if rank == 0 and not args.no_kernel_events and prog is not None:
         roofline = kernel_roofline(prog, x, steps=max(3, min(args.steps, 10)), layers_out=args.layers_out,
-                                   peak=FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else BF16_MATRIX_PEAK_TFLOPS)
+                                   peak=FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else BF16_MATRIX_PEAK_TFLOPS,
+                                   arch=args.arch, dtype=args.dtype)
 
     step_split = None
     if args.mode == "train":                                  # untimed extra steps with phase events (every rank: collectives inside)
@@ -307,6 +308,8 @@ def main():
                     acc[k] = acc.get(k, 0.0) + v / 5
         trainer.profile = False
         step_split = {k: round(v, 3) for k, v in acc.items()}
+        if rank == 0 and not args.no_kernel_events:
+            roofline = train_roofline(trainer, step, B, FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else BF16_MATRIX_PEAK_TFLOPS)
     if rank == 0:
         name = ARCH_NAMES[args.arch]
         if args.mode == "train":
@@ -322,7 +325,7 @@ def main():
                            "collectives": ("RCCL (nccl backend)" if args.dist_backend == "nccl" else "gloo") if world > 1 else "none"},
                 "gflop_per_image": round(gflop, 3), "network_tflops": round(value * gflop / 1e3, 2),
                 "network_frac_of_matrix_peak": round(value * gflop / 1e3 / ((FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else BF16_MATRIX_PEAK_TFLOPS) * world), 4),
-                "roofline": None, "cpu_baseline": None, "final_loss": float(out[0].item()), "step_split_ms": step_split}
+                "roofline": roofline, "cpu_baseline": None, "final_loss": float(out[0].item()), "step_split_ms": step_split}
         else:
             peak = FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else BF16_MATRIX_PEAK_TFLOPS
             line = {
@@ -346,6 +349,38 @@ def main():
         dist.destroy_process_group()
 
 
+def train_roofline(trainer, step, B: int, peak: float, steps: int = 3):
+    """Train step: HIP events around every conv-family launch (forward, dgrad, wgrad), recorded on the stream the launch goes to
+    (weight gradients run on the trainer's second stream), over `steps` untimed extra steps.  The dominant group is the weight
+    gradient: `sp_conv2d_wgrad` = conv_wgrad(_bf16)_kernel + its fixed-order slab reduce wgrad_reduce_kernel (the pair is timed
+    together: average launch = the sum of the two kernels' averages in profiles/*_train_*_kernel_stats.csv), priced against the
+    MFMA peak with 2 x MACs of the layer as algorithmic FLOPs.  Kernels on the two streams overlap, so a group's time is the
+    time its launches were resident, not exclusive use of the chip."""
+    import torch
+
+    trainer.kernel_events = []
+    with torch.no_grad():
+        for _ in range(steps):
+            step()
+    torch.cuda.synchronize()
+    ev, trainer.kernel_events = trainer.kernel_events, None
+    groups = {}
+    for kind, name, flops, e0, e1 in ev:
+        g = groups.setdefault(kind, [0.0, 0.0, 0])
+        g[0] += e0.elapsed_time(e1); g[1] += flops * B; g[2] += 1
+    names = {"wgrad": ("conv_wgrad_bf16_kernel" if trainer.bf16 else "conv_wgrad_kernel") + " + wgrad_reduce_kernel",
+             "forward": "conv_igemm_kernel<...> (forward launches)", "dgrad": "conv_igemm_kernel<...> (dgrad launches)"}
+    dom = max(groups, key=lambda k: groups[k][0])
+    ms, fl, n = groups[dom]
+    ach = fl / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": names[dom], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "traffic": None, "launches_per_step": n // steps, "avg_launch_us": round(1e3 * ms / n, 2),
+            "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3),
+            "by_group": {names[k]: {"launches_per_step": g[2] // steps, "ms_per_step": round(g[0] / steps, 3), "tflops": round(g[1] / (g[0] * 1e-3) / 1e12, 1)}
+                         for k, g in sorted(groups.items(), key=lambda kv: -kv[1][0])},
+            "note": "streams overlap: group times are residency, their sum exceeds the step; BN / pointwise passes are HBM-bound and listed in profiles/*_train_*"}
+
+
 def _variant_name(op):
     """Kernel instantiation a conv launch resolves to (the name rocprofv3 reports): asked of the library's own dispatch
     (sp_conv2d_kernel_name), so it cannot drift from what is launched."""
@@ -353,7 +388,28 @@ def _variant_name(op):
     return _lib.conv_kernel_name(op.desc, op.res is not None, 3 if getattr(op, "direct", False) else 0)
 
 
-def kernel_roofline(prog, x, steps: int, layers_out=None, peak=FP32_MATRIX_PEAK_TFLOPS):
+def lookup_traffic(kernel: str, arch: str, dtype: str):
+    """HBM bytes per launch of `kernel` from the committed PMC summaries (profiles/rNN_<arch>_<dtype>_traffic.json, newest round
+    first; FETCH_SIZE / WRITE_SIZE passes of this same command, gfx950 correction applied by tools/profile_summary.py).  A kernel the
+    table does not know is reported on stderr, not swallowed: a stale table must show."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{arch}_{dtype}_traffic.json")), reverse=True)
+    if arch == "dconv" and dtype == "f32":
+        cands.append(os.path.join(ROOT, "profiles", "r01_traffic.json"))
+    for path in cands:
+        try:
+            with open(path) as fh:
+                tab = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        if kernel in tab:
+            return tab[kernel].get("hbm_bytes_per_launch")
+    print(f"bench.py: no PMC traffic entry for kernel `{kernel}` ({arch} {dtype}) under profiles/ - roofline.traffic is null "
+          f"(re-run tools/run_profiles.sh at this commit)", file=sys.stderr)
+    return None
+
+
+def kernel_roofline(prog, x, steps: int, layers_out=None, peak=FP32_MATRIX_PEAK_TFLOPS, arch="dconv", dtype="f32"):
     """HIP events recorded on the launch stream around every conv launch of `steps` forward passes (same inputs as the
     timed region).  The dominant kernel = the conv_igemm instantiation with the largest total time; its achieved
     TFLOP/s = algorithmic FLOPs of its launches / their summed durations, against the fp32 matrix peak.  The
@@ -400,14 +456,7 @@ def kernel_roofline(prog, x, steps: int, layers_out=None, peak=FP32_MATRIX_PEAK_
         with open(layers_out, "w") as fh:
             json.dump([{"layer": n, "us": round(1e3 * m, 1), "gflop": round(f / 1e9, 2), "tflops": round(f / (m * 1e-3) / 1e12, 1),
                         "kernel": v} for n, m, f, v in per_layer], fh, indent=0)
-    traffic = None
-    prof = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if os.path.isfile(prof):
-        try:
-            with open(prof) as fh:
-                traffic = json.load(fh).get(dom, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    traffic = lookup_traffic(dom, arch, dtype)
     return {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": traffic,
             "launches_per_step": d_n, "avg_launch_us": round(1e3 * d_ms / d_n, 2),

@@ -234,12 +234,26 @@ class ConvT:
                     self.w_dgrad.append(wd); self.d_dgrad.append(g)
 
     # ---- launches ----
+    def _timed(self, kind: str, stream=None):
+        """bench.py's per-kernel roofline: when the trainer collects kernel events, bracket this launch family with HIP events on the
+        stream it is issued to.  Returns the closing callback (a no-op otherwise)."""
+        ke = self.tr.kernel_events
+        if ke is None:
+            return lambda: None
+        st = stream if stream is not None else torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        ke.append((kind, self.name, self.flops, e0, e1))
+        return lambda: e1.record(st)
+
     def forward(self, x: torch.Tensor, B: int, out: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None) -> torch.Tensor:
         lib, d = _lib.lib(), self.d_fwd
         d.batch = B
         if out is None:
             out = torch.empty((B, d.out_h, d.out_w, d.out_c), dtype=self._wdt, device=x.device)
+        done = self._timed("forward")
         _lib.check(lib.sp_conv2d_fwd(d, P(x), P(self.w_fwd), None, P(shift), None, P(out), _lib.current_stream()), self.name)
+        done()
         return out
 
     def forward_bn_stats(self, x: torch.Tensor, B: int):
@@ -251,8 +265,10 @@ class ConvT:
         _lib.check(lib.sp_conv2d_bn_stats_rows(d, ctypes.byref(rows)), self.name)
         part = torch.empty((2, rows.value, d.n_pad), dtype=torch.float32, device=x.device)
         out = torch.empty((B, d.out_h, d.out_w, d.out_c), dtype=self._wdt, device=x.device)
+        done = self._timed("forward")
         _lib.check(lib.sp_conv2d_fwd_bn_stats(d, P(x), P(self.w_fwd), P(out), P(part[0]), P(part[1]), rows.value, _lib.current_stream()),
                    self.name)
+        done()
         return out, part, rows.value
 
     def dgrad(self, dz: torch.Tensor, B: int, acc: Optional[torch.Tensor], bn_src: Optional["Act"] = None) -> torch.Tensor:
@@ -274,11 +290,13 @@ class ConvT:
             part = torch.empty((2, total, stride), dtype=torch.float32, device=dz.device)
             z, mean, invstd = bn_src.bn
             row0 = 0
+            done = self._timed("dgrad")
             for d, w, n in zip(self.d_dgrad, self.w_dgrad, need):
                 _lib.check(lib.sp_conv2d_dgrad_bn_bwd_stats(d, P(dz), P(w), None, P(dx), P(bn_src.data), P(z), P(mean), P(invstd),
                                                             P(part[0, row0:]), P(part[1, row0:]), n, _lib.current_stream()),
                            self.name + ".dgrad")
                 row0 += n
+            done()
             bn_src.bstats = (part, total)
             return dx
         if acc is None:
@@ -289,9 +307,11 @@ class ConvT:
             res = None
         else:
             acc_t, res = acc, acc
+        done = self._timed("dgrad")
         for d, w in zip(self.d_dgrad, self.w_dgrad):
             d.batch = B
             _lib.check(lib.sp_conv2d_fwd(d, P(dz), P(w), None, None, P(res), P(acc_t), _lib.current_stream()), self.name + ".dgrad")
+        done()
         return acc_t
 
     def wgrad(self, x: torch.Tensor, dz: torch.Tensor, B: int, stream=None):
@@ -300,9 +320,11 @@ class ConvT:
         d.batch = B
         g, a = (dz, x) if self.kind == "conv" else (x, dz)
         gc = g.shape[-1]
+        done = self._timed("wgrad", tr._wgrad_stream if stream is not None else None)
         _lib.check(lib.sp_conv2d_wgrad(d, P(g), gc, P(a), self.wg["n_valid"], self.wg["c_valid"], self.wg["kw_valid"], self.wg["s_n"],
                                        self.wg["s_c"], P(tr.flat.view(self.wname, grad=True)), P(tr.wgrad_ws), tr.wgrad_ws.numel() * 4,
                                        stream if stream is not None else _lib.current_stream()), self.name + ".wgrad")
+        done()
 
 
 class PoseTrainer:
@@ -836,6 +858,7 @@ class PoseTrainer:
         return loss
 
     fuse_optimizer = True
+    kernel_events = None       # bench.py: a list collects (kind, layer, flops per image, start event, end event) per conv-family launch
     _opt_in_backward = False   # class-level defaults: also valid for partially constructed instances (host-logic tests)
     _opt_stream = None
     _wgrad_stream = None

@@ -30,6 +30,13 @@ def _ulp_diff(a, b):
 
 
 # ---------------------------------------------------------------------------------------------- decoders
+# px per unit of |trans_inv|, pinned from gpurun_out/measured_parity.json (tests/conftest.py `measured`), round 2: Basic decoder vs
+# the reference 6.9e-6 (fp32 ulps of a 64-px coordinate), GaussTaylor vs the oracle on identical maps 0, vs the reference 3.8e-5
+BASIC_BAR = 2e-5
+GT_ORACLE_BAR = 2e-5
+GT_REFERENCE_BAR = 1.2e-4  # (BASELINE contract: 1e-3 px)
+
+
 def _decode_inputs(golden, tag):
     g4 = golden("g4_decode.npz")
     if tag == "noise":
@@ -40,7 +47,7 @@ def _decode_inputs(golden, tag):
 
 
 @pytest.mark.parametrize("tag", ["gauss", "noise", "edge", "net"])
-def test_decoders_vs_reference_golden_and_oracle(golden, tag):
+def test_decoders_vs_reference_golden_and_oracle(golden, measured, tag):
     g4 = golden("g4_decode.npz")
     maps = _decode_inputs(golden, tag)
     B = maps.shape[0]
@@ -58,12 +65,18 @@ def test_decoders_vs_reference_golden_and_oracle(golden, tag):
         ref = g4[f"{tag}/{tname}/gt_kps"]
         assert kps.shape == ref.shape and mv.shape == (B, 17, 1)
         assert np.array_equal(mv, g4[f"{tag}/{tname}/gt_max"])
-        assert np.abs(kps - ref).max() <= 1e-3 * scale, (tag, tname, np.abs(kps - ref).max())
+        measured(f"{tname}/gauss_taylor_vs_reference_px_over_scale", np.abs(kps - ref).max() / scale, GT_REFERENCE_BAR)
+        assert np.abs(kps - ref).max() <= GT_REFERENCE_BAR * scale, (tag, tname, np.abs(kps - ref).max())
         okps, omv = pose_oracle.decode_gauss_taylor(maps, tinv)
         assert np.array_equal(mv, omv)
-        assert np.abs(kps - okps).max() <= 1e-4 * scale, (tag, tname, np.abs(kps - okps).max())
+        measured(f"{tname}/gauss_taylor_vs_oracle_px_over_scale", np.abs(kps - okps).max() / scale, GT_ORACLE_BAR)
+        assert np.abs(kps - okps).max() <= GT_ORACLE_BAR * scale, (tag, tname, np.abs(kps - okps).max())
         bk, _ = basic(hm, _cuda(tinv))
-        assert np.abs(bk.cpu().numpy() - g4[f"{tag}/{tname}/basic_kps"]).max() <= 1e-4 * scale * 64
+        # coordinates reach |trans_inv| * 64 px: one fp32 ulp there is 64 * 2^-24 * scale = 4e-6 * scale; the kernel's fp64 dot vs
+        # the reference's fp32 einsum differ by a few such ulps
+        berr = np.abs(bk.cpu().numpy() - g4[f"{tag}/{tname}/basic_kps"]).max()
+        measured(f"{tname}/basic_vs_reference_px_over_scale", berr / scale, BASIC_BAR)
+        assert berr <= BASIC_BAR * scale, (tag, tname, berr)
     assert torch.equal(hm, hm_before), "decoder must not modify its input"
 
 
@@ -347,9 +360,16 @@ def _load(mod, head, seed):
     return m.to(DEV).eval()
 
 
+# pinned from gpurun_out/measured_parity.json (the `measured` fixture): heat-map error this kernel showed, and the end-to-end
+# fractions (identical arg-max cells, joints within 1e-3 px) minus one percentage point
+# (round 2: heat maps 2.59e-6 / 2.22e-6; identical cells 100 % / 100 %; within 1e-3 px 94.1 % / 100 %, worst joint 0.019 / 0.0007 px)
+FWD_REL_MEASURED = {"dconv": 2.6e-6, "duc": 2.3e-6}
+E2E_BARS = {"dconv": (0.99, 0.93), "duc": (0.99, 0.99)}
+
+
 @pytest.mark.parametrize("mod,head,fname", [(pose_resnet_dconv, "dconv", "g1_dconv_fwd.npz"),
                                             (pose_resnet_duc, "duc", "g2_duc_fwd.npz")])
-def test_forward_vs_reference_golden(golden, mod, head, fname):
+def test_forward_vs_reference_golden(golden, measured, mod, head, fname):
     g = golden(fname)
     m = _load(mod, head, int(g["seed"]))
     x = _cuda(synth.input_images(int(g["batch"]), int(g["seed"])))
@@ -358,7 +378,9 @@ def test_forward_vs_reference_golden(golden, mod, head, fname):
     assert hm.shape == (2, 17, 64, 48) and hm.dtype == torch.float32 and hm.is_cuda
     ref = g["heat_maps"]
     rel = np.abs(hm.cpu().numpy() - ref).max() / np.abs(ref).max()
+    measured("heat_map_rel_err", rel, 1e-4)
     assert rel <= 1e-4, rel                       # BASELINE.json: heat maps within 1e-4 rel fp32
+    assert rel <= 3 * FWD_REL_MEASURED[head], rel  # and no more than 3x what this kernel measured when the bar was pinned
     # end to end: decoded key points.  Noise-like maps make -H^-1 g ill-conditioned, so the
     # contract is: arg-max cell identical, and the bulk of joints within 1e-3 px; the tail is reported, not hidden.
     tinv = synth.trans_inv_batch(2)
@@ -366,9 +388,14 @@ def test_forward_vs_reference_golden(golden, mod, head, fname):
     kps, _ = GaussTaylorKeyPointDecoder()(hm, _cuda(tinv))
     co, _ = BasicKeyPointDecoder.heat_map_to_axis(hm)
     rco, _ = pose_oracle.heat_map_to_axis(ref)
-    assert (co.cpu().numpy() == rco).all(-1).mean() >= 0.97
+    same_cell = (co.cpu().numpy() == rco).all(-1).mean()
     err = np.abs(kps.cpu().numpy() - ref_kps).max(-1) / 4.0      # heat-map px
-    assert (err <= 1e-3).mean() >= 0.85, ((err <= 1e-3).mean(), err.max())
+    within = (err <= 1e-3).mean()
+    measured("argmax_cell_match_fraction", same_cell, E2E_BARS[head][0])
+    measured("joints_within_1e-3px_fraction", within, E2E_BARS[head][1])
+    measured("worst_joint_px", err.max())
+    assert same_cell >= E2E_BARS[head][0], same_cell
+    assert within >= E2E_BARS[head][1], (within, err.max())
 
 
 def test_full_batch_128_is_consistent_with_golden(golden):
@@ -490,8 +517,13 @@ def test_bf16_conv_vs_torch_on_rounded_operands(case):
     assert err < 6e-3, err            # output rounding to bf16: 2^-8 of the value
 
 
+# pinned from measured_parity.json, round 2: 1.28e-2 / 0.92e-2 / 1.45e-2 (deterministic: every tile and kernel gives the same bits);
+# torch's CPU autocast-bf16 path against its own fp32: 1.07e-2
+BF16_FWD_BAR = {"dconv": 1.5e-2, "duc": 1.5e-2, "hrnet_w32": 2e-2}
+
+
 @pytest.mark.parametrize("arch", ["dconv", "duc", "hrnet_w32"])
-def test_bf16_forward_vs_fp32_reference_golden(golden, arch):
+def test_bf16_forward_vs_fp32_reference_golden(golden, measured, arch):
     """BASELINE configs 3 and 5 (bf16 compute): heat maps against the fp32 reference within the bf16 tolerance the CPU
     autocast path itself shows (1.07e-2 relative), and against our own fp32 path."""
     import os
@@ -516,8 +548,44 @@ def test_bf16_forward_vs_fp32_reference_golden(golden, arch):
     assert hm16.dtype == torch.float32 and hm16.shape == hm32.shape
     ref = g["heat_maps"]
     rel = np.abs(hm16.cpu().numpy() - ref).max() / np.abs(ref).max()
-    assert 1e-5 < rel <= 4e-2, rel
+    measured("bf16_heat_map_rel_err", rel, BF16_FWD_BAR[arch])
+    assert 1e-5 < rel <= BF16_FWD_BAR[arch], rel
     assert np.abs(hm32.cpu().numpy() - ref).max() / np.abs(ref).max() <= 1e-4     # switching back and forth re-packs
+
+
+@pytest.mark.parametrize("arch", ["duc", "hrnet_w32"])
+def test_full_batch_128_bf16_is_consistent_with_golden(golden, measured, arch):
+    """BASELINE configs 3 and 5 at their full size (bs=128, bf16): the batch repeats the golden inputs, so every output must equal
+    its replica bit for bit (deterministic kernels, tile- and kernel-independent reduction order: the autotuned bs=128 table
+    mixes ring / implicit-GEMM / direct kernels), equal the small-batch run of the same images bit for bit, and stay within
+    the bf16 bar of the fp32 reference."""
+    import os
+    if arch == "hrnet_w32":
+        from simple_pose_amd.nets.pose_hrnet import get_pose_net, hrnet_state_dict_shapes
+        g = golden("g3_hrnet_w32_fwd.npz")
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        m = get_pose_net(os.path.join(root, "simple_pose_amd", "nets", "hrnet_w32.yaml"), pretrained=None, joint_num=17)
+        sd = synth.conditioned_state_dict(hrnet_state_dict_shapes(m.cfg, 17), int(g["seed"]))
+    else:
+        g = golden("g2_duc_fwd.npz")
+        m = pose_resnet_duc.resnet50(pretrained=False, num_classes=17)
+        sd = synth.conditioned_state_dict(nets_oracle.state_dict_shapes_resnet50("duc"), int(g["seed"]))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m = m.to(DEV).eval()
+    m.compute_dtype = "bf16"
+    n = int(g["batch"])
+    xs = synth.input_images(n, int(g["seed"]))
+    x = _cuda(np.concatenate([xs] * (128 // n), 0))
+    with torch.no_grad():
+        hm = m(x)                      # autotunes at bs=128
+        hms = m(_cuda(xs))
+    assert hm.shape == (128, 17, 64, 48)
+    for i in range(n):
+        assert torch.equal(hm[i::n], hm[i:i + 1].expand(128 // n, -1, -1, -1)), (arch, i)
+    assert torch.equal(hm[:n], hms), arch
+    rel = np.abs(hm[:n].cpu().numpy() - g["heat_maps"]).max() / np.abs(g["heat_maps"]).max()
+    measured("bf16_bs128_heat_map_rel_err", rel, BF16_FWD_BAR[arch])
+    assert rel <= BF16_FWD_BAR[arch], rel
 
 
 def test_heat_map_acc_and_collate_normalisation_vs_reference_golden(golden):

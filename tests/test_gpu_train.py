@@ -70,7 +70,14 @@ def test_train_step_vs_oracle_small(B, H, W, head):
     assert frac_close > 0.995, (frac_close, sorted(bad, reverse=True)[:5])
 
 
-def test_train_step_vs_reference_golden(golden):
+# pinned from gpurun_out/measured_parity.json, round 2: worst gradient slice 1.5e-2 of the per-element gradient scale (conv1.weight: the
+# longest fp32 chain of the net, where the reference's own oneDNN-vs-fp64 spread is 0.3-1 %); 99.86 % of the sliced parameters within
+# 2e-4 after one Adam step (lr 1e-3: a sign flip of a near-zero gradient moves a parameter by 2e-3); loss 7.8e-8 relative
+GRAD_SLICE_BAR = 2e-2
+ADAM_CLOSE_BAR = 0.995
+
+
+def test_train_step_vs_reference_golden(golden, measured):
     """One step at 256x192, B=2, against the real reference (tests/golden/g6_train_step.npz)."""
     g = golden("g6_train_step.npz")
     model, _ = _model(0)
@@ -87,7 +94,8 @@ def test_train_step_vs_reference_golden(golden):
         ref = g[key]
         got = named[k].grad.cpu().numpy()[tuple(slice(0, s) for s in ref.shape)]
         scale = float(g["gradnorm/" + k]) / np.sqrt(named[k].numel())
-        assert np.abs(got - ref).max() <= 2e-2 * scale + 1e-12, (k, np.abs(got - ref).max(), scale)
+        measured(f"grad_slice_err_over_scale/{k}", np.abs(got - ref).max() / scale, GRAD_SLICE_BAR)
+        assert np.abs(got - ref).max() <= GRAD_SLICE_BAR * scale + 1e-12, (k, np.abs(got - ref).max(), scale)
     bufs = dict(model.named_buffers())
     for k in ("bn1.running_mean", "bn1.running_var", "layer3.5.bn3.running_var", "deconv_layers.7.running_mean"):
         assert np.abs(bufs[k].cpu().numpy() - g["buf/" + k]).max() <= 1e-4 * max(1.0, np.abs(g["buf/" + k]).max()), k
@@ -98,7 +106,10 @@ def test_train_step_vs_reference_golden(golden):
         ref = g[key]
         got = named[k].detach().cpu().numpy()[tuple(slice(0, s) for s in ref.shape)]
         close.append((np.abs(got - ref) < 2e-4).mean())
-    assert np.mean(close) > 0.99, close
+        measured(f"adam_param_max_abs_diff/{k}", np.abs(got - ref).max())
+    measured("adam_fraction_within_2e-4", np.mean(close), ADAM_CLOSE_BAR)
+    measured("loss_rel_err", abs(loss.item() - float(g["loss"])) / abs(float(g["loss"])), 1e-4)
+    assert np.mean(close) > ADAM_CLOSE_BAR, close
 
 
 def test_training_is_deterministic_and_decreases_loss():

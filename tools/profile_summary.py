@@ -1,13 +1,16 @@
 #!/usr/bin/env python3
-"""Turn rocprofv3 CSV output (gpurun_out/<dir>) into the committed summaries under profiles/.
+"""Turn the rocprofv3 CSV output of tools/run_profiles.sh (gpurun_out/prof_<tag>) into the committed summaries under profiles/.
 
-    python tools/profile_summary.py gpurun_out/prof_r1 profiles/r01
+    python tools/profile_summary.py gpurun_out/prof_r02 profiles/r02
 
-writes  profiles/r01_kernel_stats.csv   (verbatim --kernel-trace --stats summary)
-        profiles/r01_traffic.json       (per kernel: launches, FETCH_SIZE / WRITE_SIZE per launch and the HBM bytes
-                                         per launch with the gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE counts
-                                         128-B requests as 64 B for wide coalesced reads -> x2; units are KiB)
-        profiles/r01_summary.md
+per config <cfg> = <arch>_<dtype> (dconv_f32, dconv_bf16, duc_bf16, hrnet_w32_bf16):
+        profiles/r02_<cfg>_kernel_stats.csv   verbatim --kernel-trace --stats summary of `bench.py --arch .. --dtype ..`
+        profiles/r02_<cfg>_traffic.json       per kernel: launches, FETCH_SIZE / WRITE_SIZE per launch and the HBM bytes per launch
+                                              with the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE counts the 128-B
+                                              requests of wide coalesced reads as 64 B -> x2; units are KiB)
+        profiles/r02_<cfg>_bench.json         the unprofiled bench line of the same config
+        profiles/r02_<cfg>_tiles.json         the tile table the profiled runs were pinned to
+plus profiles/r02_train_bf16_kernel_stats.csv / _bench.json and profiles/r02_summary.md
 """
 import collections
 import csv
@@ -20,7 +23,7 @@ import sys
 
 
 def short(name):
-    m = re.search(r"(conv_\w+_kernel<[^>]*>|\w+_kernel(?:<\d+>)?)", name)
+    m = re.search(r"(conv_\w+_kernel<[^>]*>|\w+_kernel(?:<[^>]*>)?)", name)
     return m.group(1) if m else name[:60]
 
 
@@ -35,61 +38,84 @@ def agg(path, cname):
     return d
 
 
-def main(src, dst):
-    os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
-    stats = glob.glob(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), recursive=True)[0]
-    shutil.copy(stats, dst + "_kernel_stats.csv")
-    rows = list(csv.DictReader(open(stats)))
-    f = agg(glob.glob(os.path.join(src, "fetch", "**", "*_counter_collection.csv"), recursive=True)[0], "FETCH_SIZE")
-    w = agg(glob.glob(os.path.join(src, "write", "**", "*_counter_collection.csv"), recursive=True)[0], "WRITE_SIZE")
-    traffic = {}
-    for k, (n, fs) in f.items():
-        ws = w.get(k, [n, 0.0])[1]
-        traffic[k] = {"launches_profiled": n, "fetch_size_kib_per_launch": round(fs / n, 1),
-                      "write_size_kib_per_launch": round(ws / max(w.get(k, [n])[0], 1), 1),
-                      "hbm_bytes_per_launch": int((2.0 * fs / n + ws / max(w.get(k, [n])[0], 1)) * 1024)}
-    with open(dst + "_traffic.json", "w") as fh:
-        json.dump(traffic, fh, indent=1, sort_keys=True)
-    with open(dst + "_summary.md", "w") as fh:
-        fh.write("# rocprofv3 summary (python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline, 1 x MI355X)\n\n")
-        fh.write("| kernel | calls | avg us | % GPU time | HBM MB / launch (PMC, corrected) |\n|---|---|---|---|---|\n")
-        for r in rows[:12]:
-            k = short(r["Name"])
-            t = traffic.get(k, {}).get("hbm_bytes_per_launch")
-            fh.write(f"| `{k}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} | "
-                     f"{'' if t is None else round(t / 1e6, 1)} |\n")
-        log = os.path.join(src, "bench_trace.log")
-        if os.path.isfile(log):
-            for line in open(log):
-                if line.startswith('{"metric"'):
-                    fh.write("\nbench line of the profiled run (profiling perturbs clocks; see BENCH for the unprofiled number):\n\n```\n" + line.strip() + "\n```\n")
+def first(pattern):
+    found = glob.glob(pattern, recursive=True)
+    return found[0] if found else None
 
 
-def train_summary(src, dst):
-    """profiles/<tag>_train_bf16_kernel_stats.csv + a short table appended to the summary."""
-    found = glob.glob(os.path.join(src, "train_bf16", "**", "*_kernel_stats.csv"), recursive=True)
-    if not found:
+def bench_line(path):
+    if path and os.path.isfile(path):
+        for line in open(path):
+            if line.startswith('{"metric"'):
+                return json.loads(line)
+    return None
+
+
+def one_config(src, dst, cfg, fh):
+    d = os.path.join(src, cfg)
+    stats = first(os.path.join(d, "trace", "**", "*_kernel_stats.csv"))
+    if not stats:
         return
-    shutil.copy(found[0], dst + "_train_bf16_kernel_stats.csv")
-    rows = list(csv.DictReader(open(found[0])))
-    with open(dst + "_summary.md", "a") as fh:
-        fh.write("\n## train step, bf16 compute, 32 images (python3 bench.py --mode train --dtype bf16 --batch 32 --steps 10 --warmup 3)\n\n")
-        fh.write("| kernel | calls | avg us | % GPU time |\n|---|---|---|---|\n")
-        for r in rows[:16]:
-            fh.write(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |\n")
-        for name in ("bench_train_bf16.json", "bench_train_f32.json"):
-            path = os.path.join(src, name)
-            if os.path.isfile(path):
-                for line in open(path):
-                    if line.startswith('{"metric"'):
-                        shutil.copy(path, dst + "_" + name)
-                        d = json.loads(line)
-                        fh.write(f"\n`{name}`: {d['value']} img/s, {d['ms_per_step']} ms/step, split {d.get('step_split_ms')}\n")
+    shutil.copy(stats, f"{dst}_{cfg}_kernel_stats.csv")
+    rows = list(csv.DictReader(open(stats)))
+    traffic = {}
+    fpath, wpath = first(os.path.join(d, "fetch", "**", "*_counter_collection.csv")), first(os.path.join(d, "write", "**", "*_counter_collection.csv"))
+    if fpath and wpath:
+        f, w = agg(fpath, "FETCH_SIZE"), agg(wpath, "WRITE_SIZE")
+        for k, (n, fs) in f.items():
+            wn, ws = w.get(k, [n, 0.0])
+            traffic[k] = {"launches_profiled": n, "fetch_size_kib_per_launch": round(fs / n, 1), "write_size_kib_per_launch": round(ws / max(wn, 1), 1),
+                          "hbm_bytes_per_launch": int((2.0 * fs / n + ws / max(wn, 1)) * 1024)}
+        with open(f"{dst}_{cfg}_traffic.json", "w") as out:
+            json.dump(traffic, out, indent=1, sort_keys=True)
+    if os.path.isfile(os.path.join(d, "tiles_bs128.json")):
+        shutil.copy(os.path.join(d, "tiles_bs128.json"), f"{dst}_{cfg}_tiles.json")
+    line = bench_line(os.path.join(d, "bench_unprofiled.json"))
+    if line:
+        with open(f"{dst}_{cfg}_bench.json", "w") as out:
+            out.write(json.dumps(line) + "\n")
+    prof = bench_line(os.path.join(d, "bench_trace.log"))
+    fh.write(f"\n## {cfg}: `python3 bench.py --arch {cfg.rsplit('_', 1)[0]} --dtype {cfg.rsplit('_', 1)[1]} --steps 10 --warmup 3` under rocprofv3 --kernel-trace --stats\n\n")
+    if line:
+        r = line.get("roofline") or {}
+        fh.write(f"unprofiled: **{line['value']} img/s**, {line['ms_per_step']} ms/step; dominant kernel `{r.get('kernel')}` "
+                 f"{r.get('achieved')} {r.get('unit')} = {r.get('frac')} of {r.get('peak')}, avg launch {r.get('avg_launch_us')} us (HIP events), "
+                 f"traffic {r.get('traffic')} B/launch; all conv launches {((r.get('all_conv_kernels') or {}).get('frac'))} of peak\n\n")
+    if prof:
+        fh.write(f"profiled run (profiling perturbs clocks): {prof['value']} img/s, {prof['ms_per_step']} ms/step\n\n")
+    fh.write("| kernel | calls | avg us | % GPU time | HBM MB / launch (PMC, corrected) |\n|---|---|---|---|---|\n")
+    for r in rows[:14]:
+        k = short(r["Name"])
+        t = traffic.get(k, {}).get("hbm_bytes_per_launch")
+        fh.write(f"| `{k}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} | {'' if t is None else round(t / 1e6, 1)} |\n")
+
+
+def train(src, dst, fh):
+    d = os.path.join(src, "train_bf16")
+    stats = first(os.path.join(d, "trace", "**", "*_kernel_stats.csv"))
+    if not stats:
+        return
+    shutil.copy(stats, f"{dst}_train_bf16_kernel_stats.csv")
+    rows = list(csv.DictReader(open(stats)))
+    fh.write("\n## train step, bf16 compute, 32 images (`python3 bench.py --mode train --dtype bf16 --batch 32 --steps 10 --warmup 3`)\n\n")
+    calls = sum(int(r["Calls"]) for r in rows)
+    fh.write(f"{calls} kernel launches in the profiled run = {calls / 13:.0f} per step (13 steps incl. warm-up; the bench's extra split / event steps included)\n\n")
+    fh.write("| kernel | calls | avg us | % GPU time |\n|---|---|---|---|\n")
+    for r in rows[:18]:
+        fh.write(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |\n")
+    for name, path in (("train_bf16", os.path.join(d, "bench_unprofiled.json")), ("train_f32", os.path.join(src, "bench_train_f32.json"))):
+        line = bench_line(path)
+        if line:
+            with open(f"{dst}_{name}_bench.json", "w") as out:
+                out.write(json.dumps(line) + "\n")
+            fh.write(f"\n`{name}`: {line['value']} img/s, {line['ms_per_step']} ms/step, split {line.get('step_split_ms')}, roofline {json.dumps(line.get('roofline'))}\n")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
-    train_summary(sys.argv[1], sys.argv[2])
-    for extra in ("bench_unprofiled.json",):
-        if os.path.isfile(os.path.join(sys.argv[1], extra)):
-            shutil.copy(os.path.join(sys.argv[1], extra), sys.argv[2] + "_" + extra)
+    src, dst = sys.argv[1], sys.argv[2]
+    os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
+    with open(dst + "_summary.md", "w") as fh:
+        fh.write("# rocprofv3 summaries (1 x MI355X; tools/run_profiles.sh -> tools/profile_summary.py)\n")
+        for cfg in ("dconv_f32", "dconv_bf16", "duc_bf16", "hrnet_w32_bf16"):
+            one_config(src, dst, cfg, fh)
+        train(src, dst, fh)

@@ -1,25 +1,38 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence of one round on the GPU box (run through gpurun from the repo root):
-#   bash tools/run_profiles.sh r01        -> gpurun_out/prof_r01/{trace,fetch,write,train_bf16}/...
-# then, back in the build container:     python tools/profile_summary.py gpurun_out/prof_r01 profiles/r01
-# Kernel trace and counters are separate passes (a --pmc pass never carries a trace domain).
+#   bash tools/run_profiles.sh r02        -> gpurun_out/prof_r02/<arch>_<dtype>/{trace,fetch,write}/... + train_bf16/ + bench lines
+# then, back in the build container:     python tools/profile_summary.py gpurun_out/prof_r02 profiles/r02
+# One block per BASELINE config (dconv f32 = the headline, dconv/duc/hrnet_w32 bf16); kernel trace and counters are separate passes
+# (a --pmc pass never carries a trace domain); the program itself follows `--` (python3 ..., no wrapper).
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
+CONFIGS=${2:-"dconv:f32 dconv:bf16 duc:bf16 hrnet_w32:bf16"}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
-TILES=$ROOT/profiles/${TAG}_tiles_bs128.json
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --tiles $TILES"
-# untimed: make sure the tile table exists so that the tuner's trial launches stay out of the statistics
-[ -f $TILES ] || python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --tiles $TILES > /dev/null 2>&1
-cp $TILES $OUT/ 2>/dev/null
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/bench_trace.log 2>&1
-timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $BENCH --no-kernel-events > $OUT/bench_fetch.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $BENCH --no-kernel-events > $OUT/bench_write.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train_bf16 -- python3 $ROOT/bench.py --mode train --dtype bf16 --batch 32 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_train_bf16.log 2>&1
-timeout 300 python3 $ROOT/bench.py --steps 20 --warmup 5 > $OUT/bench_unprofiled.json 2> $OUT/bench_unprofiled.err
-timeout 300 python3 $ROOT/bench.py --mode train --dtype bf16 --batch 32 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_train_bf16.json 2>/dev/null
+for cfg in $CONFIGS; do
+  arch=${cfg%%:*}; dt=${cfg##*:}
+  D=$OUT/${arch}_${dt}
+  mkdir -p $D
+  TILES=$D/tiles_bs128.json
+  BENCH="python3 $ROOT/bench.py --arch $arch --dtype $dt --steps 10 --warmup 3 --no-cpu-baseline --tiles $TILES"
+  # untimed: pin the tile table first so that the tuner's trial launches stay out of the statistics
+  timeout 300 python3 $ROOT/bench.py --arch $arch --dtype $dt --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --tiles $TILES > /dev/null 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -- $BENCH > $D/bench_trace.log 2>&1 || echo "$cfg trace failed"
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/fetch -- $BENCH --no-kernel-events > $D/bench_fetch.log 2>&1 || echo "$cfg fetch failed"
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/write -- $BENCH --no-kernel-events > $D/bench_write.log 2>&1 || echo "$cfg write failed"
+  if [ "$cfg" = "dconv:f32" ]; then
+    timeout 300 python3 $ROOT/bench.py --steps 20 --warmup 5 > $D/bench_unprofiled.json 2> $D/bench_unprofiled.err
+  else
+    timeout 300 python3 $ROOT/bench.py --arch $arch --dtype $dt --steps 20 --warmup 5 --no-cpu-baseline > $D/bench_unprofiled.json 2> $D/bench_unprofiled.err
+  fi
+  echo "$cfg done: $(grep -o '"value": [0-9.]*' $D/bench_unprofiled.json | head -1)"
+done
+T=$OUT/train_bf16
+mkdir -p $T
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $T/trace -- python3 $ROOT/bench.py --mode train --dtype bf16 --batch 32 --steps 10 --warmup 3 --no-cpu-baseline > $T/bench_trace.log 2>&1 || echo "train trace failed"
+timeout 300 python3 $ROOT/bench.py --mode train --dtype bf16 --batch 32 --steps 20 --warmup 5 --no-cpu-baseline > $T/bench_unprofiled.json 2> $T/bench_unprofiled.err
 timeout 300 python3 $ROOT/bench.py --mode train --dtype f32 --batch 32 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_train_f32.json 2>/dev/null
 # keep only the summaries (the raw per-dispatch traces are large)
 find $OUT -name "*_kernel_trace.csv" -size +8M -delete
