@@ -27,7 +27,7 @@ extern "C" {
 #define SP_EINVAL (-1)   /* bad argument / unsupported shape (message in sp_last_error) */
 #define SP_ELAUNCH (-2)  /* HIP launch or runtime failure */
 
-#define SP_ABI_VERSION 19
+#define SP_ABI_VERSION 20
 
 /* epilogue / layout flags of sp_conv_desc.flags */
 #define SP_CONV_RELU 0x1u          /* y = max(y, 0) after scale/shift (+ residual) */
@@ -75,7 +75,7 @@ typedef struct sp_conv_desc {
 /* sp_conv_desc.kernel */
 #define SP_CONV_KERNEL_IGEMM 0 /* 4-wave workgroups, register-staged double buffer: every dtype / flag / tile listed at sp_conv2d_default_tile */
 #define SP_CONV_KERNEL_RING 1  /* bf16 only: persistent 8-wave workgroups fed by an LDS-DMA ring (buffer_load ... lds, counted vmcnt);
-                                  tiles 256x256 256x128 128x256 256x64 128x128; needs sp_conv2d_ring_ok(desc) == 1 */
+                                  tiles 256x256 256x128 128x256 256x64 128x128 192x128 192x256; needs sp_conv2d_ring_ok(desc) == 1 */
 
 /* ---- library ---------------------------------------------------------------------------------- */
 int sp_abi_version(void);
@@ -260,6 +260,10 @@ int sp_bn_train_bwd_nhwc(const void* dy, int bf16, const void* relu_src, const v
  *             -> sp_bn_train_bwd_apply_nhwc(global sums, total_rows = rows over all ranks)
  * sp_bn_train_stats_nhwc / sp_bn_train_bwd_nhwc are exactly these halves back to back with total_rows = rows. */
 int sp_bn_train_partial_nhwc(const void* z, int bf16, int64_t rows, int c, double* sums, void* workspace, void* stream);
+/* the forward half without the pass over z: fold the partial rows sp_conv2d_fwd_bn_stats left into this rank's fp64 (sum, sum of
+ * squares) per channel, [c][2] as above -> all-reduce -> sp_bn_train_finalize.  Several layers may fold into consecutive slices of
+ * ONE buffer and share one all-reduce (the conv1 / downsample pair of a block's first bottleneck reads the same input). */
+int sp_bn_sums_from_conv(const float* stats_sum, const float* stats_sumsq, int partial_rows, int stride, int c, double* sums, void* stream);
 int sp_bn_train_finalize(const double* sums, int64_t total_rows, int c, float eps, float momentum, float* mean, float* invstd,
                          float* running_mean, float* running_var, void* stream);
 int sp_bn_train_bwd_reduce_nhwc(const void* dy, int bf16, const void* relu_src, const void* z, const float* mean, const float* invstd,

@@ -20,9 +20,9 @@ SP_CONV_PIXEL_SHUFFLE = 0x4
 SP_CONV_BF16 = 0x8
 SP_CONV_OUT_F32 = 0x10
 CONV_TILES = ((128, 128), (64, 128), (128, 64), (64, 64), (256, 64), (128, 32))
-ABI_VERSION = 19
+ABI_VERSION = 20
 SP_CONV_KERNEL_IGEMM, SP_CONV_KERNEL_RING = 0, 1
-RING_TILES = ((256, 256), (256, 128), (128, 256), (256, 64), (128, 128))   # kernel = SP_CONV_KERNEL_RING (bf16)
+RING_TILES = ((256, 256), (256, 128), (128, 256), (256, 64), (128, 128), (192, 128), (192, 256))   # kernel = SP_CONV_KERNEL_RING (bf16)
 
 
 class HipLibraryError(RuntimeError):
@@ -88,6 +88,7 @@ SYMBOLS = {
     "sp_conv2d_fwd_bn_stats": (c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, c_int, _P]),
     "sp_bn_train_stats_from_conv": (c_int, [_P, _P, c_int, c_int, c_int64, c_int, c_float, c_float, _P, _P, _P, _P, _P]),
     "sp_conv2d_dgrad_bn_bwd_stats": (c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
+    "sp_bn_sums_from_conv": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
     "sp_bn_bwd_sums_from_conv": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "sp_u8hwc_bgr_to_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "sp_nchw_to_nhwc4_bf16": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -422,7 +422,9 @@ int launch_ring(const RingArgs& a, hipStream_t stream) {
 }
 
 struct RingTile { int bm, bn, ns; };
-constexpr RingTile kRingTiles[] = {{256, 256, 2}, {256, 128, 3}, {128, 256, 3}, {256, 64, 3}, {128, 128, 4}};
+// (192-row tiles: at bs=128 the layer3 / layer4 GEMMs of ResNet-50 cut into exactly 192 tiles of 128x256 / 256x128 / 256x256 - three
+// quarters of the 256 CUs for one round; 192x128 and 192x256 give 256 tiles of three quarters the work)
+constexpr RingTile kRingTiles[] = {{256, 256, 2}, {256, 128, 3}, {128, 256, 3}, {256, 64, 3}, {128, 128, 4}, {192, 128, 3}, {192, 256, 2}};
 
 const RingTile* find_tile(int bm, int bn) {
     for (const RingTile& t : kRingTiles)
@@ -448,7 +450,7 @@ extern "C" int sp_conv2d_ring_ok(const sp_conv_desc* d) {
 int sp_conv_ring_launch(const sp_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift,
                         const void* residual, void* y, void* stream) {
     SP_REQUIRE(sp_conv2d_ring_ok(d), "sp_conv2d_fwd: descriptor / tile %dx%d not supported by the LDS-DMA ring kernel (bf16 NHWC in and out, "
-               "c_in %% 64 == 0, k_pad / 64 >= ring depth, tile_n | n_pad; tiles 256x256 256x128 128x256 256x64 128x128)", d->tile_m, d->tile_n);
+               "c_in %% 64 == 0, k_pad / 64 >= ring depth, tile_n | n_pad; tiles 256x256 256x128 128x256 256x64 128x128 192x128 192x256)", d->tile_m, d->tile_n);
     const long long M = (long long)d->batch * d->grid_h * d->grid_w;
     const long long in_elems = (long long)d->batch * d->in_h * d->in_w * d->c_in;
     const long long out_elems = (long long)d->batch * d->out_h * d->out_w * d->out_c;
@@ -477,6 +479,8 @@ int sp_conv_ring_launch(const sp_conv_desc* d, const void* x, const void* w_pack
     if (bm == 128 && bn == 256) return launch_ring<128, 256, 2, 4, 3>(a, s);
     if (bm == 256 && bn == 64) return launch_ring<256, 64, 4, 2, 3>(a, s);
     if (bm == 128 && bn == 128) return launch_ring<128, 128, 2, 4, 4>(a, s);
+    if (bm == 192 && bn == 128) return launch_ring<192, 128, 2, 4, 3>(a, s);
+    if (bm == 192 && bn == 256) return launch_ring<192, 256, 2, 4, 2>(a, s);
     sp_set_error("sp_conv2d_fwd: ring tile %dx%d not instantiated", bm, bn);
     return SP_EINVAL;
 }

@@ -181,6 +181,26 @@ __global__ void bn_stats_from_conv_kernel(const float* __restrict__ ps, const fl
     }
 }
 
+// SyncBatchNorm on the fused statistics: the same fold, stopped before the finalisation - this rank's (sum, sum of squares) per channel
+// in fp64, the [c][2] layout sp_bn_train_finalize consumes after the cross-rank SUM
+__global__ void bn_sums_from_conv_kernel(const float* __restrict__ ps, const float* __restrict__ pq, int nrows, int stride, int C,
+                                         double* __restrict__ sums) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    const int lane = threadIdx.x & 63;
+    double a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+    int r = lane;
+    for (; r + 64 < nrows; r += 128) {
+        a0 += (double)ps[(size_t)r * stride + c]; a1 += (double)pq[(size_t)r * stride + c];
+        b0 += (double)ps[(size_t)(r + 64) * stride + c]; b1 += (double)pq[(size_t)(r + 64) * stride + c];
+    }
+    for (; r < nrows; r += 64) { a0 += (double)ps[(size_t)r * stride + c]; a1 += (double)pq[(size_t)r * stride + c]; }
+    double s0 = a0 + b0, s1 = a1 + b1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off, SP_WAVE); s1 += __shfl_xor(s1, off, SP_WAVE); }
+    if (lane == 0) { sums[2 * c] = s0; sums[2 * c + 1] = s1; }
+}
+
 // dbeta = sum g, dgamma = sum g*xhat from the partial rows a BSTATS dgrad launch (or several: one per output phase) left
 __global__ void bn_bwd_sums_from_conv_kernel(const float* __restrict__ ps, const float* __restrict__ pq, int nrows, int stride, int C,
                                              float* __restrict__ dbeta, float* __restrict__ dgamma) {
@@ -507,6 +527,14 @@ extern "C" int sp_bn_train_stats_from_conv(const float* stats_sum, const float* 
     hipLaunchKernelGGL(bn_stats_from_conv_kernel, dim3((c + 3) / 4), dim3(256), 0, (hipStream_t)stream, stats_sum, stats_sumsq, partial_rows, stride,
                        c, (double)rows, eps, momentum, mean, invstd, running_mean, running_var);
     return sp_check_launch("bn_stats_from_conv_kernel");
+}
+
+extern "C" int sp_bn_sums_from_conv(const float* stats_sum, const float* stats_sumsq, int partial_rows, int stride, int c, double* sums,
+                                    void* stream) {
+    SP_REQUIRE(stats_sum && stats_sumsq && sums && partial_rows > 0 && stride >= c && c > 0, "sp_bn_sums_from_conv: bad argument");
+    hipLaunchKernelGGL(bn_sums_from_conv_kernel, dim3((c + 3) / 4), dim3(256), 0, (hipStream_t)stream, stats_sum, stats_sumsq, partial_rows, stride,
+                       c, sums);
+    return sp_check_launch("bn_sums_from_conv_kernel");
 }
 
 extern "C" int sp_bn_bwd_sums_from_conv(const float* sum_g, const float* sum_g_xhat, int partial_rows, int stride, int c, float* dgamma,

@@ -119,6 +119,8 @@ class DDPProcessor(object):
             x = input_tensors.to(self.device, non_blocking=True)
             targets = heat_maps.to(self.device, non_blocking=True)
             mask = masks.to(self.device, non_blocking=True)
+            if self.trainer.tuned_for_batch == 0 and x.shape[0] >= 8:
+                self.trainer.autotune(x.shape[0])             # once: fastest conv tile per layer at this per-GPU batch (results unchanged)
             loss = self.trainer.step(x, targets, mask)        # zero_grad / forward / loss / backward / all-reduce / Adam
             acc = self.acc_func(self.trainer.last_heat, targets, mask)
             self.loss_logger.update(loss[0]); self.acc_logger.update(acc)

@@ -71,8 +71,11 @@ class Act:
     c: int
     grad: Optional[torch.Tensor] = None
     needs_grad: bool = True
-    consumers: int = 0                 # forward ops that read this activation
+    consumers: int = 0                 # forward ops that read this activation (conv inputs, residual adds, shuffles)
+    contrib: int = 0                   # backward: how many of them have added their share to .grad so far
     bn: Optional[tuple] = None         # produced by BatchNorm+ReLU (no residual): (z, mean, invstd) of that layer
+    sibling: Optional[tuple] = None    # SyncBN: produced by a bare BatchNorm (projection shortcut): (z, mean, invstd, bn name)
+    presums: Optional[tuple] = None    # SyncBN backward: global (sum g*xhat, sum g) already exchanged by the consumer's message
     bstats: Optional[tuple] = None     # backward: (partial sums [2, rows, stride], rows) left by the dgrad launch that wrote .grad
 
 
@@ -272,14 +275,20 @@ class ConvT:
         return out, part, rows.value
 
     def dgrad(self, dz: torch.Tensor, B: int, acc: Optional[torch.Tensor], bn_src: Optional["Act"] = None) -> torch.Tensor:
-        """dx (+= into `acc` when given).  `bn_src`: the activation dx is the gradient of, when it came out of a BatchNorm+ReLU and
-        this launch family is its only consumer: the epilogue then also reduces that layer's backward sums (bn_src.bstats)."""
+        """dx (+= into `acc` when given).  `bn_src`: the activation dx is the gradient of, when it came out of a BatchNorm(+residual)+ReLU
+        and this launch family is the LAST of its consumers to contribute: the epilogue then holds the complete dy and also reduces
+        that layer's backward sums (bn_src.bstats)."""
         lib = _lib.lib()
         if bn_src is not None:
-            assert acc is None
             d0 = self.d_dgrad[0]
-            dx = torch.zeros((B, d0.out_h, d0.out_w, d0.out_c), dtype=torch.float32, device=dz.device) if not self.dgrad_full_cover else \
-                torch.empty((B, d0.out_h, d0.out_w, d0.out_c), dtype=torch.float32, device=dz.device)
+            if acc is not None:
+                # the other consumers' shares are already in `acc`: this launch family adds the last one in place, so its epilogue sees
+                # the COMPLETE dy (every element must be written by it: stride-2 1x1 families leave holes and are not offered here)
+                assert self.dgrad_full_cover
+                dx = acc
+            else:
+                dx = torch.zeros((B, d0.out_h, d0.out_w, d0.out_c), dtype=torch.float32, device=dz.device) if not self.dgrad_full_cover else \
+                    torch.empty((B, d0.out_h, d0.out_w, d0.out_c), dtype=torch.float32, device=dz.device)
             need = []
             for d in self.d_dgrad:
                 d.batch = B
@@ -292,7 +301,7 @@ class ConvT:
             row0 = 0
             done = self._timed("dgrad")
             for d, w, n in zip(self.d_dgrad, self.w_dgrad, need):
-                _lib.check(lib.sp_conv2d_dgrad_bn_bwd_stats(d, P(dz), P(w), None, P(dx), P(bn_src.data), P(z), P(mean), P(invstd),
+                _lib.check(lib.sp_conv2d_dgrad_bn_bwd_stats(d, P(dz), P(w), P(acc), P(dx), P(bn_src.data), P(z), P(mean), P(invstd),
                                                             P(part[0, row0:]), P(part[1, row0:]), n, _lib.current_stream()),
                            self.name + ".dgrad")
                 row0 += n
@@ -527,6 +536,60 @@ class PoseTrainer:
             _lib.check(_lib.lib().sp_permute4_batched(P(self.flat.data), tab, hi - lo, 8, stream if stream is not None else _lib.current_stream()),
                        "repack")
 
+    # ---- per-layer tile choice -----------------------------------------------------------------------------------------------
+    def autotune(self, batch: int, reps: int = 5, rounds: int = 3) -> Dict[str, tuple]:
+        """Time every legal implicit-GEMM tile of every forward and dgrad launch at this per-GPU batch (HIP events, random operands of
+        the launch's real shapes) and pin the fastest in the descriptors (`tile_m` / `tile_n`).  Results do not depend on the tile (same
+        reduction order), so this only moves speed; the built-in heuristic was fitted at bs=128 inference shapes.  The STATS / BSTATS
+        epilogues ride on the same tiles, so the plain launch is timed as their stand-in.  Untimed setup: call once before training."""
+        lib, stream, dev = _lib.lib(), _lib.current_stream(), self.flat.data.device
+        chosen: Dict[tuple, tuple] = {}
+        report: Dict[str, tuple] = {}
+
+        def best_tile(d, w) -> tuple:
+            d.batch = batch
+            key = tuple(getattr(d, f) for f, _ in ConvDesc._fields_ if f not in ("tile_m", "tile_n", "kernel"))
+            if key in chosen:
+                return chosen[key]
+            bf = bool(d.flags & SP_CONV_BF16)
+            x = torch.randn((batch, d.in_h, d.in_w, d.c_in), device=dev).to(torch.bfloat16 if bf else torch.float32)
+            out_f32 = (not bf) or bool(d.flags & (SP_CONV_OUT_F32 | SP_CONV_OUT_NCHW))
+            y = torch.empty((batch, d.out_h, d.out_w, max(d.out_c, 1)), dtype=torch.float32 if out_f32 else torch.bfloat16, device=dev)
+            timed = []
+            for bm, bn in _lib.CONV_TILES:
+                if d.n_pad % bn:
+                    continue
+                d.tile_m, d.tile_n = bm, bn
+                if lib.sp_conv2d_fwd(d, P(x), P(w), None, None, None, P(y), stream) != 0:
+                    continue                                    # a tile this descriptor cannot use
+                ts = []
+                for _ in range(rounds):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(reps):
+                        lib.sp_conv2d_fwd(d, P(x), P(w), None, None, None, P(y), stream)
+                    e1.record()
+                    e1.synchronize()
+                    ts.append(e0.elapsed_time(e1) / reps)
+                timed.append((sorted(ts)[rounds // 2], (bm, bn)))
+            assert timed, "no legal tile"
+            chosen[key] = min(timed)[1]
+            return chosen[key]
+
+        for name, layer in self.layers.items():
+            t = best_tile(layer.d_fwd, layer.w_fwd)
+            layer.d_fwd.tile_m, layer.d_fwd.tile_n = t
+            report[name] = t
+            if layer.need_dgrad:
+                for i, (d, w) in enumerate(zip(layer.d_dgrad, layer.w_dgrad)):
+                    t = best_tile(d, w)
+                    d.tile_m, d.tile_n = t
+                    report[f"{name}.dgrad{i}"] = t
+        self.tuned_for_batch = batch
+        return report
+
+    tuned_for_batch = 0
+
     # ---- keeping the packed copies in step with the parameters -------------------------------------------------------------
     def _param_version(self) -> int:
         return sum(p._version for p in self.sd.values())
@@ -625,6 +688,7 @@ class PoseTrainer:
 
         self._pending = [set(b["names"]) for b in self.buckets]
         self._works: List[Optional[object]] = [None] * len(self.buckets)
+        self.collective_count = 0          # SyncBatchNorm all-reduces of this step (gradient buckets are counted in len(self.buckets))
         sync = self.sync_bn
         if sync:
             import torch.distributed as dist
@@ -636,39 +700,69 @@ class PoseTrainer:
         def newf(shape):
             return torch.empty(shape, dtype=torch.float32, device=dev)
 
-        def conv_bn(xa: Act, cname: str, bname: str, relu: bool, res: Optional[Act] = None) -> Act:
+        def conv_stats(xa: Act, cname: str) -> dict:
+            """The conv launch of a conv + BatchNorm pair; with `fuse_bn_stats` its epilogue also leaves the per-channel partial sums."""
             layer = L[cname]
             xa.consumers += 1
-            fused_stats = self.fuse_bn_stats and not sync
-            if fused_stats:
+            if self.fuse_bn_stats:
                 z, part, prow = layer.forward_bn_stats(xa.data, B)
             else:
-                z = layer.forward(xa.data, B)
-            rows, C = z.shape[0] * z.shape[1] * z.shape[2], z.shape[3]
-            mean, invstd = newf(C), newf(C)
+                z, part, prow = layer.forward(xa.data, B), None, 0
+            return dict(layer=layer, z=z, part=part, prow=prow, rows=z.shape[0] * z.shape[1] * z.shape[2], C=z.shape[3])
+
+        def batch_stats(pends: List[dict], bnames: List[str]) -> None:
+            """Batch mean / invstd (+ running statistics) of the BatchNorm layers behind the pending convs.  SyncBatchNorm: every
+            layer folds its fp64 (sum, sum of squares) into a slice of ONE buffer and the group shares ONE all-reduce (the conv1 /
+            downsample pair of a stage's first bottleneck); no second pass over z either way when the conv left partial sums."""
+            for pd in pends:
+                pd["mean"], pd["invstd"] = newf(pd["C"]), newf(pd["C"])
+            run = lambda bn: (P(self.buffers[bn + ".running_mean"]), P(self.buffers[bn + ".running_var"]))
+            if not sync:
+                for pd, bn in zip(pends, bnames):
+                    rm, rv = run(bn)
+                    if pd["part"] is not None:
+                        part = pd["part"]
+                        _lib.check(lib.sp_bn_train_stats_from_conv(P(part[0]), P(part[1]), pd["prow"], part.shape[2], pd["rows"], pd["C"], BN_EPS,
+                                                                   BN_MOMENTUM, P(pd["mean"]), P(pd["invstd"]), rm, rv, stream), bn)
+                    else:
+                        _lib.check(lib.sp_bn_train_stats_nhwc(P(pd["z"]), bf, pd["rows"], pd["C"], BN_EPS, BN_MOMENTUM, P(pd["mean"]),
+                                                              P(pd["invstd"]), rm, rv, P(ws), stream), bn)
+                return
+            sums = torch.empty(2 * sum(pd["C"] for pd in pends), dtype=torch.float64, device=dev)
+            off = 0
+            for pd, bn in zip(pends, bnames):
+                pd["sums"] = sums[off:off + 2 * pd["C"]]
+                off += 2 * pd["C"]
+                if pd["part"] is not None:
+                    part = pd["part"]
+                    _lib.check(lib.sp_bn_sums_from_conv(P(part[0]), P(part[1]), pd["prow"], part.shape[2], pd["C"], P(pd["sums"]), stream), bn)
+                else:
+                    _lib.check(lib.sp_bn_train_partial_nhwc(P(pd["z"]), bf, pd["rows"], pd["C"], P(pd["sums"]), P(ws), stream), bn)
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.pg)
+            self.collective_count += 1
+            for pd, bn in zip(pends, bnames):
+                rm, rv = run(bn)
+                _lib.check(lib.sp_bn_train_finalize(P(pd["sums"]), pd["rows"] * W, pd["C"], BN_EPS, BN_MOMENTUM, P(pd["mean"]), P(pd["invstd"]),
+                                                    rm, rv, stream), bn)
+
+        def conv_bn(xa: Act, cname: str, bname: str, relu: bool, res: Optional[Act] = None, pend: Optional[dict] = None) -> Act:
+            if pend is None:
+                pend = conv_stats(xa, cname)
+                batch_stats([pend], [bname])
+            layer, z, mean, invstd = pend["layer"], pend["z"], pend["mean"], pend["invstd"]
+            rows, C = pend["rows"], pend["C"]
             gamma, beta = self.sd[bname + ".weight"], self.sd[bname + ".bias"]
-            if fused_stats:
-                _lib.check(lib.sp_bn_train_stats_from_conv(P(part[0]), P(part[1]), prow, part.shape[2], rows, C, BN_EPS, BN_MOMENTUM, P(mean),
-                                                           P(invstd), P(self.buffers[bname + ".running_mean"]),
-                                                           P(self.buffers[bname + ".running_var"]), stream), bname)
-            elif sync:
-                sums = torch.empty(2 * C, dtype=torch.float64, device=dev)
-                _lib.check(lib.sp_bn_train_partial_nhwc(P(z), bf, rows, C, P(sums), P(ws), stream), bname)
-                dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.pg)
-                _lib.check(lib.sp_bn_train_finalize(P(sums), rows * W, C, BN_EPS, BN_MOMENTUM, P(mean), P(invstd),
-                                                    P(self.buffers[bname + ".running_mean"]), P(self.buffers[bname + ".running_var"]),
-                                                    stream), bname)
-            else:
-                _lib.check(lib.sp_bn_train_stats_nhwc(P(z), bf, rows, C, BN_EPS, BN_MOMENTUM, P(mean), P(invstd),
-                                                      P(self.buffers[bname + ".running_mean"]), P(self.buffers[bname + ".running_var"]),
-                                                      P(ws), stream), bname)
             nbt.append(self.buffers[bname + ".num_batches_tracked"])
             y = new(z.shape)
             _lib.check(lib.sp_bn_apply_nhwc(P(z), bf, P(mean), P(invstd), P(gamma), P(beta), P(res.data) if res else None, P(y), rows, C,
                                             int(relu), stream), bname)
             ya = Act(y, z.shape[1], z.shape[2], C)
-            if relu and res is None:
-                ya.bn = (z, mean, invstd)
+            if res is not None:
+                res.consumers += 1
+            if relu:
+                ya.bn = (z, mean, invstd)      # y = relu(bn(z) [+ res]): backward masks with y > 0 either way
+            if sync and not relu and res is None:
+                ya.sibling = (z, mean, invstd, bname)      # a projection shortcut: its backward sums can ride on the consumer's message
 
             def bwd():
                 dz = new(z.shape)                      # MFMA operand of dgrad / wgrad: activation dtype
@@ -682,35 +776,57 @@ class PoseTrainer:
                     dres = res.grad
                 dgamma, dbeta = self.flat.view(bname + ".weight", True), self.flat.view(bname + ".bias", True)
                 rs = P(y) if relu else None
-                if ya.bstats is not None:
-                    # the dgrad launch that produced ya.grad already reduced sum g and sum g*xhat (sp_conv2d_dgrad_bn_bwd_stats)
-                    part, prow = ya.bstats
-                    ya.bstats = None
-                    _lib.check(lib.sp_bn_bwd_sums_from_conv(P(part[0]), P(part[1]), prow, part.shape[2], C, P(dgamma), P(dbeta), stream),
-                               bname + ".bwd")
+                if sync and ya.presums is not None:
+                    # the consumer of this (projection-shortcut) BatchNorm already reduced and exchanged its two sums
+                    sg, sb = ya.presums
+                    ya.presums = None
+                    _lib.check(lib.sp_bn_train_bwd_apply_nhwc(P(ya.grad), bf, rs, P(z), P(mean), P(invstd), P(gamma), P(sg), P(sb),
+                                                              rows * W, rows, C, P(dz), P(dres), acc, stream), bname + ".bwd")
+                elif ya.bstats is not None or sync:
+                    if ya.bstats is not None:
+                        # the dgrad launch that completed ya.grad already reduced sum g and sum g*xhat (sp_conv2d_dgrad_bn_bwd_stats)
+                        part, prow = ya.bstats
+                        ya.bstats = None
+                        _lib.check(lib.sp_bn_bwd_sums_from_conv(P(part[0]), P(part[1]), prow, part.shape[2], C, P(dgamma), P(dbeta), stream),
+                                   bname + ".bwd")
+                    else:
+                        _lib.check(lib.sp_bn_train_bwd_reduce_nhwc(P(ya.grad), bf, rs, P(z), P(mean), P(invstd), rows, C, P(dgamma), P(dbeta),
+                                                                   P(ws), stream), bname + ".bwd")
                     sg, sb, tot = dgamma, dbeta, rows
                     if sync:
-                        both = torch.cat([dgamma, dbeta])
+                        # local sums are this rank's parameter gradients (DDP averages them later); dz needs the global ones
+                        parts = [dgamma, dbeta]
+                        sib = res.sibling if (res is not None and acc == 0) else None
+                        if sib is not None:
+                            # the residual is a projection shortcut's BatchNorm output and this layer is its only consumer: its dy IS this
+                            # layer's g = dy * (y > 0), so its two sums are reduced here and travel in the same message
+                            zs, ms, ivs, sname = sib
+                            dgs, dbs = self.flat.view(sname + ".weight", True), self.flat.view(sname + ".bias", True)
+                            _lib.check(lib.sp_bn_train_bwd_reduce_nhwc(P(ya.grad), bf, rs, P(zs), P(ms), P(ivs), rows, C, P(dgs), P(dbs), P(ws),
+                                                                       stream), sname + ".bwd")
+                            parts += [dgs, dbs]
+                        both = torch.cat(parts)
                         dist.all_reduce(both, op=dist.ReduceOp.SUM, group=self.pg)
-                        sg, sb, tot = both[:C], both[C:], rows * W
+                        self.collective_count += 1
+                        if sib is not None:
+                            res.presums = (both[2 * C:3 * C], both[3 * C:])
+                        sg, sb, tot = both[:C], both[C:2 * C], rows * W
                     _lib.check(lib.sp_bn_train_bwd_apply_nhwc(P(ya.grad), bf, rs, P(z), P(mean), P(invstd), P(gamma), P(sg), P(sb), tot, rows, C,
                                                               P(dz), P(dres), acc, stream), bname + ".bwd")
-                elif sync:
-                    # local sums are this rank's parameter gradients (DDP averages them later); dz needs the global ones
-                    _lib.check(lib.sp_bn_train_bwd_reduce_nhwc(P(ya.grad), bf, rs, P(z), P(mean), P(invstd), rows, C, P(dgamma), P(dbeta), P(ws),
-                                                               stream), bname + ".bwd")
-                    both = torch.cat([dgamma, dbeta])
-                    dist.all_reduce(both, op=dist.ReduceOp.SUM, group=self.pg)
-                    _lib.check(lib.sp_bn_train_bwd_apply_nhwc(P(ya.grad), bf, rs, P(z), P(mean), P(invstd), P(gamma), P(both[:C]), P(both[C:]),
-                                                              rows * W, rows, C, P(dz), P(dres), acc, stream), bname + ".bwd")
                 else:
                     _lib.check(lib.sp_bn_train_bwd_nhwc(P(ya.grad), bf, rs, P(z), P(mean), P(invstd), P(gamma), rows, C, P(dz), P(dgamma), P(dbeta),
                                                         P(dres), acc, P(ws), stream), bname + ".bwd")
                 ya.grad = None
+                if res is not None:
+                    res.contrib += 1
                 wgrad_async(layer, xa.data, dz)
                 if xa.needs_grad and layer.need_dgrad:
-                    fuse = self.fuse_bn_bwd and xa.bn is not None and xa.consumers == 1 and xa.grad is None
+                    # the last consumer to contribute sees the complete dy of xa in its epilogue: BN backward sums for free.  (Block outputs:
+                    # the residual share lands first, conv1 of the next block - a full-cover 1x1 - accumulates last.)
+                    last = xa.contrib == xa.consumers - 1
+                    fuse = self.fuse_bn_bwd and xa.bn is not None and last and (xa.grad is None or layer.dgrad_full_cover)
                     xa.grad = layer.dgrad(dz, B, xa.grad, bn_src=xa if fuse else None)
+                    xa.contrib += 1
                 self._grads_ready(bname + ".weight", bname + ".bias", cname + ".weight")
             tape.append(bwd)
             return ya
@@ -736,9 +852,14 @@ class PoseTrainer:
         for li, n in enumerate(self.model.BLOCKS, start=1):
             for bi in range(n):
                 p = f"layer{li}.{bi}"
-                t = conv_bn(a, p + ".conv1", p + ".bn1", True)
+                p1 = pdn = None
+                if bi == 0 and sync:
+                    # conv1 and the projection shortcut read the same input: both convs first, ONE statistics all-reduce for the pair
+                    p1, pdn = conv_stats(a, p + ".conv1"), conv_stats(a, p + ".downsample.0")
+                    batch_stats([p1, pdn], [p + ".bn1", p + ".downsample.1"])
+                t = conv_bn(a, p + ".conv1", p + ".bn1", True, pend=p1)
                 t = conv_bn(t, p + ".conv2", p + ".bn2", True)
-                idn = conv_bn(a, p + ".downsample.0", p + ".downsample.1", False) if bi == 0 else a
+                idn = conv_bn(a, p + ".downsample.0", p + ".downsample.1", False, pend=pdn) if bi == 0 else a
                 a = conv_bn(t, p + ".conv3", p + ".bn3", True, res=idn)
         def shuffle(xa: Act) -> Act:
             """nn.PixelShuffle(2) and, on the tape, its inverse permutation for the gradient."""
@@ -752,6 +873,7 @@ class PoseTrainer:
                 assert xa.grad is None
                 xa.grad = newf(xa.data.shape)
                 _lib.check(lib.sp_pixel_unshuffle2_nhwc(P(ya.grad), P(xa.grad), B, xa.h, xa.w, xa.c, stream), "pixel_shuffle.bwd")
+                xa.contrib += 1
                 ya.grad = None
             tape.append(bwd)
             return ya
@@ -793,6 +915,7 @@ class PoseTrainer:
                 _lib.check(lib.sp_nchw_to_nhwc_pad(P(dheat), P(dh), 1, B, J, hh, ww, Jb, stream), "dheat.nhwc16")
             wgrad_async(fl, a.data, dh)
             a.grad = fl.dgrad(dh, B, None, bn_src=a if (self.fuse_bn_bwd and a.bn is not None and a.consumers == 1) else None)
+            a.contrib += 1
             self._grads_ready("final_layer.bias", "final_layer.weight")
             for fn in reversed(tape):
                 fn()
@@ -864,7 +987,8 @@ class PoseTrainer:
     _wgrad_stream = None
     _wgrad_tail = None
     fuse_bn_bwd = True         # BN backward sums from the epilogue of the dgrad launch that produces dy (single-consumer BN+ReLU outputs)
-    fuse_bn_stats = True       # BN batch statistics from the conv epilogue (sp_conv2d_fwd_bn_stats); SyncBN keeps the two-pass form
+    fuse_bn_stats = True       # BN batch statistics from the conv epilogue (sp_conv2d_fwd_bn_stats), SyncBN included (sp_bn_sums_from_conv)
+    collective_count = 0
 
     # ---- step-time split (BASELINE config 4 asks for fwd / bwd / all-reduce / Adam) -------------------------------------
     profile = False

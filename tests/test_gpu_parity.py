@@ -1076,7 +1076,7 @@ def test_bench_self_launches_two_ranks(mode):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8",
-           "--dist-backend", backend, "--no-cpu-baseline", "--no-kernel-events", "--mode", mode]
+           "--dist-backend", backend, "--no-cpu-baseline", "--mode", mode]   # (kernel events on: the roofline passes run on every rank)
     if mode == "train":
         cmd += ["--dtype", "bf16"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)

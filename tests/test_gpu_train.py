@@ -194,7 +194,7 @@ def _ddp_worker(rank, world, port, sync_bn, bucket_mb, out_dir, fused=False):
         torch.cuda.synchronize()
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), loss=loss, grad=grad, param=tr.flat.data.cpu().numpy(),
                  rm=tr.buffers["layer4.2.bn3.running_mean"].cpu().numpy(), rv=tr.buffers["bn1.running_var"].cpu().numpy(),
-                 n_buckets=len(tr.buckets), n_launched=n_launched)
+                 n_buckets=len(tr.buckets), n_launched=n_launched, n_bn_collectives=tr.collective_count)
     finally:
         dist.destroy_process_group()
 
@@ -216,6 +216,9 @@ def test_two_rank_step_matches_single_rank(sync_bn, fused, tmp_path):
     assert int(r0["n_buckets"]) > 4 and int(r0["n_launched"]) >= int(r0["n_buckets"]) - 1      # buckets went out during backward
     np.testing.assert_array_equal(r0["grad"], r1["grad"])
     np.testing.assert_array_equal(r0["param"], r1["param"])
+    # SyncBatchNorm exchanges per step: 56 BN layers, the conv1 / projection-shortcut pair of the 4 stage-opening bottlenecks shares one
+    # forward message and the bn3 / shortcut pair one backward message -> 52 + 52 (was 56 + 56 plus a second pass over every z)
+    assert int(r0["n_bn_collectives"]) == (104 if sync_bn else 0), int(r0["n_bn_collectives"])
     if not sync_bn:
         return
     np.testing.assert_array_equal(r0["rm"], r1["rm"])
