@@ -94,8 +94,9 @@ int sp_nchw_to_nhwc4(const float* x_nchw, float* y_nhwc4, int batch, int channel
 int sp_conv2d_fwd(const sp_conv_desc* desc, const void* x, const void* w_packed, const float* scale,
                   const float* shift, const void* residual, void* y, void* stream);
 
-/* Direct (non-im2col) 3x3 stride-1 pad-1 convolution for 32 -> 32 channels in bf16 (HRNet's high-resolution branch): the halo tile of
- * an 8x16 output tile goes through LDS once instead of once per tap.  Same arguments and bit-identical results as sp_conv2d_fwd for
+/* Direct (non-im2col) 3x3 stride-1 pad-1 convolution for 32 -> 32 and 64 -> 64 channels in bf16 (HRNet's two high-resolution branches,
+ * nets/pose_hrnet.py BasicBlock; ResNet-50 layer1.*.conv2): the halo tile of an 8x16 / 16x8 output tile goes through LDS once instead of
+ * once per tap; the filter stays in registers (32 channels) or in LDS in MFMA-fragment order (64 channels) for a persistent workgroup.  Same arguments and bit-identical results as sp_conv2d_fwd for
  * the descriptors sp_conv3x3_direct_ok accepts (returns 1 / 0); tile fields are ignored. */
 int sp_conv3x3_direct_ok(const sp_conv_desc* desc);
 int sp_conv3x3_direct(const sp_conv_desc* desc, const void* x, const void* w_packed, const float* scale, const float* shift,

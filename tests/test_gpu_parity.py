@@ -1031,26 +1031,30 @@ def test_bf16_stem_on_pixel_pairs_vs_fp64(k, pad, H, W):
     assert err < 6e-3, err
 
 
+@pytest.mark.parametrize("C", [32, 64])
 @pytest.mark.parametrize("B,H,W,res_on,relu,affine", [(2, 20, 17, True, True, True), (3, 8, 16, False, False, False), (1, 7, 5, True, False, True),
-                                                      (5, 33, 47, False, True, True), (128, 64, 48, True, True, True)])
-def test_direct_3x3_c32_kernel_is_bit_identical_to_the_implicit_gemm(B, H, W, res_on, relu, affine):
-    """sp_conv3x3_direct (halo tile through LDS once, weights in registers, persistent workgroups) keeps the implicit GEMM's reduction
-    order, so it must reproduce sp_conv2d_fwd bit for bit - ragged tiles, image borders, with / without scale-shift, residual, ReLU."""
+                                                      (5, 33, 47, False, True, True), (128, 64, 48, True, True, True), (128, 32, 24, True, True, True),
+                                                      (300, 16, 8, False, True, True)])
+def test_direct_3x3_kernels_are_bit_identical_to_the_implicit_gemm(B, H, W, res_on, relu, affine, C):
+    """sp_conv3x3_direct (halo tile through LDS once; 32 channels: filter in registers, 64 channels: filter resident in LDS in fragment
+    order; persistent workgroups) keeps the implicit GEMM's reduction order, so it must reproduce sp_conv2d_fwd bit for bit - ragged
+    tiles, image borders, several tiles per workgroup, with / without scale-shift, residual, ReLU."""
     lib, P = _lib.lib(), _lib.ptr
-    w = torch.from_numpy(synth.tensor_normal(1, "d/w", (32, 32, 3, 3), std=(2.0 / 288) ** 0.5))
-    scale = torch.from_numpy(synth.tensor_uniform(1, "d/s", (32,), 0.5, 1.5)).to(DEV) if affine else None
-    shift = torch.from_numpy(synth.tensor_normal(1, "d/b", (32,), std=0.3)).to(DEV) if affine else None
+    w = torch.from_numpy(synth.tensor_normal(1, f"d/w{C}", (C, C, 3, 3), std=(2.0 / (9 * C)) ** 0.5))
+    scale = torch.from_numpy(synth.tensor_uniform(1, f"d/s{C}", (C,), 0.5, 1.5)).to(DEV) if affine else None
+    shift = torch.from_numpy(synth.tensor_normal(1, f"d/b{C}", (C,), std=0.3)).to(DEV) if affine else None
     b = engine.ProgramBuilder(H, W, dtype="bf16")
-    b.p.shapes["input"] = (H, W, 32)
-    b.p.shapes["res"] = (H, W, 32)
+    b.p.shapes["input"] = (H, W, C)
+    b.p.shapes["res"] = (H, W, C)
     b.conv("input", w.to(DEV), pad=1, scale=scale, shift=shift, relu=relu, res="res" if res_on else None, name="c")
     op = b.p.ops[-1]
     assert op.direct and lib.sp_conv3x3_direct_ok(op.desc) == 1
     d = op.desc
     d.batch = B
-    x = torch.from_numpy(synth.tensor_normal(2, "d/x", (B, H, W, 32))).to(DEV).bfloat16()
-    r = torch.from_numpy(synth.tensor_normal(2, "d/r", (B, H, W, 32))).to(DEV).bfloat16()
-    y0 = torch.full((B, H, W, 32), float("nan"), dtype=torch.bfloat16, device=DEV)
+    assert _lib.conv_kernel_name(d, res_on, 3) == f"conv3x3_c{C}_direct_kernel"
+    x = torch.from_numpy(synth.tensor_normal(2, "d/x", (B, H, W, C))).to(DEV).bfloat16()
+    r = torch.from_numpy(synth.tensor_normal(2, "d/r", (B, H, W, C))).to(DEV).bfloat16()
+    y0 = torch.full((B, H, W, C), float("nan"), dtype=torch.bfloat16, device=DEV)
     y1 = y0.clone()
     st, rp = _lib.current_stream(), (P(r) if res_on else None)
     _lib.check(lib.sp_conv2d_fwd(d, P(x), P(op.w), P(scale), P(shift), rp, P(y0), st))
@@ -1058,7 +1062,7 @@ def test_direct_3x3_c32_kernel_is_bit_identical_to_the_implicit_gemm(B, H, W, re
     torch.cuda.synchronize()
     assert torch.isfinite(y1.float()).all() and torch.equal(y0, y1)
     # and what it refuses
-    d.c_out = 64
+    d.c_out = 96
     assert lib.sp_conv3x3_direct_ok(d) == 0 and lib.sp_conv3x3_direct(d, P(x), P(op.w), None, None, None, P(y1), st) != 0
 
 
