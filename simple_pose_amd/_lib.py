@@ -146,10 +146,25 @@ def ptr(t):
     return None if t is None else c_void_p(t.data_ptr())
 
 
-def current_stream():
+def current_stream(device=None):
+    """torch's current stream of `device` (a tensor's .device; default: the current device) as a hipStream_t."""
     import torch
 
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def same_device(*tensors):
+    """The one GPU every given tensor lives on (None entries skipped); raises when operands are spread over devices - the kernels
+    take raw pointers, a foreign pointer would fault."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise HipLibraryError(f"operands on different devices: {dev} and {t.device}")
+    return dev
 
 
 def require_cuda_f32(t, name: str):

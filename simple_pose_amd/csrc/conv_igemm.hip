@@ -742,14 +742,21 @@ int launch_t(const ConvArgs& a, int phases, bool uniform, hipStream_t stream) {
     p.tiles_n = a.n_pad / BN;
     const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float) + (size_t)BM * 4 * sizeof(int);
     dim3 grid(p.tiles_m * p.tiles_n, phases, 1), block(256, 1, 1);
-    // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel instantiation
-    static const hipError_t attr_u = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, true, BF16, OUT16, STATS, DEEP, BSTATS>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    static const hipError_t attr_c = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, false, BF16, OUT16, STATS, DEEP, BSTATS>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (attr_u != hipSuccess || attr_c != hipSuccess) {
-        sp_set_error("conv_igemm: hipFuncSetAttribute(max dynamic LDS = %zu) failed", lds);
-        return SP_ELAUNCH;
+    // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel instantiation AND per device (the attribute belongs to the
+    // function on the device that is current: a process driving several GPUs must not inherit device 0's opt-in)
+    static bool opted[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!opted[dev]) {
+        const hipError_t eu = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, true, BF16, OUT16, STATS, DEEP, BSTATS>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const hipError_t ec = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, false, BF16, OUT16, STATS, DEEP, BSTATS>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (eu != hipSuccess || ec != hipSuccess) {
+            sp_set_error("conv_igemm: hipFuncSetAttribute(max dynamic LDS = %zu) failed on device %d", lds, dev);
+            return SP_ELAUNCH;
+        }
+        opted[dev] = true;       // (a benign race: two threads may both set the same attribute to the same value)
     }
     if (uniform)
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, true, BF16, OUT16, STATS, DEEP, BSTATS>), grid, block, lds, stream, p);

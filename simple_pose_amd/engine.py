@@ -238,19 +238,24 @@ class Program:
         else:
             raise ValueError(op.kind)
 
-    def run(self, x: torch.Tensor) -> torch.Tensor:
-        """x: fp32 NCHW [B,3,H,W] on the GPU (or uint8 BGR crops [B,H,W,3], normalised on the fly as datasets/coco.py:136 does) ->
+    def run(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`out`: optional preallocated fp32 [B,J,H/4,W/4] result (a steady-state caller reuses one; default: a fresh tensor per call,
+        which the caller may keep - torch's caching allocator makes that a pointer bump, no hipMalloc).
+        x: fp32 NCHW [B,3,H,W] on the GPU (or uint8 BGR crops [B,H,W,3], normalised on the fly as datasets/coco.py:136 does) ->
         heat maps fp32 NCHW [B,J,H/4,W/4].  Ops are issued in program order; ops of
         different lanes (independent HRNet branches) go to different HIP streams and overlap on the GPU, ordered by events."""
         lib = _lib.lib()
         B = x.shape[0]
         bufs = dict(self._alloc(B, x.device))
         bufs["input"] = x
-        out = torch.empty((B,) + tuple(self.out_shape), dtype=torch.float32, device=x.device)
+        if out is None:
+            out = torch.empty((B,) + tuple(self.out_shape), dtype=torch.float32, device=x.device)
+        elif tuple(out.shape) != (B,) + tuple(self.out_shape) or out.dtype != torch.float32 or out.device != x.device or not out.is_contiguous():
+            raise ValueError(f"out: expected a contiguous fp32 {(B,) + tuple(self.out_shape)} tensor on {x.device}")
         bufs[self.out_name] = out
         n_lanes = 1 + max((op.lane for op in self.ops), default=0) if self.multi_stream else 1
         if n_lanes == 1:
-            stream = _lib.current_stream()
+            stream = _lib.current_stream(x.device)             # the INPUT's device, not whatever device happens to be current
             for op in self.ops:
                 self._launch(lib, op, bufs, B, stream)
             return out

@@ -22,6 +22,7 @@ def _prep(heat_map, trans_inv=None):
         trans_inv = _lib.require_cuda_f32(trans_inv, "trans_inv")
         if tuple(trans_inv.shape) != (B, 2, 3):
             raise ValueError(f"trans_inv must be [{B},2,3], got {tuple(trans_inv.shape)}")
+        _lib.same_device(heat_map, trans_inv)
     return heat_map, trans_inv
 
 
@@ -34,7 +35,7 @@ class BasicKeyPointDecoder(object):
         coords = torch.empty((B, J, 2), dtype=torch.float32, device=heat_map.device)
         max_val = torch.empty((B, J, 1), dtype=torch.float32, device=heat_map.device)
         _lib.check(_lib.lib().sp_heat_map_to_axis(_lib.ptr(heat_map), B, J, H, W, _lib.ptr(coords), _lib.ptr(max_val),
-                                                  _lib.current_stream()), "sp_heat_map_to_axis")
+                                                  _lib.current_stream(heat_map.device)), "sp_heat_map_to_axis")
         return coords, max_val
 
     @torch.no_grad()
@@ -45,7 +46,7 @@ class BasicKeyPointDecoder(object):
         kps = torch.empty((B, J, 2), dtype=torch.float32, device=heat_map.device)
         max_val = torch.empty((B, J, 1), dtype=torch.float32, device=heat_map.device)
         _lib.check(_lib.lib().sp_decode_basic(_lib.ptr(heat_map), _lib.ptr(trans_inv), B, J, H, W, _lib.ptr(kps),
-                                              _lib.ptr(max_val), _lib.current_stream()), "sp_decode_basic")
+                                              _lib.ptr(max_val), _lib.current_stream(heat_map.device)), "sp_decode_basic")
         return kps, max_val
 
 
@@ -67,7 +68,7 @@ class GaussTaylorKeyPointDecoder(BasicKeyPointDecoder):
         kps = torch.empty((B, J, 2), dtype=torch.float32, device=heat_map.device)
         max_val = torch.empty((B, J, 1), dtype=torch.float32, device=heat_map.device)
         _lib.check(_lib.lib().sp_decode_gauss_taylor(_lib.ptr(heat_map), _lib.ptr(trans_inv), B, J, H, W, self.kernel_size,
-                                                     _lib.ptr(kps), _lib.ptr(max_val), _lib.current_stream()),
+                                                     _lib.ptr(kps), _lib.ptr(max_val), _lib.current_stream(heat_map.device)),
                    "sp_decode_gauss_taylor")
         return kps, max_val
 
