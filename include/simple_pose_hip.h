@@ -27,7 +27,7 @@ extern "C" {
 #define SP_EINVAL (-1)   /* bad argument / unsupported shape (message in sp_last_error) */
 #define SP_ELAUNCH (-2)  /* HIP launch or runtime failure */
 
-#define SP_ABI_VERSION 20
+#define SP_ABI_VERSION 21
 
 /* epilogue / layout flags of sp_conv_desc.flags */
 #define SP_CONV_RELU 0x1u          /* y = max(y, 0) after scale/shift (+ residual) */
@@ -101,6 +101,15 @@ int sp_conv2d_fwd(const sp_conv_desc* desc, const void* x, const void* w_packed,
 int sp_conv3x3_direct_ok(const sp_conv_desc* desc);
 int sp_conv3x3_direct(const sp_conv_desc* desc, const void* x, const void* w_packed, const float* scale, const float* shift,
                       const void* residual, void* y, void* stream);
+
+/* One HRNet BasicBlock (nets/pose_hrnet.py:34-51) of a 32-channel branch in ONE launch, bf16: y = relu(bn2(conv3x3(relu(bn1(conv3x3(x))))) + x).
+ * `desc` describes either of the block's two convolutions (same geometry; sp_basic_block_c32_ok(desc) == 1: what sp_conv3x3_direct_ok
+ * accepts at 32 channels); w1 / w2 packed as for sp_conv2d_fwd, scale / shift = the folded BatchNorms.  The intermediate stays in LDS
+ * (rounded to bf16 exactly as the two-launch path stores it) and the residual comes from the input halo the workgroup already holds:
+ * 2.5x less HBM traffic, bit-identical results.  y must not alias x. */
+int sp_basic_block_c32_ok(const sp_conv_desc* desc);
+int sp_basic_block_c32(const sp_conv_desc* desc, const void* x, const void* w1_packed, const float* scale1, const float* shift1,
+                       const void* w2_packed, const float* scale2, const float* shift2, void* y, void* stream);
 
 /* 1 when `desc` (flags, shapes, tile_m x tile_n) can run with kernel = SP_CONV_KERNEL_RING: bf16 NHWC in and out (ReLU, residual and
  * fused PixelShuffle allowed; no NCHW / fp32 output), c_in % 64 == 0, taps <= 32, k_pad / 64 >= the tile's ring depth, tile_n | n_pad. */

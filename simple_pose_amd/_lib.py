@@ -20,7 +20,7 @@ SP_CONV_PIXEL_SHUFFLE = 0x4
 SP_CONV_BF16 = 0x8
 SP_CONV_OUT_F32 = 0x10
 CONV_TILES = ((128, 128), (64, 128), (128, 64), (64, 64), (256, 64), (128, 32))
-ABI_VERSION = 20
+ABI_VERSION = 21
 SP_CONV_KERNEL_IGEMM, SP_CONV_KERNEL_RING = 0, 1
 RING_TILES = ((256, 256), (256, 128), (128, 256), (256, 64), (128, 128), (192, 128), (192, 256))   # kernel = SP_CONV_KERNEL_RING (bf16)
 
@@ -94,6 +94,8 @@ SYMBOLS = {
     "sp_nchw_to_nhwc4_bf16": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "sp_conv3x3_direct_ok": (c_int, [ctypes.POINTER(ConvDesc)]),
     "sp_conv3x3_direct": (c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
+    "sp_basic_block_c32_ok": (c_int, [ctypes.POINTER(ConvDesc)]),
+    "sp_basic_block_c32": (c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sp_masked_mse": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
     "sp_conv_packed_dims": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "sp_pack_conv_weights": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),

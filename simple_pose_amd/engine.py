@@ -97,7 +97,7 @@ class HipPacker:
 # ------------------------------------------------------------------------------------------------
 @dataclass
 class Op:
-    kind: str                    # "conv" | "maxpool" | "to_nhwc4" | "upsample_add"
+    kind: str                    # "conv" | "bb32" (fused BasicBlock) | "maxpool" | "to_nhwc4" | "upsample_add" | ...
     src: str
     dst: str
     res: Optional[str] = None
@@ -207,6 +207,11 @@ class Program:
             fn = lib.sp_conv3x3_direct if op.direct else lib.sp_conv2d_fwd
             _lib.check(fn(op.desc, P(bufs[op.src]), P(op.w), P(op.scale), P(op.shift),
                           P(bufs[op.res]) if op.res else None, P(bufs[op.dst]), stream), op.name)
+        elif op.kind == "bb32":
+            op.desc.batch = B
+            w2, scale2, shift2 = op.args
+            _lib.check(lib.sp_basic_block_c32(op.desc, P(bufs[op.src]), P(op.w), P(op.scale), P(op.shift), P(w2), P(scale2), P(shift2),
+                                              P(bufs[op.dst]), stream), op.name)
         elif op.kind == "maxpool":
             h, w, c = op.args
             fn = lib.sp_maxpool3x3s2_nhwc_bf16 if self.dtype == "bf16" else lib.sp_maxpool3x3s2_nhwc
@@ -357,7 +362,11 @@ class Program:
                     _lib.check(fn(d, P(bufs[op.src]), P(op.w), P(op.scale), P(op.shift), P(bufs[op.res]) if op.res else None,
                                   P(bufs[op.dst]), stream), op.name)               # warm-up (and validates the candidate)
                     ts = sorted(time_once(op, cand, reps) for _ in range(rounds))
-                    timed.append((ts[len(ts) // 2], cand))
+                    # the 64-channel direct kernel owns a whole CU's LDS (one workgroup per CU): timed alone it ties with the implicit
+                    # GEMM on HRNet's 32x24 branch, inside the multi-stream network it then keeps the other branches' workgroups off
+                    # the CU (measured 26 vs 20 us per layer).  It has to win by a margin to be picked.
+                    handicap = 1.10 if (cand[0] < 0 and d.c_in == 64) else 1.0
+                    timed.append((ts[len(ts) // 2] * handicap, cand))
                     if verbose:
                         print(f"  {op.name:28s} {cand[0]:3d}x{cand[1]:<3d} k{cand[2]} {timed[-1][0] * 1e3:8.1f} us")
                 timed.sort()
@@ -448,6 +457,10 @@ class ProgramBuilder:
         if dtype not in ("fp32", "bf16"):
             raise ValueError(dtype)
         self.packer = packer or HipPacker()         # parameters -> kernel layouts (device kernels behind the C ABI)
+        # bf16: whole 32-channel BasicBlocks as one launch (sp_basic_block_c32: same bits, 2.5x less HBM traffic).  Opt-in: measured at
+        # bs=128 it ties with the two direct-conv launches it replaces (40 vs 2 x 20 us per block) - both are bound by the per-tile chain
+        # of dependent steps at two waves per SIMD, not by bytes (profiles/r02_pmc_hrnet_blocks.md) - and the network step is not faster
+        self.fuse_blocks = False
         self.p = Program(dtype=dtype)
         self.bf16 = dtype == "bf16"
         self.cpad = 8 if self.bf16 else 4           # channels per 16-byte chunk
@@ -533,6 +546,31 @@ class ProgramBuilder:
         # small-channel 3x3 layers (HRNet's 32-channel branch): the direct kernel is the default, the tuner may still pick a GEMM tile
         op.direct = bool(self.bf16 and _lib.lib().sp_conv3x3_direct_ok(d))
         self._add(op)
+        return dst
+
+    def basic_block_c32(self, src: str, w1: torch.Tensor, scale1, shift1, w2: torch.Tensor, scale2, shift2, name: str) -> Optional[str]:
+        """HRNet BasicBlock on a 32-channel bf16 activation as one launch (sp_basic_block_c32); None when the shapes do not qualify."""
+        h, w, c = self.p.shapes[src]
+        if not (self.bf16 and self.fuse_blocks and c == 32 and tuple(w1.shape) == (32, 32, 3, 3) and tuple(w2.shape) == (32, 32, 3, 3)):
+            return None
+        p1, th, tw, ci, k_pad = self.packer.conv(w1, bf16=True)
+        p2 = self.packer.conv(w2, bf16=True)[0]
+        d = ConvDesc()
+        d.batch, d.in_h, d.in_w, d.c_in = 1, h, w, ci
+        d.grid_h, d.grid_w, d.c_out, d.n_pad = h, w, 32, p1.shape[0]
+        d.taps_h, d.taps_w, d.k_pad, d.stride = th, tw, k_pad, 1
+        d.dy0, d.dy_step, d.dx0, d.dx_step = -1, 1, -1, 1
+        d.phases_y = d.phases_x = 1
+        d.out_h, d.out_w, d.out_c = h, w, 32
+        d.oy_mul = d.ox_mul = 1
+        d.oy_add = d.ox_add = 0
+        d.flags = SP_CONV_RELU | SP_CONV_BF16
+        if not _lib.lib().sp_basic_block_c32_ok(d):
+            return None
+        dst = self._fresh(name)
+        self.p.shapes[dst] = (h, w, 32)
+        self._add(Op("bb32", src, dst, desc=d, w=p1, scale=scale1, shift=shift1, args=(p2, scale2, shift2), name=name,
+                     flops=2 * (2 * h * w * 32 * 32 * 9)))
         return dst
 
     def deconv_k4s2p1(self, src: str, weight: torch.Tensor, *, scale=None, shift=None, relu: bool = False,
@@ -660,8 +698,11 @@ def resnet_program(sd: Dict[str, torch.Tensor], head: str, in_h: int = 256, in_w
 def _basic_block(b: ProgramBuilder, sd, x: str, p: str) -> str:
     """BasicBlock.forward (pose_hrnet.py:34-51): conv3x3-bn-relu, conv3x3-bn, + x, relu (stride 1, no downsample)."""
     s1, h1 = _bn(b, sd, p + ".bn1")
-    t = b.conv(x, sd[p + ".conv1.weight"], pad=1, scale=s1, shift=h1, relu=True, name=p + ".conv1")
     s2, h2 = _bn(b, sd, p + ".bn2")
+    fused = b.basic_block_c32(x, sd[p + ".conv1.weight"], s1, h1, sd[p + ".conv2.weight"], s2, h2, name=p)
+    if fused is not None:
+        return fused
+    t = b.conv(x, sd[p + ".conv1.weight"], pad=1, scale=s1, shift=h1, relu=True, name=p + ".conv1")
     return b.conv(t, sd[p + ".conv2.weight"], pad=1, scale=s2, shift=h2, relu=True, res=x, name=p + ".conv2")
 
 
@@ -704,10 +745,14 @@ def _hr_module(b: ProgramBuilder, sd, xs: List[str], base: str, num_blocks: List
     return outs
 
 
-def hrnet_program(sd: Dict[str, torch.Tensor], cfg: dict, in_h: int = 256, in_w: int = 192, dtype: str = "fp32", packer=None) -> Program:
-    """Lower a reference-layout HRNet state_dict into a Program (PoseHighResolutionNet.forward, pose_hrnet.py:419-454)."""
+def hrnet_program(sd: Dict[str, torch.Tensor], cfg: dict, in_h: int = 256, in_w: int = 192, dtype: str = "fp32", packer=None,
+                  fuse_blocks: bool = False) -> Program:
+    """Lower a reference-layout HRNet state_dict into a Program (PoseHighResolutionNet.forward, pose_hrnet.py:419-454).
+    `fuse_blocks`: bf16 32-channel BasicBlocks as one launch each (sp_basic_block_c32; same bits as the two conv launches; opt-in,
+    see ProgramBuilder.fuse_blocks)."""
     extra = cfg["MODEL"]["EXTRA"]
     b = ProgramBuilder(in_h, in_w, dtype, packer)
+    b.fuse_blocks = fuse_blocks
     x = b.to_nhwc4("input")
     s, h = _bn(b, sd, "bn1")
     x = b.conv(x, sd["conv1.weight"], stride=2, pad=1, scale=s, shift=h, relu=True, name="conv1")

@@ -1066,6 +1066,66 @@ def test_direct_3x3_kernels_are_bit_identical_to_the_implicit_gemm(B, H, W, res_
     assert lib.sp_conv3x3_direct_ok(d) == 0 and lib.sp_conv3x3_direct(d, P(x), P(op.w), None, None, None, P(y1), st) != 0
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 20, 17), (3, 8, 16), (1, 7, 5), (5, 33, 47), (128, 64, 48), (37, 9, 40)])
+def test_fused_basic_block_c32_is_bit_identical_to_its_two_convs(B, H, W):
+    """sp_basic_block_c32 (HRNet BasicBlock of the 32-channel branch in one launch: conv1 on the halo'd tile, t kept in LDS as bf16,
+    zero outside the image, residual from the input halo) against the two conv launches it replaces - bit for bit on ragged tiles and
+    image borders - and against the fp64 block on the same bf16 operands."""
+    lib, P = _lib.lib(), _lib.ptr
+    w1, w2 = (torch.from_numpy(synth.tensor_normal(3, f"bb/w{i}", (32, 32, 3, 3), std=(2.0 / 288) ** 0.5)).bfloat16().float() for i in (1, 2))
+    s1, s2 = (torch.from_numpy(synth.tensor_uniform(3, f"bb/s{i}", (32,), 0.5, 1.5)) for i in (1, 2))
+    h1, h2 = (torch.from_numpy(synth.tensor_normal(3, f"bb/h{i}", (32,), std=0.3)) for i in (1, 2))
+    x = torch.from_numpy(synth.tensor_normal(3, "bb/x", (B, 32, H, W))).bfloat16()
+    outs = []
+    for fuse in (True, False):
+        b = engine.ProgramBuilder(H, W, dtype="bf16")
+        b.fuse_blocks = fuse
+        b.p.shapes["input"] = (H, W, 32)
+        y = b.basic_block_c32("input", w1.to(DEV), s1.to(DEV), h1.to(DEV), w2.to(DEV), s2.to(DEV), h2.to(DEV), name="blk")
+        if not fuse:
+            assert y is None
+            t = b.conv("input", w1.to(DEV), pad=1, scale=s1.to(DEV), shift=h1.to(DEV), relu=True, name="c1")
+            y = b.conv(t, w2.to(DEV), pad=1, scale=s2.to(DEV), shift=h2.to(DEV), relu=True, res="input", name="c2")
+        assert [o.kind for o in b.p.ops] == (["bb32"] if fuse else ["conv", "conv"])
+        bufs = dict(b.p._alloc(B, torch.device(DEV)))
+        bufs["input"] = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+        bufs[y].fill_(float("nan"))
+        for op in b.p.ops:
+            b.p._launch(lib, op, bufs, B, _lib.current_stream())
+        torch.cuda.synchronize()
+        outs.append(bufs[y].clone().view(B, H, W, 32))
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), int((outs[0] != outs[1]).sum())
+    xd = x.double()
+    t = torch.relu(torch.nn.functional.conv2d(xd, w1.double(), padding=1) * s1.double().view(1, -1, 1, 1) + h1.double().view(1, -1, 1, 1))
+    t = t.bfloat16().double()                                   # the block's intermediate is a bf16 tensor
+    ref = torch.relu(torch.nn.functional.conv2d(t, w2.double(), padding=1) * s2.double().view(1, -1, 1, 1) + h2.double().view(1, -1, 1, 1) + xd)
+    got = outs[0].float().cpu().permute(0, 3, 1, 2).double()
+    assert (got - ref).abs().max() / ref.abs().max() < 8e-3
+
+
+def test_hrnet_with_fused_basic_blocks_equals_the_per_conv_program_bitwise(golden):
+    """HRNet-W32 bf16 end to end with `fuse_blocks` (32 BasicBlocks of the high-resolution branch as one launch each): same heat maps,
+    bit for bit, as the default one-launch-per-conv program."""
+    import os
+    from simple_pose_amd.nets.pose_hrnet import get_pose_net, hrnet_state_dict_shapes
+    g = golden("g3_hrnet_w32_fwd.npz")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    m = get_pose_net(os.path.join(root, "simple_pose_amd", "nets", "hrnet_w32.yaml"), pretrained=None, joint_num=17)
+    sd = synth.conditioned_state_dict(hrnet_state_dict_shapes(m.cfg, 17), int(g["seed"]))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m = m.to(DEV).eval()
+    m.compute_dtype = "bf16"
+    x = _cuda(synth.input_images(3, 7))
+    with torch.no_grad():
+        plain = m(x).clone()
+        assert sum(op.kind == "bb32" for op in m.hip_program(x).ops) == 0
+        m.fuse_blocks = True
+        fused = m(x)
+        assert sum(op.kind == "bb32" for op in m.hip_program(x).ops) == 32
+    assert torch.equal(plain, fused)
+
+
 # ---------------------------------------------------------------------------------------------- bench.py --gpus N as the driver invokes it
 @pytest.mark.parametrize("mode", ["infer", "train"])
 def test_bench_self_launches_two_ranks(mode):
