@@ -8,15 +8,15 @@ rm -rf $OUT; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 B="python3 $ROOT/bench.py --arch $ARCH --dtype $DT --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events --single-stream"
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d $OUT/a -- $B > $OUT/a.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT/b -- $B > $OUT/b.log 2>&1
-python3 - <<PY
-import csv, glob, collections
+OUT=$OUT KSUB=$KSUB python3 - <<'PY'
+import csv, glob, collections, os
 d=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.Counter()
 for tag in "ab":
-    for f in glob.glob("$OUT/%s/**/*counter_collection.csv" % tag, recursive=True):
+    for f in glob.glob(os.environ["OUT"] + "/%s/**/*counter_collection.csv" % tag, recursive=True):
         for r in csv.DictReader(open(f)):
             k=r["Kernel_Name"]
-            if "$KSUB" not in k: continue
-            k=k.replace("void (anonymous namespace)::","").split("(")[0][:70]
+            if os.environ["KSUB"] not in k: continue
+            k=k.replace("void ","").replace("(anonymous namespace)::","").split("(")[0][:70]
             d[k][r["Counter_Name"]]+=float(r["Counter_Value"]); n[(k,r["Counter_Name"])]+=1
 print("| kernel | launches | WAIT_ANY | WAIT_INST_ANY | ACTIVE_INST_ANY | WAIT_INST_LDS | LDS conflict / LDS active | MFMA busy share | wave-cycles / launch |")
 print("|---|---|---|---|---|---|---|---|---|")

@@ -7,15 +7,15 @@ OUT=$ROOT/gpurun_out/pmc_kernel
 rm -rf $OUT; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d $OUT/a -- python3 $ROOT/tools/bench_conv_layers.py --arch $ARCH --dtype bf16 --only $ONLY --reps 3 --rounds 1 > $OUT/a.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT/b -- python3 $ROOT/tools/bench_conv_layers.py --arch $ARCH --dtype bf16 --only $ONLY --reps 3 --rounds 1 > $OUT/b.log 2>&1
-python3 - <<PY
-import csv, glob, collections
+OUT=$OUT KSUB=$KSUB python3 - <<'PY'
+import csv, glob, collections, os
 for tag in "ab":
-    fs=glob.glob("$OUT/%s/**/*counter_collection.csv" % tag, recursive=True)
+    fs=glob.glob(os.environ["OUT"] + "/%s/**/*counter_collection.csv" % tag, recursive=True)
     d=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.Counter()
     for f in fs:
         for r in csv.DictReader(open(f)):
             k=r["Kernel_Name"]
-            if "$KSUB" not in k or "conv" not in k: continue
+            if os.environ["KSUB"] not in k or "conv" not in k: continue
             k=k[k.index("conv"):][:60]
             d[k][r["Counter_Name"]]+=float(r["Counter_Value"])
             n[(k,r["Counter_Name"])]+=1

@@ -23,9 +23,9 @@ for cfg in $CONFIGS; do
   timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/fetch -- $BENCH --no-kernel-events > $D/bench_fetch.log 2>&1 || echo "$cfg fetch failed"
   timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/write -- $BENCH --no-kernel-events > $D/bench_write.log 2>&1 || echo "$cfg write failed"
   if [ "$cfg" = "dconv:f32" ]; then
-    timeout 300 python3 $ROOT/bench.py --steps 20 --warmup 5 > $D/bench_unprofiled.json 2> $D/bench_unprofiled.err
+    timeout 300 python3 $ROOT/bench.py --steps 20 --warmup 5 --tiles $TILES > $D/bench_unprofiled.json 2> $D/bench_unprofiled.err
   else
-    timeout 300 python3 $ROOT/bench.py --arch $arch --dtype $dt --steps 20 --warmup 5 --no-cpu-baseline > $D/bench_unprofiled.json 2> $D/bench_unprofiled.err
+    timeout 300 python3 $ROOT/bench.py --arch $arch --dtype $dt --steps 20 --warmup 5 --no-cpu-baseline --tiles $TILES > $D/bench_unprofiled.json 2> $D/bench_unprofiled.err
   fi
   echo "$cfg done: $(grep -o '"value": [0-9.]*' $D/bench_unprofiled.json | head -1)"
 done
