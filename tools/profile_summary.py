@@ -68,7 +68,7 @@ def one_config(src, dst, cfg, fh):
                           "hbm_bytes_per_launch": int((2.0 * fs / n + ws / max(wn, 1)) * 1024)}
         with open(f"{dst}_{cfg}_traffic.json", "w") as out:
             json.dump(traffic, out, indent=1, sort_keys=True)
-    if os.path.isfile(os.path.join(d, "tiles_bs128.json")):
+    if os.path.isfile(os.path.join(d, "tiles_bs128.json")) and not os.path.isfile(f"{dst}_{cfg}_tiles.json"):
         shutil.copy(os.path.join(d, "tiles_bs128.json"), f"{dst}_{cfg}_tiles.json")
     line = bench_line(os.path.join(d, "bench_unprofiled.json"))
     if line:

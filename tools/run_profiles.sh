@@ -15,10 +15,12 @@ for cfg in $CONFIGS; do
   arch=${cfg%%:*}; dt=${cfg##*:}
   D=$OUT/${arch}_${dt}
   mkdir -p $D
-  TILES=$D/tiles_bs128.json
+  TILES=$ROOT/profiles/${TAG}_${arch}_${dt}_tiles.json      # the tracked table (what bench.py loads by default); picked if missing
   BENCH="python3 $ROOT/bench.py --arch $arch --dtype $dt --steps 10 --warmup 3 --no-cpu-baseline --tiles $TILES"
-  # untimed: pin the tile table first so that the tuner's trial launches stay out of the statistics
-  timeout 300 python3 $ROOT/bench.py --arch $arch --dtype $dt --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --tiles $TILES > /dev/null 2>&1
+  # untimed: the tile table is pinned so that the tuner's trial launches stay out of the statistics (tools/pick_tiles.py: the
+  # fastest of several tuner runs on the whole forward)
+  [ -f $TILES ] || timeout 300 python3 $ROOT/tools/pick_tiles.py --arch $arch --dtype $dt --out $TILES > $D/pick_tiles.log 2>&1
+  cp $TILES $D/tiles_bs128.json
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -- $BENCH > $D/bench_trace.log 2>&1 || echo "$cfg trace failed"
   timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/fetch -- $BENCH --no-kernel-events > $D/bench_fetch.log 2>&1 || echo "$cfg fetch failed"
   timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/write -- $BENCH --no-kernel-events > $D/bench_write.log 2>&1 || echo "$cfg write failed"
