@@ -39,8 +39,9 @@ def agg(path, cname):
 
 
 def first(pattern):
+    """Newest match (gpurun merges every call's output into gpurun_out/, so older collections' files linger next to the new ones)."""
     found = glob.glob(pattern, recursive=True)
-    return found[0] if found else None
+    return max(found, key=os.path.getmtime) if found else None
 
 
 def bench_line(path):
@@ -72,6 +73,12 @@ def one_config(src, dst, cfg, fh):
         shutil.copy(os.path.join(d, "tiles_bs128.json"), f"{dst}_{cfg}_tiles.json")
     line = bench_line(os.path.join(d, "bench_unprofiled.json"))
     if line:
+        r = line.get("roofline") or {}
+        if r and r.get("traffic") is None and r.get("kernel") in traffic:
+            # the bench run preceded this summary (the table it looked in was the previous collection's): join the same collection's PMC
+            # figure for the kernel it named
+            r["traffic"] = traffic[r["kernel"]]["hbm_bytes_per_launch"]
+            r["traffic_source"] = "joined by tools/profile_summary.py from the FETCH_SIZE / WRITE_SIZE passes of the same collection"
         with open(f"{dst}_{cfg}_bench.json", "w") as out:
             out.write(json.dumps(line) + "\n")
     prof = bench_line(os.path.join(d, "bench_trace.log"))
