@@ -277,8 +277,10 @@ def main():
                 _, kps, mv = graphed()                  # inputs already sit in the graph's static buffers (resident in HBM)
                 return kps, mv
         else:
+            hm_buf = torch.empty((B,) + tuple(prog.out_shape), dtype=torch.float32, device=dev)   # steady state: one resident result buffer
+
             def step():
-                hm = prog.run(x)
+                hm = prog.run(x, out=hm_buf)
                 return decoder(hm, tinv)
 
     with torch.no_grad():

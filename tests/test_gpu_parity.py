@@ -420,6 +420,20 @@ def test_full_batch_128_is_consistent_with_golden(golden):
     assert not torch.allclose(hm3, hm2)
 
 
+def test_program_run_writes_into_a_caller_owned_result_and_refuses_a_wrong_one(golden):
+    g = golden("g1_dconv_fwd.npz")
+    m = _load(pose_resnet_dconv, "dconv", int(g["seed"]))
+    x = _cuda(synth.input_images(2, int(g["seed"])))
+    prog = m.hip_program(x)
+    out = torch.full((2, 17, 64, 48), float("nan"), device=DEV)
+    ret = prog.run(x, out=out)
+    assert ret.data_ptr() == out.data_ptr() and torch.equal(out, prog.run(x))
+    with pytest.raises(ValueError):
+        prog.run(x, out=torch.empty((2, 17, 64, 47), device=DEV))
+    with pytest.raises(ValueError):
+        prog.run(x, out=torch.empty((2, 17, 64, 48), device=DEV, dtype=torch.float64))
+
+
 def test_masked_mse_vs_oracle():
     B, J, H, W = 6, 17, 64, 48
     pred = synth.tensor_normal(8, "mse/p", (B, J, H, W))

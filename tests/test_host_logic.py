@@ -255,3 +255,16 @@ def test_conv_kernel_name_query_matches_dispatch():
     d.tile_m, d.tile_n, d.kernel = 64, 128, _lib.SP_CONV_KERNEL_IGEMM
     d.c_in, d.k_pad = 256, 2304
     assert _lib.conv_kernel_name(d, False).startswith("conv_igemm_kernel<64, 128, 2, 2, true, false, false")
+
+
+def test_hip_packer_has_no_host_path():
+    """engine.HipPacker is the C ABI on device memory only: CPU tensors are refused loudly (the torch restatement of the layouts lives in
+    tests/desc_interp.py and is never imported by the package)."""
+    import simple_pose_amd
+    w = torch.zeros((8, 4, 3, 3))
+    with pytest.raises(_lib.HipLibraryError):
+        engine.HipPacker().conv(w)
+    with pytest.raises(_lib.HipLibraryError):
+        engine.HipPacker().fold_bn(torch.ones(4), torch.zeros(4), torch.zeros(4), torch.ones(4))
+    src = open(os.path.join(ROOT, "simple_pose_amd", "engine.py")).read()
+    assert "desc_interp" not in src.replace("tests/desc_interp.TorchPacker restates", "") and "import oracle" not in src
