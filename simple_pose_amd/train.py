@@ -539,8 +539,10 @@ class PoseTrainer:
     # ---- per-layer tile choice -----------------------------------------------------------------------------------------------
     def autotune(self, batch: int, reps: int = 5, rounds: int = 3) -> Dict[str, tuple]:
         """Time every legal implicit-GEMM tile of every forward and dgrad launch at this per-GPU batch (HIP events, random operands of
-        the launch's real shapes) and pin the fastest in the descriptors (`tile_m` / `tile_n`).  Results do not depend on the tile (same
-        reduction order), so this only moves speed; the built-in heuristic was fitted at bs=128 inference shapes.  The STATS / BSTATS
+        the launch's real shapes) and pin the fastest in the descriptors (`tile_m` / `tile_n`).  Conv outputs and gradients do not depend
+        on the tile (same reduction order); the BatchNorm partial sums are grouped per tile row block (fp32 sums of <= 64 values,
+        folded in fp64), so batch statistics agree across tile tables to fp32 rounding (~1e-7 relative), not bit for bit.  The
+        built-in heuristic was fitted at bs=128 inference shapes.  The STATS / BSTATS
         epilogues ride on the same tiles, so the plain launch is timed as their stand-in.  Untimed setup: call once before training."""
         lib, stream, dev = _lib.lib(), _lib.current_stream(), self.flat.data.device
         chosen: Dict[tuple, tuple] = {}

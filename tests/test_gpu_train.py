@@ -321,6 +321,27 @@ def test_streamed_schedule_equals_plain_schedule(dtype):
     assert all(torch.equal(a, b) for a, b in zip(w0, w1))
 
 
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-5), ("bf16", 2e-2)])
+def test_trainer_autotune_only_moves_speed(dtype, tol):
+    """PoseTrainer.autotune pins another tile per forward / dgrad launch: conv results are tile-independent, BN partial sums regroup
+    (fp32 rounding of <= 64-term sums), so a step with the tuned table must reproduce the untuned step to rounding."""
+    x, t, w = _batch(8, 128, 96, 5)
+    xs, ts, ws = (torch.from_numpy(v).to(DEV) for v in (x, t, w))
+    res = []
+    for tune in (False, True):
+        model, _ = _model(3)
+        tr = PoseTrainer(model, in_h=128, in_w=96, lr=1e-3, dtype=dtype)
+        if tune:
+            table = tr.autotune(8, reps=2, rounds=1)
+            assert tr.tuned_for_batch == 8 and len(table) > 100
+        loss = tr.forward_backward(xs, ts, ws).item()
+        res.append((loss, tr.flat.grad.clone()))
+    (l0, g0), (l1, g1) = res
+    assert abs(l0 - l1) <= 1e-5 * abs(l0), (l0, l1)
+    rel = float((g0 - g1).norm() / g0.norm())
+    assert rel <= tol, rel
+
+
 @pytest.mark.parametrize("dtype,tol", [("fp32", 2e-5), ("bf16", 5e-3)])
 def test_full_size_step_properties(dtype, tol):
     """BASELINE config 4 size (32 images of 256x192 per GPU), where the oracle is too slow to be the checker: size-independent
