@@ -169,14 +169,14 @@ def test_bf16_training_is_deterministic_and_decreases_loss():
 
 
 # ---- N > 1: two ranks sharing the one GPU of the box (gloo carries the collectives) ---------------------------------------
-def _ddp_worker(rank, world, port, sync_bn, bucket_mb, out_dir, fused=False):
+def _ddp_worker(rank, world, port, sync_bn, bucket_mb, out_dir, fused=False, head="dconv"):
     import os
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from simple_pose_amd.sharding import rank_indices
-        model, _ = _model(3 + rank)                  # deliberately different initial weights per rank: the ctor broadcasts rank 0's
+        model, _ = _model(3 + rank, head)            # deliberately different initial weights per rank: the ctor broadcasts rank 0's
         x, t, w = _batch(4, 64, 64, 11)
         idx = rank_indices(4, rank, world)
         xs, ts, ws = (torch.from_numpy(v[idx]).to(DEV) for v in (x, t, w))
@@ -204,25 +204,26 @@ def _l2(a, b):
     return float(np.sqrt(((a - b) ** 2).sum()) / (np.sqrt((b * b).sum()) + 1e-30))
 
 
-@pytest.mark.parametrize("sync_bn,fused", [(True, False), (False, False), (True, True)])
-def test_two_rank_step_matches_single_rank(sync_bn, fused, tmp_path):
+@pytest.mark.parametrize("sync_bn,fused,head", [(True, False, "dconv"), (False, False, "dconv"), (True, True, "dconv"), (True, False, "duc")])
+def test_two_rank_step_matches_single_rank(sync_bn, fused, head, tmp_path):
     """DDP + SyncBatchNorm semantics (ddp...:89-93): 2 ranks x 2 images == 1 rank x 4 images when BN statistics are synced;
     without SyncBN both ranks still end with identical parameters (same averaged gradient, same Adam)."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_ddp_worker, args=(2, port, sync_bn, 8.0, str(tmp_path), fused), nprocs=2, join=True)
+    mp.spawn(_ddp_worker, args=(2, port, sync_bn, 8.0, str(tmp_path), fused, head), nprocs=2, join=True)
     r0, r1 = (np.load(tmp_path / f"rank{r}.npz") for r in (0, 1))
     assert int(r0["n_buckets"]) > 4 and int(r0["n_launched"]) >= int(r0["n_buckets"]) - 1      # buckets went out during backward
     np.testing.assert_array_equal(r0["grad"], r1["grad"])
     np.testing.assert_array_equal(r0["param"], r1["param"])
     # SyncBatchNorm exchanges per step: 56 BN layers, the conv1 / projection-shortcut pair of the 4 stage-opening bottlenecks shares one
     # forward message and the bn3 / shortcut pair one backward message -> 52 + 52 (was 56 + 56 plus a second pass over every z)
-    assert int(r0["n_bn_collectives"]) == (104 if sync_bn else 0), int(r0["n_bn_collectives"])
+    # (DUC head: 55 BN layers - two DUC blocks instead of three deconvs -> 51 + 51)
+    assert int(r0["n_bn_collectives"]) == ((104 if head == "dconv" else 102) if sync_bn else 0), int(r0["n_bn_collectives"])
     if not sync_bn:
         return
     np.testing.assert_array_equal(r0["rm"], r1["rm"])
-    model, _ = _model(3)
+    model, _ = _model(3, head)
     x, t, w = _batch(4, 64, 64, 11)
     xs, ts, ws = (torch.from_numpy(v).to(DEV) for v in (x, t, w))
     tr = PoseTrainer(model, in_h=64, in_w=64, lr=1e-3)
@@ -234,13 +235,13 @@ def test_two_rank_step_matches_single_rank(sync_bn, fused, tmp_path):
     assert _l2(r0["grad"], grad) < 2e-3, _l2(r0["grad"], grad)
     np.testing.assert_allclose(r0["rm"], tr.buffers["layer4.2.bn3.running_mean"].cpu().numpy(), rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(r0["rv"], tr.buffers["bn1.running_var"].cpu().numpy(), rtol=1e-4, atol=1e-7)
-    agree = np.mean(np.sign(r0["param"] - _flat_init(3)) == np.sign(tr.flat.data.cpu().numpy() - _flat_init(3)))
+    agree = np.mean(np.sign(r0["param"] - _flat_init(3, head)) == np.sign(tr.flat.data.cpu().numpy() - _flat_init(3, head)))
     assert agree > 0.99, agree                     # first Adam step = lr * sign(grad): the update direction agrees
 
 
-def _flat_init(seed):
+def _flat_init(seed, head="dconv"):
     from simple_pose_amd.train import FlatParams
-    m, _ = _model(seed)
+    m, _ = _model(seed, head)
     return FlatParams(m).data.cpu().numpy()
 
 
