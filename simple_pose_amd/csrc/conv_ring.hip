@@ -18,6 +18,25 @@
 #include "sp_common.h"
 #include <type_traits>
 
+#ifdef SP_RING_DIAG
+// DIAGNOSTIC BUILD ONLY (tools/diag_ring.py; never the shipped library): per-wave cycle sums of the stage segments, read back with
+// sp_ring_debug_read().  [block % 256][wave][8]: 0 vmcnt wait, 1 barrier wait, 2 fragment + MFMA section, 3 epilogues, 4 stages,
+// 5 kernel lifetime, 6 100 MHz ticks of the lifetime, 7 output tiles
+__device__ unsigned long long sp_ring_dbg[256 * 8 * 8];
+extern "C" int sp_ring_debug_read(unsigned long long* dst, int n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(sp_ring_dbg), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);
+}
+extern "C" int sp_ring_debug_clear() {
+    static unsigned long long z[256 * 8 * 8];
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(sp_ring_dbg), z, sizeof(z), 0, hipMemcpyHostToDevice);
+}
+#define SP_RSTAMP(var)                                                                      \
+    unsigned long long var;                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");           \
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -92,6 +111,12 @@ __global__ __launch_bounds__(512, 2) void conv_ring_kernel(const RingArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WC, wc = wave % WC;
     const int fr = lane & 31, fh = lane >> 5;
+#ifdef SP_RING_DIAG
+    unsigned long long dg_wait = 0, dg_bar = 0, dg_mma = 0, dg_epi = 0, dg_tiles = 0;
+    SP_RSTAMP(dg_entry)
+    unsigned long long dg_rt0;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dg_rt0)::"memory");
+#endif
 
     // ---- this workgroup's tiles: T = perm + G * i.  Blocks b and b+8 share an XCD (and its L2): each XCD takes a contiguous
     // chunk of every round of G tiles, N tiles fastest, so the workgroups that share A rows run on one L2 at the same time ----
@@ -346,8 +371,16 @@ __global__ __launch_bounds__(512, 2) void conv_ring_kernel(const RingArgs p) {
                                                                     acc[i][n], 0, 0, 0);
                 if (ISSUE) {
                     const int qq = j * TM * TN + q;        // every DMA piece in the shadow of an MFMA of its own
+                    if constexpr (NS == 2) {
+                        // one K tile ahead only: the pieces must land before the NEXT barrier, so they go out with the first L MFMAs
+                        // of the stage instead of being spread over all of it (tools/diag_ring.py: the wait at the next stage's
+                        // vmcnt(0) went from 330-470 to 45-85 of ~3,800 cycles per stage; +4-5 % on the DUC convs.  With two or
+                        // three tiles ahead - NS >= 3 - front-loading measured neutral to slightly worse)
+                        if (qq < L) loader_piece(qq);
+                    } else {
 #pragma unroll
-                    for (int o = (qq * L) / NM; o < ((qq + 1) * L) / NM; ++o) loader_piece(o);
+                        for (int o = (qq * L) / NM; o < ((qq + 1) * L) / NM; ++o) loader_piece(o);
+                    }
                 }
                 SP_SB();
             }
@@ -356,9 +389,18 @@ __global__ __launch_bounds__(512, 2) void conv_ring_kernel(const RingArgs p) {
         const int used = slot;
         slot = (slot + 1 == NS) ? 0 : slot + 1;
         if (++kt == nk) {
+#ifdef SP_RING_DIAG
+            SP_RSTAMP(dg_e0)
+#endif
             __builtin_amdgcn_s_barrier();                 // every wave is done reading `used`: it becomes the transpose scratch
             SP_SB();
             epilogue(ti, used);
+#ifdef SP_RING_DIAG
+            SP_RSTAMP(dg_e1)
+            dg_epi += dg_e1 - dg_e0;
+            dg_mma -= dg_e1 - dg_e0;                      // (the caller books the whole stage as MFMA section)
+            ++dg_tiles;
+#endif
             kt = 0;
             ++ti;
         }
@@ -366,19 +408,50 @@ __global__ __launch_bounds__(512, 2) void conv_ring_kernel(const RingArgs p) {
     // stage g has landed once at most the D-1 younger stages are still outstanding (each wave waits for ITS pieces; the barrier then
     // makes every wave's pieces visible, and says everyone is done reading the slot the new DMA overwrites)
     int g = 0;
+#ifdef SP_RING_DIAG
+#define SP_RD0 SP_RSTAMP(dg_t0)
+#define SP_RD1 SP_RSTAMP(dg_t1)
+#define SP_RD2 SP_RSTAMP(dg_t2)
+#define SP_RD3 { SP_RSTAMP(dg_t3) dg_wait += dg_t1 - dg_t0; dg_bar += dg_t2 - dg_t1; dg_mma += dg_t3 - dg_t2; }
+#else
+#define SP_RD0
+#define SP_RD1
+#define SP_RD2
+#define SP_RD3
+#endif
     for (; g + D < S; ++g) {
+        SP_RD0
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * L) : "memory");
+        SP_RD1
         __builtin_amdgcn_s_barrier();
         SP_SB();
+        SP_RD2
         stage(std::true_type{});
+        SP_RD3
     }
     for (; g < S; ++g) {                                   // the last D stages: nothing left to request
+        SP_RD0
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SP_RD1
         __builtin_amdgcn_s_barrier();
         SP_SB();
+        SP_RD2
         stage(std::false_type{});
+        SP_RD3
     }
 #undef SP_SB
+#ifdef SP_RING_DIAG
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SP_RSTAMP(dg_end)
+        unsigned long long dg_rt1;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dg_rt1)::"memory");
+        if (lane == 0) {
+            unsigned long long* o = sp_ring_dbg + ((blockIdx.x & 255) * 8 + wave) * 8;
+            o[0] = dg_wait; o[1] = dg_bar; o[2] = dg_mma; o[3] = dg_epi; o[4] = (unsigned long long)S; o[5] = dg_end - dg_entry; o[6] = dg_rt1 - dg_rt0; o[7] = dg_tiles;
+        }
+    }
+#endif
 }
 
 int device_cus() {                       // CUs of the current device (cached per device index)
