@@ -28,7 +28,9 @@ def _run(fn_name, joints, sigma, shape, stride=None):
     targets = torch.empty((B, J, H, W), dtype=torch.float32, device=j.device)
     weights = torch.empty((B, J), dtype=torch.float32, device=j.device)
     lib = _lib.lib()
-    if stride is None:
+    if B == 0:
+        rc = 0                          # empty batch: empty targets / weights, nothing to launch
+    elif stride is None:
         rc = lib.sp_encode_gauss_refine(_lib.ptr(j), B, J, H, W, float(sigma), _lib.ptr(targets), _lib.ptr(weights),
                                         _lib.current_stream())
     else:

@@ -20,6 +20,8 @@ def normalize_crops(img_u8_bhwc_bgr: torch.Tensor) -> torch.Tensor:
     t = t.contiguous()
     B, H, W, _ = t.shape
     out = torch.empty((B, 3, H, W), dtype=torch.float32, device=t.device)
+    if B == 0:
+        return out
     mean = (ctypes.c_float * 3)(*rgb_mean)
     _lib.check(_lib.lib().sp_u8hwc_bgr_to_nchw_f32(_lib.ptr(t), _lib.ptr(out), B, H, W, mean, _lib.current_stream()),
                "sp_u8hwc_bgr_to_nchw_f32")

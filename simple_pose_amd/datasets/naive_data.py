@@ -70,6 +70,8 @@ def filter_poses(kps: torch.Tensor, box_score, area, img_ids: Sequence, in_vis_t
     image in first-appearance order, each image's poses in pick order."""
     kps = _lib.require_cuda_f32(kps, "kps")
     Pn, J, _ = kps.shape
+    if Pn == 0:
+        return []
     ids, perm, seg_h = _segments(list(img_ids))
     dev = kps.device
     perm_t = torch.tensor(perm, dtype=torch.int64, device=dev)
@@ -114,6 +116,8 @@ def crop_boxes(img: torch.Tensor, boxes, input_shape=(192, 256), output_shape=(4
         _, tinv[i] = get_affine_transform(center, scale, 0, output_shape)
         centers[i], scales[i] = center, scale
     crops = torch.empty((n, input_shape[1], input_shape[0], 3), dtype=torch.uint8, device=img.device)
+    if n == 0:                          # no detections in this image: empty crops / matrices, nothing to launch
+        return crops, torch.from_numpy(tinv).to(img.device), centers, scales, scales[:, 0] * scales[:, 1]
     _lib.check(_lib.lib().sp_warp_affine_u8c3(P(img), img.shape[0], img.shape[1], m_fwd.ctypes.data, n, P(crops), input_shape[1], input_shape[0],
                                               _lib.current_stream()), "sp_warp_affine_u8c3")
     return crops, torch.from_numpy(tinv).to(img.device), centers, scales, scales[:, 0] * scales[:, 1]

@@ -258,6 +258,8 @@ class Program:
         elif tuple(out.shape) != (B,) + tuple(self.out_shape) or out.dtype != torch.float32 or out.device != x.device or not out.is_contiguous():
             raise ValueError(f"out: expected a contiguous fp32 {(B,) + tuple(self.out_shape)} tensor on {x.device}")
         bufs[self.out_name] = out
+        if B == 0:                      # nothing to launch (a detector-driven caller with an image without persons)
+            return out
         n_lanes = 1 + max((op.lane for op in self.ops), default=0) if self.multi_stream else 1
         if n_lanes == 1:
             stream = _lib.current_stream(x.device)             # the INPUT's device, not whatever device happens to be current

@@ -34,6 +34,8 @@ class BasicKeyPointDecoder(object):
         B, J, H, W = heat_map.shape
         coords = torch.empty((B, J, 2), dtype=torch.float32, device=heat_map.device)
         max_val = torch.empty((B, J, 1), dtype=torch.float32, device=heat_map.device)
+        if B == 0:                      # an empty batch (an image without detections): empty results, as the reference's torch ops give
+            return coords, max_val
         _lib.check(_lib.lib().sp_heat_map_to_axis(_lib.ptr(heat_map), B, J, H, W, _lib.ptr(coords), _lib.ptr(max_val),
                                                   _lib.current_stream(heat_map.device)), "sp_heat_map_to_axis")
         return coords, max_val
@@ -45,6 +47,8 @@ class BasicKeyPointDecoder(object):
         B, J, H, W = heat_map.shape
         kps = torch.empty((B, J, 2), dtype=torch.float32, device=heat_map.device)
         max_val = torch.empty((B, J, 1), dtype=torch.float32, device=heat_map.device)
+        if B == 0:
+            return kps, max_val
         _lib.check(_lib.lib().sp_decode_basic(_lib.ptr(heat_map), _lib.ptr(trans_inv), B, J, H, W, _lib.ptr(kps),
                                               _lib.ptr(max_val), _lib.current_stream(heat_map.device)), "sp_decode_basic")
         return kps, max_val
@@ -67,6 +71,8 @@ class GaussTaylorKeyPointDecoder(BasicKeyPointDecoder):
             raise ValueError(f"decoder built for {self.num_joints} joints, heat map has {J}")
         kps = torch.empty((B, J, 2), dtype=torch.float32, device=heat_map.device)
         max_val = torch.empty((B, J, 1), dtype=torch.float32, device=heat_map.device)
+        if B == 0:
+            return kps, max_val
         _lib.check(_lib.lib().sp_decode_gauss_taylor(_lib.ptr(heat_map), _lib.ptr(trans_inv), B, J, H, W, self.kernel_size,
                                                      _lib.ptr(kps), _lib.ptr(max_val), _lib.current_stream(heat_map.device)),
                    "sp_decode_gauss_taylor")
@@ -104,6 +110,8 @@ def kps_to_dict_(predicts: torch.Tensor, scores: torch.Tensor, img_ids, set_in_l
     predicts = _lib.require_cuda_f32(predicts, "predicts")
     scores = _lib.require_cuda_f32(scores, "scores")
     B, J = predicts.shape[0], predicts.shape[1]
+    if B == 0:
+        return
     sc = torch.empty(B, dtype=torch.float32, device=predicts.device)
     _lib.check(_lib.lib().sp_pose_score(_lib.ptr(scores), B, J, _lib.ptr(sc), _lib.current_stream()), "sp_pose_score")
     flat = torch.cat([predicts, scores.reshape(B, J, 1)], dim=-1).reshape(B, -1).cpu().tolist()    # output formatting only

@@ -434,6 +434,38 @@ def test_program_run_writes_into_a_caller_owned_result_and_refuses_a_wrong_one(g
         prog.run(x, out=torch.empty((2, 17, 64, 48), device=DEV, dtype=torch.float64))
 
 
+def test_empty_batches_give_empty_results_without_a_launch(golden):
+    """An image without detections reaches every stage of the detector-driven path as a batch of ZERO (crop_boxes -> forward_crops ->
+    decode -> rescoring + OKS-NMS): the reference's torch / numpy ops return empty tensors there, and so do the mirrors - no launch,
+    no error."""
+    from simple_pose_amd.datasets.coco import normalize_crops
+    from simple_pose_amd.datasets.naive_data import crop_boxes, filter_poses, oks_nms
+    from simple_pose_amd.metrics.pose_metrics import kps_to_dict_
+    g = golden("g1_dconv_fwd.npz")
+    m = _load(pose_resnet_dconv, "dconv", int(g["seed"]))
+    img = torch.zeros((480, 640, 3), dtype=torch.uint8, device=DEV)
+    crops, tinv, centers, scales, areas = crop_boxes(img, np.zeros((0, 4), np.float32))
+    assert crops.shape == (0, 256, 192, 3) and tinv.shape == (0, 2, 3) and centers.shape == (0, 2) and areas.shape == (0,)
+    assert normalize_crops(crops).shape == (0, 3, 256, 192)
+    with torch.no_grad():
+        hm = m.forward_crops(crops)
+        hm2 = m(torch.empty((0, 3, 256, 192), device=DEV))
+    assert hm.shape == (0, 17, 64, 48) and hm2.shape == (0, 17, 64, 48)
+    for dec in (GaussTaylorKeyPointDecoder(), BasicKeyPointDecoder()):
+        kps, mv = dec(hm, tinv)
+        assert kps.shape == (0, 17, 2) and mv.shape == (0, 17, 1)
+    co, mv = BasicKeyPointDecoder.heat_map_to_axis(hm)
+    assert co.shape == (0, 17, 2) and mv.shape == (0, 17, 1)
+    t, w = RefineSimpleTransform.get_heat_map(torch.empty((0, 17, 3), device=DEV), 2.0, (48, 64))
+    assert t.shape == (0, 17, 64, 48) and w.shape == (0, 17)
+    out = []
+    kps_to_dict_(kps, mv, [], out)
+    assert out == []
+    assert filter_poses(torch.empty((0, 17, 3), device=DEV), np.zeros(0), np.zeros(0, np.float32), []) == []
+    assert oks_nms(np.zeros((0, 17, 3)), np.zeros(0), np.zeros(0), 0.9) == []
+    torch.cuda.synchronize()
+
+
 def test_masked_mse_vs_oracle():
     B, J, H, W = 6, 17, 64, 48
     pred = synth.tensor_normal(8, "mse/p", (B, J, H, W))
