@@ -398,6 +398,26 @@ def test_forward_vs_reference_golden(golden, measured, mod, head, fname):
     assert within >= E2E_BARS[head][1], (within, err.max())
 
 
+@pytest.mark.parametrize("head,H,W,dtype", [("dconv", 384, 288, "fp32"), ("duc", 128, 96, "fp32"), ("dconv", 320, 224, "bf16"), ("duc", 384, 288, "bf16")])
+def test_resnets_at_other_resolutions_vs_oracle(measured, head, H, W, dtype):
+    """The ResNets at input sizes other than the 256x192 of the golden vectors (the reference's 384x288 setting; small and odd-tile
+    sizes): every launch descriptor, tile count and phase geometry changes with the resolution.  Checked against the forward oracle
+    (torch-CPU restatement, itself pinned to the goldens at 256x192): fp32 within the BASELINE 1e-4, bf16 within its bar."""
+    mod = pose_resnet_dconv if head == "dconv" else pose_resnet_duc
+    m = _load(mod, head, 4)
+    sd = {k: torch.from_numpy(v) for k, v in synth.conditioned_state_dict(nets_oracle.state_dict_shapes_resnet50(head), 4).items()}
+    x = synth.input_images(3, 12, h=H, w=W)
+    with torch.no_grad():
+        ref = nets_oracle.FORWARDS["resnet50_" + head](sd, torch.from_numpy(x)).numpy()
+        m.compute_dtype = dtype if dtype == "bf16" else "fp32"
+        hm = m(_cuda(x))
+    assert hm.shape == (3, 17, H // 4, W // 4) and hm.dtype == torch.float32
+    rel = np.abs(hm.cpu().numpy() - ref).max() / np.abs(ref).max()
+    bar = 8e-6 if dtype == "fp32" else 2e-2        # measured (round 2): 2.6e-6 / 1.8e-6 fp32, 1.11e-2 / 0.95e-2 bf16 (BASELINE contract: 1e-4 fp32)
+    measured("heat_map_rel_err", rel, bar)
+    assert rel <= bar, rel
+
+
 def test_full_batch_128_is_consistent_with_golden(golden):
     """BASELINE configs[1] size (bs=128): images repeat the two golden inputs, so every output must equal the
     golden pair's - bitwise among replicas (deterministic kernels), 1e-4 rel against the reference."""
