@@ -265,7 +265,7 @@ def main():
                 prog.set_tiles(json.load(fh), B)
             tiles_src = os.path.relpath(pinned, ROOT)
         else:
-            tiles = prog.autotune(x)
+            tiles = prog.autotune(x, in_situ=True)     # top candidates re-timed inside the running forward (untimed setup)
             if args.tiles and rank == 0:
                 with open(args.tiles, "w") as fh:
                     json.dump(tiles, fh)

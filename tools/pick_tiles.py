@@ -48,6 +48,7 @@ def main():
             tables.append(("tracked", {k: tuple(v) for k, v in json.load(fh).items()}))
     for i in range(a.tunes):
         tables.append((f"tune{i}", dict(prog.autotune(x))))
+        tables.append((f"tune{i}+in-situ", dict(prog.autotune(x, in_situ=True))))   # the top candidates re-timed inside the running forward
     scored = []
     for rnd in range(2):                         # two passes over all tables, interleaved: a clock ramp hits every table alike
         for name, t in tables:
