@@ -393,8 +393,8 @@ class Program:
         n_lanes = 1 + max((op.lane for op in self.ops), default=0)
         if refine is None:
             refine = self.multi_stream and n_lanes > 1
-        if in_situ:
-            report.update(self._retime_in_situ(x, by_key, ranked, chosen, apply, verbose))
+        if in_situ and not (self.multi_stream and n_lanes > 1):     # (a multi-stream program is not what a one-stream forward times:
+            report.update(self._retime_in_situ(x, by_key, ranked, chosen, apply, verbose))   #  there the whole-step refinement below decides)
         if refine:
             report.update(self._refine_on_whole_step(x, by_key, ranked, chosen, apply, verbose))
         return report
