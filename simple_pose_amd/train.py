@@ -541,7 +541,8 @@ class PoseTrainer:
         """Time every legal implicit-GEMM tile of every forward and dgrad launch at this per-GPU batch (HIP events, random operands of
         the launch's real shapes) and pin the fastest in the descriptors (`tile_m` / `tile_n`).  Conv outputs and gradients do not depend
         on the tile (same reduction order); the BatchNorm partial sums are grouped per tile row block (fp32 sums of <= 64 values,
-        folded in fp64), so batch statistics agree across tile tables to fp32 rounding (~1e-7 relative), not bit for bit.  The
+        folded in fp64), so batch statistics agree across tile tables to fp32 rounding (~1e-7 relative), not bit for bit (gradients
+        then differ by what this net makes of such a rounding: up to 4e-4 relative L2 in fp32, far more in bf16).  The
         built-in heuristic was fitted at bs=128 inference shapes.  The STATS / BSTATS
         epilogues ride on the same tiles, so the plain launch is timed as their stand-in.  Untimed setup: call once before training."""
         lib, stream, dev = _lib.lib(), _lib.current_stream(), self.flat.data.device
