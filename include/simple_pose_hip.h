@@ -27,7 +27,7 @@ extern "C" {
 #define SP_EINVAL (-1)   /* bad argument / unsupported shape (message in sp_last_error) */
 #define SP_ELAUNCH (-2)  /* HIP launch or runtime failure */
 
-#define SP_ABI_VERSION 21
+#define SP_ABI_VERSION 22
 
 /* epilogue / layout flags of sp_conv_desc.flags */
 #define SP_CONV_RELU 0x1u          /* y = max(y, 0) after scale/shift (+ residual) */
@@ -295,14 +295,33 @@ int sp_maxpool3x3s2_bwd_nhwc(const void* x, int bf16, const void* dy, void* dx, 
 int sp_maxpool3x3s2_idx_nhwc(const void* x, int bf16, void* y, void* idx, int batch, int h, int w, int c, void* stream);
 int sp_maxpool3x3s2_bwd_idx_nhwc(const void* idx, const void* dy, int bf16, void* dx, int batch, int h, int w, int c, void* stream);
 /* torch.optim.Adam (amsgrad False, weight_decay 0) over flat buffers of n (multiple of 4) floats, `step` = 1,2,...;
- * grad is multiplied by grad_scale first (1/world_size after a SUM all-reduce) - ddp...:70-72,119 */
-int sp_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
-                 float beta2, float eps, int step, float grad_scale, void* stream);
+ * grad is multiplied by grad_scale first (1/world_size after a SUM all-reduce) - ddp...:70-72,119.  lr / betas / eps are doubles:
+ * 1 - beta, the bias corrections and lr / (1 - beta1^step) are formed in double and rounded to fp32 once, as torch does */
+int sp_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
+                 double beta2, double eps, int step, float grad_scale, void* stream);
 /* weight gradient of one conv / transposed-conv launch family: dW[n][(ty,tx,c)] = sum_m g[m][n] * im2col(a)[m][(ty,tx,c)],
  * `desc` describing how `a` is gathered (as in sp_conv2d_fwd; tile/out_* ignored; flags & SP_CONV_BF16: g and a are
  * bf16, dW stays fp32), g = [rows, g_channels] NHWC.
  * The result is written in the reference's weight layout: dw[n*dst_stride_n + c*dst_stride_c + ty*kw_valid + tx]
- * for n < n_valid, c < c_valid, tx < kw_valid.  workspace: split partial slabs (error message states the need). */
+ * for n < n_valid, c < c_valid, tx < kw_valid (every such element is overwritten).
+ *
+ * sp_conv2d_wgrad_batched runs the weight gradients of up to 64 layers in a handful of launches (nets/pose_resnet_dconv.py:99-103,
+ * 158,236-244 under loss.backward(), ddp...:117-119): the pixel range of every layer is cut into units of about equal cost (the
+ * cut depends on the layer alone, so a layer's bits do not depend on its companions and equal sp_conv2d_wgrad's), all units of
+ * the layers that share a dW tile shape run as ONE launch, every unit leaves its partial tile in `workspace`, and one fold
+ * launch sums each layer's partials in index order into `dw`: deterministic, no float atomics.
+ * workspace: sp_conv2d_wgrad_workspace(jobs, n_jobs, &bytes) bytes (the error message of a short one states the need). */
+typedef struct sp_wgrad_job {
+    sp_conv_desc desc;
+    const void* g;   /* [rows, g_channels] */
+    const void* a;   /* NHWC tensor gathered through desc */
+    float* dw;
+    int64_t dst_stride_n, dst_stride_c;
+    int32_t g_channels, n_valid, c_valid, kw_valid;
+} sp_wgrad_job;
+int sp_conv2d_wgrad_workspace(const sp_wgrad_job* jobs, int n_jobs, int64_t* bytes);
+int sp_conv2d_wgrad_batched(const sp_wgrad_job* jobs, int n_jobs, void* workspace, int64_t workspace_bytes, void* stream);
+/* one layer: sp_conv2d_wgrad_batched with a single job */
 int sp_conv2d_wgrad(const sp_conv_desc* desc, const void* g, int g_channels, const void* a, int n_valid, int c_valid,
                     int kw_valid, int64_t dst_stride_n, int64_t dst_stride_c, float* dw, void* workspace,
                     int64_t workspace_bytes, void* stream);

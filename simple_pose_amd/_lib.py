@@ -20,7 +20,7 @@ SP_CONV_PIXEL_SHUFFLE = 0x4
 SP_CONV_BF16 = 0x8
 SP_CONV_OUT_F32 = 0x10
 CONV_TILES = ((128, 128), (64, 128), (128, 64), (64, 64), (256, 64), (128, 32))
-ABI_VERSION = 21
+ABI_VERSION = 22
 SP_CONV_KERNEL_IGEMM, SP_CONV_KERNEL_RING = 0, 1
 RING_TILES = ((256, 256), (256, 128), (128, 256), (256, 64), (128, 128), (192, 128), (192, 256))   # kernel = SP_CONV_KERNEL_RING (bf16)
 
@@ -35,6 +35,12 @@ class ConvDesc(ctypes.Structure):
         "batch", "in_h", "in_w", "c_in", "grid_h", "grid_w", "c_out", "n_pad", "taps_h", "taps_w", "k_pad", "stride",
         "dy0", "dy_step", "dx0", "dx_step", "out_h", "out_w", "out_c", "oy_mul", "oy_add", "ox_mul", "ox_add",
         "phases_y", "phases_x")] + [("flags", c_uint32), ("tile_m", c_int32), ("tile_n", c_int32), ("stride_x", c_int32), ("kernel", c_int32)]
+
+
+class WgradJob(ctypes.Structure):
+    """Mirror of `sp_wgrad_job` (one layer of sp_conv2d_wgrad_batched)."""
+    _fields_ = [("desc", ConvDesc), ("g", c_void_p), ("a", c_void_p), ("dw", c_void_p), ("dst_stride_n", c_int64), ("dst_stride_c", c_int64),
+                ("g_channels", c_int32), ("n_valid", c_int32), ("c_valid", c_int32), ("kw_valid", c_int32)]
 
 
 # every symbol include/simple_pose_hip.h declares: name -> (restype, argtypes)
@@ -72,8 +78,10 @@ SYMBOLS = {
     "sp_bn_train_bwd_nhwc": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P, c_int, _P, _P]),
     "sp_channel_sum_nhwc": (c_int, [_P, c_int64, c_int, _P, _P, _P]),
     "sp_maxpool3x3s2_bwd_nhwc": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),
-    "sp_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int, c_float, _P]),
+    "sp_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_double, c_double, c_double, c_double, c_int, c_float, _P]),
     "sp_conv2d_wgrad": (c_int, [ctypes.POINTER(ConvDesc), _P, c_int, _P, c_int, c_int, c_int, c_int64, c_int64, _P, _P, c_int64, _P]),
+    "sp_conv2d_wgrad_workspace": (c_int, [ctypes.POINTER(WgradJob), c_int, ctypes.POINTER(c_int64)]),
+    "sp_conv2d_wgrad_batched": (c_int, [ctypes.POINTER(WgradJob), c_int, _P, c_int64, _P]),
     "sp_permute4_f32": (c_int, [_P, _P, c_int, ctypes.POINTER(c_int32), ctypes.POINTER(c_int64), ctypes.POINTER(c_int32), c_int64, c_int64, _P]),
     "sp_permute4_batched": (c_int, [_P, _P, c_int, c_int, _P]),
     "sp_pose_score": (c_int, [_P, c_int, c_int, _P, _P]),

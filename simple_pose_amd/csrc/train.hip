@@ -406,15 +406,14 @@ __global__ void nchw_to_nhwc_pad_kernel(const float* __restrict__ x, void* __res
 
 // torch.optim.Adam (no amsgrad, weight_decay 0) on flat buffers; g is multiplied by grad_scale first (1/world after a SUM all-reduce)
 __global__ void adam_kernel(f32x4* __restrict__ p, const f32x4* __restrict__ g, f32x4* __restrict__ m, f32x4* __restrict__ v, long long n4,
-                            float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, float grad_scale) {
-    const float step_size = lr / bc1;
+                            float step_size, float b1, float b2, float omb1, float omb2, float eps, float bc2_sqrt, float grad_scale) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         f32x4 pp = p[i], gg = g[i], mm = m[i], vv = v[i];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float gr = gg[e] * grad_scale;
-            mm[e] = mm[e] * b1 + (1.f - b1) * gr;              // exp_avg.mul_(beta1).add_(grad, alpha=1-beta1)
-            vv[e] = vv[e] * b2 + (1.f - b2) * gr * gr;         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+            mm[e] = mm[e] * b1 + omb1 * gr;                    // exp_avg.mul_(beta1).add_(grad, alpha=1-beta1)
+            vv[e] = vv[e] * b2 + omb2 * gr * gr;               // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
             const float denom = sqrtf(vv[e]) / bc2_sqrt + eps; // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
             pp[e] = pp[e] - step_size * (mm[e] / denom);       // param.addcdiv_(exp_avg, denom, value=-step_size)
         }
@@ -663,15 +662,17 @@ extern "C" int sp_nchw_to_nhwc_pad(const float* x, void* y, int y_bf16, int batc
     return sp_check_launch("nchw_to_nhwc_pad_kernel");
 }
 
-extern "C" int sp_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
-                            float beta2, float eps, int step, float grad_scale, void* stream) {
+// Hyper-parameters arrive as doubles: torch forms 1 - beta, 1 - beta^step and lr / (1 - beta1^step) in Python doubles and only then hands
+// them to its fp32 kernels; forming them from fp32 betas is a 1.3e-5 relative error in 1 - beta2 (0.999f = 0.99900001287).
+extern "C" int sp_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
+                            double beta2, double eps, int step, float grad_scale, void* stream) {
     SP_REQUIRE(param && grad && exp_avg && exp_avg_sq, "sp_adam_step: null pointer");
     SP_REQUIRE(n > 0 && n % 4 == 0 && step >= 1, "sp_adam_step: n=%lld must be a positive multiple of 4 and step >= 1", (long long)n);
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<f32x4*>(param),
-                       reinterpret_cast<const f32x4*>(grad), reinterpret_cast<f32x4*>(exp_avg), reinterpret_cast<f32x4*>(exp_avg_sq), n / 4, lr,
-                       beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale);
+                       reinterpret_cast<const f32x4*>(grad), reinterpret_cast<f32x4*>(exp_avg), reinterpret_cast<f32x4*>(exp_avg_sq), n / 4,
+                       (float)(lr / bc1), (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)sqrt(bc2), grad_scale);
     return sp_check_launch("adam_kernel");
 }
 

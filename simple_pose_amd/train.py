@@ -323,6 +323,17 @@ class ConvT:
         done()
         return acc_t
 
+    def wgrad_job(self, x: torch.Tensor, dz: torch.Tensor, B: int, job: Optional["_lib.WgradJob"] = None) -> "_lib.WgradJob":
+        """This layer's record of a sp_conv2d_wgrad_batched call (conv: g = dz, a = x; transposed conv: g = x, a = dz)."""
+        job = job if job is not None else _lib.WgradJob()
+        self.d_wgrad.batch = B
+        ctypes.memmove(ctypes.byref(job.desc), ctypes.byref(self.d_wgrad), ctypes.sizeof(ConvDesc))
+        g, a = (dz, x) if self.kind == "conv" else (x, dz)
+        job.g, job.a, job.dw = g.data_ptr(), a.data_ptr(), self.tr.flat.view(self.wname, grad=True).data_ptr()
+        job.g_channels, job.n_valid, job.c_valid, job.kw_valid = g.shape[-1], self.wg["n_valid"], self.wg["c_valid"], self.wg["kw_valid"]
+        job.dst_stride_n, job.dst_stride_c = self.wg["s_n"], self.wg["s_c"]
+        return job
+
     def wgrad(self, x: torch.Tensor, dz: torch.Tensor, B: int, stream=None):
         lib, tr = _lib.lib(), self.tr
         d = self.d_wgrad
@@ -432,6 +443,7 @@ class PoseTrainer:
             self._pending[i].discard(n)
             if self._pending[i] or self._works[i] is not None:
                 continue
+            self._wgrad_flush()                            # the bucket's last weight gradients may still be queued
             b = self.buckets[i]
             main = torch.cuda.current_stream()
             if not fused:
@@ -460,6 +472,57 @@ class PoseTrainer:
                 self.repack(self._pack_rows_of_bucket[i], _lib.c_void_p(opt.cuda_stream))
             ev[1].record(opt)
             self._works[i] = ev[1]
+
+    def _wgrad_flush(self) -> None:
+        """Launch the queued weight gradients as one group (on the wgrad stream when `overlap_wgrad`)."""
+        q = getattr(self, "_wg_queue", None)
+        if not q:
+            return
+        lib, B, side, dev = _lib.lib(), self._wg_batch, self._wg_side, self._wg_dev
+        jobs = (_lib.WgradJob * len(q))()
+        for j, (layer, xin, dzt) in zip(jobs, q):
+            layer.wgrad_job(xin, dzt, B, j)
+        need = ctypes.c_int64(0)
+        _lib.check(lib.sp_conv2d_wgrad_workspace(jobs, len(q), ctypes.byref(need)), "wgrad workspace")
+        if need.value > self.wgrad_ws.numel() * 4:
+            if side is not None:
+                side.synchronize()                      # (first steps only: the slab buffer grows to the largest group)
+            self.wgrad_ws = torch.empty((need.value + 3) // 4 + (1 << 20), dtype=torch.float32, device=dev)
+        flops = sum(layer.flops for layer, _, _ in q)
+        ke = self.kernel_events
+        if side is None:
+            st = torch.cuda.current_stream(dev)
+            if ke is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(st)
+            _lib.check(lib.sp_conv2d_wgrad_batched(jobs, len(q), P(self.wgrad_ws), self.wgrad_ws.numel() * 4, _lib.current_stream()), "wgrad group")
+            if ke is not None:
+                e1.record(st)
+                ke.append(("wgrad", f"group of {len(q)}", flops, e0, e1))
+        else:
+            main = torch.cuda.current_stream(dev)
+            n = self._wg_flushes = getattr(self, "_wg_flushes", 0) + 1
+            ev = self._wgrad_events.get(n)
+            if ev is None:
+                ev = self._wgrad_events[n] = (torch.cuda.Event(), torch.cuda.Event())
+            ev[0].record(main)                              # every queued dz (and everything before it) is ready
+            side.wait_event(ev[0])
+            if ke is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(side)
+            _lib.check(lib.sp_conv2d_wgrad_batched(jobs, len(q), P(self.wgrad_ws), self.wgrad_ws.numel() * 4, _lib.c_void_p(side.cuda_stream)),
+                       "wgrad group")
+            if ke is not None:
+                e1.record(side)
+                ke.append(("wgrad", f"group of {len(q)}", flops, e0, e1))
+            for _, _, dzt in q:
+                dzt.record_stream(side)                     # dz was released by the tape already: the allocator must wait for `side`
+            ev[1].record(side)
+            self._wgrad_tail = ev[1]
+        self._wg_queue = []
+        self._wg_queued_flops = 0.0
+
+    wgrad_group_gflop = 60.0   # queued weight-gradient work (all images of the rank) that triggers a group launch
 
     # ---- static structure -------------------------------------------------------------------------------------------
     def _conv(self, name, h, w, **kw) -> ConvT:
@@ -664,6 +727,7 @@ class PoseTrainer:
 
         bf = int(self.bf16)
         self._wgrad_tail = None
+        self._wg_flushes = 0
         side = side_h = None
         if self.overlap_wgrad:
             # weight gradients only feed the optimizer: they run on a second HIP stream beside the dgrad / BN-backward chain, which
@@ -675,19 +739,18 @@ class PoseTrainer:
             side_h = _lib.c_void_p(side.cuda_stream)
             main = torch.cuda.current_stream(dev)
 
+        self._wg_queue = []
+        self._wg_queued_flops = 0.0
+        self._wg_batch, self._wg_side, self._wg_dev = B, side, dev
+
         def wgrad_async(layer, xin: torch.Tensor, dzt: torch.Tensor):
-            if side is None:
-                layer.wgrad(xin, dzt, B)
-                return
-            ev = self._wgrad_events.get(layer.name)
-            if ev is None:
-                ev = self._wgrad_events[layer.name] = (torch.cuda.Event(), torch.cuda.Event())
-            ev[0].record(main)                              # dz (and everything before it) is ready
-            side.wait_event(ev[0])
-            layer.wgrad(xin, dzt, B, stream=side_h)
-            dzt.record_stream(side)                         # dz is released by the tape right after: the allocator must wait for `side`
-            ev[1].record(side)
-            self._wgrad_tail = ev[1]
+            # weight gradients are launched in GROUPS (sp_conv2d_wgrad_batched: every layer of a group in one launch per dW tile shape plus
+            # one fold launch): a layer alone has too few dW tiles to fill 256 CUs without cutting its pixels into hundreds of partial
+            # slabs.  The group goes out when a gradient bucket completes, when `wgrad_group_gflop` of work is queued, or at the end.
+            self._wg_queue.append((layer, xin, dzt))
+            self._wg_queued_flops += layer.flops * B
+            if self._wg_queued_flops >= self.wgrad_group_gflop * 1e9:
+                self._wgrad_flush()
 
         self._pending = [set(b["names"]) for b in self.buckets]
         self._works: List[Optional[object]] = [None] * len(self.buckets)
@@ -922,6 +985,7 @@ class PoseTrainer:
             self._grads_ready("final_layer.bias", "final_layer.weight")
             for fn in reversed(tape):
                 fn()
+            self._wgrad_flush()
             if self._wgrad_tail is not None:
                 torch.cuda.current_stream(dev).wait_event(self._wgrad_tail)      # join: the optimizer reads every weight gradient
             if self._opt_in_backward:

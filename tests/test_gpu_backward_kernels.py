@@ -1,0 +1,358 @@
+"""Per-kernel parity of the BACKWARD half of the train step, each entry point of the C ABI on its own against
+float64 torch on well-conditioned random operands - the whole-net comparisons of test_gpu_train.py are chaos-limited (B=2 BatchNorm
+net: bars of 2e-2) and would hide a 1e-3 error in one layer.
+
+Reference semantics: loss.backward() through nn.Conv2d / nn.ConvTranspose2d(4,2,1) / nn.BatchNorm2d / nn.ReLU
+(nets/pose_resnet_dconv.py:99-103,158,236-244) and torch.optim.Adam (processors/ddp_pose_resnet_solver.py:70-72,117-119).
+
+Every bar below is pinned to what was measured on the MI355X (`measured` fixture -> gpurun_out/measured_parity.json), never looser
+than 3x the measurement.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from simple_pose_amd import _lib  # noqa: E402
+from simple_pose_amd.train import ConvT, FlatParams  # noqa: E402
+
+DEV = "cuda:0"
+P = _lib.ptr
+
+
+class _OneLayer:
+    """The slice of PoseTrainer a ConvT needs: flat parameter / gradient buffers of ONE layer, the wgrad workspace, and the layer's
+    pack jobs run one by one through sp_permute4_f32 (PoseTrainer.repack batches the same jobs through sp_permute4_batched)."""
+    kernel_events = None
+    _wgrad_stream = None
+
+    def __init__(self, kind, weight, h, w, bf16, **kw):
+        self.bf16 = bf16
+        mod = torch.nn.Module()
+        mod.c = torch.nn.Module()
+        mod.c.weight = torch.nn.Parameter(weight.to(DEV))
+        self.flat = FlatParams(mod)
+        self.wgrad_ws = torch.empty(48 * 1024 * 1024, dtype=torch.float32, device=DEV)
+        self.layer = ConvT(self, "c", kind, mod.c.weight.detach(), h, w, **kw)
+        lib, st = _lib.lib(), _lib.current_stream()
+        for j in self.layer.pack_jobs:
+            o, _ = self.flat.offsets[j.src_name]
+            _lib.check(lib.sp_permute4_f32(P(self.flat.data), P(j.dst), int(j.dst.dtype == torch.bfloat16), (ctypes.c_int32 * 4)(*j.dims),
+                                           (ctypes.c_int64 * 4)(*j.strides), (ctypes.c_int32 * 4)(*j.valid), o + j.base, j.dst_off, st), "pack")
+
+
+def _rel(got, ref):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    return float((got - ref).abs().max() / ref.pow(2).mean().sqrt())
+
+
+def _rel_bf16(got, ref):
+    """for a bf16 result: max |got - ref| / max(|ref|, rms(ref)) - one rounding to 8 significant bits is 2^-9 = 1.95e-3 of the value"""
+    got, ref = got.double().cpu(), ref.double().cpu()
+    return float(((got - ref).abs() / torch.maximum(ref.abs(), ref.pow(2).mean().sqrt())).max())
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+def _nhwc(t, c_buf=None, dtype=torch.float32):
+    """NCHW float64 host tensor -> NHWC device tensor of `dtype`, channels zero-padded to c_buf."""
+    t = t.permute(0, 2, 3, 1)
+    if c_buf is not None and c_buf > t.shape[-1]:
+        t = F.pad(t, (0, c_buf - t.shape[-1]))
+    return t.contiguous().to(dtype).to(DEV)
+
+
+# name, kind, I, O, k, stride, pad, H, W, B
+LAYERS = [
+    ("1x1", "conv", 64, 128, 1, 1, 0, 12, 10, 3),
+    ("1x1_wide_m", "conv", 64, 256, 1, 1, 0, 64, 48, 4),           # M = 12,288 pixels: many pixel splits per dW tile
+    ("1x1_deep_k", "conv", 1024, 256, 1, 1, 0, 4, 3, 5),           # M = 60: fewer pixels than one split
+    ("3x3_s1", "conv", 64, 64, 3, 1, 1, 9, 7, 2),
+    ("3x3_s1_k4608", "conv", 512, 128, 3, 1, 1, 8, 6, 2),
+    ("3x3_s2", "conv", 64, 128, 3, 2, 1, 12, 8, 2),
+    ("1x1_s2_shortcut", "conv", 64, 128, 1, 2, 0, 12, 8, 2),       # dgrad reaches phase (0,0) only
+    ("final_1x1_17", "conv", 64, 17, 1, 1, 0, 16, 12, 2),          # 17 heat-map channels in a K-tile-padded gradient buffer
+    ("final_3x3_17", "conv", 128, 17, 3, 1, 1, 16, 12, 2),         # the DUC head's final layer
+    ("deconv_k4s2p1", "deconv", 128, 64, 4, 2, 1, 6, 5, 2),
+    ("deconv_k4s2p1_2048", "deconv", 2048, 256, 4, 2, 1, 4, 3, 2),
+]
+EPS32 = 2.0 ** -24
+# Error = max |got - ref| over rms(ref).  Measured on the MI355X (round 3):
+#   wgrad (reduction over the M pixels, cut into ranges of ~800 (fp32) / ~1,700 (bf16) pixels that are summed in order by one workgroup
+#   each and folded in a fixed order): one fp32 accumulation chain per range, so the error grows like sqrt(min(M, range)):
+#   fp32 <= 2.1e-6 up to M = 400, 5.9e-6 at M = 12,288 (0.9 x EPS32 sqrt(M)); bf16 operands (exact products, fp32 accumulation;
+#   reference = float64 on the same bf16-rounded operands, dW stays fp32) <= 6.7e-7, 1.4e-6 at M = 12,288;
+#   dgrad = one fp32 accumulation chain of length K per output (v_mfma_f32_32x32x2_f32 == an fmaf chain in k order): the error grows
+#   like sqrt(K): measured 2.5-3.5 x EPS32 sqrt(K) in fp32 (1.7e-6 at K = 64 ... 1.3e-5 at K = 4096), 0.8-1.0 x EPS32 sqrt(K) in bf16.
+def wgrad_bar(bf16, M):
+    return max(1.5e-6, 0.5 * EPS32 * float(np.sqrt(M))) if bf16 else max(4e-6, 2.0 * EPS32 * float(np.sqrt(M)))
+DGRAD_BAR_K = {False: 6.0, True: 2.0}        # x EPS32 * sqrt(K)
+
+
+def _reference(kind, I, O, k, s, p, H, W, B, bf16, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, I, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn((O, I, k, k) if kind == "conv" else (I, O, k, k), generator=g, dtype=torch.float64) / np.sqrt(I * k * k / (4 if kind == "deconv" else 1))
+    w = w.float().double()                      # the layer's master weight is fp32
+    if bf16:
+        x = _bf(x)
+    wq = _bf(w) if bf16 else w                   # packed copies are bf16 in bf16 mode
+    xr, wr = x.clone().requires_grad_(True), wq.clone().requires_grad_(True)
+    y = F.conv2d(xr, wr, stride=s, padding=p) if kind == "conv" else F.conv_transpose2d(xr, wr, stride=2, padding=1)
+    dz = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    if bf16:
+        dz = _bf(dz)
+    y.backward(dz)
+    return x, w, dz, xr.grad, wr.grad
+
+
+@pytest.mark.parametrize("bf16", [False, True], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("case", LAYERS, ids=[c[0] for c in LAYERS])
+def test_wgrad_and_dgrad_vs_float64(case, bf16, measured):
+    name, kind, I, O, k, s, p, H, W, B = case
+    x, w, dz, dx_ref, dw_ref = _reference(kind, I, O, k, s, p, H, W, B, bf16, seed=11)
+    one = _OneLayer(kind, w.float(), H, W, bf16, stride=s, pad=p)
+    L = one.layer
+    lib, st = _lib.lib(), _lib.current_stream()
+    adt = torch.bfloat16 if bf16 else torch.float32
+    xd = _nhwc(x, dtype=adt)
+    dzd = _nhwc(dz, c_buf=L.c_out_buf, dtype=adt)
+    # ---- wgrad: written straight into the reference weight layout inside the flat gradient buffer ----
+    L.d_wgrad.batch = B
+    gt, at = (dzd, xd) if kind == "conv" else (xd, dzd)
+    one.flat.grad.fill_(float("nan"))            # every element of the layer's gradient must be written
+    _lib.check(lib.sp_conv2d_wgrad(L.d_wgrad, P(gt), gt.shape[-1], P(at), L.wg["n_valid"], L.wg["c_valid"], L.wg["kw_valid"], L.wg["s_n"],
+                                   L.wg["s_c"], P(one.flat.view("c.weight", grad=True)), P(one.wgrad_ws), one.wgrad_ws.numel() * 4, st), name)
+    torch.cuda.synchronize()
+    dw = one.flat.view("c.weight", grad=True).view(w.shape)
+    assert torch.isfinite(dw).all()
+    e = _rel(dw, dw_ref)
+    wbar = wgrad_bar(bf16, L.d_wgrad.batch * L.d_wgrad.grid_h * L.d_wgrad.grid_w)
+    measured("wgrad_rel", e, wbar)
+    assert e <= wbar
+    # a second launch reproduces the bits (fixed reduction order, no float atomics)
+    first = dw.clone()
+    _lib.check(lib.sp_conv2d_wgrad(L.d_wgrad, P(gt), gt.shape[-1], P(at), L.wg["n_valid"], L.wg["c_valid"], L.wg["kw_valid"], L.wg["s_n"],
+                                   L.wg["s_c"], P(one.flat.view("c.weight", grad=True)), P(one.wgrad_ws), one.wgrad_ws.numel() * 4, st), name)
+    torch.cuda.synchronize()
+    assert torch.equal(first, dw)
+    # ---- dgrad: the forward kernel on the re-packed weights (flipped taps / stride-2 phases / deconv as a 4x4 stride-2 conv) ----
+    full = L.dgrad_full_cover
+    dxd = (torch.empty if full else torch.zeros)((B, H, W, I), dtype=torch.float32, device=DEV)
+    for d, wd in zip(L.d_dgrad, L.w_dgrad):
+        d.batch = B
+        _lib.check(lib.sp_conv2d_fwd(d, P(dzd), P(wd), None, None, None, P(dxd), st), name + ".dgrad")
+    torch.cuda.synchronize()
+    dbar = DGRAD_BAR_K[bf16] * EPS32 * float(np.sqrt(max(d.k_pad for d in L.d_dgrad)))
+    e = _rel(dxd.permute(0, 3, 1, 2), dx_ref)
+    measured("dgrad_rel", e, dbar)
+    assert e <= dbar
+    # accumulate form (residual fan-out): dx = acc + dgrad, in place
+    if full:
+        acc = torch.randn(B, H, W, I, generator=torch.Generator().manual_seed(3)).to(DEV)
+        acc0 = acc.clone()
+        for d, wd in zip(L.d_dgrad, L.w_dgrad):
+            _lib.check(lib.sp_conv2d_fwd(d, P(dzd), P(wd), None, None, P(acc), P(acc), st), name + ".dgrad+")
+        torch.cuda.synchronize()
+        e = _rel(acc.permute(0, 3, 1, 2), dx_ref + acc0.cpu().double().permute(0, 3, 1, 2))
+        measured("dgrad_accumulate_rel", e, dbar)
+        assert e <= dbar
+
+
+@pytest.mark.parametrize("bf16", [False, True], ids=["fp32", "bf16"])
+def test_batched_wgrad_equals_layer_by_layer_bitwise(bf16):
+    """sp_conv2d_wgrad_batched over every test layer at once (mixed dW tile shapes, more layers than one launch's table holds) leaves
+    the same bits as one sp_conv2d_wgrad call per layer: how a layer's pixels are cut depends on the layer alone."""
+    lib, st = _lib.lib(), _lib.current_stream()
+    adt = torch.bfloat16 if bf16 else torch.float32
+    keep, single = [], []
+    cases = LAYERS + [(n + "_again", *rest) for n, *rest in LAYERS[:8]]          # 19 jobs: two unit launches
+    jobs = (_lib.WgradJob * len(cases))()
+    for job, (name, kind, I, O, k, s, p, H, W, B) in zip(jobs, cases):
+        x, w, dz, _, _ = _reference(kind, I, O, k, s, p, H, W, B, bf16, seed=len(keep))
+        one = _OneLayer(kind, w.float(), H, W, bf16, stride=s, pad=p)
+        L = one.layer
+        xd, dzd = _nhwc(x, dtype=adt), _nhwc(dz, c_buf=L.c_out_buf, dtype=adt)
+        L.wgrad(xd, dzd, B)
+        torch.cuda.synchronize()
+        single.append(one.flat.view("c.weight", grad=True).clone())
+        one.flat.grad.fill_(float("nan"))
+        L.wgrad_job(xd, dzd, B, job)
+        keep.append((one, xd, dzd))
+    need = ctypes.c_int64(0)
+    _lib.check(lib.sp_conv2d_wgrad_workspace(jobs, len(cases), ctypes.byref(need)))
+    ws = torch.empty(need.value // 4 + 16, dtype=torch.float32, device=DEV)
+    assert lib.sp_conv2d_wgrad_batched(jobs, len(cases), P(ws), need.value - 4, st) != 0          # a short workspace is refused
+    assert b"workspace too small" in lib.sp_last_error()
+    _lib.check(lib.sp_conv2d_wgrad_batched(jobs, len(cases), P(ws), need.value, st), "batched")
+    torch.cuda.synchronize()
+    for (one, _, _), ref, case in zip(keep, single, cases):
+        assert torch.equal(one.flat.view("c.weight", grad=True), ref), case[0]
+
+
+@pytest.mark.parametrize("bf16", [False, True], ids=["fp32", "bf16"])
+def test_stem_7x7_wgrad_vs_float64(bf16, measured):
+    """conv1 (3 -> 64, 7x7 s2 p3) reads the image as NHWC4 (fp32) / NHWC8 (bf16) with 8 packed taps per row; only its weight
+    gradient exists (the input needs none)."""
+    I, O, k, s, p, H, W, B = 3, 64, 7, 2, 3, 32, 24, 3
+    x, w, dz, _, dw_ref = _reference("conv", I, O, k, s, p, H, W, B, bf16, seed=5)
+    cbuf = 8 if bf16 else 4
+    one = _OneLayer("conv", w.float(), H, W, bf16, stride=s, pad=p, c_in_buf=cbuf, need_dgrad=False)
+    L = one.layer
+    adt = torch.bfloat16 if bf16 else torch.float32
+    xd, dzd = _nhwc(x, c_buf=cbuf, dtype=adt), _nhwc(dz, dtype=adt)
+    L.d_wgrad.batch = B
+    one.flat.grad.fill_(float("nan"))
+    _lib.check(_lib.lib().sp_conv2d_wgrad(L.d_wgrad, P(dzd), dzd.shape[-1], P(xd), L.wg["n_valid"], L.wg["c_valid"], L.wg["kw_valid"],
+                                          L.wg["s_n"], L.wg["s_c"], P(one.flat.view("c.weight", grad=True)), P(one.wgrad_ws),
+                                          one.wgrad_ws.numel() * 4, _lib.current_stream()), "stem")
+    torch.cuda.synchronize()
+    dw = one.flat.view("c.weight", grad=True).view(w.shape)
+    assert torch.isfinite(dw).all()
+    e = _rel(dw, dw_ref)
+    wbar = wgrad_bar(bf16, B * L.d_wgrad.grid_h * L.d_wgrad.grid_w)
+    measured("wgrad_rel", e, wbar)
+    assert e <= wbar
+
+
+# measured (round 3): fp32: dz <= 1.6e-6 of its rms, dgamma / dbeta <= 3.8e-7, dres <= 6.8e-7; mean <= 1.3e-7, invstd <= 1.6e-7.  bf16
+# activations: y and dz are stored as bf16 - one rounding, 2^-9 of the value (_rel_bf16); the sums stay fp32
+BN_BAR = {False: dict(dz=3e-6, sums=1e-6, stats=4e-7, dres=1.5e-6), True: dict(dz=4e-3, sums=1e-6, stats=4e-7, dres=1.5e-6)}
+
+
+@pytest.mark.parametrize("bf16", [False, True], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("rows_hw,C,relu,res_on", [((4, 16, 12), 64, True, False), ((3, 9, 7), 256, True, True), ((2, 5, 3), 2048, False, False),
+                                                   ((8, 32, 24), 128, True, True)])
+def test_batchnorm_train_backward_vs_float64(rows_hw, C, relu, res_on, bf16, measured):
+    """y = [relu](bn_train(z) [+ res]) -> (dz, dgamma, dbeta, dres) through sp_bn_train_bwd_nhwc and through its two halves
+    sp_bn_train_bwd_reduce_nhwc + sp_bn_train_bwd_apply_nhwc (the SyncBatchNorm form), against float64 autograd."""
+    B, H, W = rows_hw
+    rows = B * H * W
+    g = torch.Generator().manual_seed(C + rows)
+    z = torch.randn(rows, C, generator=g, dtype=torch.float64) * (0.5 + torch.rand(C, generator=g, dtype=torch.float64)) + torch.randn(C, generator=g, dtype=torch.float64)
+    res = torch.randn(rows, C, generator=g, dtype=torch.float64) if res_on else None
+    gamma = (0.75 + 0.5 * torch.rand(C, generator=g, dtype=torch.float64)).float().double()
+    beta = (0.1 * torch.randn(C, generator=g, dtype=torch.float64)).float().double()
+    dy = torch.randn(rows, C, generator=g, dtype=torch.float64).float().double()
+    adt = torch.bfloat16 if bf16 else torch.float32
+    if bf16:
+        z = _bf(z)
+        res = _bf(res) if res_on else None
+    lib, st = _lib.lib(), _lib.current_stream()
+    ws = torch.empty(4 << 20, dtype=torch.uint8, device=DEV)
+    zd, dyd = z.to(adt).to(DEV), dy.float().to(DEV)
+    resd = res.to(adt).to(DEV) if res_on else None
+    gd, bd = gamma.float().to(DEV), beta.float().to(DEV)
+    mean, invstd = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    _lib.check(lib.sp_bn_train_stats_nhwc(P(zd), int(bf16), rows, C, 1e-5, 0.1, P(mean), P(invstd), P(rm), P(rv), P(ws), st), "stats")
+    yd = torch.empty((rows, C), dtype=adt, device=DEV)
+    _lib.check(lib.sp_bn_apply_nhwc(P(zd), int(bf16), P(mean), P(invstd), P(gd), P(bd), P(resd), P(yd), rows, C, int(relu), st), "apply")
+    torch.cuda.synchronize()
+    # float64 reference; the ReLU mask is taken from the kernel's own y (a pre-activation within rounding of 0 has no defined sign)
+    zr = z.clone().requires_grad_(True)
+    rr = res.clone().requires_grad_(True) if res_on else None
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    m64, v64 = zr.mean(0), zr.var(0, unbiased=False)
+    pre = (zr - m64) / torch.sqrt(v64 + 1e-5) * gr + br
+    if res_on:
+        pre = pre + rr
+    mask = (yd.double().cpu() > 0).double() if relu else torch.ones_like(pre)
+    (pre * mask).backward(dy)
+    measured("mean_rel", _rel(mean, m64.detach()), BN_BAR[bf16]["stats"])
+    measured("invstd_rel", _rel(invstd, 1 / torch.sqrt(v64.detach() + 1e-5)), BN_BAR[bf16]["stats"])
+    assert _rel(mean, m64.detach()) <= BN_BAR[bf16]["stats"] and _rel(invstd, 1 / torch.sqrt(v64.detach() + 1e-5)) <= BN_BAR[bf16]["stats"]
+    assert _rel(rm, 0.1 * m64.detach()) <= 1e-6 and _rel(rv, 0.9 + 0.1 * zr.detach().var(0, unbiased=True)) <= 1e-6
+    y_ref = torch.relu(pre.detach()) if relu else pre.detach()
+    e = (_rel_bf16 if bf16 else _rel)(yd.float(), y_ref)
+    measured("y_rel", e, 4e-3 if bf16 else 2e-6)
+    assert e <= (4e-3 if bf16 else 2e-6)
+
+    def check(tag, dz, dgamma, dbeta, dres):
+        for nm, got, ref, bar in (("dz", dz.float(), zr.grad, BN_BAR[bf16]["dz"]), ("dgamma", dgamma, gr.grad, BN_BAR[bf16]["sums"]),
+                                  ("dbeta", dbeta, br.grad, BN_BAR[bf16]["sums"])) + ((("dres", dres, rr.grad, BN_BAR[bf16]["dres"]),) if res_on else ()):
+            e = (_rel_bf16 if (bf16 and nm == "dz") else _rel)(got, ref)
+            measured(f"{tag}/{nm}_rel", e, bar)
+            assert e <= bar, (tag, nm, e)
+
+    rs = P(yd) if relu else None
+    dz = torch.empty((rows, C), dtype=adt, device=DEV)
+    dgam, dbet = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    dres = torch.empty((rows, C), device=DEV) if res_on else None
+    _lib.check(lib.sp_bn_train_bwd_nhwc(P(dyd), int(bf16), rs, P(zd), P(mean), P(invstd), P(gd), rows, C, P(dz), P(dgam), P(dbet), P(dres), 0,
+                                        P(ws), st), "bwd")
+    torch.cuda.synchronize()
+    check("one_call", dz, dgam, dbet, dres)
+    # the two halves, dres accumulated onto an existing gradient
+    dz2 = torch.empty_like(dz)
+    dgam2, dbet2 = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    base = torch.randn(rows, C, generator=torch.Generator().manual_seed(1)).to(DEV) if res_on else None
+    dres2 = base.clone() if res_on else None
+    _lib.check(lib.sp_bn_train_bwd_reduce_nhwc(P(dyd), int(bf16), rs, P(zd), P(mean), P(invstd), rows, C, P(dgam2), P(dbet2), P(ws), st), "reduce")
+    _lib.check(lib.sp_bn_train_bwd_apply_nhwc(P(dyd), int(bf16), rs, P(zd), P(mean), P(invstd), P(gd), P(dgam2), P(dbet2), rows, rows, C, P(dz2),
+                                              P(dres2), 1, st), "apply")
+    torch.cuda.synchronize()
+    check("two_halves", dz2, dgam2, dbet2, (dres2 - base) if res_on else None)
+    assert torch.equal(dz, dz2) and torch.equal(dgam, dgam2) and torch.equal(dbet, dbet2)
+
+
+def _ulp_diff(a: torch.Tensor, b: torch.Tensor, *operands) -> float:
+    """max |a - b| in units of the fp32 spacing at the largest magnitude among b and the operands it was formed from (a sum that
+    cancels has no meaningful ulp of its own; a parameter far smaller than its update is as accurate as the update)"""
+    a, b = a.double().cpu(), b.double().cpu()
+    mag = b.abs()
+    for o in operands:
+        mag = torch.maximum(mag, o.double().cpu().abs() if isinstance(o, torch.Tensor) else torch.full_like(mag, abs(o)))
+    spacing = torch.from_numpy(np.spacing(mag.float().numpy())).double()
+    return float(((a - b).abs() / spacing).max())
+
+
+def test_adam_ten_steps_vs_torch_optim(measured):
+    """sp_adam_step against torch.optim.Adam (lr 1e-3, betas (0.9, 0.999), eps 1e-8, no weight decay; ddp...:70-72): ten steps with fresh
+    gradients, (a) per step from the same state, (b) free running.  Unit: fp32 spacing at the largest operand of each result (the
+    moments' two terms; max(|p|, lr) for a parameter) - torch 2.x forms exp_avg with lerp_, the reference's torch >= 1.5 with mul_ / add_,
+    the kernel with one fused multiply-add: the same value to an ulp of the larger term."""
+    n = 1 << 16
+    g = torch.Generator().manual_seed(9)
+    p0 = torch.randn(n, generator=g)
+    grads = [torch.randn(n, generator=g) * (10.0 ** float(torch.randint(-4, 1, (1,), generator=g))) for _ in range(10)]
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    lib, st = _lib.lib(), _lib.current_stream()
+    free_p, free_m, free_v = p0.clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    worst_step = worst_free = worst_state = 0.0
+    for t, gt in enumerate(grads, start=1):
+        # (a) one step from torch's state before the step
+        state = opt.state[ref] if t > 1 else None
+        sp = ref.detach().clone().to(DEV)
+        sm = state["exp_avg"].clone().to(DEV) if state else torch.zeros(n, device=DEV)
+        sv = state["exp_avg_sq"].clone().to(DEV) if state else torch.zeros(n, device=DEV)
+        gd = gt.to(DEV)
+        m_before, v_before = sm.cpu(), sv.cpu()
+        _lib.check(lib.sp_adam_step(P(sp), P(gd), P(sm), P(sv), n, 1e-3, 0.9, 0.999, 1e-8, t, 1.0, st), "adam")
+        _lib.check(lib.sp_adam_step(P(free_p), P(gd), P(free_m), P(free_v), n, 1e-3, 0.9, 0.999, 1e-8, t, 1.0, st), "adam")
+        ref.grad = gt.clone()
+        opt.step()
+        torch.cuda.synchronize()
+        worst_step = max(worst_step, _ulp_diff(sp, ref.detach(), 1e-3))
+        worst_state = max(worst_state, _ulp_diff(sm, opt.state[ref]["exp_avg"], m_before, 0.1 * gt),
+                          _ulp_diff(sv, opt.state[ref]["exp_avg_sq"], v_before, 1e-3 * gt * gt))
+        worst_free = max(worst_free, _ulp_diff(free_p, ref.detach(), 1e-3))
+    measured("param_ulp_per_step", worst_step, 2)
+    measured("moment_ulp_per_step", worst_state, 2)
+    measured("param_ulp_free_running_10_steps", worst_free, 25)        # (different moments after a few steps: measured 12.5)
+    assert worst_step <= 2 and worst_state <= 2 and worst_free <= 25
+    # grad_scale (1 / world size after a SUM all-reduce) == scaling the gradient first
+    a_p, a_m, a_v = p0.clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    b_p, b_m, b_v = p0.clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    g8 = (grads[0] * 8).to(DEV)
+    _lib.check(lib.sp_adam_step(P(a_p), P(g8), P(a_m), P(a_v), n, 1e-3, 0.9, 0.999, 1e-8, 1, 0.125, st), "adam")
+    _lib.check(lib.sp_adam_step(P(b_p), P(grads[0].to(DEV)), P(b_m), P(b_v), n, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, st), "adam")
+    torch.cuda.synchronize()
+    assert torch.equal(a_p, b_p) and torch.equal(a_m, b_m) and torch.equal(a_v, b_v)
