@@ -41,6 +41,10 @@ def parse():
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
                     help="infer = forward + GaussTaylor decode (BASELINE metric, default); train = fwd+bwd+Adam step (config 4, fp32)")
     ap.add_argument("--no-sync-bn", action="store_true", help="train mode, N > 1: per-rank BN statistics (the reference's DDP solver syncs them)")
+    ap.add_argument("--sync-bn-latency-us", type=float, default=0.0,
+                    help="train mode: every SyncBatchNorm message additionally costs this many microseconds (a delay kernel on a side stream the "
+                         "consumer waits for); at N = 1 it switches the SyncBatchNorm path on with nothing to exchange: an emulation of what "
+                         "the 104 small messages per step expose on xGMI, for boxes with one GPU")
     ap.add_argument("--bucket-mb", type=float, default=32.0, help="train mode, N > 1: gradient all-reduce bucket size")
     ap.add_argument("--single-stream", action="store_true", help="infer mode: issue independent branches (HRNet) on one stream")
     ap.add_argument("--graph", action="store_true", help="infer mode: replay the step (forward + decode) as one captured hipGraph")
@@ -50,7 +54,67 @@ def parse():
     ap.add_argument("--retune", action="store_true", help="ignore the tracked tile table: time every (tile, kernel) per layer shape on this GPU")
     ap.add_argument("--layers-out", default=None, help="write the per-layer timing table (JSON) here")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (roofline object)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="preflight of the N-rank job without touching a GPU: start the N ranks exactly as a real run does, rendezvous over gloo, "
+                         "check the rank -> device mapping, one barrier and the MAX/SUM reductions of the measurement, print ONE JSON line; "
+                         "non-zero exit when any rank dies")
+    ap.add_argument("--hsa-ipc-legacy", default="0", choices=["0", "1", "inherit"],
+                    help="HSA_ENABLE_IPC_MODE_LEGACY for the ranks (recorded in config): 0 = dmabuf IPC, what this pool's host driver supports "
+                         "(RCCL / tensor sharing across processes fails with hipIpcGetMemHandle otherwise); inherit = leave the environment alone")
     return ap.parse_args()
+
+
+def apply_ipc_mode(args, env) -> str:
+    """Set (or leave) HSA_ENABLE_IPC_MODE_LEGACY in `env` as --hsa-ipc-legacy says; returns what the ranks will see."""
+    if args.hsa_ipc_legacy != "inherit":
+        env["HSA_ENABLE_IPC_MODE_LEGACY"] = args.hsa_ipc_legacy
+    return env.get("HSA_ENABLE_IPC_MODE_LEGACY", "unset")
+
+
+def dry_rank(args) -> int:
+    """One rank of `bench.py --gpus N --dry-launch` (no GPU call): the same environment contract, rendezvous and reductions as a real
+    rank, over gloo on the CPU."""
+    import torch
+    import torch.distributed as dist
+    from simple_pose_amd.sharding import aggregate_throughput, rank_indices
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    n_dev = torch.cuda.device_count()                         # (counting devices does not initialise HIP)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    if os.environ.get("SP_BENCH_DRY_FAIL_RANK") == str(rank):    # test hook: a rank that dies after the rendezvous
+        os._exit(3)
+    device = local_rank % n_dev if n_dev else None
+    mine = torch.tensor([rank, local_rank, -1 if device is None else device], dtype=torch.int64)
+    table = [torch.zeros_like(mine) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(table, mine)
+        dist.barrier()
+    else:
+        table = [mine]
+    # the measurement's own reductions on known numbers: SUM of the units, MAX of the elapsed time
+    units, elapsed, value = aggregate_throughput(float(args.batch * args.steps), 1.0 + 0.01 * rank)
+    ok = units == float(args.batch * args.steps * world) and abs(elapsed - (1.0 + 0.01 * (world - 1))) < 1e-9
+    ranks = [int(t[0]) for t in table]
+    devs = [int(t[2]) for t in table]
+    ok = ok and ranks == list(range(world)) and [int(t[1]) for t in table] == list(range(world))
+    one_per_device = n_dev >= world and devs == list(range(world))
+    covered = sorted(i for r in range(world) for i in rank_indices(args.batch * world, r, world))
+    ok = ok and covered == list(range(args.batch * world))      # DistributedSampler rule: every sample on exactly one rank
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_ranks": world, "rendezvous": "gloo, env:// on 127.0.0.1", "ranks_seen": ranks,
+                          "visible_devices": n_dev, "rank_to_device": devs, "one_device_per_rank": one_per_device,
+                          "reductions_ok": ok, "config": {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "unset")}}),
+              flush=True)
+    return 0 if ok else 1
 
 
 def cpu_baseline(arch: str):
@@ -117,7 +181,7 @@ def launch_ranks(args) -> int:
     base = dict(os.environ)
     base.update({"WORLD_SIZE": str(args.gpus), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": base.get("MASTER_PORT", str(port)),
                  "LOCAL_WORLD_SIZE": str(args.gpus), "SP_BENCH_CHILD": "1"})
-    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    apply_ipc_mode(args, base)
     base.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
     procs = []
     for r in range(args.gpus):
@@ -177,7 +241,9 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args))        # before torch is imported or the GPU is touched
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this host driver: before the first HIP call
+    ipc_mode = apply_ipc_mode(args, os.environ)         # before the first HIP call (default 0: dmabuf IPC, the only mode this pool's driver has)
+    if args.dry_launch:
+        raise SystemExit(dry_rank(args))
     import torch
     import torch.distributed as dist
 
@@ -237,7 +303,7 @@ def main():
         from simple_pose_amd.train import PoseTrainer
         model.train()
         trainer = PoseTrainer(model, lr=1e-3, dtype="bf16" if args.dtype == "bf16" else "fp32", sync_bn=not args.no_sync_bn,
-                              bucket_mb=args.bucket_mb)
+                              bucket_mb=args.bucket_mb, sync_bn_latency_us=args.sync_bn_latency_us)
         if not args.no_train_autotune:
             trainer.autotune(B)                        # untimed setup: fastest tile per forward / dgrad launch at this batch
         joints = torch.from_numpy(synth.joints_batch(B, 17, seed=200 + rank)).to(dev)
@@ -296,6 +362,7 @@ def main():
     with torch.no_grad():
         for _ in range(args.steps):
             out = step()
+    host_enqueue_ms = 1e3 * (time.perf_counter() - t0) / args.steps     # the host's share: close to ms_per_step = launch-bound
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -337,11 +404,12 @@ def main():
                 "config": {"workload": f"{name} 256x192 train step, bs={B} per GPU, {'fp32' if args.dtype == 'f32' else 'bf16 compute + fp32 master weights/Adam'}, train-mode BN (batch statistics), Adam lr 1e-3, "
                                        "targets from the HIP encoder; N > 1: SyncBatchNorm " + ("off" if args.no_sync_bn else "on") +
                                        f", gradients all-reduced in {args.bucket_mb:g} MB buckets overlapped with backward (RCCL)",
-                           "images_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                           "images_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}", "HSA_ENABLE_IPC_MODE_LEGACY": ipc_mode,
                            "collectives": ("RCCL (nccl backend)" if args.dist_backend == "nccl" else "gloo") if world > 1 else "none"},
                 "gflop_per_image": round(gflop, 3), "network_tflops": round(value * gflop / 1e3, 2),
                 "network_frac_of_matrix_peak": round(value * gflop / 1e3 / ((FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else BF16_MATRIX_PEAK_TFLOPS) * world), 4),
                 "roofline": roofline, "cpu_baseline": None, "final_loss": float(out[0].item()), "step_split_ms": step_split,
+                "host_enqueue_ms_per_step": round(host_enqueue_ms, 3), "sync_bn_latency_us_emulated": args.sync_bn_latency_us,
                 "collectives_per_step": {"gradient_buckets": len(trainer.buckets) if world > 1 else 0, "sync_bn": trainer.collective_count}}
         else:
             peak = FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else BF16_MATRIX_PEAK_TFLOPS
@@ -354,7 +422,8 @@ def main():
                                        "(NCHW in -> heat maps) + GaussTaylor decode, eval-mode BN, conditioned random weights",
                            "images_per_gpu": B, "global_batch": B * world, "parallelism": f"replicas x{world} (no collective)",
                            "ranks": f"{world} process(es), one per GPU" + (f", {args.dist_backend} for the barrier / MAX only" if world > 1 else ""),
-                           "launch": "one hipGraph per step" if args.graph else "stream launches", "tile_table": tiles_src},
+                           "launch": "one hipGraph per step" if args.graph else "stream launches", "tile_table": tiles_src,
+                           "HSA_ENABLE_IPC_MODE_LEGACY": ipc_mode},
                 "gflop_per_image": round(prog.flops_per_image / 1e9, 4),
                 "network_tflops": round(value * prog.flops_per_image / 1e12, 2),
                 "network_frac_of_matrix_peak": round(value * prog.flops_per_image / 1e12 / (peak * world), 4),
@@ -368,10 +437,10 @@ def main():
 
 def train_roofline(trainer, step, B: int, peak: float, steps: int = 3):
     """Train step: HIP events around every conv-family launch (forward, dgrad, wgrad), recorded on the stream the launch goes to
-    (weight gradients run on the trainer's second stream), over `steps` untimed extra steps.  The dominant group is the weight
-    gradient: `sp_conv2d_wgrad` = conv_wgrad(_bf16)_kernel + its fixed-order slab reduce wgrad_reduce_kernel (the pair is timed
-    together: average launch = the sum of the two kernels' averages in profiles/*_train_*_kernel_stats.csv), priced against the
-    MFMA peak with 2 x MACs of the layer as algorithmic FLOPs.  Kernels on the two streams overlap, so a group's time is the
+    (weight gradients run on the trainer's second stream), over `steps` untimed extra steps.  The weight gradients go out in groups:
+    one `sp_conv2d_wgrad_batched` call = conv_wgrad_group_kernel (every layer of the group) + its fixed-order wgrad_fold_kernel, timed
+    together (a launch's time = the sum of the two kernels in profiles/*_train_*_kernel_stats.csv); every group is priced against the
+    MFMA peak with 2 x MACs of its layers as algorithmic FLOPs.  Kernels on the two streams overlap, so a group's time is the
     time its launches were resident, not exclusive use of the chip."""
     import torch
 
@@ -385,7 +454,7 @@ def train_roofline(trainer, step, B: int, peak: float, steps: int = 3):
     for kind, name, flops, e0, e1 in ev:
         g = groups.setdefault(kind, [0.0, 0.0, 0])
         g[0] += e0.elapsed_time(e1); g[1] += flops * B; g[2] += 1
-    names = {"wgrad": ("conv_wgrad_bf16_kernel" if trainer.bf16 else "conv_wgrad_kernel") + " + wgrad_reduce_kernel",
+    names = {"wgrad": f"conv_wgrad_group_kernel<{'true' if trainer.bf16 else 'false'}> + wgrad_fold_kernel",
              "forward": "conv_igemm_kernel<...> (forward launches)", "dgrad": "conv_igemm_kernel<...> (dgrad launches)"}
     dom = max(groups, key=lambda k: groups[k][0])
     ms, fl, n = groups[dom]

@@ -335,6 +335,10 @@ int sp_permute4_f32(const float* src, void* dst, int dst_bf16, const int32_t* ds
  * (dst_address = device pointer of the destination incl. its offset), blocks_per_job workgroups grid-stride over a job */
 int sp_permute4_batched(const float* src, const void* jobs_device, int n_jobs, int blocks_per_job, void* stream);
 
+/* measurement aid: occupies `stream` for `us` microseconds (one idle wave on the 100 MHz constant clock) - bench.py's stand-in for the
+ * latency of a SyncBatchNorm message (ddp...:89-90) on a box with a single GPU */
+int sp_stream_delay_us(double us, void* stream);
+
 /* ---- parameter packing: the reference's tensors -> what the launches above read ------------------------------------------
  * (all pointers are device memory; every call fills its whole destination, padding included)
  *

@@ -50,8 +50,15 @@ def _bottleneck(x, sd, p, stride, training=False):
     return F.relu(out + x)
 
 
+def blocks_of(sd) -> tuple:
+    """Bottlenecks per stage, read off the state_dict keys ((3, 4, 6, 3) for resnet50, (3, 4, 23, 3) resnet101, (3, 8, 36, 3) resnet152:
+    nets/pose_resnet_dconv.py:306-339)."""
+    return tuple(1 + max(int(k.split(".")[1]) for k in sd if k.startswith(f"layer{li}.")) for li in (1, 2, 3, 4))
+
+
 def resnet_trunk(sd: Dict[str, torch.Tensor], x: torch.Tensor, training=False,
-                 tap: Optional[Callable[[str, torch.Tensor], None]] = None, blocks=RESNET50_BLOCKS):
+                 tap: Optional[Callable[[str, torch.Tensor], None]] = None, blocks=None):
+    blocks = blocks or blocks_of(sd)
     x = F.relu(_bn(F.conv2d(x, sd["conv1.weight"], stride=2, padding=3), sd, "bn1", training))
     x = F.max_pool2d(x, 3, 2, 1)
     if tap:

@@ -82,6 +82,7 @@ SYMBOLS = {
     "sp_conv2d_wgrad": (c_int, [ctypes.POINTER(ConvDesc), _P, c_int, _P, c_int, c_int, c_int, c_int64, c_int64, _P, _P, c_int64, _P]),
     "sp_conv2d_wgrad_workspace": (c_int, [ctypes.POINTER(WgradJob), c_int, ctypes.POINTER(c_int64)]),
     "sp_conv2d_wgrad_batched": (c_int, [ctypes.POINTER(WgradJob), c_int, _P, c_int64, _P]),
+    "sp_stream_delay_us": (c_int, [c_double, _P]),
     "sp_permute4_f32": (c_int, [_P, _P, c_int, ctypes.POINTER(c_int32), ctypes.POINTER(c_int64), ctypes.POINTER(c_int32), c_int64, c_int64, _P]),
     "sp_permute4_batched": (c_int, [_P, _P, c_int, c_int, _P]),
     "sp_pose_score": (c_int, [_P, c_int, c_int, _P, _P]),

@@ -150,25 +150,55 @@ __global__ void pair_sum_final_kernel(const double* __restrict__ part, int nblk,
     if (o1) o1[c] = (float)s1;
 }
 
-// BN forward statistics from the per-(phase, M tile, wave row) partial sums the STATS conv epilogue wrote (fp32 sums of <= 64 values
-// each): one wave per channel adds them in index order in fp64, then the same finalisation as above.
-__global__ void bn_stats_from_conv_kernel(const float* __restrict__ ps, const float* __restrict__ pq, int nrows, int stride, int C, double M,
+// Fold of the per-(phase, M tile, wave row) partial rows a STATS / BSTATS conv epilogue wrote ([nrows][stride] fp32, two arrays): a
+// workgroup of 1,024 threads takes 16 channels x 64 row lanes, so a wave reads four 64-byte row segments per load (one wave per channel
+// with the lanes over the rows touched 64 lines per load, 16x the bytes through L2: 12-14 us on layer1's 1,536 rows); thread (row lane
+// rl, channel) adds rows rl, rl + 64, ... in fp64 (two chains), the 64 row lanes of a channel are then added in index order through
+// LDS (8 x 8): every order is fixed by the shape -> deterministic.  Returns true on the one thread per channel that holds the sums.
+constexpr int FC_CH = 16, FC_RL = 64;
+__device__ __forceinline__ bool fold_conv_rows(const float* __restrict__ ps, const float* __restrict__ pq, int nrows, int stride, int C, int& c,
+                                               double& s0, double& s1) {
+    __shared__ double sh[2][FC_RL][FC_CH];
+    const int ch = threadIdx.x & (FC_CH - 1), rl = threadIdx.x >> 4;
+    c = blockIdx.x * FC_CH + ch;
+    double a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+    if (c < C) {
+        int r = rl;
+        for (; r + FC_RL < nrows; r += 2 * FC_RL) {
+            a0 += (double)ps[(size_t)r * stride + c]; a1 += (double)pq[(size_t)r * stride + c];
+            b0 += (double)ps[(size_t)(r + FC_RL) * stride + c]; b1 += (double)pq[(size_t)(r + FC_RL) * stride + c];
+        }
+        for (; r < nrows; r += FC_RL) { a0 += (double)ps[(size_t)r * stride + c]; a1 += (double)pq[(size_t)r * stride + c]; }
+    }
+    sh[0][rl][ch] = a0 + b0;
+    sh[1][rl][ch] = a1 + b1;
+    __syncthreads();
+    if (rl < 8) {
+        double t0 = 0, t1 = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { t0 += sh[0][rl * 8 + i][ch]; t1 += sh[1][rl * 8 + i][ch]; }
+        __syncthreads();            // (all 8 x 16 readers are done before the slots are overwritten)
+        sh[0][rl][ch] = t0;
+        sh[1][rl][ch] = t1;
+    } else {
+        __syncthreads();
+    }
+    __syncthreads();
+    if (rl != 0 || c >= C) return false;
+    s0 = 0; s1 = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s0 += sh[0][i][ch]; s1 += sh[1][i][ch]; }
+    return true;
+}
+
+// BN forward statistics from the partial sums of the STATS conv epilogue (fp32 sums of <= 64 values each), then the same finalisation
+// as bn_stats_final_kernel
+__global__ __launch_bounds__(1024) void bn_stats_from_conv_kernel(const float* __restrict__ ps, const float* __restrict__ pq, int nrows, int stride, int C, double M,
                                           float eps, float momentum, float* __restrict__ mean, float* __restrict__ invstd,
                                           float* __restrict__ run_mean, float* __restrict__ run_var) {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= C) return;
-    const int lane = threadIdx.x & 63;
-    double a0 = 0, a1 = 0, b0 = 0, b1 = 0;
-    int r = lane;
-    for (; r + 64 < nrows; r += 128) {
-        a0 += (double)ps[(size_t)r * stride + c]; a1 += (double)pq[(size_t)r * stride + c];
-        b0 += (double)ps[(size_t)(r + 64) * stride + c]; b1 += (double)pq[(size_t)(r + 64) * stride + c];
-    }
-    for (; r < nrows; r += 64) { a0 += (double)ps[(size_t)r * stride + c]; a1 += (double)pq[(size_t)r * stride + c]; }
-    double s0 = a0 + b0, s1 = a1 + b1;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off, SP_WAVE); s1 += __shfl_xor(s1, off, SP_WAVE); }
-    if (lane != 0) return;
+    int c;
+    double s0, s1;
+    if (!fold_conv_rows(ps, pq, nrows, stride, C, c, s0, s1)) return;
     const double mu = s0 / M;
     double var = s1 / M - mu * mu;
     if (var < 0) var = 0;
@@ -183,41 +213,23 @@ __global__ void bn_stats_from_conv_kernel(const float* __restrict__ ps, const fl
 
 // SyncBatchNorm on the fused statistics: the same fold, stopped before the finalisation - this rank's (sum, sum of squares) per channel
 // in fp64, the [c][2] layout sp_bn_train_finalize consumes after the cross-rank SUM
-__global__ void bn_sums_from_conv_kernel(const float* __restrict__ ps, const float* __restrict__ pq, int nrows, int stride, int C,
+__global__ __launch_bounds__(1024) void bn_sums_from_conv_kernel(const float* __restrict__ ps, const float* __restrict__ pq, int nrows, int stride, int C,
                                          double* __restrict__ sums) {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= C) return;
-    const int lane = threadIdx.x & 63;
-    double a0 = 0, a1 = 0, b0 = 0, b1 = 0;
-    int r = lane;
-    for (; r + 64 < nrows; r += 128) {
-        a0 += (double)ps[(size_t)r * stride + c]; a1 += (double)pq[(size_t)r * stride + c];
-        b0 += (double)ps[(size_t)(r + 64) * stride + c]; b1 += (double)pq[(size_t)(r + 64) * stride + c];
-    }
-    for (; r < nrows; r += 64) { a0 += (double)ps[(size_t)r * stride + c]; a1 += (double)pq[(size_t)r * stride + c]; }
-    double s0 = a0 + b0, s1 = a1 + b1;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off, SP_WAVE); s1 += __shfl_xor(s1, off, SP_WAVE); }
-    if (lane == 0) { sums[2 * c] = s0; sums[2 * c + 1] = s1; }
+    int c;
+    double s0, s1;
+    if (!fold_conv_rows(ps, pq, nrows, stride, C, c, s0, s1)) return;
+    sums[2 * c] = s0;
+    sums[2 * c + 1] = s1;
 }
 
 // dbeta = sum g, dgamma = sum g*xhat from the partial rows a BSTATS dgrad launch (or several: one per output phase) left
-__global__ void bn_bwd_sums_from_conv_kernel(const float* __restrict__ ps, const float* __restrict__ pq, int nrows, int stride, int C,
+__global__ __launch_bounds__(1024) void bn_bwd_sums_from_conv_kernel(const float* __restrict__ ps, const float* __restrict__ pq, int nrows, int stride, int C,
                                              float* __restrict__ dbeta, float* __restrict__ dgamma) {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= C) return;
-    const int lane = threadIdx.x & 63;
-    double a0 = 0, a1 = 0, b0 = 0, b1 = 0;
-    int r = lane;
-    for (; r + 64 < nrows; r += 128) {
-        a0 += (double)ps[(size_t)r * stride + c]; a1 += (double)pq[(size_t)r * stride + c];
-        b0 += (double)ps[(size_t)(r + 64) * stride + c]; b1 += (double)pq[(size_t)(r + 64) * stride + c];
-    }
-    for (; r < nrows; r += 64) { a0 += (double)ps[(size_t)r * stride + c]; a1 += (double)pq[(size_t)r * stride + c]; }
-    double s0 = a0 + b0, s1 = a1 + b1;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off, SP_WAVE); s1 += __shfl_xor(s1, off, SP_WAVE); }
-    if (lane == 0) { dbeta[c] = (float)s0; dgamma[c] = (float)s1; }
+    int c;
+    double s0, s1;
+    if (!fold_conv_rows(ps, pq, nrows, stride, C, c, s0, s1)) return;
+    dbeta[c] = (float)s0;
+    dgamma[c] = (float)s1;
 }
 
 // SyncBatchNorm halves: per-rank (sum, sum of squares) kept in fp64 so that the cross-rank SUM is order-insensitive to ~1e-16
@@ -523,7 +535,7 @@ extern "C" int sp_bn_train_stats_from_conv(const float* stats_sum, const float* 
     SP_REQUIRE(stats_sum && stats_sumsq && mean && invstd, "sp_bn_train_stats_from_conv: null pointer");
     SP_REQUIRE(partial_rows > 0 && stride >= c && c > 0 && rows > 0, "sp_bn_train_stats_from_conv: bad shape");
     SP_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "sp_bn_train_stats_from_conv: running stats come in pairs");
-    hipLaunchKernelGGL(bn_stats_from_conv_kernel, dim3((c + 3) / 4), dim3(256), 0, (hipStream_t)stream, stats_sum, stats_sumsq, partial_rows, stride,
+    hipLaunchKernelGGL(bn_stats_from_conv_kernel, dim3((c + FC_CH - 1) / FC_CH), dim3(FC_CH * FC_RL), 0, (hipStream_t)stream, stats_sum, stats_sumsq, partial_rows, stride,
                        c, (double)rows, eps, momentum, mean, invstd, running_mean, running_var);
     return sp_check_launch("bn_stats_from_conv_kernel");
 }
@@ -531,7 +543,7 @@ extern "C" int sp_bn_train_stats_from_conv(const float* stats_sum, const float* 
 extern "C" int sp_bn_sums_from_conv(const float* stats_sum, const float* stats_sumsq, int partial_rows, int stride, int c, double* sums,
                                     void* stream) {
     SP_REQUIRE(stats_sum && stats_sumsq && sums && partial_rows > 0 && stride >= c && c > 0, "sp_bn_sums_from_conv: bad argument");
-    hipLaunchKernelGGL(bn_sums_from_conv_kernel, dim3((c + 3) / 4), dim3(256), 0, (hipStream_t)stream, stats_sum, stats_sumsq, partial_rows, stride,
+    hipLaunchKernelGGL(bn_sums_from_conv_kernel, dim3((c + FC_CH - 1) / FC_CH), dim3(FC_CH * FC_RL), 0, (hipStream_t)stream, stats_sum, stats_sumsq, partial_rows, stride,
                        c, sums);
     return sp_check_launch("bn_sums_from_conv_kernel");
 }
@@ -539,7 +551,7 @@ extern "C" int sp_bn_sums_from_conv(const float* stats_sum, const float* stats_s
 extern "C" int sp_bn_bwd_sums_from_conv(const float* sum_g, const float* sum_g_xhat, int partial_rows, int stride, int c, float* dgamma,
                                         float* dbeta, void* stream) {
     SP_REQUIRE(sum_g && sum_g_xhat && dgamma && dbeta && partial_rows > 0 && stride >= c && c > 0, "sp_bn_bwd_sums_from_conv: bad argument");
-    hipLaunchKernelGGL(bn_bwd_sums_from_conv_kernel, dim3((c + 3) / 4), dim3(256), 0, (hipStream_t)stream, sum_g, sum_g_xhat, partial_rows, stride,
+    hipLaunchKernelGGL(bn_bwd_sums_from_conv_kernel, dim3((c + FC_CH - 1) / FC_CH), dim3(FC_CH * FC_RL), 0, (hipStream_t)stream, sum_g, sum_g_xhat, partial_rows, stride,
                        c, dbeta, dgamma);
     return sp_check_launch("bn_bwd_sums_from_conv_kernel");
 }
@@ -674,6 +686,18 @@ extern "C" int sp_adam_step(float* param, const float* grad, float* exp_avg, flo
                        reinterpret_cast<const f32x4*>(grad), reinterpret_cast<f32x4*>(exp_avg), reinterpret_cast<f32x4*>(exp_avg_sq), n / 4,
                        (float)(lr / bc1), (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)sqrt(bc2), grad_scale);
     return sp_check_launch("adam_kernel");
+}
+
+// Measurement aid (bench.py --sync-bn-latency-us): keep `stream` busy for `us` microseconds of the 100 MHz constant clock - a stand-in
+// for the latency of a small cross-GPU message on a box with one GPU.  One wave, no memory traffic.
+__global__ void stream_delay_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+extern "C" int sp_stream_delay_us(double us, void* stream) {
+    SP_REQUIRE(us >= 0 && us <= 1e6, "sp_stream_delay_us: 0 .. 1e6 us");
+    hipLaunchKernelGGL(stream_delay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)(us * 100.0));
+    return sp_check_launch("stream_delay_kernel");
 }
 
 extern "C" int sp_permute4_f32(const float* src, void* dst, int dst_bf16, const int32_t* dst_dims, const int64_t* src_strides, const int32_t* valid,

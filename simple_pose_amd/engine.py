@@ -531,6 +531,9 @@ class GraphedForward:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.outputs = self._body()
+        # the graph's nodes hold raw device pointers into this batch shape's activation pool: keep the pool alive from here, whatever
+        # Program._alloc evicts later (MAX_POOLS); a replay after an eviction would otherwise read and write freed memory
+        self._pool = prog._pools[(x.shape[0], str(x.device))]
 
     def _body(self):
         # one stream inside the capture: hipStreamEndCapture of ROCm 7.2 crashed on the forked multi-stream HRNet schedule

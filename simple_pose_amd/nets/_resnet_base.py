@@ -46,8 +46,10 @@ class PoseResNetBase(nn.Module):
     HEAD = ""
     BLOCKS = (3, 4, 6, 3)
 
-    def __init__(self, num_classes: int = 17, reduction: bool = False):
+    def __init__(self, num_classes: int = 17, reduction: bool = False, blocks=None):
         super().__init__()
+        if blocks is not None:           # resnet101 / resnet152: same bottleneck trunk, other depths (pose_resnet_dconv.py:318-339)
+            self.BLOCKS = tuple(blocks)
         self.reduction = reduction     # SELayer on the first block of every layer (pose_resnet_dconv.py:215-218)
         self.num_classes = num_classes
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)

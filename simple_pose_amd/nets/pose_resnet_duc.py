@@ -10,7 +10,7 @@ from torch import nn
 from ._resnet_base import PoseResNetBase, load_pretrained_like_reference
 from .commons import DUC
 
-__all__ = ["ResNet", "resnet50"]
+__all__ = ["ResNet", "resnet50", "resnet101", "resnet152"]
 
 
 class ResNet(PoseResNetBase):
@@ -21,10 +21,25 @@ class ResNet(PoseResNetBase):
         self.final_layer = nn.Conv2d(128, num_classes, kernel_size=3, padding=1)
 
 
-def resnet50(pretrained: bool = False, progress: bool = True, **kwargs) -> ResNet:
-    model = ResNet(num_classes=kwargs.pop("num_classes", 1000), reduction=kwargs.pop("reduction", False))
+def _resnet(arch: str, blocks, pretrained: bool, kwargs) -> ResNet:
+    model = ResNet(num_classes=kwargs.pop("num_classes", 1000), reduction=kwargs.pop("reduction", False), blocks=blocks)
     if kwargs:
-        raise TypeError(f"unsupported arguments for the HIP ResNet-50: {sorted(kwargs)}")
+        raise TypeError(f"unsupported arguments for the HIP {arch}: {sorted(kwargs)}")
     if pretrained:
-        load_pretrained_like_reference(model, "resnet50")
+        load_pretrained_like_reference(model, arch)
     return model
+
+
+def resnet50(pretrained: bool = False, progress: bool = True, **kwargs) -> ResNet:
+    """Same call shape as the reference factory: resnet50(pretrained=..., num_classes=J, reduction=bool)."""
+    return _resnet("resnet50", (3, 4, 6, 3), pretrained, kwargs)
+
+
+def resnet101(pretrained: bool = False, progress: bool = True, **kwargs) -> ResNet:
+    """Bottleneck depths [3, 4, 23, 3] (reference factory of the same name, pose_resnet_duc.py)."""
+    return _resnet("resnet101", (3, 4, 23, 3), pretrained, kwargs)
+
+
+def resnet152(pretrained: bool = False, progress: bool = True, **kwargs) -> ResNet:
+    """Bottleneck depths [3, 8, 36, 3] (reference factory of the same name, pose_resnet_duc.py)."""
+    return _resnet("resnet152", (3, 8, 36, 3), pretrained, kwargs)

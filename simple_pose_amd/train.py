@@ -353,7 +353,7 @@ class PoseTrainer:
 
     def __init__(self, model, in_h: int = 256, in_w: int = 192, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  process_group=None, dtype: str = "fp32", sync_bn: Optional[bool] = None, bucket_mb: float = 32.0,
-                 broadcast_init: bool = True, overlap_wgrad: bool = True, collectives: bool = True):
+                 broadcast_init: bool = True, overlap_wgrad: bool = True, collectives: bool = True, sync_bn_latency_us: float = 0.0):
         """dtype "bf16": bf16 activations and packed weights (v_mfma_f32_32x32x16_bf16 for forward, dgrad and wgrad); the
         gradient w.r.t. a block output stays fp32 until the BatchNorm backward has subtracted its per-channel mean (rounding
         it to bf16 first costs 10-50 % gradient error in this net: the useful part is a small difference of large terms), the
@@ -386,6 +386,12 @@ class PoseTrainer:
         # caller - e.g. torch's DistributedDataParallel wrapper, as in ddp...:91-93 - owns the gradient exchange)
         self.world = dist.get_world_size(self.pg) if (collectives and dist.is_available() and dist.is_initialized()) else 1
         self.sync_bn = (self.world > 1) if sync_bn is None else (bool(sync_bn) and self.world > 1)
+        # measurement aid (bench.py --sync-bn-latency-us): every SyncBatchNorm message additionally costs this many microseconds on a
+        # side stream the consumer waits for; on ONE rank it switches the SyncBatchNorm code path on with nothing to exchange, which
+        # bounds what the 104 messages per step would expose on xGMI without an 8-GPU node
+        self.sync_bn_latency_us = float(sync_bn_latency_us)
+        if self.sync_bn_latency_us > 0 and (sync_bn is None or sync_bn):
+            self.sync_bn = True
         self.flat = FlatParams(model, attach_grads=collectives)
         dev = self.flat.data.device
         self.exp_avg = torch.zeros_like(self.flat.data)
@@ -473,6 +479,34 @@ class PoseTrainer:
             ev[1].record(opt)
             self._works[i] = ev[1]
 
+    # ---- SyncBatchNorm messages: issued where the sums exist, waited for where the statistics are consumed -----------------------
+    def _exchange(self, t: torch.Tensor):
+        """SUM `t` over the ranks, asynchronously (RCCL runs the all-reduce on its own stream behind the compute stream's current
+        position); returns the token `_exchange_wait` takes.  Whatever is launched between the two calls runs under the message."""
+        self.collective_count += 1
+        work = ev = None
+        if self.world > 1:
+            import torch.distributed as dist
+            work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        if self.sync_bn_latency_us > 0:
+            dev = t.device
+            if getattr(self, "_comm_stream", None) is None:
+                self._comm_stream = torch.cuda.Stream(device=dev)
+            comm, main = self._comm_stream, torch.cuda.current_stream(dev)
+            e0, ev = torch.cuda.Event(), torch.cuda.Event()
+            e0.record(main)
+            comm.wait_event(e0)
+            _lib.check(_lib.lib().sp_stream_delay_us(self.sync_bn_latency_us, _lib.c_void_p(comm.cuda_stream)), "delay")
+            ev.record(comm)
+        return work, ev
+
+    def _exchange_wait(self, token) -> None:
+        work, ev = token
+        if work is not None:
+            work.wait()                       # RCCL: the compute stream waits for the collective's stream; gloo: the host does
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
     def _wgrad_flush(self) -> None:
         """Launch the queued weight gradients as one group (on the wgrad stream when `overlap_wgrad`)."""
         q = getattr(self, "_wg_queue", None)
@@ -521,6 +555,10 @@ class PoseTrainer:
             self._wgrad_tail = ev[1]
         self._wg_queue = []
         self._wg_queued_flops = 0.0
+
+    def _wgrad_flush_if(self, fraction: float) -> None:
+        if getattr(self, "_wg_queued_flops", 0.0) >= fraction * self.wgrad_group_gflop * 1e9:
+            self._wgrad_flush()
 
     wgrad_group_gflop = 60.0   # queued weight-gradient work (all images of the rank) that triggers a group launch
 
@@ -756,8 +794,6 @@ class PoseTrainer:
         self._works: List[Optional[object]] = [None] * len(self.buckets)
         self.collective_count = 0          # SyncBatchNorm all-reduces of this step (gradient buckets are counted in len(self.buckets))
         sync = self.sync_bn
-        if sync:
-            import torch.distributed as dist
         W = self.world
 
         def new(shape, dtype=None):
@@ -804,8 +840,7 @@ class PoseTrainer:
                     _lib.check(lib.sp_bn_sums_from_conv(P(part[0]), P(part[1]), pd["prow"], part.shape[2], pd["C"], P(pd["sums"]), stream), bn)
                 else:
                     _lib.check(lib.sp_bn_train_partial_nhwc(P(pd["z"]), bf, pd["rows"], pd["C"], P(pd["sums"]), P(ws), stream), bn)
-            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.pg)
-            self.collective_count += 1
+            self._exchange_wait(self._exchange(sums))
             for pd, bn in zip(pends, bnames):
                 rm, rv = run(bn)
                 _lib.check(lib.sp_bn_train_finalize(P(pd["sums"]), pd["rows"] * W, pd["C"], BN_EPS, BN_MOMENTUM, P(pd["mean"]), P(pd["invstd"]),
@@ -872,8 +907,9 @@ class PoseTrainer:
                                                                        stream), sname + ".bwd")
                             parts += [dgs, dbs]
                         both = torch.cat(parts)
-                        dist.all_reduce(both, op=dist.ReduceOp.SUM, group=self.pg)
-                        self.collective_count += 1
+                        token = self._exchange(both)
+                        self._wgrad_flush_if(0.5)            # queued weight gradients go out under the message rather than after it
+                        self._exchange_wait(token)
                         if sib is not None:
                             res.presums = (both[2 * C:3 * C], both[3 * C:])
                         sg, sb, tot = both[:C], both[C:2 * C], rows * W

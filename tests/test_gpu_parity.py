@@ -418,6 +418,27 @@ def test_resnets_at_other_resolutions_vs_oracle(measured, head, H, W, dtype):
     assert rel <= bar, rel
 
 
+@pytest.mark.parametrize("factory,head", [("resnet101", "dconv"), ("resnet152", "duc")])
+def test_deeper_resnet_factories_vs_oracle(measured, factory, head):
+    """resnet101 / resnet152 (nets/pose_resnet_dconv.py:318-339 and the DUC twin): same bottleneck trunk at depths [3,4,23,3] / [3,8,36,3];
+    eval forward against the torch-CPU forward oracle on the model's own state_dict layout."""
+    from simple_pose_amd.nets import pose_resnet_duc
+    mod = pose_resnet_dconv if head == "dconv" else pose_resnet_duc
+    m = getattr(mod, factory)(pretrained=False, num_classes=17)
+    layout = [(k, tuple(v.shape), str(v.dtype)) for k, v in m.state_dict().items()]
+    sd = synth.conditioned_state_dict(layout, seed=3)
+    assert nets_oracle.blocks_of(sd) == {"resnet101": (3, 4, 23, 3), "resnet152": (3, 8, 36, 3)}[factory]
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m = m.to(DEV).eval()
+    x = synth.input_images(2, 9, h=128, w=96)
+    with torch.no_grad():
+        got = m(torch.from_numpy(x).to(DEV)).cpu().numpy()
+        ref = nets_oracle.FORWARDS["resnet50_" + head]({k: torch.from_numpy(v) for k, v in sd.items()}, torch.from_numpy(x)).numpy()
+    err = np.abs(got - ref).max() / np.sqrt((ref * ref).mean())
+    measured("heat_rel_err", err, 2e-5)
+    assert got.shape == (2, 17, 32, 24) and err < 2e-5
+
+
 def test_full_batch_128_is_consistent_with_golden(golden):
     """BASELINE configs[1] size (bs=128): images repeat the two golden inputs, so every output must equal the
     golden pair's - bitwise among replicas (deterministic kernels), 1e-4 rel against the reference."""

@@ -236,6 +236,31 @@ def test_bench_self_launch_fails_loudly_without_a_gpu():
     assert r.stderr.count("no CPU path") == 2          # both ranks started, both refused
 
 
+def test_bench_dry_launch_eight_ranks_over_gloo():
+    """`python bench.py --gpus 8 --dry-launch`: the launcher starts 8 fresh interpreters with the env:// contract of a real run; they
+    rendezvous over gloo, agree on the rank table, run the measurement's SUM / MAX reductions on known numbers and the sampler rule,
+    rank 0 prints ONE JSON line.  A rank that dies after the rendezvous ends the job with its exit code instead of a hang."""
+    import json
+    import subprocess
+    import sys
+
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "SP_BENCH_DRY_FAIL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-launch", "--batch", "32", "--steps", "3"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["dry_launch"] and d["n_ranks"] == 8 and d["ranks_seen"] == list(range(8)) and d["reductions_ok"]
+    assert d["config"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"                 # the explicit default, recorded
+    n_dev = torch.cuda.device_count()
+    assert d["one_device_per_rank"] == (n_dev >= 8)
+    r = subprocess.run(cmd + ["--hsa-ipc-legacy", "1"], env=dict(env, SP_BENCH_DRY_FAIL_RANK="5"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 3 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
 def test_conv_kernel_name_query_matches_dispatch():
     """sp_conv2d_kernel_name (used by bench.py's roofline object and the profile summaries) names what the dispatch launches."""
     d = _lib.ConvDesc()
