@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL over xGMI, default); gloo only to exercise the N > 1 code path on a single-GPU box")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="compute dtype of the network (BASELINE metric: f32)")
-    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
+    ap.add_argument("--mode", default="infer", choices=["infer", "train", "micro"],
                     help="infer = forward + GaussTaylor decode (BASELINE metric, default); train = fwd+bwd+Adam step (config 4, fp32)")
     ap.add_argument("--no-sync-bn", action="store_true", help="train mode, N > 1: per-rank BN statistics (the reference's DDP solver syncs them)")
     ap.add_argument("--sync-bn-latency-us", type=float, default=0.0,
@@ -244,6 +244,10 @@ def main():
     ipc_mode = apply_ipc_mode(args, os.environ)         # before the first HIP call (default 0: dmabuf IPC, the only mode this pool's driver has)
     if args.dry_launch:
         raise SystemExit(dry_rank(args))
+    if args.mode == "micro":                           # the HBM-bound kernels of the path one by one (tools/bench_micro.py)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_micro
+        raise SystemExit(bench_micro.main([]))
     import torch
     import torch.distributed as dist
 
@@ -304,8 +308,22 @@ def main():
         model.train()
         trainer = PoseTrainer(model, lr=1e-3, dtype="bf16" if args.dtype == "bf16" else "fp32", sync_bn=not args.no_sync_bn,
                               bucket_mb=args.bucket_mb, sync_bn_latency_us=args.sync_bn_latency_us)
+        # untimed setup: the tile of every forward / dgrad launch.  Default: the tracked table of this dtype under profiles/ (the one the
+        # committed rocprofv3 summaries were taken with: no tuner launches in a profiled run, same launches on every rank and box);
+        # --retune / a missing table: timed on rank 0 at this batch and shared
+        tiles_src = "built-in heuristic"
+        tpath = args.tiles or (None if args.retune else tracked_tiles("train", args.dtype))
         if not args.no_train_autotune:
-            trainer.autotune(B)                        # untimed setup: fastest tile per forward / dgrad launch at this batch
+            if tpath and os.path.isfile(tpath) and B == 32:
+                with open(tpath) as fh:
+                    trainer.set_tiles(json.load(fh), B)
+                tiles_src = os.path.relpath(tpath, ROOT)
+            else:
+                table = trainer.autotune_shared(B)
+                tiles_src = "autotuned on rank 0 (untimed setup)"
+                if args.tiles and rank == 0:
+                    with open(args.tiles, "w") as fh:
+                        json.dump(table, fh)
         joints = torch.from_numpy(synth.joints_batch(B, 17, seed=200 + rank)).to(dev)
         targets, mask = RefineSimpleTransform.get_heat_map(joints, 2.0, (48, 64))   # HIP encoder, on device
         prog = None
@@ -404,7 +422,7 @@ def main():
                 "config": {"workload": f"{name} 256x192 train step, bs={B} per GPU, {'fp32' if args.dtype == 'f32' else 'bf16 compute + fp32 master weights/Adam'}, train-mode BN (batch statistics), Adam lr 1e-3, "
                                        "targets from the HIP encoder; N > 1: SyncBatchNorm " + ("off" if args.no_sync_bn else "on") +
                                        f", gradients all-reduced in {args.bucket_mb:g} MB buckets overlapped with backward (RCCL)",
-                           "images_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}", "HSA_ENABLE_IPC_MODE_LEGACY": ipc_mode,
+                           "images_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}", "HSA_ENABLE_IPC_MODE_LEGACY": ipc_mode, "tile_table": tiles_src,
                            "collectives": ("RCCL (nccl backend)" if args.dist_backend == "nccl" else "gloo") if world > 1 else "none"},
                 "gflop_per_image": round(gflop, 3), "network_tflops": round(value * gflop / 1e3, 2),
                 "network_frac_of_matrix_peak": round(value * gflop / 1e3 / ((FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else BF16_MATRIX_PEAK_TFLOPS) * world), 4),
@@ -459,8 +477,13 @@ def train_roofline(trainer, step, B: int, peak: float, steps: int = 3):
     dom = max(groups, key=lambda k: groups[k][0])
     ms, fl, n = groups[dom]
     ach = fl / (ms * 1e-3) / 1e12
+    traffic = None
+    if dom == "wgrad":                                  # a group launch = the unit kernel + its fold: PMC bytes of both (profiles/rNN_train_*_traffic.json)
+        dt = "bf16" if trainer.bf16 else "f32"
+        parts = [lookup_traffic(k, "train", dt) for k in (f"conv_wgrad_group_kernel<{'true' if trainer.bf16 else 'false'}>", "wgrad_fold_kernel")]
+        traffic = None if any(p is None for p in parts) else int(sum(parts))
     return {"bound": "mfma", "kernel": names[dom], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-            "traffic": None, "launches_per_step": n // steps, "avg_launch_us": round(1e3 * ms / n, 2),
+            "traffic": traffic, "launches_per_step": n // steps, "avg_launch_us": round(1e3 * ms / n, 2),
             "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3),
             "by_group": {names[k]: {"launches_per_step": g[2] // steps, "ms_per_step": round(g[0] / steps, 3), "tflops": round(g[1] / (g[0] * 1e-3) / 1e12, 1)}
                          for k, g in sorted(groups.items(), key=lambda kv: -kv[1][0])},

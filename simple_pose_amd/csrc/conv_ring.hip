@@ -79,7 +79,8 @@ __device__ __forceinline__ u32x4 make_rsrc(const void* base, int bytes) {
 // to LDS at lds_addr + 16 * l (wave-uniform base in M0).  Inline asm on purpose: hipcc treats the builtin form as an LDS store it
 // must wait for (`s_waitcnt vmcnt(0)` in front of every later LDS access), which would drain the ring at every K tile; issued
 // from asm the transfers are invisible to its bookkeeping and ordered by this file's own counted `s_waitcnt vmcnt(N)` + s_barrier.
-// M0 is written in the statement that uses it (the compiler keeps nothing live in M0 on gfx950); `s_nop 4` covers the
+// M0 is written in the statement that uses it (hipcc keeps nothing live in M0 across statements on gfx950, and it does not accept
+// "m0" in a clobber list - "inline asm clobber list contains reserved registers" - so the dependence cannot be declared); `s_nop 4` covers the
 // M0-write -> LDS-DMA and the VALU-written-SGPR -> VMEM wait states, which nothing pads inside an asm statement.
 __device__ __forceinline__ void dma16(unsigned lds_addr, unsigned voff, u32x4 rsrc, unsigned soff) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(voff),
@@ -517,6 +518,13 @@ extern "C" int sp_conv2d_ring_ok(const sp_conv_desc* d) {
     if (d->c_in <= 0 || d->c_in % 64 || d->taps_h * d->taps_w > 32) return 0;           // a K tile lies inside one tap
     if (d->k_pad != d->taps_h * d->taps_w * d->c_in || d->k_pad / 64 < t->ns) return 0; // the ring must fit inside one output tile's K
     if (d->c_out % 8 || d->n_pad % t->bn) return 0;
+    // the epilogue hands each lane 8 consecutive packed columns as ONE 16-byte store: with the fused PixelShuffle a lane's chunk must
+    // stay inside one sub-pixel (out_c = c_out / 4 a multiple of 8, no padded rows), without it the columns are the output channels
+    if (d->flags & SP_CONV_PIXEL_SHUFFLE) {
+        if (d->out_c % 8 || d->out_c * 4 != d->c_out || d->n_pad != d->c_out) return 0;
+    } else if (d->out_c != d->c_out) {
+        return 0;
+    }
     return 1;
 }
 

@@ -121,6 +121,14 @@ class PoseResNetBase(nn.Module):
         if self.reduction:
             raise NotImplementedError("training with SELayer (reduction=True) is not lowered; eval-mode forward is")
         from ..train import PoseTrainer
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and not getattr(self, "_warned_local_bn", False):
+            # the reference converts to SyncBatchNorm under DDP (ddp...:89-90); this surface computes LOCAL gradients and leaves the
+            # exchange to the caller's DistributedDataParallel wrapper, so its BatchNorm statistics are per rank
+            import warnings
+            warnings.warn("simple_pose_amd: model(x) in train() mode under an initialised process group uses per-rank BatchNorm statistics "
+                          "(sync_bn: False behaviour); PoseTrainer(model, process_group=..., sync_bn=True).step() is the SyncBatchNorm path")
+            self._warned_local_bn = True
         key = (x.shape[2], x.shape[3], str(x.device), self.compute_dtype)
         tr = getattr(self, "_trainer", None)
         if tr is None or self._trainer_key != key or not tr.still_owns_parameters():

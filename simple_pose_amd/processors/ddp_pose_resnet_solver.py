@@ -120,7 +120,9 @@ class DDPProcessor(object):
             targets = heat_maps.to(self.device, non_blocking=True)
             mask = masks.to(self.device, non_blocking=True)
             if self.trainer.tuned_for_batch == 0 and x.shape[0] >= 8:
-                self.trainer.autotune(x.shape[0])             # once: fastest conv tile per layer at this per-GPU batch (results unchanged)
+                # once: fastest conv tile per layer at this per-GPU batch, timed on rank 0 and shared (the BatchNorm partial sums are
+                # grouped per tile, so a per-rank choice would let the ranks' statistics differ by rounding)
+                self.trainer.autotune_shared(x.shape[0])
             loss = self.trainer.step(x, targets, mask)        # zero_grad / forward / loss / backward / all-reduce / Adam
             acc = self.acc_func(self.trainer.last_heat, targets, mask)
             self.loss_logger.update(loss[0]); self.acc_logger.update(acc)

@@ -237,6 +237,13 @@ class ConvT:
                     self.w_dgrad.append(wd); self.d_dgrad.append(g)
 
     # ---- launches ----
+    def _new(self, shape, dtype, device, zero: bool = False) -> torch.Tensor:
+        """A result / scratch tensor: from the trainer's step arena when it has one (PoseTrainer._take), else a fresh allocation."""
+        take = getattr(self.tr, "_take", None)
+        if take is not None:
+            return take(tuple(shape), dtype, device, zero)
+        return (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=device)
+
     def _timed(self, kind: str, stream=None):
         """bench.py's per-kernel roofline: when the trainer collects kernel events, bracket this launch family with HIP events on the
         stream it is issued to.  Returns the closing callback (a no-op otherwise)."""
@@ -253,7 +260,7 @@ class ConvT:
         lib, d = _lib.lib(), self.d_fwd
         d.batch = B
         if out is None:
-            out = torch.empty((B, d.out_h, d.out_w, d.out_c), dtype=self._wdt, device=x.device)
+            out = self._new((B, d.out_h, d.out_w, d.out_c), self._wdt, x.device)
         done = self._timed("forward")
         _lib.check(lib.sp_conv2d_fwd(d, P(x), P(self.w_fwd), None, P(shift), None, P(out), _lib.current_stream()), self.name)
         done()
@@ -266,8 +273,8 @@ class ConvT:
         d.batch = B
         rows = ctypes.c_int(0)
         _lib.check(lib.sp_conv2d_bn_stats_rows(d, ctypes.byref(rows)), self.name)
-        part = torch.empty((2, rows.value, d.n_pad), dtype=torch.float32, device=x.device)
-        out = torch.empty((B, d.out_h, d.out_w, d.out_c), dtype=self._wdt, device=x.device)
+        part = self._new((2, rows.value, d.n_pad), torch.float32, x.device)
+        out = self._new((B, d.out_h, d.out_w, d.out_c), self._wdt, x.device)
         done = self._timed("forward")
         _lib.check(lib.sp_conv2d_fwd_bn_stats(d, P(x), P(self.w_fwd), P(out), P(part[0]), P(part[1]), rows.value, _lib.current_stream()),
                    self.name)
@@ -287,8 +294,7 @@ class ConvT:
                 assert self.dgrad_full_cover
                 dx = acc
             else:
-                dx = torch.zeros((B, d0.out_h, d0.out_w, d0.out_c), dtype=torch.float32, device=dz.device) if not self.dgrad_full_cover else \
-                    torch.empty((B, d0.out_h, d0.out_w, d0.out_c), dtype=torch.float32, device=dz.device)
+                dx = self._new((B, d0.out_h, d0.out_w, d0.out_c), torch.float32, dz.device, zero=not self.dgrad_full_cover)
             need = []
             for d in self.d_dgrad:
                 d.batch = B
@@ -296,7 +302,7 @@ class ConvT:
                 _lib.check(lib.sp_conv2d_bn_stats_rows(d, ctypes.byref(r)), self.name + ".dgrad")
                 need.append(r.value)
             total, stride = sum(need), self.d_dgrad[0].n_pad
-            part = torch.empty((2, total, stride), dtype=torch.float32, device=dz.device)
+            part = self._new((2, total, stride), torch.float32, dz.device)
             z, mean, invstd = bn_src.bn
             row0 = 0
             done = self._timed("dgrad")
@@ -311,8 +317,7 @@ class ConvT:
         if acc is None:
             d0 = self.d_dgrad[0]
             shape = (B, d0.out_h, d0.out_w, d0.out_c)
-            acc_t = torch.empty(shape, dtype=torch.float32, device=dz.device) if self.dgrad_full_cover else \
-                torch.zeros(shape, dtype=torch.float32, device=dz.device)
+            acc_t = self._new(shape, torch.float32, dz.device, zero=not self.dgrad_full_cover)
             res = None
         else:
             acc_t, res = acc, acc
@@ -479,6 +484,30 @@ class PoseTrainer:
             ev[1].record(opt)
             self._works[i] = ev[1]
 
+    # ---- step arena ---------------------------------------------------------------------------------------------------------------
+    # PoseTrainer.step / forward_backward request the same tensors in the same order every step (~300 activations, gradients and
+    # partial-sum buffers): the arena hands out last step's tensor for the i-th request instead of going through the caching allocator
+    # (3-4 us of host time each; the host needs ~5 ms to enqueue a 6.7 ms step).  Nothing of one step is read after the next one
+    # starts: the step ends with the main stream joined to the weight-gradient and optimizer streams.  The autograd surface
+    # (forward_tape / backward called by torch) allocates normally: there the caller decides how long a forward's tensors live.
+    _arena_on = False
+
+    def _take(self, shape, dtype, device, zero: bool = False) -> torch.Tensor:
+        if not self._arena_on:
+            return (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=device)
+        a, i = self._arena, self._arena_i
+        self._arena_i = i + 1
+        if i < len(a):
+            t = a[i]
+            if tuple(t.shape) == tuple(shape) and t.dtype == dtype and t.device == device:
+                if zero:
+                    t.zero_()
+                return t
+            del a[i:]                      # the request sequence changed (another batch size): rebuild from here on
+        t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=device)
+        a.append(t)
+        return t
+
     # ---- SyncBatchNorm messages: issued where the sums exist, waited for where the statistics are consumed -----------------------
     def _exchange(self, t: torch.Tensor):
         """SUM `t` over the ranks, asynchronously (RCCL runs the all-reduce on its own stream behind the compute stream's current
@@ -493,7 +522,11 @@ class PoseTrainer:
             if getattr(self, "_comm_stream", None) is None:
                 self._comm_stream = torch.cuda.Stream(device=dev)
             comm, main = self._comm_stream, torch.cuda.current_stream(dev)
-            e0, ev = torch.cuda.Event(), torch.cuda.Event()
+            pool = self.__dict__.setdefault("_ex_events", {})
+            pair = pool.get(self.collective_count)          # one event pair per message of the step, made once
+            if pair is None:
+                pair = pool[self.collective_count] = (torch.cuda.Event(), torch.cuda.Event())
+            e0, ev = pair
             e0.record(main)
             comm.wait_event(e0)
             _lib.check(_lib.lib().sp_stream_delay_us(self.sync_bn_latency_us, _lib.c_void_p(comm.cuda_stream)), "delay")
@@ -694,6 +727,44 @@ class PoseTrainer:
 
     tuned_for_batch = 0
 
+    def get_tiles(self) -> Dict[str, list]:
+        """The pinned tile of every forward / dgrad launch ("<layer>" / "<layer>.dgrad<i>" -> [tile_m, tile_n]; [0, 0] = built-in choice)."""
+        out = {}
+        for name, layer in self.layers.items():
+            out[name] = [layer.d_fwd.tile_m, layer.d_fwd.tile_n]
+            if layer.need_dgrad:
+                for i, d in enumerate(layer.d_dgrad):
+                    out[f"{name}.dgrad{i}"] = [d.tile_m, d.tile_n]
+        return out
+
+    def set_tiles(self, table: Dict[str, list], batch: int) -> None:
+        """Pin a tile table (`get_tiles` / `autotune` of another run or rank).  The BatchNorm partial sums are grouped per tile row block,
+        so ranks (and runs) that must agree to the last bit share ONE table: `autotune_shared` tunes on rank 0 and broadcasts it."""
+        for name, layer in self.layers.items():
+            if name in table:
+                layer.d_fwd.tile_m, layer.d_fwd.tile_n = (int(v) for v in table[name])
+            if layer.need_dgrad:
+                for i, d in enumerate(layer.d_dgrad):
+                    if f"{name}.dgrad{i}" in table:
+                        d.tile_m, d.tile_n = (int(v) for v in table[f"{name}.dgrad{i}"])
+        self.tuned_for_batch = batch
+
+    def autotune_shared(self, batch: int) -> Dict[str, list]:
+        """`autotune` on rank 0, the table broadcast to every rank: tile choice is a timing outcome, and per-rank choices would make the
+        BatchNorm statistics (hence the whole step) differ between ranks and between runs by rounding."""
+        import torch.distributed as dist
+        if self.world == 1:
+            self.autotune(batch)
+            return self.get_tiles()
+        src = dist.get_global_rank(self.pg, 0) if self.pg is not None else 0
+        box = [None]
+        if dist.get_rank() == src:
+            self.autotune(batch)
+            box[0] = self.get_tiles()
+        dist.broadcast_object_list(box, src=src, group=self.pg)
+        self.set_tiles(box[0], batch)
+        return box[0]
+
     # ---- keeping the packed copies in step with the parameters -------------------------------------------------------------
     def _param_version(self) -> int:
         return sum(p._version for p in self.sd.values())
@@ -738,13 +809,19 @@ class PoseTrainer:
         lib, stream = _lib.lib(), _lib.current_stream()
         targets = _lib.require_cuda_f32(targets, "targets")
         mask = _lib.require_cuda_f32(mask, "mask")
-        heat, backward = self.forward_tape(x)
-        B, J, hh, ww = heat.shape
-        # ---- loss + d loss / d heat ----
-        dheat = torch.empty_like(heat)
-        _lib.check(lib.sp_masked_mse(P(heat), P(targets), P(mask), B, J, hh * ww, P(self.loss_buf), P(dheat), P(self.mse_ws), stream), "mse")
-        self._mark("forward_loss")
-        backward(dheat)
+        if getattr(self, "_arena", None) is None:
+            self._arena = []
+        self._arena_on, self._arena_i = self.use_arena, 0
+        try:
+            heat, backward = self.forward_tape(x)
+            B, J, hh, ww = heat.shape
+            # ---- loss + d loss / d heat ----
+            dheat = self._take(tuple(heat.shape), torch.float32, heat.device)
+            _lib.check(lib.sp_masked_mse(P(heat), P(targets), P(mask), B, J, hh * ww, P(self.loss_buf), P(dheat), P(self.mse_ws), stream), "mse")
+            self._mark("forward_loss")
+            backward(dheat)
+        finally:
+            self._arena_on = False
         return self.loss_buf
 
     def forward_tape(self, x: torch.Tensor):
@@ -797,10 +874,10 @@ class PoseTrainer:
         W = self.world
 
         def new(shape, dtype=None):
-            return torch.empty(shape, dtype=dtype or self.act_dtype, device=dev)
+            return self._take((shape,) if isinstance(shape, int) else tuple(shape), dtype or self.act_dtype, dev)
 
         def newf(shape):
-            return torch.empty(shape, dtype=torch.float32, device=dev)
+            return self._take((shape,) if isinstance(shape, int) else tuple(shape), torch.float32, dev)
 
         def conv_stats(xa: Act, cname: str) -> dict:
             """The conv launch of a conv + BatchNorm pair; with `fuse_bn_stats` its epilogue also leaves the per-channel partial sums."""
@@ -830,7 +907,7 @@ class PoseTrainer:
                         _lib.check(lib.sp_bn_train_stats_nhwc(P(pd["z"]), bf, pd["rows"], pd["C"], BN_EPS, BN_MOMENTUM, P(pd["mean"]),
                                                               P(pd["invstd"]), rm, rv, P(ws), stream), bn)
                 return
-            sums = torch.empty(2 * sum(pd["C"] for pd in pends), dtype=torch.float64, device=dev)
+            sums = self._take((2 * sum(pd["C"] for pd in pends),), torch.float64, dev)
             off = 0
             for pd, bn in zip(pends, bnames):
                 pd["sums"] = sums[off:off + 2 * pd["C"]]
@@ -939,7 +1016,7 @@ class PoseTrainer:
         _lib.check((lib.sp_nchw_to_nhwc8_bf16 if self.bf16 else lib.sp_nchw_to_nhwc4)(P(x), P(x4), B, 3, self.in_h, self.in_w, stream), "to_nhwc")
         a = conv_bn(Act(x4, self.in_h, self.in_w, cp, needs_grad=False), "conv1", "bn1", True)
         pooled = new((B, a.h // 2, a.w // 2, a.c))
-        pool_idx = torch.empty(pooled.shape, dtype=torch.uint8, device=dev)       # winning tap per output element
+        pool_idx = self._take(tuple(pooled.shape), torch.uint8, dev)               # winning tap per output element
         _lib.check(lib.sp_maxpool3x3s2_idx_nhwc(P(a.data), bf, P(pooled), P(pool_idx), B, a.h, a.w, a.c, stream), "maxpool")
         pa = Act(pooled, a.h // 2, a.w // 2, a.c)
         stem_out = a
@@ -1084,6 +1161,7 @@ class PoseTrainer:
         return loss
 
     fuse_optimizer = True
+    use_arena = True           # step / forward_backward reuse last step's tensors request by request (see _take)
     kernel_events = None       # bench.py: a list collects (kind, layer, flops per image, start event, end event) per conv-family launch
     _opt_in_backward = False   # class-level defaults: also valid for partially constructed instances (host-logic tests)
     _opt_stream = None

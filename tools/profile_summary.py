@@ -98,24 +98,63 @@ def one_config(src, dst, cfg, fh):
 
 
 def train(src, dst, fh):
-    d = os.path.join(src, "train_bf16")
-    stats = first(os.path.join(d, "trace", "**", "*_kernel_stats.csv"))
-    if not stats:
-        return
-    shutil.copy(stats, f"{dst}_train_bf16_kernel_stats.csv")
-    rows = list(csv.DictReader(open(stats)))
-    fh.write("\n## train step, bf16 compute, 32 images (`python3 bench.py --mode train --dtype bf16 --batch 32 --steps 10 --warmup 3`)\n\n")
-    calls = sum(int(r["Calls"]) for r in rows)
-    fh.write(f"{calls} kernel launches in the profiled run = {calls / 13:.0f} per step (13 steps incl. warm-up; the bench's extra split / event steps included)\n\n")
-    fh.write("| kernel | calls | avg us | % GPU time |\n|---|---|---|---|\n")
-    for r in rows[:18]:
-        fh.write(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |\n")
-    for name, path in (("train_bf16", os.path.join(d, "bench_unprofiled.json")), ("train_f32", os.path.join(src, "bench_train_f32.json"))):
-        line = bench_line(path)
+    for dt in ("bf16", "f32"):
+        d = os.path.join(src, f"train_{dt}")
+        stats = first(os.path.join(d, "trace", "**", "*_kernel_stats.csv"))
+        if not stats:
+            continue
+        shutil.copy(stats, f"{dst}_train_{dt}_kernel_stats.csv")
+        if os.path.isfile(os.path.join(d, "tiles_bs32.json")) and not os.path.isfile(f"{dst}_train_{dt}_tiles.json"):
+            shutil.copy(os.path.join(d, "tiles_bs32.json"), f"{dst}_train_{dt}_tiles.json")
+        rows = list(csv.DictReader(open(stats)))
+        traffic = {}
+        fpath, wpath = first(os.path.join(d, "fetch", "**", "*_counter_collection.csv")), first(os.path.join(d, "write", "**", "*_counter_collection.csv"))
+        if fpath and wpath:
+            f, w = agg(fpath, "FETCH_SIZE"), agg(wpath, "WRITE_SIZE")
+            for k, (n, fs) in f.items():
+                wn, ws = w.get(k, [n, 0.0])
+                traffic[k] = {"launches_profiled": n, "fetch_size_kib_per_launch": round(fs / n, 1), "write_size_kib_per_launch": round(ws / max(wn, 1), 1),
+                              "hbm_bytes_per_launch": int((2.0 * fs / n + ws / max(wn, 1)) * 1024)}
+            with open(f"{dst}_train_{dt}_traffic.json", "w") as out:
+                json.dump(traffic, out, indent=1, sort_keys=True)
+        steps = 3 + 10 + 5            # warm-up + timed + the bench's step-split steps (no kernel-event steps: --no-kernel-events)
+        fh.write(f"\n## train step, {dt} compute, 32 images (`python3 bench.py --mode train --dtype {dt} --batch 32 --steps 10 --warmup 3 --no-kernel-events --tiles <tracked>`)\n\n")
+        step_kernels = [r for r in rows if "copyBuffer" not in r["Name"] and "pack_" not in r["Name"] and "at::native" not in r["Name"].split("<")[0]]
+        calls = sum(int(r["Calls"]) for r in rows)
+        fh.write(f"{calls} kernel launches in the profiled run of {steps} steps (tile table pinned: no tuner launches; one-time weight upload / "
+                 f"packing included) = **{calls / steps:.0f} per step**\n\n")
+        fh.write("| kernel | calls | per step | avg us | % GPU time | HBM MB / launch (PMC, corrected) |\n|---|---|---|---|---|---|\n")
+        for r in rows[:24]:
+            k = short(r["Name"])
+            t = traffic.get(k, {}).get("hbm_bytes_per_launch")
+            fh.write(f"| `{k}` | {r['Calls']} | {int(r['Calls']) / steps:.1f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} | "
+                     f"{'' if t is None else round(t / 1e6, 1)} |\n")
+        line = bench_line(os.path.join(d, "bench_unprofiled.json"))
         if line:
-            with open(f"{dst}_{name}_bench.json", "w") as out:
+            r = line.get("roofline") or {}
+            if r and r.get("traffic") is None and traffic:
+                parts = [traffic.get(k, {}).get("hbm_bytes_per_launch") for k in r.get("kernel", "").split(" + ")]
+                if parts and all(p is not None for p in parts):
+                    r["traffic"] = int(sum(parts))
+                    r["traffic_source"] = "joined by tools/profile_summary.py from the FETCH_SIZE / WRITE_SIZE passes of the same collection"
+            with open(f"{dst}_train_{dt}_bench.json", "w") as out:
                 out.write(json.dumps(line) + "\n")
-            fh.write(f"\n`{name}`: {line['value']} img/s, {line['ms_per_step']} ms/step, split {line.get('step_split_ms')}, roofline {json.dumps(line.get('roofline'))}\n")
+            fh.write(f"\n`train_{dt}`: {line['value']} img/s, {line['ms_per_step']} ms/step, host enqueue {line.get('host_enqueue_ms_per_step')} ms/step, "
+                     f"split {line.get('step_split_ms')}, roofline {json.dumps(line.get('roofline'))}\n")
+
+
+def micro(src, dst, fh):
+    d = os.path.join(src, "micro")
+    stats = first(os.path.join(d, "trace", "**", "*_kernel_stats.csv"))
+    if stats:
+        shutil.copy(stats, f"{dst}_micro_kernel_stats.csv")
+    for ext in ("json", "md"):
+        if os.path.isfile(os.path.join(d, f"table.{ext}")):
+            shutil.copy(os.path.join(d, f"table.{ext}"), f"{dst}_micro_table.{ext}")
+    if os.path.isfile(os.path.join(d, "table.md")):
+        fh.write("\n## HBM-bound kernels one by one (`python3 tools/bench_micro.py`, HIP events; rocprofv3 durations of the same run: "
+                 f"`{os.path.basename(dst)}_micro_kernel_stats.csv`)\n\n")
+        fh.write(open(os.path.join(d, "table.md")).read())
 
 
 if __name__ == "__main__":
@@ -126,3 +165,4 @@ if __name__ == "__main__":
         for cfg in ("dconv_f32", "dconv_bf16", "duc_bf16", "hrnet_w32_bf16"):
             one_config(src, dst, cfg, fh)
         train(src, dst, fh)
+        micro(src, dst, fh)

@@ -31,11 +31,24 @@ for cfg in $CONFIGS; do
   fi
   echo "$cfg done: $(grep -o '"value": [0-9.]*' $D/bench_unprofiled.json | head -1)"
 done
-T=$OUT/train_bf16
-mkdir -p $T
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $T/trace -- python3 $ROOT/bench.py --mode train --dtype bf16 --batch 32 --steps 10 --warmup 3 --no-cpu-baseline > $T/bench_trace.log 2>&1 || echo "train trace failed"
-timeout 300 python3 $ROOT/bench.py --mode train --dtype bf16 --batch 32 --steps 20 --warmup 5 --no-cpu-baseline > $T/bench_unprofiled.json 2> $T/bench_unprofiled.err
-timeout 300 python3 $ROOT/bench.py --mode train --dtype f32 --batch 32 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_train_f32.json 2>/dev/null
+# ---- train step (config 4's per-GPU batch), both compute types: tile table pinned (no tuner launches in the profiled runs), kernel trace,
+# FETCH_SIZE / WRITE_SIZE passes, unprofiled line ----
+for dt in bf16 f32; do
+  T=$OUT/train_$dt
+  mkdir -p $T
+  TILES=$ROOT/profiles/${TAG}_train_${dt}_tiles.json
+  BENCH="python3 $ROOT/bench.py --mode train --dtype $dt --batch 32 --steps 10 --warmup 3 --no-cpu-baseline --tiles $TILES"
+  [ -f $TILES ] || timeout 300 $BENCH --no-kernel-events > $T/pick_tiles.log 2>&1      # first run times the tiles on this GPU and writes the table
+  cp $TILES $T/tiles_bs32.json
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $T/trace -- $BENCH --no-kernel-events > $T/bench_trace.log 2>&1 || echo "train $dt trace failed"
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $T/fetch -- $BENCH --no-kernel-events > $T/bench_fetch.log 2>&1 || echo "train $dt fetch failed"
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $T/write -- $BENCH --no-kernel-events > $T/bench_write.log 2>&1 || echo "train $dt write failed"
+  timeout 300 python3 $ROOT/bench.py --mode train --dtype $dt --batch 32 --steps 20 --warmup 5 --no-cpu-baseline --tiles $TILES > $T/bench_unprofiled.json 2> $T/bench_unprofiled.err
+  echo "train $dt done: $(grep -o '"value": [0-9.]*' $T/bench_unprofiled.json | head -1)"
+done
+# ---- the HBM-bound kernels one by one ----
+mkdir -p $OUT/micro
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/micro/trace -- python3 $ROOT/tools/bench_micro.py --out $OUT/micro/table.json --md $OUT/micro/table.md > $OUT/micro/bench.log 2>&1 || echo "micro failed"
 # keep only the summaries (the raw per-dispatch traces are large)
 find $OUT -name "*_kernel_trace.csv" -size +8M -delete
 find $OUT -name "*.db" -delete
