@@ -478,10 +478,14 @@ def train_roofline(trainer, step, B: int, peak: float, steps: int = 3):
     ms, fl, n = groups[dom]
     ach = fl / (ms * 1e-3) / 1e12
     traffic = None
+    dt = "bf16" if trainer.bf16 else "f32"
     if dom == "wgrad":                                  # a group launch = the unit kernel + its fold: PMC bytes of both (profiles/rNN_train_*_traffic.json)
-        dt = "bf16" if trainer.bf16 else "f32"
         parts = [lookup_traffic(k, "train", dt) for k in (f"conv_wgrad_group_kernel<{'true' if trainer.bf16 else 'false'}>", "wgrad_fold_kernel")]
         traffic = None if any(p is None for p in parts) else int(sum(parts))
+    else:
+        # a family of conv_igemm instantiations: forward launches carry the STATS epilogue (8th template flag), dgrad launches do not -
+        # launch-weighted mean of the family's PMC bytes per launch
+        traffic = family_traffic("train", dt, stats=(dom == "forward"))
     return {"bound": "mfma", "kernel": names[dom], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "traffic": traffic, "launches_per_step": n // steps, "avg_launch_us": round(1e3 * ms / n, 2),
             "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3),
@@ -504,6 +508,28 @@ def tracked_tiles(arch: str, dtype: str):
     import glob
     cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{arch}_{dtype}_tiles.json")), reverse=True)
     return cands[0] if cands else None
+
+
+def family_traffic(arch: str, dtype: str, stats: bool):
+    """Launch-weighted mean HBM bytes per launch over the conv_igemm_kernel instantiations of the newest profiles/rNN_<arch>_<dtype>_traffic.json
+    whose STATS template flag (the 8th) equals `stats`; None without a table."""
+    import glob
+    import re
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{arch}_{dtype}_traffic.json")), reverse=True)
+    if not cands:
+        return None
+    with open(cands[0]) as fh:
+        tab = json.load(fh)
+    num = den = 0.0
+    for k, v in tab.items():
+        m = re.match(r"conv_igemm_kernel<(.*)>", k)
+        if not m:
+            continue
+        flags = [t.strip() for t in m.group(1).split(",")]
+        if len(flags) >= 8 and (flags[7] == "true") == stats:
+            num += v["hbm_bytes_per_launch"] * v["launches_profiled"]
+            den += v["launches_profiled"]
+    return int(num / den) if den else None
 
 
 def lookup_traffic(kernel: str, arch: str, dtype: str):

@@ -151,6 +151,11 @@ int sp_maxpool3x3s2_nhwc_bf16(const void* x, void* y, int batch, int h, int w, i
 int sp_pixel_shuffle2_nhwc_bf16(const void* x, void* y, int batch, int h, int w, int c, void* stream);
 int sp_upsample_add_nhwc_bf16(const void* x, const void* base, void* y, int batch, int h, int w, int c, int factor,
                               int relu, void* stream);
+/* SELayer (nets/commons.py:4-18) on bf16 tensors: squeeze (fp64 sums, bf16 result [B, c]) and excite + add + ReLU; gate_logits = the
+ * bf16 output of the second FC (a 1x1 sp_conv2d_fwd on the [B,1,1,c] tensor) */
+int sp_global_avg_pool_nhwc_bf16(const void* x, void* y, int batch, int hw, int c, void* stream);
+int sp_se_gate_add_relu_nhwc_bf16(const void* x, const void* gate_logits, const void* identity, void* y, int batch, int hw,
+                                  int c, void* stream);
 
 /* ---- decoders: metrics/pose_metrics.py --------------------------------------------------------- */
 

@@ -62,6 +62,8 @@ SYMBOLS = {
     "sp_maxpool3x3s2_nhwc_bf16": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "sp_pixel_shuffle2_nhwc_bf16": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "sp_upsample_add_nhwc_bf16": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "sp_global_avg_pool_nhwc_bf16": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "sp_se_gate_add_relu_nhwc_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "sp_heat_map_to_axis": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "sp_decode_gauss_taylor": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "sp_decode_basic": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),

@@ -110,7 +110,77 @@ __global__ void upsample_add_bf16_kernel(const u32x4* __restrict__ x, const u32x
     }
 }
 
+// SELayer in bf16 (nets/commons.py:4-18): squeeze = mean over the pixels of one image, 8 channels per lane, fp64 sums, bf16 result (the
+// two FCs run as bf16 1x1 convolutions on the [B,1,1,C] tensor)
+__global__ __launch_bounds__(256) void global_avg_pool_bf16_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ y, int HW, int C8) {
+    const int b = blockIdx.y;
+    const int lanes_c = C8 < 64 ? C8 : 64;
+    const int stripes = 256 / lanes_c;
+    const int tc = threadIdx.x % lanes_c, ts = threadIdx.x / lanes_c;
+    const int c8 = blockIdx.x * lanes_c + tc;
+    __shared__ double sm[256 * 8];
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c8 < C8 && ts < stripes)
+        for (int p = ts; p < HW; p += stripes) {
+            const bf16x8 v = __builtin_bit_cast(bf16x8, x[((size_t)b * HW + p) * C8 + c8]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += (double)(float)v[e];
+        }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sm[threadIdx.x * 8 + e] = acc[e];
+    __syncthreads();
+    if (ts == 0 && c8 < C8) {
+        for (int k = 1; k < stripes; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += sm[(k * lanes_c + tc) * 8 + e];
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)(float)(acc[e] / (double)HW);
+        y[(size_t)b * C8 + c8] = __builtin_bit_cast(u32x4, o);
+    }
+}
+
+// excite + block tail: y = relu(x * sigmoid(gate[b, c]) + identity), fp32 arithmetic on bf16 tensors
+__global__ void se_gate_add_relu_bf16_kernel(const u32x4* __restrict__ x, const u32x4* __restrict__ g, const u32x4* __restrict__ idn,
+                                             u32x4* __restrict__ y, int HW, int C8, long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % C8);
+        const long long b = i / ((long long)HW * C8);
+        const bf16x8 gv = __builtin_bit_cast(bf16x8, g[b * C8 + c8]);
+        const bf16x8 v = __builtin_bit_cast(bf16x8, x[i]), r = __builtin_bit_cast(bf16x8, idn[i]);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float sg = 1.f / (1.f + expf(-(float)gv[e]));
+            const float t = (float)v[e] * sg + (float)r[e];
+            o[e] = (__bf16)(t > 0.f ? t : 0.f);
+        }
+        y[i] = __builtin_bit_cast(u32x4, o);
+    }
+}
+
 }  // namespace
+
+extern "C" int sp_global_avg_pool_nhwc_bf16(const void* x, void* y, int batch, int hw, int c, void* stream) {
+    SP_REQUIRE(x && y, "sp_global_avg_pool_nhwc_bf16: null pointer");
+    SP_REQUIRE(batch > 0 && hw > 0 && c > 0 && c % 8 == 0, "sp_global_avg_pool_nhwc_bf16: bad shape");
+    const int c8 = c / 8, lanes = c8 < 64 ? c8 : 64;
+    hipLaunchKernelGGL(global_avg_pool_bf16_kernel, dim3((c8 + lanes - 1) / lanes, batch), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const u32x4*>(x), reinterpret_cast<u32x4*>(y), hw, c8);
+    return sp_check_launch("global_avg_pool_bf16_kernel");
+}
+
+extern "C" int sp_se_gate_add_relu_nhwc_bf16(const void* x, const void* gate_logits, const void* identity, void* y, int batch, int hw, int c,
+                                             void* stream) {
+    SP_REQUIRE(x && gate_logits && identity && y, "sp_se_gate_add_relu_nhwc_bf16: null pointer");
+    SP_REQUIRE(batch > 0 && hw > 0 && c > 0 && c % 8 == 0, "sp_se_gate_add_relu_nhwc_bf16: bad shape");
+    const long long total = (long long)batch * hw * (c / 8);
+    SP_REQUIRE(total * 16 < (1ll << 32), "sp_se_gate_add_relu_nhwc_bf16: tensor too large");
+    hipLaunchKernelGGL(se_gate_add_relu_bf16_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const u32x4*>(x), reinterpret_cast<const u32x4*>(gate_logits), reinterpret_cast<const u32x4*>(identity),
+                       reinterpret_cast<u32x4*>(y), hw, c / 8, total);
+    return sp_check_launch("se_gate_add_relu_bf16_kernel");
+}
 
 extern "C" int sp_nchw_to_nhwc8_bf16(const float* x, void* y, int batch, int channels, int h, int w, void* stream) {
     SP_REQUIRE(x && y, "sp_nchw_to_nhwc8_bf16: null pointer");

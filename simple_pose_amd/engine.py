@@ -231,11 +231,12 @@ class Program:
             _lib.check(fn(P(bufs[op.src]), P(bufs[op.dst]), B, h, w, c, stream), op.name)
         elif op.kind == "gap":
             hw, c = op.args
-            _lib.check(lib.sp_global_avg_pool_nhwc(P(bufs[op.src]), P(bufs[op.dst]), B, hw, c, stream), op.name)
+            fn = lib.sp_global_avg_pool_nhwc_bf16 if self.dtype == "bf16" else lib.sp_global_avg_pool_nhwc
+            _lib.check(fn(P(bufs[op.src]), P(bufs[op.dst]), B, hw, c, stream), op.name)
         elif op.kind == "se_gate":
             hw, c, gate = op.args
-            _lib.check(lib.sp_se_gate_add_relu_nhwc(P(bufs[op.src]), P(bufs[gate]), P(bufs[op.res]), P(bufs[op.dst]), B, hw, c,
-                                                    stream), op.name)
+            fn = lib.sp_se_gate_add_relu_nhwc_bf16 if self.dtype == "bf16" else lib.sp_se_gate_add_relu_nhwc
+            _lib.check(fn(P(bufs[op.src]), P(bufs[gate]), P(bufs[op.res]), P(bufs[op.dst]), B, hw, c, stream), op.name)
         elif op.kind == "upsample_add":
             h, w, c, f, relu = op.args
             fn = lib.sp_upsample_add_nhwc_bf16 if self.dtype == "bf16" else lib.sp_upsample_add_nhwc
@@ -710,8 +711,6 @@ class ProgramBuilder:
         return dst
 
     def gap(self, src: str) -> str:
-        if self.bf16:
-            raise NotImplementedError("SELayer is lowered in fp32 only")
         h, w, c = self.p.shapes[src]
         dst = self._fresh("gap")
         self.p.shapes[dst] = (1, 1, c)

@@ -559,6 +559,25 @@ def test_se_variant_forward_vs_reference_golden(golden):
     assert torch.equal(hm32[17], hm[0])
 
 
+def test_se_variant_in_bf16_vs_fp32_reference_golden(golden, measured):
+    """reduction=True with bf16 operands (sp_global_avg_pool_nhwc_bf16, the two FCs as bf16 1x1 convs, sp_se_gate_add_relu_nhwc_bf16)
+    against the fp32 reference heat maps: the bf16 bar of the plain DConv net (CPU autocast itself: 1.07e-2)."""
+    g = golden("g1s_dconv_se_fwd.npz")
+    m = pose_resnet_dconv.resnet50(pretrained=False, num_classes=17, reduction=True)
+    sd = synth.conditioned_state_dict(nets_oracle.state_dict_shapes_resnet50("dconv", se=True), int(g["seed"]))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m = m.to(DEV).eval()
+    m.compute_dtype = "bf16"
+    with torch.no_grad():
+        hm = m(_cuda(synth.input_images(1, int(g["seed"]))))
+        hm32 = m(_cuda(np.repeat(synth.input_images(1, int(g["seed"])), 32, 0)))
+    ref = g["heat_maps"]
+    rel = np.abs(hm.cpu().numpy() - ref).max() / np.abs(ref).max()
+    measured("bf16_se_heat_map_rel_err", rel, 2e-2)
+    assert 1e-5 < rel <= 2e-2
+    assert torch.equal(hm32[17], hm[0])
+
+
 # ---------------------------------------------------------------------------------------------- bf16 operand path
 def _bf16_round(t):
     return t.to(torch.bfloat16).float()

@@ -129,13 +129,27 @@ def train(src, dst, fh):
             t = traffic.get(k, {}).get("hbm_bytes_per_launch")
             fh.write(f"| `{k}` | {r['Calls']} | {int(r['Calls']) / steps:.1f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} | "
                      f"{'' if t is None else round(t / 1e6, 1)} |\n")
+        if traffic:
+            tot = sum(v["hbm_bytes_per_launch"] * v["launches_profiled"] for v in traffic.values()) / steps
+            fh.write(f"\nHBM bytes per step, all kernels (PMC, corrected): **{tot / 1e9:.2f} GB** = {tot / 32 / 1e6:.0f} MB per image\n")
         line = bench_line(os.path.join(d, "bench_unprofiled.json"))
         if line:
             r = line.get("roofline") or {}
             if r and r.get("traffic") is None and traffic:
-                parts = [traffic.get(k, {}).get("hbm_bytes_per_launch") for k in r.get("kernel", "").split(" + ")]
+                name = r.get("kernel", "")
+                parts = [traffic.get(k, {}).get("hbm_bytes_per_launch") for k in name.split(" + ")]
                 if parts and all(p is not None for p in parts):
                     r["traffic"] = int(sum(parts))
+                elif "launches)" in name:          # a family of conv_igemm instantiations: forward = STATS epilogue (8th flag), dgrad = not
+                    want, num, den = "forward" in name, 0.0, 0.0
+                    for k, v in traffic.items():
+                        m = re.match(r"conv_igemm_kernel<(.*)>", k)
+                        fl = [t.strip() for t in m.group(1).split(",")] if m else []
+                        if len(fl) >= 8 and (fl[7] == "true") == want:
+                            num += v["hbm_bytes_per_launch"] * v["launches_profiled"]; den += v["launches_profiled"]
+                    if den:
+                        r["traffic"] = int(num / den)
+                if r.get("traffic") is not None:
                     r["traffic_source"] = "joined by tools/profile_summary.py from the FETCH_SIZE / WRITE_SIZE passes of the same collection"
             with open(f"{dst}_train_{dt}_bench.json", "w") as out:
                 out.write(json.dumps(line) + "\n")
