@@ -410,7 +410,8 @@ def main():
         trainer.profile = False
         step_split = {k: round(v, 3) for k, v in acc.items()}
         if not args.no_kernel_events:      # every rank runs the extra steps (collectives inside); rank 0 reports its own events
-            roofline = train_roofline(trainer, step, B, FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else BF16_MATRIX_PEAK_TFLOPS)
+            roofline = train_roofline(trainer, step, B, FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else BF16_MATRIX_PEAK_TFLOPS,
+                                      layers_out=args.layers_out)
     if rank == 0:
         name = ARCH_NAMES[args.arch]
         if args.mode == "train":
@@ -453,7 +454,7 @@ def main():
         dist.destroy_process_group()
 
 
-def train_roofline(trainer, step, B: int, peak: float, steps: int = 3):
+def train_roofline(trainer, step, B: int, peak: float, steps: int = 3, layers_out=None):
     """Train step: HIP events around every conv-family launch (forward, dgrad, wgrad), recorded on the stream the launch goes to
     (weight gradients run on the trainer's second stream), over `steps` untimed extra steps.  The weight gradients go out in groups:
     one `sp_conv2d_wgrad_batched` call = conv_wgrad_group_kernel (every layer of the group) + its fixed-order wgrad_fold_kernel, timed
@@ -469,9 +470,17 @@ def train_roofline(trainer, step, B: int, peak: float, steps: int = 3):
     torch.cuda.synchronize()
     ev, trainer.kernel_events = trainer.kernel_events, None
     groups = {}
+    per = {}
     for kind, name, flops, e0, e1 in ev:
         g = groups.setdefault(kind, [0.0, 0.0, 0])
-        g[0] += e0.elapsed_time(e1); g[1] += flops * B; g[2] += 1
+        ms = e0.elapsed_time(e1)
+        g[0] += ms; g[1] += flops * B; g[2] += 1
+        q = per.setdefault((kind, name), [0.0, flops * B, 0])
+        q[0] += ms; q[2] += 1
+    if layers_out:
+        with open(layers_out, "w") as fh:
+            json.dump([{"kind": k, "layer": n, "us": round(1e3 * v[0] / v[2] * (v[2] / steps if k == "wgrad" else 1.0), 1), "gflop": round(v[1] / 1e9, 2),
+                        "tflops": round(v[1] / (v[0] / v[2] * 1e-3) / 1e12, 1)} for (k, n), v in per.items()], fh, indent=0)
     names = {"wgrad": f"conv_wgrad_group_kernel<{'true' if trainer.bf16 else 'false'}> + wgrad_fold_kernel",
              "forward": "conv_igemm_kernel<...> (forward launches)", "dgrad": "conv_igemm_kernel<...> (dgrad launches)"}
     dom = max(groups, key=lambda k: groups[k][0])
