@@ -111,6 +111,17 @@ int sp_basic_block_c32_ok(const sp_conv_desc* desc);
 int sp_basic_block_c32(const sp_conv_desc* desc, const void* x, const void* w1_packed, const float* scale1, const float* shift1,
                        const void* w2_packed, const float* scale2, const float* shift2, void* y, void* stream);
 
+/* One ResNet Bottleneck (nets/pose_resnet_dconv.py:112-133) with an identity shortcut, stride 1, 256 -> 64 -> 64 -> 256 channels, in ONE
+ * launch, bf16: y = relu(bn3(conv1x1(relu(bn2(conv3x3(relu(bn1(conv1x1(x)))))))) + x).  `desc` describes the block's 3x3 convolution
+ * (sp_bottleneck_c64_ok(desc) == 1: what sp_conv3x3_direct_ok accepts at 64 channels); w1 [>=64][256], w2 [>=64][576], w3 [256][64]
+ * packed as for sp_conv2d_fwd, scale / shift = the folded BatchNorms.  x is read once (halo included) and y written once: 2.4x less
+ * HBM traffic than the three launches; the intermediates are rounded to bf16 exactly where those store them: bit-identical results.
+ * y must not alias x. */
+int sp_bottleneck_c64_ok(const sp_conv_desc* desc);
+int sp_bottleneck_c64(const sp_conv_desc* desc, const void* x, const void* w1_packed, const float* scale1, const float* shift1,
+                      const void* w2_packed, const float* scale2, const float* shift2, const void* w3_packed, const float* scale3,
+                      const float* shift3, void* y, void* stream);
+
 /* 1 when `desc` (flags, shapes, tile_m x tile_n) can run with kernel = SP_CONV_KERNEL_RING: bf16 NHWC in and out (ReLU, residual and
  * fused PixelShuffle allowed; no NCHW / fp32 output), c_in % 64 == 0, taps <= 32, k_pad / 64 >= the tile's ring depth, tile_n | n_pad. */
 int sp_conv2d_ring_ok(const sp_conv_desc* desc);

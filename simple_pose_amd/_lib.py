@@ -107,6 +107,8 @@ SYMBOLS = {
     "sp_conv3x3_direct": (c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
     "sp_basic_block_c32_ok": (c_int, [ctypes.POINTER(ConvDesc)]),
     "sp_basic_block_c32": (c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "sp_bottleneck_c64_ok": (c_int, [ctypes.POINTER(ConvDesc)]),
+    "sp_bottleneck_c64": (c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sp_masked_mse": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
     "sp_conv_packed_dims": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "sp_pack_conv_weights": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),

@@ -97,7 +97,7 @@ class HipPacker:
 # ------------------------------------------------------------------------------------------------
 @dataclass
 class Op:
-    kind: str                    # "conv" | "bb32" (fused BasicBlock) | "maxpool" | "to_nhwc4" | "upsample_add" | ...
+    kind: str                    # "conv" | "bb32" (fused BasicBlock) | "bneck64" (fused Bottleneck) | "maxpool" | "to_nhwc4" | "upsample_add" | ...
     src: str
     dst: str
     res: Optional[str] = None
@@ -212,6 +212,11 @@ class Program:
             w2, scale2, shift2 = op.args
             _lib.check(lib.sp_basic_block_c32(op.desc, P(bufs[op.src]), P(op.w), P(op.scale), P(op.shift), P(w2), P(scale2), P(shift2),
                                               P(bufs[op.dst]), stream), op.name)
+        elif op.kind == "bneck64":
+            op.desc.batch = B
+            w1, s1, h1, w3, s3, h3 = op.args
+            _lib.check(lib.sp_bottleneck_c64(op.desc, P(bufs[op.src]), P(w1), P(s1), P(h1), P(op.w), P(op.scale), P(op.shift), P(w3), P(s3), P(h3),
+                                             P(bufs[op.dst]), stream), op.name)
         elif op.kind == "maxpool":
             h, w, c = op.args
             fn = lib.sp_maxpool3x3s2_nhwc_bf16 if self.dtype == "bf16" else lib.sp_maxpool3x3s2_nhwc
@@ -570,6 +575,9 @@ class ProgramBuilder:
         # bs=128 it ties with the two direct-conv launches it replaces (40 vs 2 x 20 us per block) - both are bound by the per-tile chain
         # of dependent steps at two waves per SIMD, not by bytes (profiles/r02_pmc_hrnet_blocks.md) - and the network step is not faster
         self.fuse_blocks = False
+        # bf16: whole identity-shortcut Bottlenecks with 64 mid channels (ResNet-50 layer1.1 / layer1.2) as one launch
+        # (sp_bottleneck_c64: same bits, x read once and y written once)
+        self.fuse_bottlenecks = False
         self.p = Program(dtype=dtype)
         self.bf16 = dtype == "bf16"
         self.cpad = 8 if self.bf16 else 4           # channels per 16-byte chunk
@@ -682,6 +690,34 @@ class ProgramBuilder:
                      flops=2 * (2 * h * w * 32 * 32 * 9)))
         return dst
 
+    def bottleneck_c64(self, src: str, w1, s1, h1, w2, s2, h2, w3, s3, h3, name: str) -> Optional[str]:
+        """Identity-shortcut Bottleneck 256 -> 64 -> 64 -> 256 on a bf16 activation as one launch (sp_bottleneck_c64); None when the shapes
+        do not qualify or the fusion is off."""
+        h, w, c = self.p.shapes[src]
+        if not (self.bf16 and self.fuse_bottlenecks and c == 256 and tuple(w1.shape) == (64, 256, 1, 1) and tuple(w2.shape) == (64, 64, 3, 3)
+                and tuple(w3.shape) == (256, 64, 1, 1)):
+            return None
+        p1 = self.packer.conv(w1, bf16=True)[0]
+        p2, th, tw, ci, k_pad = self.packer.conv(w2, bf16=True)
+        p3 = self.packer.conv(w3, bf16=True)[0]
+        d = ConvDesc()
+        d.batch, d.in_h, d.in_w, d.c_in = 1, h, w, ci
+        d.grid_h, d.grid_w, d.c_out, d.n_pad = h, w, 64, p2.shape[0]
+        d.taps_h, d.taps_w, d.k_pad, d.stride = th, tw, k_pad, 1
+        d.dy0, d.dy_step, d.dx0, d.dx_step = -1, 1, -1, 1
+        d.phases_y = d.phases_x = 1
+        d.out_h, d.out_w, d.out_c = h, w, 64
+        d.oy_mul = d.ox_mul = 1
+        d.oy_add = d.ox_add = 0
+        d.flags = SP_CONV_RELU | SP_CONV_BF16
+        if not _lib.lib().sp_bottleneck_c64_ok(d) or p1.shape[1] != 256 or p3.shape != (256, 64):
+            return None
+        dst = self._fresh(name)
+        self.p.shapes[dst] = (h, w, 256)
+        self._add(Op("bneck64", src, dst, desc=d, w=p2, scale=s2, shift=h2, args=(p1, s1, h1, p3, s3, h3), name=name,
+                     flops=2 * h * w * (256 * 64 + 64 * 64 * 9 + 64 * 256)))
+        return dst
+
     def deconv_k4s2p1(self, src: str, weight: torch.Tensor, *, scale=None, shift=None, relu: bool = False,
                       name: str = "deconv") -> str:
         h, w, c = self.p.shapes[src]
@@ -743,6 +779,13 @@ def _bn(b: "ProgramBuilder", sd, prefix, pixel_shuffle: bool = False):
 
 
 def _bottleneck(b: ProgramBuilder, sd, x: str, p: str, stride: int) -> str:
+    if b.fuse_bottlenecks and stride == 1 and (p + ".downsample.0.weight") not in sd and (p + ".se.fc.0.weight") not in sd:
+        s1, h1 = _bn(b, sd, p + ".bn1")
+        s2, h2 = _bn(b, sd, p + ".bn2")
+        s3, h3 = _bn(b, sd, p + ".bn3")
+        y = b.bottleneck_c64(x, sd[p + ".conv1.weight"], s1, h1, sd[p + ".conv2.weight"], s2, h2, sd[p + ".conv3.weight"], s3, h3, name=p)
+        if y is not None:
+            return y
     s1, h1 = _bn(b, sd, p + ".bn1")
     t = b.conv(x, sd[p + ".conv1.weight"], scale=s1, shift=h1, relu=True, name=p + ".conv1")
     s2, h2 = _bn(b, sd, p + ".bn2")
@@ -766,9 +809,11 @@ def _bottleneck(b: ProgramBuilder, sd, x: str, p: str, stride: int) -> str:
 
 
 def resnet_program(sd: Dict[str, torch.Tensor], head: str, in_h: int = 256, in_w: int = 192,
-                   blocks=(3, 4, 6, 3), dtype: str = "fp32", packer=None) -> Program:
-    """Lower a reference-layout state_dict into a Program.  `sd` tensors must be on the GPU."""
+                   blocks=(3, 4, 6, 3), dtype: str = "fp32", packer=None, fuse_bottlenecks: bool = False) -> Program:
+    """Lower a reference-layout state_dict into a Program.  `sd` tensors must be on the GPU.
+    `fuse_bottlenecks`: bf16 identity-shortcut Bottlenecks with 64 mid channels as one launch each (sp_bottleneck_c64; same bits)."""
     b = ProgramBuilder(in_h, in_w, dtype, packer)
+    b.fuse_bottlenecks = fuse_bottlenecks
     x = b.to_nhwc4("input")
     s, h = _bn(b, sd, "bn1")
     x = b.conv(x, sd["conv1.weight"], stride=2, pad=3, scale=s, shift=h, relu=True, name="conv1")

@@ -84,9 +84,11 @@ class PoseResNetBase(nn.Module):
         raise NotImplementedError
 
     # -- HIP dispatch ------------------------------------------------------------------------------------
+    fuse_bottlenecks = False   # True: bf16 layer1.1 / layer1.2 as one launch each (sp_bottleneck_c64); same bits
+
     def _tensors_key(self, x):
         sd = self.state_dict(keep_vars=True)
-        return (tuple(x.shape[2:]), str(x.device), self.compute_dtype) + tuple((v.data_ptr(), v._version) for v in sd.values())
+        return (tuple(x.shape[2:]), str(x.device), self.compute_dtype, self.fuse_bottlenecks) + tuple((v.data_ptr(), v._version) for v in sd.values())
 
     def hip_program(self, x: torch.Tensor) -> engine.Program:
         key = self._tensors_key(x)
@@ -96,7 +98,7 @@ class PoseResNetBase(nn.Module):
                 if v.device != x.device:
                     raise HipLibraryError(f"parameter {k} is on {v.device} but the input is on {x.device}; call .to(device)")
             self._program = engine.resnet_program(sd, self.HEAD, in_h=x.shape[2], in_w=x.shape[3], blocks=self.BLOCKS,
-                                                   dtype=self.compute_dtype)
+                                                   dtype=self.compute_dtype, fuse_bottlenecks=self.fuse_bottlenecks)
             self._program_key = key
         return self._program
 

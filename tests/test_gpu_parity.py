@@ -439,6 +439,28 @@ def test_deeper_resnet_factories_vs_oracle(measured, factory, head):
     assert got.shape == (2, 17, 32, 24) and err < 2e-5
 
 
+@pytest.mark.parametrize("head,B,H,W", [("dconv", 3, 256, 192), ("duc", 2, 128, 96), ("dconv", 1, 96, 160)])
+def test_fused_bottlenecks_equal_the_per_conv_program_bitwise(head, B, H, W):
+    """model.fuse_bottlenecks: layer1.1 / layer1.2 (identity shortcut, 256 -> 64 -> 64 -> 256) as ONE launch each (sp_bottleneck_c64) give
+    the heat maps of the conv-by-conv bf16 program bit for bit - same accumulation chains, intermediates rounded to bf16 at the same
+    places; incl. sizes whose 16x8 tiles are ragged (96x160 input: 24x40 maps)."""
+    m = {"dconv": pose_resnet_dconv, "duc": pose_resnet_duc}[head].resnet50(pretrained=False, num_classes=17)
+    sd = synth.conditioned_state_dict(nets_oracle.state_dict_shapes_resnet50(head), 6)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m = m.to(DEV).eval()
+    m.compute_dtype = "bf16"
+    m.autotune = False
+    x = _cuda(synth.input_images(B, 21, h=H, w=W))
+    with torch.no_grad():
+        ref = m(x).clone()
+        n_ref = len(m.hip_program(x).ops)
+        m.fuse_bottlenecks = True
+        got = m(x)
+        prog = m.hip_program(x)
+    assert sum(op.kind == "bneck64" for op in prog.ops) == 2 and len(prog.ops) == n_ref - 4
+    assert torch.equal(got, ref)
+
+
 def test_full_batch_128_is_consistent_with_golden(golden):
     """BASELINE configs[1] size (bs=128): images repeat the two golden inputs, so every output must equal the
     golden pair's - bitwise among replicas (deterministic kernels), 1e-4 rel against the reference."""
