@@ -130,8 +130,12 @@ __global__ __launch_bounds__(256, 1) void bottleneck_c64_kernel(const BneckArgs 
         for (int e = 0; e < 8; ++e) { sc3[nb][e] = p.s3 ? p.s3[ch + e] : 1.f; sh3[nb][e] = p.b3 ? p.b3[ch + e] : 0.f; }
     }
     const int nbA = wave & 1, mb0 = wave >> 1;               // stage A: column block of this wave, its halo row blocks mb0, mb0+2, mb0+4
-    const int cA = nbA * 32 + fr, chunkA = cA >> 3, eA = (cA & 7) * 2;
-    const float s1v = p.s1 ? p.s1[cA] : 1.f, b1v = p.b1 ? p.b1[cA] : 0.f;
+    float sc1[8], sh1[8];                                    // folded bn1 of this lane's 8 channels in the t1 store layout
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ch = nbA * 32 + (lane & 3) * 8 + e;
+        sc1[e] = p.s1 ? p.s1[ch] : 1.f; sh1[e] = p.b1 ? p.b1[ch] : 0.f;
+    }
     const float s2v0 = p.s2 ? p.s2[fr] : 1.f, b2v0 = p.b2 ? p.b2[fr] : 0.f, s2v1 = p.s2 ? p.s2[32 + fr] : 1.f, b2v1 = p.b2 ? p.b2[32 + fr] : 0.f;
     const unsigned char* const w1frag = Ws1 + (fh * 32 + fr) * 16 + nbA * 1024;
     const unsigned char* const w2frag = Ws2 + (fh * 32 + fr) * 16;
@@ -186,40 +190,38 @@ __global__ __launch_bounds__(256, 1) void bottleneck_c64_kernel(const BneckArgs 
         }
         SP_BSTAMP(ta1)
         SP_BACC(0, ta0, ta1)
-        // t1 -> LDS (bf16; exactly zero outside the image).  C/D map: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5): with the
-        // row block a compile-time constant both candidates (fh = 0 / 1), their halo coordinates and LDS offsets are constants and one
-        // select picks the lane's
+        // t1 -> LDS (bf16; exactly zero outside the image) through the wave's transpose slab, so that a lane owns 8 consecutive channels of
+        // one halo pixel: two 16-byte LDS stores per row block half instead of sixteen 2-byte ones per accumulator (a first form wrote
+        // every accumulator register on its own: 48 x ~18 vector instructions, 3,500 cycles per tile)
         {
-            int y0q = y0 - 1, x0q = x0 - 1, fhq = fh;
-            asm volatile("" : "+v"(fhq), "+s"(y0q), "+s"(x0q));   // (formed HERE, not hoisted above the MFMA loop into ~100 registers)
-            auto put = [&](const f32x16& acc, auto mbtag) __attribute__((always_inline)) {
-                constexpr int mb = decltype(mbtag)::value;
+            auto put = [&](const f32x16& acc, int mb) __attribute__((always_inline)) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int P0 = mb * 32 + (r & 3) + 8 * (r >> 2), P1 = P0 + 4;
-                    if (P0 < NHALO) {
-                        const int hy0 = P0 / BH_W, hx0 = P0 % BH_W, hy1 = P1 / BH_W, hx1 = P1 % BH_W;
-                        const int sw0 = ((hx0 >> 1) & 1) | ((hy0 & 3) << 1), sw1 = ((hx1 >> 1) & 1) | ((hy1 & 3) << 1);
-                        const int hy = fhq ? hy1 : hy0, hx = fhq ? hx1 : hx0;
-                        const int pix = fhq ? (hy1 * BH_W + hx1) * PIXM : (hy0 * BH_W + hx0) * PIXM;
-                        const int sw = fhq ? sw1 : sw0;
-                        const bool here = P1 < NHALO || !fhq;
-                        const bool in = (unsigned)(y0q + hy) < (unsigned)p.H && (unsigned)(x0q + hx) < (unsigned)p.W;
-                        float v = acc[r] * s1v + b1v;
-                        v = v > 0.f ? v : 0.f;
-                        if (here) *reinterpret_cast<__bf16*>(T1 + pix + ((chunkA ^ sw) << 4) + eA) = (__bf16)(in ? v : 0.f);
+                for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + 4 * fh) * 32 + fr] = acc[r];
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int row = it * 16 + (lane >> 2), chunk = lane & 3;
+                    float v[8];
+#pragma unroll
+                    for (int e4 = 0; e4 < 2; ++e4) {
+                        const f32x4 tt = *reinterpret_cast<const f32x4*>(tr + row * 32 + chunk * 8 + 4 * e4);
+                        v[4 * e4] = tt[0]; v[4 * e4 + 1] = tt[1]; v[4 * e4 + 2] = tt[2]; v[4 * e4 + 3] = tt[3];
                     }
+                    const int P = mb * 32 + row;
+                    const int hy = P / BH_W, hx = P - hy * BH_W;
+                    const bool in = (unsigned)(y0 - 1 + hy) < (unsigned)p.H && (unsigned)(x0 - 1 + hx) < (unsigned)p.W;
+                    bf16x8 o8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float q = v[e] * sc1[e] + sh1[e];
+                        q = q > 0.f ? q : 0.f;
+                        o8[e] = (__bf16)(in ? q : 0.f);
+                    }
+                    if (P < NHALO) *reinterpret_cast<u32x4*>(T1 + t1off(hy, hx, nbA * 4 + chunk)) = __builtin_bit_cast(u32x4, o8);
                 }
             };
-            if (mb0 == 0) {
-                put(a0, std::integral_constant<int, 0>{});
-                put(a1, std::integral_constant<int, 2>{});
-                put(a2, std::integral_constant<int, 4>{});
-            } else {
-                put(a0, std::integral_constant<int, 1>{});
-                put(a1, std::integral_constant<int, 3>{});
-                put(a2, std::integral_constant<int, 5>{});
-            }
+            put(a0, mb0);
+            put(a1, mb0 + 2);
+            put(a2, mb0 + 4);
         }
         SP_BSTAMP(ta2)
         SP_BACC(1, ta1, ta2)
