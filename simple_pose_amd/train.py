@@ -645,13 +645,16 @@ class PoseTrainer:
                 step = max(1, 65536 // inner)
                 for r0 in range(0, j.dims[0], step):
                     n0 = min(step, j.dims[0] - r0)
+                    # how the kernel walks the slab (sp_permute4_batched): filters with taps read a run of taps per (i0, i3) pair, 1x1
+                    # filters packed transposed go through LDS tiles, the rest (sources contiguous along the last index) in destination order
+                    walk = 1 if j.dims[1] * j.dims[2] > 1 else (2 if abs(j.strides[0]) == 1 and abs(j.strides[3]) > 1 else 0)
                     rows.append(((n0,) + tuple(j.dims[1:]), j.strides, (max(0, min(n0, j.valid[0] - r0)),) + tuple(j.valid[1:]),
                                  o + j.base + r0 * j.strides[0], j.dst.data_ptr() + (j.dst_off + r0 * inner) * es, n0 * inner,
-                                 int(j.dst.dtype == torch.bfloat16)))
+                                 int(j.dst.dtype == torch.bfloat16), walk))
             tab = np.zeros(len(rows), dtype=rec)
-            for i, (d, st, lim, base, dst, total, b16) in enumerate(rows):
+            for i, (d, st, lim, base, dst, total, b16, walk) in enumerate(rows):
                 tab[i]["d"], tab[i]["s"], tab[i]["lim"] = d, st, lim
-                tab[i]["base"], tab[i]["dst"], tab[i]["total"], tab[i]["bf16"] = base, dst, total, b16
+                tab[i]["base"], tab[i]["dst"], tab[i]["total"], tab[i]["bf16"], tab[i]["pad"] = base, dst, total, b16, walk
             assert rec.itemsize == 96, rec.itemsize
             self._pack_table = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(self.flat.data.device)
             self._pack_n = len(rows)

@@ -275,6 +275,28 @@ def test_maxpool_index_pair_matches_gather_kernel_and_torch(bf16):
     assert torch.equal(dx_new.cpu(), ref_dx)
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_repack_walks_give_the_same_packed_weights(dtype):
+    """sp_permute4_batched visits a job in destination order, as a tap loop per (i0, i3) pair, or as a tiled transpose (the `walk` field of
+    a job): every packed forward / dgrad copy of the whole net must come out bit for bit the same whichever walk wrote it."""
+    model, _ = _model(5)
+    tr = PoseTrainer(model, dtype=dtype)
+    names = [(n, "fwd", L.w_fwd) for n, L in tr.layers.items()] + [(n, f"dgrad{i}", w) for n, L in tr.layers.items() if L.need_dgrad
+                                                                       for i, w in enumerate(L.w_dgrad)]
+    with_walks = [w.clone() for _, _, w in names]
+    tab = tr._pack_table.cpu().numpy().view(np.uint8).reshape(-1, 96).copy()
+    walks = tab[:, 92:96].view(np.int32).reshape(-1)
+    assert set(walks.tolist()) == {0, 1, 2}                 # all three walks occur in ResNet-50
+    tab[:, 92:96] = 0                                        # destination order everywhere
+    tr._pack_table = torch.from_numpy(tab.reshape(-1)).to(DEV)
+    for _, _, w in names:
+        w.fill_(7.0)
+    tr.repack()
+    torch.cuda.synchronize()
+    for (n, kind, w), ref in zip(names, with_walks):
+        assert torch.equal(w, ref), (n, kind)
+
+
 def test_solver_counterpart_trains_validates_and_checkpoints(tmp_path):
     """DDPProcessor (ddp...:20-212) on synthetic data, single process: two epochs with a MultiStepLR drop, loss goes down, val()
     runs the eval-mode forward with the UPDATED weights, and the checkpoint has the reference's {"ema": state_dict, "epoch"} form."""
