@@ -272,6 +272,13 @@ int sp_conv2d_dgrad_bn_bwd_stats(const sp_conv_desc* desc, const void* dz, const
                                  float* sum_g_xhat, int stats_rows_capacity, void* stream);
 int sp_bn_bwd_sums_from_conv(const float* sum_g, const float* sum_g_xhat, int partial_rows, int stride, int c, float* dgamma,
                              float* dbeta, void* stream);
+/* The same launch when dy is the gradient of a block output y = relu(bn3(z) + bn_ds(z2)) with a projection shortcut (the first
+ * Bottleneck of a stage, pose_resnet_dconv.py:124-131): the shortcut BatchNorm's dy is the same g, so the epilogue also leaves
+ * the partial sums of g * xhat2 (its d gamma; its d beta is sum g): sp_bn_bwd_sums_from_conv(sum_g, sum_g_xhat2, ...) folds them. */
+int sp_conv2d_dgrad_bn_bwd_stats2(const sp_conv_desc* desc, const void* dz, const void* w_packed, const void* accumulate, void* dx,
+                                  const void* bn_y, const void* bn_z, const float* bn_mean, const float* bn_invstd, float* sum_g,
+                                  float* sum_g_xhat, const void* bn2_z, const float* bn2_mean, const float* bn2_invstd,
+                                  float* sum_g_xhat2, int stats_rows_capacity, void* stream);
 /* y = [relu]((z - mean) * invstd * gamma + beta [+ residual])   (Bottleneck.forward tail, pose_resnet_dconv.py:124-131) */
 int sp_bn_apply_nhwc(const void* z, int bf16, const float* mean, const float* invstd, const float* gamma, const float* beta,
                      const void* residual, void* y, int64_t rows, int c, int relu, void* stream);

@@ -99,6 +99,7 @@ SYMBOLS = {
     "sp_conv2d_fwd_bn_stats": (c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, c_int, _P]),
     "sp_bn_train_stats_from_conv": (c_int, [_P, _P, c_int, c_int, c_int64, c_int, c_float, c_float, _P, _P, _P, _P, _P]),
     "sp_conv2d_dgrad_bn_bwd_stats": (c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
+    "sp_conv2d_dgrad_bn_bwd_stats2": (c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "sp_bn_sums_from_conv": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
     "sp_bn_bwd_sums_from_conv": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "sp_u8hwc_bgr_to_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),

@@ -88,6 +88,12 @@ struct ConvArgs {
     const float* bmean;
     const float* binvstd;
     int bz_bytes;
+    // a SECOND BatchNorm whose dy is the same g (the projection shortcut of a stage's first bottleneck: its output is added to bn3's, so
+    // its dy is bn3's g): sum of g * xhat2 -> stats_q2 (sum g is shared); null: none
+    const void* bz2;
+    const float* bmean2;
+    const float* binvstd2;
+    float* stats_q2;
 };
 
 constexpr int BK = 32;  // floats per K tile (8 chunks of 16 B)
@@ -548,21 +554,28 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
         static_assert(!(STATS && BSTATS) && (!BSTATS || !OUT16), "BSTATS: an fp32 gradient store");
         float st_s[(STATS || BSTATS) ? CPL : 1], st_q[(STATS || BSTATS) ? CPL : 1];   // column sums over this lane's rows
         float b_mu[BSTATS ? CPL : 1], b_is[BSTATS ? CPL : 1];
+        float st_q2[BSTATS ? CPL : 1], b_mu2[BSTATS ? CPL : 1], b_is2[BSTATS ? CPL : 1];
         if constexpr (STATS || BSTATS) {
 #pragma unroll
             for (int e = 0; e < CPL; ++e) { st_s[e] = 0.f; st_q[e] = 0.f; }
         }
         if constexpr (BSTATS) {
 #pragma unroll
-            for (int e = 0; e < CPL; ++e) { b_mu[e] = 0.f; b_is[e] = 0.f; }
+            for (int e = 0; e < CPL; ++e) { b_mu[e] = 0.f; b_is[e] = 0.f; st_q2[e] = 0.f; b_mu2[e] = 0.f; b_is2[e] = 0.f; }
             if (col_ok) {
                 const f32x4 m4 = *reinterpret_cast<const f32x4*>(p.bmean + col), i4 = *reinterpret_cast<const f32x4*>(p.binvstd + col);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { b_mu[e] = m4[e]; b_is[e] = i4[e]; }
+                if (p.bz2) {
+                    const f32x4 m2 = *reinterpret_cast<const f32x4*>(p.bmean2 + col), i2 = *reinterpret_cast<const f32x4*>(p.binvstd2 + col);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { b_mu2[e] = m2[e]; b_is2[e] = i2[e]; }
+                }
             }
         }
         const __amdgpu_buffer_rsrc_t byr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(BSTATS ? p.by : p.y), (short)0, BSTATS ? p.bz_bytes : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t bzr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(BSTATS ? p.bz : p.y), (short)0, BSTATS ? p.bz_bytes : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t bz2r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>((BSTATS && p.bz2) ? p.bz2 : p.y), (short)0, (BSTATS && p.bz2) ? p.bz_bytes : 0, 0x00020000);
         u32x4 rv[NIT];
         if (p.res) {  // every residual load of the tile in flight before the first use
 #pragma unroll
@@ -616,6 +629,7 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
                 }
                 if constexpr (BSTATS) {       // v = dy (complete: the residual input carried the other contributions)
                     f32x4 yy, zz;
+                    f32x4 z2 = {0.f, 0.f, 0.f, 0.f};
                     if constexpr (BF16) {     // activations are bf16: 8 bytes per 4 channels at half the fp32 byte offset
                         const unsigned ho = off[it] == OOB ? OOB : off[it] >> 1;
                         typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
@@ -624,9 +638,15 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
                         const bf16x4_ z4 = __builtin_bit_cast(bf16x4_, __builtin_amdgcn_raw_buffer_load_b64(bzr, ho, 0, 0));
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { yy[e] = (float)y4[e]; zz[e] = (float)z4[e]; }
+                        if (p.bz2) {
+                            const bf16x4_ q4 = __builtin_bit_cast(bf16x4_, __builtin_amdgcn_raw_buffer_load_b64(bz2r, ho, 0, 0));
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) z2[e] = (float)q4[e];
+                        }
                     } else {
                         yy = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(byr, off[it], 0, 0));
                         zz = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bzr, off[it], 0, 0));
+                        if (p.bz2) z2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bz2r, off[it], 0, 0));
                     }
                     if (off[it] != OOB) {
 #pragma unroll
@@ -634,6 +654,7 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
                             const float g = yy[e] > 0.f ? v[e] : 0.f;
                             st_s[e] += g;
                             st_q[e] += g * ((zz[e] - b_mu[e]) * b_is[e]);
+                            st_q2[e] += g * ((z2[e] - b_mu2[e]) * b_is2[e]);
                         }
                     }
                 }
@@ -647,6 +668,12 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
             for (int o = CPR; o < 64; o <<= 1) {
 #pragma unroll
                 for (int e = 0; e < CPL; ++e) { st_s[e] += __shfl_xor(st_s[e], o, 64); st_q[e] += __shfl_xor(st_q[e], o, 64); }
+                if constexpr (BSTATS) {
+                    if (p.bz2) {
+#pragma unroll
+                        for (int e = 0; e < CPL; ++e) st_q2[e] += __shfl_xor(st_q2[e], o, 64);
+                    }
+                }
             }
             if (rsub == 0 && col_ok) {
                 const size_t base = ((size_t)(phase * p.tiles_m + tm) * WR + wr) * p.stats_stride + col;
@@ -656,6 +683,12 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
                     const f32x4 b4 = {st_q[4 * e4], st_q[4 * e4 + 1], st_q[4 * e4 + 2], st_q[4 * e4 + 3]};
                     *reinterpret_cast<f32x4*>(p.stats_s + base + 4 * e4) = a4;
                     *reinterpret_cast<f32x4*>(p.stats_q + base + 4 * e4) = b4;
+                    if constexpr (BSTATS) {
+                        if (p.bz2) {
+                            const f32x4 c4 = {st_q2[4 * e4], st_q2[4 * e4 + 1], st_q2[4 * e4 + 2], st_q2[4 * e4 + 3]};
+                            *reinterpret_cast<f32x4*>(p.stats_q2 + base + 4 * e4) = c4;
+                        }
+                    }
                 }
             }
         }
@@ -790,7 +823,7 @@ int sp_conv_ring_launch(const sp_conv_desc* d, const void* x, const void* w_pack
 
 static int tile_rows_per_block(int bm, int bn) { return (bm == 256 && bn == 64) || (bm == 128 && bn == 32) ? 4 : 2; }   // WR of the tile
 
-struct BnBwdSrc { const void* y; const void* z; const float* mean; const float* invstd; };
+struct BnBwdSrc { const void* y; const void* z; const float* mean; const float* invstd; const void* z2; const float* mean2; const float* invstd2; float* q2; };
 
 static int conv_fwd_impl(const sp_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift,
                          const void* residual, void* y, float* stats_s, float* stats_q, int stats_rows_capacity, void* stream,
@@ -852,6 +885,7 @@ static int conv_fwd_impl(const sp_conv_desc* d, const void* x, const void* w_pac
     a.y_bytes = (int)(out_elems * (((d->flags & SP_CONV_OUT_NCHW) || !out16) ? 4 : 2));
     a.stats_s = stats_s; a.stats_q = stats_q; a.stats_stride = d->n_pad;
     a.by = bsrc ? bsrc->y : nullptr; a.bz = bsrc ? bsrc->z : nullptr; a.bmean = bsrc ? bsrc->mean : nullptr; a.binvstd = bsrc ? bsrc->invstd : nullptr;
+    a.bz2 = bsrc ? bsrc->z2 : nullptr; a.bmean2 = bsrc ? bsrc->mean2 : nullptr; a.binvstd2 = bsrc ? bsrc->invstd2 : nullptr; a.stats_q2 = bsrc ? bsrc->q2 : nullptr;
     a.bz_bytes = (int)(out_elems * es);
     const int phases = d->phases_y * d->phases_x;
     hipStream_t s = (hipStream_t)stream;
@@ -910,7 +944,7 @@ extern "C" int sp_conv2d_kernel_name(const sp_conv_desc* d, int has_residual, in
     }
     void* const dummy = reinterpret_cast<void*>(16);        // never dereferenced: the launch functions return before launching
     float* const fdummy = reinterpret_cast<float*>(16);
-    const BnBwdSrc src = {dummy, dummy, fdummy, fdummy};
+    const BnBwdSrc src = {dummy, dummy, fdummy, fdummy, nullptr, nullptr, nullptr, nullptr};
     sp_name_query_begin();
     const int rc = conv_fwd_impl(d, dummy, dummy, nullptr, nullptr, has_residual ? dummy : nullptr, dummy, variant ? fdummy : nullptr,
                                  variant ? fdummy : nullptr, 1 << 30, nullptr, variant == 2 ? &src : nullptr);
@@ -939,7 +973,16 @@ extern "C" int sp_conv2d_fwd_bn_stats(const sp_conv_desc* d, const void* x, cons
 extern "C" int sp_conv2d_dgrad_bn_bwd_stats(const sp_conv_desc* d, const void* dz, const void* w_packed, const void* accumulate, void* dx,
                                            const void* bn_y, const void* bn_z, const float* bn_mean, const float* bn_invstd,
                                            float* sum_g, float* sum_g_xhat, int stats_rows_capacity, void* stream) {
-    const BnBwdSrc src = {bn_y, bn_z, bn_mean, bn_invstd};
+    const BnBwdSrc src = {bn_y, bn_z, bn_mean, bn_invstd, nullptr, nullptr, nullptr, nullptr};
+    return conv_fwd_impl(d, dz, w_packed, nullptr, nullptr, accumulate, dx, sum_g, sum_g_xhat, stats_rows_capacity, stream, &src);
+}
+
+extern "C" int sp_conv2d_dgrad_bn_bwd_stats2(const sp_conv_desc* d, const void* dz, const void* w_packed, const void* accumulate, void* dx,
+                                            const void* bn_y, const void* bn_z, const float* bn_mean, const float* bn_invstd,
+                                            float* sum_g, float* sum_g_xhat, const void* bn2_z, const float* bn2_mean, const float* bn2_invstd,
+                                            float* sum_g_xhat2, int stats_rows_capacity, void* stream) {
+    SP_REQUIRE(bn2_z && bn2_mean && bn2_invstd && sum_g_xhat2, "sp_conv2d_dgrad_bn_bwd_stats2: null pointer");
+    const BnBwdSrc src = {bn_y, bn_z, bn_mean, bn_invstd, bn2_z, bn2_mean, bn2_invstd, sum_g_xhat2};
     return conv_fwd_impl(d, dz, w_packed, nullptr, nullptr, accumulate, dx, sum_g, sum_g_xhat, stats_rows_capacity, stream, &src);
 }
 

@@ -77,6 +77,8 @@ class Act:
     sibling: Optional[tuple] = None    # SyncBN: produced by a bare BatchNorm (projection shortcut): (z, mean, invstd, bn name)
     presums: Optional[tuple] = None    # SyncBN backward: global (sum g*xhat, sum g) already exchanged by the consumer's message
     bstats: Optional[tuple] = None     # backward: (partial sums [2, rows, stride], rows) left by the dgrad launch that wrote .grad
+    bn2: Optional[tuple] = None        # block output with a projection shortcut: (z, mean, invstd, bn name) of the shortcut's BatchNorm, whose
+                                       # dy is this output's g: its sum g * xhat rides on the same dgrad epilogue (part[2])
 
 
 @dataclass
@@ -302,14 +304,21 @@ class ConvT:
                 _lib.check(lib.sp_conv2d_bn_stats_rows(d, ctypes.byref(r)), self.name + ".dgrad")
                 need.append(r.value)
             total, stride = sum(need), self.d_dgrad[0].n_pad
-            part = self._new((2, total, stride), torch.float32, dz.device)
+            two = bn_src.bn2 is not None
+            part = self._new((3 if two else 2, total, stride), torch.float32, dz.device)
             z, mean, invstd = bn_src.bn
             row0 = 0
             done = self._timed("dgrad")
             for d, w, n in zip(self.d_dgrad, self.w_dgrad, need):
-                _lib.check(lib.sp_conv2d_dgrad_bn_bwd_stats(d, P(dz), P(w), P(acc), P(dx), P(bn_src.data), P(z), P(mean), P(invstd),
-                                                            P(part[0, row0:]), P(part[1, row0:]), n, _lib.current_stream()),
-                           self.name + ".dgrad")
+                if two:
+                    z2, mean2, invstd2, _ = bn_src.bn2
+                    _lib.check(lib.sp_conv2d_dgrad_bn_bwd_stats2(d, P(dz), P(w), P(acc), P(dx), P(bn_src.data), P(z), P(mean), P(invstd),
+                                                                 P(part[0, row0:]), P(part[1, row0:]), P(z2), P(mean2), P(invstd2),
+                                                                 P(part[2, row0:]), n, _lib.current_stream()), self.name + ".dgrad")
+                else:
+                    _lib.check(lib.sp_conv2d_dgrad_bn_bwd_stats(d, P(dz), P(w), P(acc), P(dx), P(bn_src.data), P(z), P(mean), P(invstd),
+                                                                P(part[0, row0:]), P(part[1, row0:]), n, _lib.current_stream()),
+                               self.name + ".dgrad")
                 row0 += n
             done()
             bn_src.bstats = (part, total)
@@ -942,8 +951,10 @@ class PoseTrainer:
                 res.consumers += 1
             if relu:
                 ya.bn = (z, mean, invstd)      # y = relu(bn(z) [+ res]): backward masks with y > 0 either way
-            if sync and not relu and res is None:
-                ya.sibling = (z, mean, invstd, bname)      # a projection shortcut: its backward sums can ride on the consumer's message
+            if not relu and res is None:
+                ya.sibling = (z, mean, invstd, bname)      # a projection shortcut: its backward sums ride on its consumer's (message / epilogue)
+            if relu and res is not None and res.sibling is not None and not sync and self.fuse_bn_bwd:
+                ya.bn2 = res.sibling                       # the shortcut's dy is this layer's g = dy * (y > 0): one more sum in the same epilogue
 
             def bwd():
                 dz = new(z.shape)                      # MFMA operand of dgrad / wgrad: activation dtype
@@ -957,8 +968,8 @@ class PoseTrainer:
                     dres = res.grad
                 dgamma, dbeta = self.flat.view(bname + ".weight", True), self.flat.view(bname + ".bias", True)
                 rs = P(y) if relu else None
-                if sync and ya.presums is not None:
-                    # the consumer of this (projection-shortcut) BatchNorm already reduced and exchanged its two sums
+                if ya.presums is not None:
+                    # the consumer of this (projection-shortcut) BatchNorm already reduced (SyncBatchNorm: and exchanged) its two sums
                     sg, sb = ya.presums
                     ya.presums = None
                     _lib.check(lib.sp_bn_train_bwd_apply_nhwc(P(ya.grad), bf, rs, P(z), P(mean), P(invstd), P(gamma), P(sg), P(sb),
@@ -970,6 +981,13 @@ class PoseTrainer:
                         ya.bstats = None
                         _lib.check(lib.sp_bn_bwd_sums_from_conv(P(part[0]), P(part[1]), prow, part.shape[2], C, P(dgamma), P(dbeta), stream),
                                    bname + ".bwd")
+                        if part.shape[0] == 3 and res is not None and acc == 0:
+                            # the projection shortcut's sums came out of the same epilogue: d beta = sum g (shared), d gamma = sum g * xhat2
+                            sname = ya.bn2[3]
+                            dgs, dbs = self.flat.view(sname + ".weight", True), self.flat.view(sname + ".bias", True)
+                            _lib.check(lib.sp_bn_bwd_sums_from_conv(P(part[0]), P(part[2]), prow, part.shape[2], C, P(dgs), P(dbs), stream),
+                                       sname + ".bwd")
+                            res.presums = (dgs, dbs)
                     else:
                         _lib.check(lib.sp_bn_train_bwd_reduce_nhwc(P(ya.grad), bf, rs, P(z), P(mean), P(invstd), rows, C, P(dgamma), P(dbeta),
                                                                    P(ws), stream), bname + ".bwd")
