@@ -309,6 +309,9 @@ int sp_pixel_unshuffle2_nhwc(const float* dy, float* dx, int batch, int h, int w
 /* x [B,channels,h,w] fp32 -> y [B,h,w,c_pad] (fp32, or bf16 when y_bf16), channels >= `channels` zero-filled: puts
  * d loss / d heat-map (sp_masked_mse's grad) into the layout and K-tile padding the final layer's backward launches read */
 int sp_nchw_to_nhwc_pad(const float* x, void* y, int y_bf16, int batch, int channels, int h, int w, int c_pad, void* stream);
+/* sum over batch and pixels of an NCHW tensor [batch, channels, hw] -> [channels]: the final layer's bias gradient straight from
+ * d loss / d heat maps (sp_masked_mse's grad), written where the caller's flat gradient buffer keeps it */
+int sp_channel_sum_nchw(const float* x, int batch, int channels, int hw, float* sum, void* stream);
 /* sum over rows of a [rows, c] tensor (conv bias gradient) */
 int sp_channel_sum_nhwc(const float* a, int64_t rows, int c, float* sum, void* workspace, void* stream);
 /* backward of nn.MaxPool2d(3,2,1) (first maximum of a window wins, as torch); x = the pool's input */

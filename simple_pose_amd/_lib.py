@@ -78,6 +78,7 @@ SYMBOLS = {
     "sp_bn_train_bwd_reduce_nhwc": (c_int, [_P, c_int, _P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P]),
     "sp_bn_train_bwd_apply_nhwc": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, _P, _P, c_int, _P]),
     "sp_bn_train_bwd_nhwc": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P, c_int, _P, _P]),
+    "sp_channel_sum_nchw": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "sp_channel_sum_nhwc": (c_int, [_P, c_int64, c_int, _P, _P, _P]),
     "sp_maxpool3x3s2_bwd_nhwc": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "sp_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_double, c_double, c_double, c_double, c_int, c_float, _P]),

@@ -660,6 +660,31 @@ extern "C" int sp_bn_train_bwd_nhwc(const void* dy, int bf16, const void* relu_s
     return sp_bn_train_bwd_apply_nhwc(dy, bf16, relu_src, z, mean, invstd, gamma, dgamma, dbeta, rows, rows, c, dz, dres, dres_accumulate, stream);
 }
 
+// sum over batch and pixels of an NCHW tensor, one workgroup per channel (the final layer's bias gradient straight from d loss / d heat
+// maps: 17 channels): thread t adds elements t, t + 256, ... of every image in fp64, then a fixed-order tree - deterministic
+__global__ __launch_bounds__(256) void channel_sum_nchw_kernel(const float* __restrict__ x, int batch, int channels, int hw, float* __restrict__ out) {
+    __shared__ double sm[256];
+    const int c = blockIdx.x;
+    double acc = 0;
+    for (int b = 0; b < batch; ++b) {
+        const float* src = x + ((size_t)b * channels + c) * hw;
+        for (int i = threadIdx.x; i < hw; i += 256) acc += (double)src[i];
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = (float)sm[0];
+}
+
+extern "C" int sp_channel_sum_nchw(const float* x, int batch, int channels, int hw, float* sum, void* stream) {
+    SP_REQUIRE(x && sum && batch > 0 && channels > 0 && hw > 0, "sp_channel_sum_nchw: bad argument");
+    hipLaunchKernelGGL(channel_sum_nchw_kernel, dim3(channels), dim3(256), 0, (hipStream_t)stream, x, batch, channels, hw, sum);
+    return sp_check_launch("channel_sum_nchw_kernel");
+}
+
 extern "C" int sp_channel_sum_nhwc(const float* a, int64_t rows, int c, float* sum, void* workspace, void* stream) {
     SP_REQUIRE(a && sum && workspace && rows > 0 && c > 0 && c % 4 == 0 && rows < (1ll << 31), "sp_channel_sum_nhwc: bad argument");
     hipStream_t s = (hipStream_t)stream;

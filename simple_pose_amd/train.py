@@ -1105,14 +1105,10 @@ class PoseTrainer:
         dev, ws = dheat.device, self.red_ws
         if True:   # (block kept for a minimal diff of the tape below)
             Jb = fl.c_out_buf                              # heat-map channels padded to a K tile of the backward launches
-            dh = newf((B, hh, ww, Jb))
-            _lib.check(lib.sp_nchw_to_nhwc_pad(P(dheat), P(dh), 0, B, J, hh, ww, Jb, stream), "dheat.nhwc")
-            bsum = newf(Jb)
-            _lib.check(lib.sp_channel_sum_nhwc(P(dh), B * hh * ww, Jb, P(bsum), P(ws), stream), "final_layer.bias.grad")
-            self.flat.view("final_layer.bias", True).copy_(bsum[:J])          # 17-float device copy into the flat gradient buffer
-            if self.bf16:
-                dh = new((B, hh, ww, Jb))
-                _lib.check(lib.sp_nchw_to_nhwc_pad(P(dheat), P(dh), 1, B, J, hh, ww, Jb, stream), "dheat.nhwc16")
+            # final_layer.bias.grad = sum over batch and pixels of d loss / d heat, straight from the NCHW gradient into the flat buffer
+            _lib.check(lib.sp_channel_sum_nchw(P(dheat), B, J, hh * ww, P(self.flat.view("final_layer.bias", True)), stream), "final_layer.bias.grad")
+            dh = new((B, hh, ww, Jb)) if self.bf16 else newf((B, hh, ww, Jb))
+            _lib.check(lib.sp_nchw_to_nhwc_pad(P(dheat), P(dh), int(self.bf16), B, J, hh, ww, Jb, stream), "dheat.nhwc")
             wgrad_async(fl, a.data, dh)
             a.grad = fl.dgrad(dh, B, None, bn_src=a if (self.fuse_bn_bwd and a.bn is not None and a.consumers == 1) else None)
             a.contrib += 1
