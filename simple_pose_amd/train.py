@@ -599,10 +599,10 @@ class PoseTrainer:
         self._wg_queued_flops = 0.0
 
     def _wgrad_flush_if(self, fraction: float) -> None:
-        if getattr(self, "_wg_queued_flops", 0.0) >= fraction * self.wgrad_group_gflop * 1e9:
+        if getattr(self, "_wg_queued_flops", 0.0) >= fraction * getattr(self, "_group_gflop", self.wgrad_group_gflop) * 1e9:
             self._wgrad_flush()
 
-    wgrad_group_gflop = 60.0   # queued weight-gradient work (all images of the rank) that triggers a group launch
+    wgrad_group_gflop = 40.0   # queued weight-gradient work (all images of the rank) that triggers a group launch
 
     # ---- static structure -------------------------------------------------------------------------------------------
     def _conv(self, name, h, w, **kw) -> ConvT:
@@ -869,6 +869,8 @@ class PoseTrainer:
         self._wg_queue = []
         self._wg_queued_flops = 0.0
         self._wg_batch, self._wg_side, self._wg_dev = B, side, dev
+        import os
+        self._group_gflop = float(os.environ.get("SP_WGRAD_GROUP_GFLOP", self.wgrad_group_gflop))     # (env: development knob)
 
         def wgrad_async(layer, xin: torch.Tensor, dzt: torch.Tensor):
             # weight gradients are launched in GROUPS (sp_conv2d_wgrad_batched: every layer of a group in one launch per dW tile shape plus
@@ -876,7 +878,7 @@ class PoseTrainer:
             # slabs.  The group goes out when a gradient bucket completes, when `wgrad_group_gflop` of work is queued, or at the end.
             self._wg_queue.append((layer, xin, dzt))
             self._wg_queued_flops += layer.flops * B
-            if self._wg_queued_flops >= self.wgrad_group_gflop * 1e9:
+            if self._wg_queued_flops >= self._group_gflop * 1e9:
                 self._wgrad_flush()
 
         self._pending = [set(b["names"]) for b in self.buckets]
