@@ -514,6 +514,10 @@ def _variant_name(op):
     from simple_pose_amd import _lib
     if op.kind == "bb32":
         return "basic_block_c32_kernel"
+    if op.kind == "bneck64":
+        return "bottleneck_c64_kernel"
+    if op.kind == "stem7":                        # conv1 + bn1 + relu + maxpool in one launch (its time includes the pooling)
+        return "stem_pool_kernel<%s>" % ("true" if op.w.element_size() == 2 else "false")
     return _lib.conv_kernel_name(op.desc, op.res is not None, 3 if getattr(op, "direct", False) else 0)
 
 
@@ -582,14 +586,15 @@ def kernel_roofline(prog, x, steps: int, layers_out=None, peak=FP32_MATRIX_PEAK_
     bufs = dict(prog._alloc(B, x.device))
     bufs["input"] = x
     bufs[prog.out_name] = torch.empty((B,) + tuple(prog.out_shape), dtype=torch.float32, device=x.device)
-    conv_ops = [op for op in prog.ops if op.kind in ("conv", "bb32")]      # every launch that carries algorithmic FLOPs
+    FLOP_KINDS = ("conv", "bb32", "bneck64", "stem7")
+    conv_ops = [op for op in prog.ops if op.kind in FLOP_KINDS]            # every launch that carries algorithmic FLOPs
     ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in conv_ops]
           for _ in range(steps)]
     stream = _lib.current_stream()
     for s in range(steps):
         ci = 0
         for op in prog.ops:                      # the program's own dispatcher (one stream), events around the conv launches
-            if op.kind in ("conv", "bb32"):
+            if op.kind in FLOP_KINDS:
                 ev[s][ci][0].record()
                 prog._launch(lib, op, bufs, B, stream)
                 ev[s][ci][1].record()

@@ -27,7 +27,7 @@ extern "C" {
 #define SP_EINVAL (-1)   /* bad argument / unsupported shape (message in sp_last_error) */
 #define SP_ELAUNCH (-2)  /* HIP launch or runtime failure */
 
-#define SP_ABI_VERSION 22
+#define SP_ABI_VERSION 23
 
 /* epilogue / layout flags of sp_conv_desc.flags */
 #define SP_CONV_RELU 0x1u          /* y = max(y, 0) after scale/shift (+ residual) */
@@ -121,6 +121,16 @@ int sp_bottleneck_c64_ok(const sp_conv_desc* desc);
 int sp_bottleneck_c64(const sp_conv_desc* desc, const void* x, const void* w1_packed, const float* scale1, const float* shift1,
                       const void* w2_packed, const float* scale2, const float* shift2, const void* w3_packed, const float* scale3,
                       const float* shift3, void* y, void* stream);
+
+/* The ResNet stem (nets/pose_resnet_dconv.py:158-162: conv1 7x7 s2 p3, bn1, relu, maxpool 3x3 s2 p1) in ONE launch, fp32 or bf16 compute:
+ * x fp32 NCHW [batch,3,h,w] -> y NHWC [batch,hp,wp,64] (fp32, or bf16 when `bf16`), hp = ((h+6-7)/2+1 + 2-3)/2+1.  w_packed / k_pad: the
+ * stem weights exactly as sp_conv2d_fwd takes them for conv1 (fp32: sp_pack_conv_weights with c_in_packed 4, taps_w_packed 8 ->
+ * [64][224]; bf16: c_in_packed 8, taps_w_packed 4, pair_s0 1 -> [64][256]); scale / shift = the folded bn1.  The 128 x 96 x 64 map
+ * between conv and pooling never reaches HBM and K is not padded to a GEMM tile: bit-identical to
+ * sp_nchw_to_nhwc4[_bf16] -> sp_conv2d_fwd -> sp_maxpool3x3s2_nhwc[_bf16].  sp_stem7_pool_ok: the sizes the kernel's 32-bit offsets cover. */
+int sp_stem7_pool_ok(int batch, int h, int w);
+int sp_stem7_pool(const float* x, const void* w_packed, int k_pad, const float* scale, const float* shift, void* y, int bf16,
+                  int batch, int h, int w, void* stream);
 
 /* 1 when `desc` (flags, shapes, tile_m x tile_n) can run with kernel = SP_CONV_KERNEL_RING: bf16 NHWC in and out (ReLU, residual and
  * fused PixelShuffle allowed; no NCHW / fp32 output), c_in % 64 == 0, taps <= 32, k_pad / 64 >= the tile's ring depth, tile_n | n_pad. */

@@ -660,19 +660,44 @@ extern "C" int sp_bn_train_bwd_nhwc(const void* dy, int bf16, const void* relu_s
     return sp_bn_train_bwd_apply_nhwc(dy, bf16, relu_src, z, mean, invstd, gamma, dgamma, dbeta, rows, rows, c, dz, dres, dres_accumulate, stream);
 }
 
-// sum over batch and pixels of an NCHW tensor, one workgroup per channel (the final layer's bias gradient straight from d loss / d heat
-// maps: 17 channels): thread t adds elements t, t + 256, ... of every image in fp64, then a fixed-order tree - deterministic
-__global__ __launch_bounds__(256) void channel_sum_nchw_kernel(const float* __restrict__ x, int batch, int channels, int hw, float* __restrict__ out) {
-    __shared__ double sm[256];
+// sum over batch and pixels of an NCHW tensor, one 1024-thread workgroup per channel (the final layer's bias gradient straight from
+// d loss / d heat maps: 17 channels of 32 x 3072 floats).  Only 17 workgroups exist, so the time is one workgroup's load latency chain:
+// the (image, pixel-quad) space is walked with float4 loads, eight independent ones in flight per thread.  Thread t owns quads t,
+// t + 1024, ... in fp64, then a fixed-order tree - deterministic.  VEC = 1 is the any-size fallback.
+template <int VEC>
+__global__ __launch_bounds__(1024) void channel_sum_nchw_kernel(const float* __restrict__ x, int batch, int channels, int hw, float* __restrict__ out) {
+    __shared__ double sm[1024];
     const int c = blockIdx.x;
+    const int per = hw / VEC;                              // vectors per image plane
+    const int total = batch * per;
     double acc = 0;
-    for (int b = 0; b < batch; ++b) {
-        const float* src = x + ((size_t)b * channels + c) * hw;
-        for (int i = threadIdx.x; i < hw; i += 256) acc += (double)src[i];
+    for (int i0 = threadIdx.x; i0 < total; i0 += 8 * 1024) {
+        float v[8][VEC];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 1024;
+            const int b = i / per, q = i - b * per;
+            const float* src = x + ((size_t)b * channels + c) * hw + (size_t)q * VEC;
+            if (i < total) {
+                if constexpr (VEC == 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(src);
+                    v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w;
+                } else {
+                    v[u][0] = src[0];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[u][e] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc += (double)v[u][e];
     }
     sm[threadIdx.x] = acc;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = 512; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
         __syncthreads();
     }
@@ -680,8 +705,11 @@ __global__ __launch_bounds__(256) void channel_sum_nchw_kernel(const float* __re
 }
 
 extern "C" int sp_channel_sum_nchw(const float* x, int batch, int channels, int hw, float* sum, void* stream) {
-    SP_REQUIRE(x && sum && batch > 0 && channels > 0 && hw > 0, "sp_channel_sum_nchw: bad argument");
-    hipLaunchKernelGGL(channel_sum_nchw_kernel, dim3(channels), dim3(256), 0, (hipStream_t)stream, x, batch, channels, hw, sum);
+    SP_REQUIRE(x && sum && batch > 0 && channels > 0 && hw > 0 && (int64_t)batch * hw < (1ll << 31), "sp_channel_sum_nchw: bad argument");
+    if (hw % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+        hipLaunchKernelGGL(channel_sum_nchw_kernel<4>, dim3(channels), dim3(1024), 0, (hipStream_t)stream, x, batch, channels, hw, sum);
+    else
+        hipLaunchKernelGGL(channel_sum_nchw_kernel<1>, dim3(channels), dim3(1024), 0, (hipStream_t)stream, x, batch, channels, hw, sum);
     return sp_check_launch("channel_sum_nchw_kernel");
 }
 

@@ -97,7 +97,7 @@ class HipPacker:
 # ------------------------------------------------------------------------------------------------
 @dataclass
 class Op:
-    kind: str                    # "conv" | "bb32" (fused BasicBlock) | "bneck64" (fused Bottleneck) | "maxpool" | "to_nhwc4" | "upsample_add" | ...
+    kind: str                    # "conv" | "bb32" (fused BasicBlock) | "bneck64" (fused Bottleneck) | "stem7" (fused ResNet stem) | "maxpool" | "to_nhwc4" | ...
     src: str
     dst: str
     res: Optional[str] = None
@@ -217,6 +217,19 @@ class Program:
             w1, s1, h1, w3, s3, h3 = op.args
             _lib.check(lib.sp_bottleneck_c64(op.desc, P(bufs[op.src]), P(w1), P(s1), P(h1), P(op.w), P(op.scale), P(op.shift), P(w3), P(s3), P(h3),
                                              P(bufs[op.dst]), stream), op.name)
+        elif op.kind == "stem7":
+            h, w, k_pad, unfused = op.args
+            src = bufs[op.src]
+            if src.dtype == torch.uint8:           # BGR crops: the three-launch lowering, whose first launch normalises them
+                tmp = dict(bufs)
+                for u in unfused[:-1]:
+                    uh, uw, uc = self.shapes[u.dst]
+                    tmp[u.dst] = torch.empty(B * uh * uw * uc, dtype=torch.bfloat16 if self.dtype == "bf16" else torch.float32, device=src.device)
+                for u in unfused:
+                    self._launch(lib, u, tmp, B, stream)
+            else:
+                _lib.check(lib.sp_stem7_pool(P(src), P(op.w), k_pad, P(op.scale), P(op.shift), P(bufs[op.dst]), int(self.dtype == "bf16"),
+                                             B, h, w, stream), op.name)
         elif op.kind == "maxpool":
             h, w, c = op.args
             fn = lib.sp_maxpool3x3s2_nhwc_bf16 if self.dtype == "bf16" else lib.sp_maxpool3x3s2_nhwc
@@ -578,6 +591,9 @@ class ProgramBuilder:
         # bf16: whole identity-shortcut Bottlenecks with 64 mid channels (ResNet-50 layer1.1 / layer1.2) as one launch
         # (sp_bottleneck_c64: same bits, x read once and y written once)
         self.fuse_bottlenecks = False
+        # the ResNet stem (conv1 7x7 s2 + bn1 + relu + maxpool) as one launch on the fp32 NCHW image (sp_stem7_pool: same bits, the
+        # 128 x 96 x 64 map between conv and pooling never reaches HBM, K is not padded to a GEMM tile)
+        self.fuse_stem = True
         self.p = Program(dtype=dtype)
         self.bf16 = dtype == "bf16"
         self.cpad = 8 if self.bf16 else 4           # channels per 16-byte chunk
@@ -601,6 +617,24 @@ class ProgramBuilder:
         self.p.shapes[dst] = (h, w, 4)
         self._add(Op("to_nhwc4", src, dst, args=(c, h, w), name="to_nhwc4"))
         return dst
+
+    def stem_pool(self, src: str, weight: torch.Tensor, scale, shift, name: str = "conv1") -> str:
+        """relu(bn(conv 7x7 s2 p3 (3 -> 64))) followed by maxpool 3x3 s2 p1 (pose_resnet_dconv.py:158-162).  With `fuse_stem` the three
+        launches (layout change, implicit GEMM, pooling) become one `stem7` op that reads the fp32 NCHW image directly; the three are
+        kept inside it for uint8 crop input, whose first launch also normalises the pixels."""
+        first = len(self.p.ops)
+        x4 = self.to_nhwc4(src)
+        y = self.conv(x4, weight, stride=2, pad=3, scale=scale, shift=shift, relu=True, name=name)
+        out = self.maxpool(y)
+        h, w, _ = self.p.shapes[src]
+        if not (self.fuse_stem and tuple(weight.shape) == (64, 3, 7, 7) and _lib.lib().sp_stem7_pool_ok(1, h, w)):
+            return out
+        unfused = self.p.ops[first:]
+        del self.p.ops[first:]
+        conv = unfused[1]
+        self._add(Op("stem7", src, out, w=conv.w, scale=scale, shift=shift, args=(h, w, conv.desc.k_pad, tuple(unfused)), name=name,
+                     flops=conv.flops))
+        return out
 
     def maxpool(self, src: str) -> str:
         h, w, c = self.p.shapes[src]
@@ -809,15 +843,14 @@ def _bottleneck(b: ProgramBuilder, sd, x: str, p: str, stride: int) -> str:
 
 
 def resnet_program(sd: Dict[str, torch.Tensor], head: str, in_h: int = 256, in_w: int = 192,
-                   blocks=(3, 4, 6, 3), dtype: str = "fp32", packer=None, fuse_bottlenecks: bool = False) -> Program:
+                   blocks=(3, 4, 6, 3), dtype: str = "fp32", packer=None, fuse_bottlenecks: bool = False, fuse_stem: bool = True) -> Program:
     """Lower a reference-layout state_dict into a Program.  `sd` tensors must be on the GPU.
     `fuse_bottlenecks`: bf16 identity-shortcut Bottlenecks with 64 mid channels as one launch each (sp_bottleneck_c64; same bits)."""
     b = ProgramBuilder(in_h, in_w, dtype, packer)
     b.fuse_bottlenecks = fuse_bottlenecks
-    x = b.to_nhwc4("input")
+    b.fuse_stem = fuse_stem
     s, h = _bn(b, sd, "bn1")
-    x = b.conv(x, sd["conv1.weight"], stride=2, pad=3, scale=s, shift=h, relu=True, name="conv1")
-    x = b.maxpool(x)
+    x = b.stem_pool("input", sd["conv1.weight"], s, h, name="conv1")
     for li, n in enumerate(blocks, start=1):
         for bi in range(n):
             x = _bottleneck(b, sd, x, f"layer{li}.{bi}", 2 if (bi == 0 and li > 1) else 1)

@@ -85,10 +85,11 @@ class PoseResNetBase(nn.Module):
 
     # -- HIP dispatch ------------------------------------------------------------------------------------
     fuse_bottlenecks = False   # True: bf16 layer1.1 / layer1.2 as one launch each (sp_bottleneck_c64); same bits
+    fuse_stem = True           # conv1 + bn1 + relu + maxpool as one launch on the fp32 NCHW image (sp_stem7_pool); same bits
 
     def _tensors_key(self, x):
         sd = self.state_dict(keep_vars=True)
-        return (tuple(x.shape[2:]), str(x.device), self.compute_dtype, self.fuse_bottlenecks) + tuple((v.data_ptr(), v._version) for v in sd.values())
+        return (tuple(x.shape[2:]), str(x.device), self.compute_dtype, self.fuse_bottlenecks, self.fuse_stem) + tuple((v.data_ptr(), v._version) for v in sd.values())
 
     def hip_program(self, x: torch.Tensor) -> engine.Program:
         key = self._tensors_key(x)
@@ -98,7 +99,7 @@ class PoseResNetBase(nn.Module):
                 if v.device != x.device:
                     raise HipLibraryError(f"parameter {k} is on {v.device} but the input is on {x.device}; call .to(device)")
             self._program = engine.resnet_program(sd, self.HEAD, in_h=x.shape[2], in_w=x.shape[3], blocks=self.BLOCKS,
-                                                   dtype=self.compute_dtype, fuse_bottlenecks=self.fuse_bottlenecks)
+                                                   dtype=self.compute_dtype, fuse_bottlenecks=self.fuse_bottlenecks, fuse_stem=self.fuse_stem)
             self._program_key = key
         return self._program
 

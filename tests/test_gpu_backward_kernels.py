@@ -356,3 +356,25 @@ def test_adam_ten_steps_vs_torch_optim(measured):
     _lib.check(lib.sp_adam_step(P(b_p), P(grads[0].to(DEV)), P(b_m), P(b_v), n, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, st), "adam")
     torch.cuda.synchronize()
     assert torch.equal(a_p, b_p) and torch.equal(a_m, b_m) and torch.equal(a_v, b_v)
+
+
+@pytest.mark.parametrize("B,J,hw", [(32, 17, 64 * 48), (3, 5, 35), (1, 17, 4), (130, 2, 9000)])
+def test_bias_gradient_channel_sum_nchw_vs_float64(B, J, hw, measured):
+    """sp_channel_sum_nchw (final_layer.bias.grad = d loss / d heat maps summed over batch and pixels, ddp...:117-118): accumulated in
+    fp64 on the device, so the result is the correctly rounded fp32 of the exact sum (both the float4 walk and the any-size fallback);
+    a view at an odd float offset takes the fallback too."""
+    g = torch.Generator().manual_seed(B * 1000 + hw)
+    x = (torch.randn((B, J, hw), generator=g) * 3.0).to(DEV)
+    lib, st = _lib.lib(), _lib.current_stream()
+    worst = 0.0
+    for off in (0, 1):                                      # off = 1: a start that is only 4-byte aligned (scalar walk)
+        buf = torch.empty(B * J * hw + 1, device=DEV)
+        src = buf[off:off + B * J * hw].view(B, J, hw)
+        src.copy_(x)
+        out = torch.full((J,), float("nan"), device=DEV)
+        _lib.check(lib.sp_channel_sum_nchw(P(src), B, J, hw, P(out), st), "bias.grad")
+        torch.cuda.synchronize()
+        ref = src.double().sum(dim=(0, 2))
+        worst = max(worst, float(((out.double() - ref).abs() / torch.from_numpy(np.spacing(ref.float().abs().cpu().numpy())).double().to(DEV)).max()))
+    measured("ulp_of_exact_sum", worst, 0.51)
+    assert worst <= 0.51

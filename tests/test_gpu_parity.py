@@ -461,6 +461,63 @@ def test_fused_bottlenecks_equal_the_per_conv_program_bitwise(head, B, H, W):
     assert torch.equal(got, ref)
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("head,B,H,W", [("dconv", 3, 256, 192), ("duc", 2, 128, 96), ("dconv", 1, 96, 160), ("dconv", 5, 64, 64)])
+def test_fused_stem_equals_the_three_launch_stem_bitwise(head, B, H, W, dtype):
+    """model.fuse_stem (the default): conv1 + bn1 + relu + maxpool (pose_resnet_dconv.py:158-162) as ONE launch on the fp32 NCHW image
+    (sp_stem7_pool) gives the heat maps of the layout-change / implicit-GEMM / pooling program bit for bit in both compute dtypes -
+    the same MFMA instruction on the same k positions in the same order, only all-padding instructions dropped."""
+    m = {"dconv": pose_resnet_dconv, "duc": pose_resnet_duc}[head].resnet50(pretrained=False, num_classes=17)
+    sd = synth.conditioned_state_dict(nets_oracle.state_dict_shapes_resnet50(head), 8)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m = m.to(DEV).eval()
+    m.compute_dtype = dtype
+    m.autotune = False
+    x = _cuda(synth.input_images(B, 23, h=H, w=W))
+    with torch.no_grad():
+        m.fuse_stem = False
+        ref = m(x).clone()
+        n_ref = len(m.hip_program(x).ops)
+        m.fuse_stem = True
+        got = m(x)
+        prog = m.hip_program(x)
+    assert prog.ops[0].kind == "stem7" and len(prog.ops) == n_ref - 2
+    assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("B,H,W", [(2, 70, 50), (1, 8, 8), (3, 34, 130), (1, 258, 62)])
+def test_fused_stem_kernel_on_ragged_sizes_bitwise(B, H, W, dtype):
+    """sp_stem7_pool through the C ABI against sp_nchw_to_nhwc4 -> sp_conv2d_fwd -> sp_maxpool3x3s2_nhwc on sizes whose pooled maps are
+    not multiples of the 8 x 8 tile (the nets only see multiples of 32): ragged tiles, image borders inside every patch, one-tile
+    images.  Values include negatives after BatchNorm (ReLU clamps) and a NaN and an inf pixel (treated alike by both paths)."""
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    w = torch.randn((64, 3, 7, 7), generator=g).to(DEV) * 0.1
+    scale = (torch.rand(64, generator=g) + 0.5).to(DEV)
+    shift = (torch.randn(64, generator=g) * 0.3).to(DEV)
+    x = torch.randn((B, 3, H, W), generator=g).to(DEV)
+    x[0, 0, H // 2, W // 2] = float("inf")
+    x[B - 1, 2, 1, 1] = float("nan")
+    outs = []
+    for fuse in (False, True):
+        b = engine.ProgramBuilder(H, W, dtype)
+        b.fuse_stem = fuse
+        out = b.stem_pool("input", w, scale, shift)
+        prog = b.p
+        assert [op.kind for op in prog.ops] == (["stem7"] if fuse else ["to_nhwc4", "conv", "maxpool"])
+        bufs = dict(prog._alloc(B, x.device))
+        bufs["input"] = x
+        for op in prog.ops:
+            prog._launch(_lib.lib(), op, bufs, B, _lib.current_stream())
+        torch.cuda.synchronize()
+        outs.append(bufs[out].clone())
+    hp, wp = ((H - 1) // 2 + 1 - 1) // 2 + 1, ((W - 1) // 2 + 1 - 1) // 2 + 1
+    assert outs[0].numel() == B * hp * wp * 64
+    assert torch.equal(outs[0].view(torch.int16 if dtype == "bf16" else torch.int32), outs[1].view(torch.int16 if dtype == "bf16" else torch.int32))
+    # (the ReLU `v > 0 ? v : 0` of every path turns a NaN accumulator into 0; +inf survives it)
+    assert float(torch.nan_to_num(outs[1].float(), nan=0.0, posinf=0.0).abs().max()) > 0 and bool(torch.isinf(outs[1].float()).any())
+
+
 def test_full_batch_128_is_consistent_with_golden(golden):
     """BASELINE configs[1] size (bs=128): images repeat the two golden inputs, so every output must equal the
     golden pair's - bitwise among replicas (deterministic kernels), 1e-4 rel against the reference."""
