@@ -47,7 +47,13 @@ def parse():
                          "the 104 small messages per step expose on xGMI, for boxes with one GPU")
     ap.add_argument("--bucket-mb", type=float, default=32.0, help="train mode, N > 1: gradient all-reduce bucket size")
     ap.add_argument("--single-stream", action="store_true", help="infer mode: issue independent branches (HRNet) on one stream")
-    ap.add_argument("--graph", action="store_true", help="infer mode: replay the step (forward + decode) as one captured hipGraph")
+    ap.add_argument("--graph", action="store_true", help="replay the step as one captured hipGraph (infer: forward + decode; train: PoseTrainer.capture - "
+                    "forward, loss, backward, collectives, Adam and repack on their three streams)")
+    ap.add_argument("--torch-collectives", action="store_true", help="train mode: issue the step's collectives through torch.distributed (each on RCCL's own "
+                    "stream, fenced by events) instead of RCCL directly on the step's streams (sp_comm_allreduce_sum_f32); also where the emulated "
+                    "--sync-bn-latency-us is spent")
+    ap.add_argument("--preflight-rccl", action="store_true", help="train mode on ONE GPU: join a 1-rank RCCL group and issue every SyncBatchNorm / gradient "
+                    "all-reduce of the step through it (nothing to exchange, but the calls, their streams and - with --graph - their capture are real)")
     ap.add_argument("--tiles", default=None, help="JSON tile table: loaded if it exists (skips autotune), else written.  Default: the tracked "
                     "table of this (arch, dtype) under profiles/ when the batch is 128 (the table the committed rocprofv3 summaries were taken with)")
     ap.add_argument("--no-train-autotune", action="store_true", help="train mode: keep the built-in tile heuristic")
@@ -266,6 +272,11 @@ def main():
         raise SystemExit(f"--gpus {world} on a node with {n_dev} GPU(s): RCCL needs one device per rank "
                          "(--dist-backend gloo shares devices, for exercising the N > 1 path only)")
     dev_index = local_rank % n_dev
+    if world == 1 and args.preflight_rccl:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29000 + os.getpid() % 2000))
+        torch.cuda.set_device(dev_index)
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", dev_index))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(dev_index)
@@ -312,7 +323,8 @@ def main():
         from simple_pose_amd.train import PoseTrainer
         model.train()
         trainer = PoseTrainer(model, lr=1e-3, dtype="bf16" if args.dtype == "bf16" else "fp32", sync_bn=not args.no_sync_bn,
-                              bucket_mb=args.bucket_mb, sync_bn_latency_us=args.sync_bn_latency_us)
+                              bucket_mb=args.bucket_mb, sync_bn_latency_us=args.sync_bn_latency_us,
+                              native_comm=False if args.torch_collectives else None, sync_bn_inline=not args.torch_collectives)
         # untimed setup: the tile of every forward / dgrad launch.  Default: the tracked table of this dtype under profiles/ (the one the
         # committed rocprofv3 summaries were taken with: no tuner launches in a profiled run, same launches on every rank and box);
         # --retune / a missing table: timed on rank 0 at this batch and shared
@@ -332,10 +344,22 @@ def main():
         joints = torch.from_numpy(synth.joints_batch(B, 17, seed=200 + rank)).to(dev)
         targets, mask = RefineSimpleTransform.get_heat_map(joints, 2.0, (48, 64))   # HIP encoder, on device
         prog = None
+        if args.preflight_rccl and world == 1:
+            trainer.force_collectives = True
+            trainer.sync_bn = not args.no_sync_bn
+            if not args.torch_collectives:
+                trainer._open_native_comm()
 
-        def step():
+        def eager_step():
             loss = trainer.step(x, targets, mask)      # fwd + loss + bwd + gradient all-reduce (N > 1) + Adam + repack
             return (loss,)
+        step = eager_step
+        graphed_step = None
+        if args.graph:
+            graphed_step = trainer.capture(x, targets, mask)      # untimed setup: three eager steps, then the capture
+
+            def step():
+                return (graphed_step.step(graphed_step.x, graphed_step.targets, graphed_step.mask),)   # the batch is resident in the static inputs
     else:
         prog = model.hip_program(x)
         prog.multi_stream = not args.single_stream
@@ -405,6 +429,9 @@ def main():
 
     step_split = None
     if args.mode == "train":                                  # untimed extra steps with phase events (every rank: collectives inside)
+        if graphed_step is not None:                          # (timing events cannot live inside a graph: these steps run eagerly)
+            graphed_step.release()
+            step = eager_step
         trainer.profile = True
         acc = {}
         with torch.no_grad():
@@ -434,6 +461,8 @@ def main():
                 "network_frac_of_matrix_peak": round(value * gflop / 1e3 / ((FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else BF16_MATRIX_PEAK_TFLOPS) * world), 4),
                 "roofline": roofline, "cpu_baseline": None, "final_loss": float(out[0].item()), "step_split_ms": step_split,
                 "host_enqueue_ms_per_step": round(host_enqueue_ms, 3), "sync_bn_latency_us_emulated": args.sync_bn_latency_us,
+                "step_as_hip_graph": bool(args.graph), "rccl_preflight_one_rank": bool(args.preflight_rccl and world == 1),
+                "collective_path": "torch.distributed" if (args.torch_collectives or trainer._comm is None and world > 1) else ("sp_comm (RCCL on the step's streams)" if trainer._comm is not None else "none"),
                 "collectives_per_step": {"gradient_buckets": len(trainer.buckets) if world > 1 else 0, "sync_bn": trainer.collective_count}}
         else:
             peak = FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else BF16_MATRIX_PEAK_TFLOPS

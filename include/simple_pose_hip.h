@@ -27,7 +27,7 @@ extern "C" {
 #define SP_EINVAL (-1)   /* bad argument / unsupported shape (message in sp_last_error) */
 #define SP_ELAUNCH (-2)  /* HIP launch or runtime failure */
 
-#define SP_ABI_VERSION 23
+#define SP_ABI_VERSION 24
 
 /* epilogue / layout flags of sp_conv_desc.flags */
 #define SP_CONV_RELU 0x1u          /* y = max(y, 0) after scale/shift (+ residual) */
@@ -335,6 +335,13 @@ int sp_maxpool3x3s2_bwd_idx_nhwc(const void* idx, const void* dy, int bf16, void
  * 1 - beta, the bias corrections and lr / (1 - beta1^step) are formed in double and rounded to fp32 once, as torch does */
 int sp_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
                  double beta2, double eps, int step, float grad_scale, void* stream);
+
+/* The same update with the step's eight scalars (step size, betas, 1 - betas, eps, sqrt of the second bias correction, gradient scale) in
+ * device memory: sp_adam_set_scalars forms them on the host exactly as sp_adam_step does and writes them with one tiny launch;
+ * sp_adam_step_dev launches then have arguments that never change from step to step, so a captured train step (hipGraph: PoseTrainer.capture)
+ * replays - bit-identical to sp_adam_step with the same hyper-parameters. */
+int sp_adam_set_scalars(double lr, double beta1, double beta2, double eps, int step, float grad_scale, float* scalars8, void* stream);
+int sp_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* scalars8, void* stream);
 /* weight gradient of one conv / transposed-conv launch family: dW[n][(ty,tx,c)] = sum_m g[m][n] * im2col(a)[m][(ty,tx,c)],
  * `desc` describing how `a` is gathered (as in sp_conv2d_fwd; tile/out_* ignored; flags & SP_CONV_BF16: g and a are
  * bf16, dW stays fp32), g = [rows, g_channels] NHWC.
@@ -377,6 +384,17 @@ int sp_permute4_batched(const float* src, const void* jobs_device, int n_jobs, i
 /* measurement aid: occupies `stream` for `us` microseconds (one idle wave on the 100 MHz constant clock) - bench.py's stand-in for the
  * latency of a SyncBatchNorm message (ddp...:89-90) on a box with a single GPU */
 int sp_stream_delay_us(double us, void* stream);
+
+/* RCCL called directly, for the collectives that sit on the train step's critical path (replaces the `SyncBatchNorm` exchanges and the
+ * DistributedDataParallel gradient all-reduces of ddp...:89-93 issued through torch.distributed): sp_comm_allreduce_sum_f32 enqueues ONE
+ * in-place fp32 SUM all-reduce on the caller's stream - stream order is the dependency, one host call per message.  librccl is resolved
+ * at run time (sp_comm_available() == 0 where it is absent; everything single-GPU still works).  sp_comm_unique_id: rank 0 makes the 128-byte
+ * id, the caller ships it to the other ranks (any channel), every rank calls sp_comm_create on its own device. */
+int sp_comm_available(void);
+int sp_comm_unique_id(void* id128);
+int sp_comm_create(const void* id128, int world, int rank, void** comm);
+int sp_comm_allreduce_sum_f32(void* comm, float* buf, int64_t n, void* stream);
+int sp_comm_destroy(void* comm);
 
 /* ---- parameter packing: the reference's tensors -> what the launches above read ------------------------------------------
  * (all pointers are device memory; every call fills its whole destination, padding included)

@@ -20,7 +20,7 @@ SP_CONV_PIXEL_SHUFFLE = 0x4
 SP_CONV_BF16 = 0x8
 SP_CONV_OUT_F32 = 0x10
 CONV_TILES = ((128, 128), (64, 128), (128, 64), (64, 64), (256, 64), (128, 32))
-ABI_VERSION = 23
+ABI_VERSION = 24
 SP_CONV_KERNEL_IGEMM, SP_CONV_KERNEL_RING = 0, 1
 RING_TILES = ((256, 256), (256, 128), (128, 256), (256, 64), (128, 128), (192, 128), (192, 256))   # kernel = SP_CONV_KERNEL_RING (bf16)
 
@@ -82,6 +82,13 @@ SYMBOLS = {
     "sp_channel_sum_nhwc": (c_int, [_P, c_int64, c_int, _P, _P, _P]),
     "sp_maxpool3x3s2_bwd_nhwc": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "sp_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_double, c_double, c_double, c_double, c_int, c_float, _P]),
+    "sp_adam_set_scalars": (c_int, [c_double, c_double, c_double, c_double, c_int, c_float, _P, _P]),
+    "sp_adam_step_dev": (c_int, [_P, _P, _P, _P, c_int64, _P, _P]),
+    "sp_comm_available": (c_int, []),
+    "sp_comm_unique_id": (c_int, [_P]),
+    "sp_comm_create": (c_int, [_P, c_int, c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "sp_comm_allreduce_sum_f32": (c_int, [_P, _P, c_int64, _P]),
+    "sp_comm_destroy": (c_int, [_P]),
     "sp_conv2d_wgrad": (c_int, [ctypes.POINTER(ConvDesc), _P, c_int, _P, c_int, c_int, c_int, c_int64, c_int64, _P, _P, c_int64, _P]),
     "sp_conv2d_wgrad_workspace": (c_int, [ctypes.POINTER(WgradJob), c_int, ctypes.POINTER(c_int64)]),
     "sp_conv2d_wgrad_batched": (c_int, [ctypes.POINTER(WgradJob), c_int, _P, c_int64, _P]),

@@ -48,7 +48,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.run(cmd, check=True)
         objs.append(obj)
-    cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

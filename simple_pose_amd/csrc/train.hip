@@ -417,8 +417,15 @@ __global__ void nchw_to_nhwc_pad_kernel(const float* __restrict__ x, void* __res
 }
 
 // torch.optim.Adam (no amsgrad, weight_decay 0) on flat buffers; g is multiplied by grad_scale first (1/world after a SUM all-reduce)
+struct AdamScalars { float step_size, b1, b2, omb1, omb2, eps, bc2_sqrt, grad_scale; };
+
+// DEV: the eight scalars come from device memory (sp_adam_set_scalars wrote them) instead of the kernel arguments - the launch is then
+// the same every step, which is what lets a captured train step (hipGraph) be replayed
+template <bool DEV>
 __global__ void adam_kernel(f32x4* __restrict__ p, const f32x4* __restrict__ g, f32x4* __restrict__ m, f32x4* __restrict__ v, long long n4,
-                            float step_size, float b1, float b2, float omb1, float omb2, float eps, float bc2_sqrt, float grad_scale) {
+                            AdamScalars a, const AdamScalars* __restrict__ dev) {
+    if constexpr (DEV) a = *dev;
+    const float step_size = a.step_size, b1 = a.b1, b2 = a.b2, omb1 = a.omb1, omb2 = a.omb2, eps = a.eps, bc2_sqrt = a.bc2_sqrt, grad_scale = a.grad_scale;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         f32x4 pp = p[i], gg = g[i], mm = m[i], vv = v[i];
 #pragma unroll
@@ -432,6 +439,8 @@ __global__ void adam_kernel(f32x4* __restrict__ p, const f32x4* __restrict__ g, 
         p[i] = pp; m[i] = mm; v[i] = vv;
     }
 }
+
+__global__ void adam_set_scalars_kernel(AdamScalars a, AdamScalars* __restrict__ dst) { *dst = a; }
 
 // generic 4-D gather-copy: dst[((a*D1 + b)*D2 + c)*D3 + d] = (in range) ? src[a*s0 + b*s1 + c*s2 + d*s3 + base] : 0
 struct Permute4 {
@@ -779,15 +788,37 @@ extern "C" int sp_nchw_to_nhwc_pad(const float* x, void* y, int y_bf16, int batc
 
 // Hyper-parameters arrive as doubles: torch forms 1 - beta, 1 - beta^step and lr / (1 - beta1^step) in Python doubles and only then hands
 // them to its fp32 kernels; forming them from fp32 betas is a 1.3e-5 relative error in 1 - beta2 (0.999f = 0.99900001287).
+static AdamScalars adam_scalars(double lr, double beta1, double beta2, double eps, int step, float grad_scale) {
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    return AdamScalars{(float)(lr / bc1), (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)sqrt(bc2), grad_scale};
+}
+
 extern "C" int sp_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
                             double beta2, double eps, int step, float grad_scale, void* stream) {
     SP_REQUIRE(param && grad && exp_avg && exp_avg_sq, "sp_adam_step: null pointer");
     SP_REQUIRE(n > 0 && n % 4 == 0 && step >= 1, "sp_adam_step: n=%lld must be a positive multiple of 4 and step >= 1", (long long)n);
-    const double bc1 = 1.0 - pow(beta1, (double)step);
-    const double bc2 = 1.0 - pow(beta2, (double)step);
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<f32x4*>(param),
+    hipLaunchKernelGGL(adam_kernel<false>, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<f32x4*>(param),
                        reinterpret_cast<const f32x4*>(grad), reinterpret_cast<f32x4*>(exp_avg), reinterpret_cast<f32x4*>(exp_avg_sq), n / 4,
-                       (float)(lr / bc1), (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)sqrt(bc2), grad_scale);
+                       adam_scalars(lr, beta1, beta2, eps, step, grad_scale), nullptr);
+    return sp_check_launch("adam_kernel");
+}
+
+// The same update with the step's scalars in device memory: sp_adam_set_scalars (one tiny launch per step, the values formed on the host
+// exactly as sp_adam_step forms them) + any number of sp_adam_step_dev launches whose arguments never change - a captured step replays
+extern "C" int sp_adam_set_scalars(double lr, double beta1, double beta2, double eps, int step, float grad_scale, float* scalars8, void* stream) {
+    SP_REQUIRE(scalars8 && step >= 1, "sp_adam_set_scalars: null pointer or step < 1");
+    hipLaunchKernelGGL(adam_set_scalars_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, adam_scalars(lr, beta1, beta2, eps, step, grad_scale),
+                       reinterpret_cast<AdamScalars*>(scalars8));
+    return sp_check_launch("adam_set_scalars_kernel");
+}
+
+extern "C" int sp_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* scalars8, void* stream) {
+    SP_REQUIRE(param && grad && exp_avg && exp_avg_sq && scalars8, "sp_adam_step_dev: null pointer");
+    SP_REQUIRE(n > 0 && n % 4 == 0, "sp_adam_step_dev: n=%lld must be a positive multiple of 4", (long long)n);
+    hipLaunchKernelGGL(adam_kernel<true>, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<f32x4*>(param),
+                       reinterpret_cast<const f32x4*>(grad), reinterpret_cast<f32x4*>(exp_avg), reinterpret_cast<f32x4*>(exp_avg_sq), n / 4,
+                       AdamScalars{}, reinterpret_cast<const AdamScalars*>(scalars8));
     return sp_check_launch("adam_kernel");
 }
 

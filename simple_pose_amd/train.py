@@ -367,7 +367,8 @@ class PoseTrainer:
 
     def __init__(self, model, in_h: int = 256, in_w: int = 192, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  process_group=None, dtype: str = "fp32", sync_bn: Optional[bool] = None, bucket_mb: float = 32.0,
-                 broadcast_init: bool = True, overlap_wgrad: bool = True, collectives: bool = True, sync_bn_latency_us: float = 0.0):
+                 broadcast_init: bool = True, overlap_wgrad: bool = True, collectives: bool = True, sync_bn_latency_us: float = 0.0,
+                 native_comm: Optional[bool] = None, sync_bn_inline: bool = True):
         """dtype "bf16": bf16 activations and packed weights (v_mfma_f32_32x32x16_bf16 for forward, dgrad and wgrad); the
         gradient w.r.t. a block output stays fp32 until the BatchNorm backward has subtracted its per-channel mean (rounding
         it to bf16 first costs 10-50 % gradient error in this net: the useful part is a small difference of large terms), the
@@ -379,7 +380,13 @@ class PoseTrainer:
           * `sync_bn` (default: on, as `SyncBatchNorm.convert_sync_batchnorm` at ddp...:89-90): batch statistics and the two
             backward sums of every BN layer are summed over ranks (one [2C] all-reduce each way per layer);
           * the flat gradient buffer is all-reduced in `bucket_mb`-sized contiguous slices, each launched (async, on RCCL's
-            own stream) as soon as backward has produced its last gradient - final_layer's end of the buffer first."""
+            own stream) as soon as backward has produced its last gradient - final_layer's end of the buffer first.
+        `native_comm` (default: on when the group's backend is nccl and librccl resolves): the step's collectives go to RCCL directly
+        (`sp_comm_allreduce_sum_f32`, csrc/comm.hip) - a SyncBatchNorm message is then ONE host call that enqueues the all-reduce on the
+        compute stream (the chain of dependent launches leaves nothing to run under it; through torch.distributed each message costs
+        five stream / event calls from Python and the step becomes host-bound), a gradient bucket one call on the optimizer stream.
+        `sync_bn_inline`: where the emulated message latency (`sync_bn_latency_us`) is spent - on the compute stream (as the native
+        path does) or on a message stream fenced by events (as torch.distributed does)."""
         if dtype not in ("fp32", "bf16"):
             raise ValueError(dtype)
         self.bf16 = dtype == "bf16"
@@ -404,8 +411,11 @@ class PoseTrainer:
         # side stream the consumer waits for; on ONE rank it switches the SyncBatchNorm code path on with nothing to exchange, which
         # bounds what the 104 messages per step would expose on xGMI without an 8-GPU node
         self.sync_bn_latency_us = float(sync_bn_latency_us)
+        self.sync_bn_inline = bool(sync_bn_inline)
         if self.sync_bn_latency_us > 0 and (sync_bn is None or sync_bn):
             self.sync_bn = True
+        self._comm = None
+        self._native_comm_wanted = native_comm
         self.flat = FlatParams(model, attach_grads=collectives)
         dev = self.flat.data.device
         self.exp_avg = torch.zeros_like(self.flat.data)
@@ -426,6 +436,47 @@ class PoseTrainer:
                 dist.broadcast(b, src=dist.get_global_rank(self.pg, 0) if self.pg is not None else 0, group=self.pg)
         self._plan_buckets(bucket_mb)
         self.repack()
+        if self.world > 1:
+            self._open_native_comm()
+
+    def _open_native_comm(self) -> None:
+        """One RCCL communicator of our own over the ranks of the process group (the 128-byte id travels through the group itself)."""
+        import torch.distributed as dist
+        want = self._native_comm_wanted
+        lib = _lib.lib()
+        usable = dist.get_backend(self.pg) == "nccl" and bool(lib.sp_comm_available())
+        if want is None:
+            want = usable
+        if not want:
+            return
+        if not usable:
+            raise _lib.HipLibraryError("native_comm=True needs an nccl-backed process group and librccl (sp_comm_available() == 1)")
+        dev = self.flat.data.device
+        world, rank = dist.get_world_size(self.pg), dist.get_rank(self.pg)
+        idt = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = (ctypes.c_ubyte * 128)()
+            _lib.check(lib.sp_comm_unique_id(buf), "sp_comm_unique_id")
+            idt = torch.tensor(list(buf), dtype=torch.uint8)
+        idt = idt.to(dev)
+        if world > 1:
+            dist.broadcast(idt, src=dist.get_global_rank(self.pg, 0) if self.pg is not None else 0, group=self.pg)
+        raw = bytes(idt.cpu().tolist())
+        comm = ctypes.c_void_p()
+        with torch.cuda.device(dev):
+            _lib.check(lib.sp_comm_create(raw, world, rank, ctypes.byref(comm)), "sp_comm_create")
+        self._comm = comm
+
+    def close(self) -> None:
+        """Release the RCCL communicator (if any); the trainer must not step afterwards."""
+        if self._comm is not None:
+            torch.cuda.synchronize(self.flat.data.device)
+            _lib.check(_lib.lib().sp_comm_destroy(self._comm), "sp_comm_destroy")
+            self._comm = None
+
+    def _all_reduce_sum(self, t: torch.Tensor, stream) -> None:
+        """In-place SUM over the ranks on `stream` through our own communicator."""
+        _lib.check(_lib.lib().sp_comm_allreduce_sum_f32(self._comm, P(t), t.numel(), stream), "all-reduce")
 
     # ---- gradient buckets (DDP reducer, reverse parameter order) ---------------------------------------------------------
     def _plan_buckets(self, bucket_mb: float):
@@ -483,12 +534,11 @@ class PoseTrainer:
             if self._wgrad_tail is not None:
                 opt.wait_event(self._wgrad_tail)
             with torch.cuda.stream(opt):
-                if self.world > 1:
+                if self._comm is not None:
+                    self._all_reduce_sum(self.flat.grad[b["lo"]:b["hi"]], _lib.c_void_p(opt.cuda_stream))
+                elif self.world > 1 or self.force_collectives:
                     dist.all_reduce(self.flat.grad[b["lo"]:b["hi"]], op=dist.ReduceOp.SUM, group=self.pg)
-                sl = slice(b["lo"], b["hi"])
-                _lib.check(_lib.lib().sp_adam_step(P(self.flat.data[sl]), P(self.flat.grad[sl]), P(self.exp_avg[sl]), P(self.exp_avg_sq[sl]),
-                                                   b["hi"] - b["lo"], self.lr, self.betas[0], self.betas[1], self.eps, self.step_count,
-                                                   1.0 / self.world, _lib.c_void_p(opt.cuda_stream)), "adam")
+                self._adam(slice(b["lo"], b["hi"]), 1.0 / self.world, _lib.c_void_p(opt.cuda_stream))
                 self.repack(self._pack_rows_of_bucket[i], _lib.c_void_p(opt.cuda_stream))
             ev[1].record(opt)
             self._works[i] = ev[1]
@@ -519,15 +569,21 @@ class PoseTrainer:
 
     # ---- SyncBatchNorm messages: issued where the sums exist, waited for where the statistics are consumed -----------------------
     def _exchange(self, t: torch.Tensor):
-        """SUM `t` over the ranks, asynchronously (RCCL runs the all-reduce on its own stream behind the compute stream's current
-        position); returns the token `_exchange_wait` takes.  Whatever is launched between the two calls runs under the message."""
+        """SUM the fp32 tensor `t` over the ranks; returns the token `_exchange_wait` takes.  Native path: the all-reduce is enqueued on
+        the compute stream right here (one call; the consumer is simply the next launch).  torch.distributed path: asynchronously on
+        RCCL's own stream behind the compute stream's current position - whatever is launched between the two calls runs under it."""
         self.collective_count += 1
         work = ev = None
-        if self.world > 1:
+        if self._comm is not None:
+            self._all_reduce_sum(t, _lib.current_stream(t.device))
+        elif self.world > 1 or self.force_collectives:
             import torch.distributed as dist
             work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         if self.sync_bn_latency_us > 0:
             dev = t.device
+            if self.sync_bn_inline:
+                _lib.check(_lib.lib().sp_stream_delay_us(self.sync_bn_latency_us, _lib.current_stream(dev)), "delay")
+                return work, ev
             if getattr(self, "_comm_stream", None) is None:
                 self._comm_stream = torch.cuda.Stream(device=dev)
             comm, main = self._comm_stream, torch.cuda.current_stream(dev)
@@ -1147,11 +1203,26 @@ class PoseTrainer:
         self._works = None
         return 1.0 / self.world
 
+    def _adam(self, sl: slice, grad_scale: float, stream) -> None:
+        """torch.optim.Adam on a slice of the flat buffers (ddp...:70-72,119).  Under `capture()` the step's scalars live in device memory
+        (written once per step by `_adam_scalars_for_step`), so the launch is identical every step."""
+        lib, n = _lib.lib(), sl.stop - sl.start
+        if self._adam_scalars is not None:
+            _lib.check(lib.sp_adam_step_dev(P(self.flat.data[sl]), P(self.flat.grad[sl]), P(self.exp_avg[sl]), P(self.exp_avg_sq[sl]), n,
+                                            P(self._adam_scalars), stream), "adam")
+        else:
+            _lib.check(lib.sp_adam_step(P(self.flat.data[sl]), P(self.flat.grad[sl]), P(self.exp_avg[sl]), P(self.exp_avg_sq[sl]), n,
+                                        self.lr, self.betas[0], self.betas[1], self.eps, self.step_count, grad_scale, stream), "adam")
+
+    def _adam_scalars_for_step(self, grad_scale: float) -> None:
+        """Next optimizer step: count it and hand its scalars to the device (outside the captured region, before the replay)."""
+        self.step_count += 1
+        _lib.check(_lib.lib().sp_adam_set_scalars(self.lr, self.betas[0], self.betas[1], self.eps, self.step_count, grad_scale,
+                                                  P(self._adam_scalars), _lib.current_stream()), "adam scalars")
+
     def optimizer_step(self, grad_scale: float = 1.0):
         self.step_count += 1
-        _lib.check(_lib.lib().sp_adam_step(P(self.flat.data), P(self.flat.grad), P(self.exp_avg), P(self.exp_avg_sq), self.flat.numel,
-                                           self.lr, self.betas[0], self.betas[1], self.eps, self.step_count, grad_scale,
-                                           _lib.current_stream()), "adam")
+        self._adam(slice(0, self.flat.numel), grad_scale, _lib.current_stream())
         self.repack()
         if getattr(self.model, "_program", None) is not None:
             self.model._program = None        # the eval-mode program holds BN-folded copies of the weights the kernel just changed
@@ -1167,7 +1238,8 @@ class PoseTrainer:
             self.optimizer_step(scale)
             self._mark("adam_repack")
             return loss
-        self.step_count += 1
+        if self._adam_scalars is None:
+            self.step_count += 1                           # (a captured step is counted by GraphedStep, outside the graph)
         self._opt_in_backward = True
         try:
             loss = self.forward_backward(x, targets, mask)
@@ -1179,6 +1251,14 @@ class PoseTrainer:
         self._mark("adam_repack")
         return loss
 
+    def capture(self, x: torch.Tensor, targets: torch.Tensor, mask: torch.Tensor, warmup: int = 3) -> "GraphedStep":
+        """Record `step()` for this batch shape into ONE hipGraph: the ~400 launches on three streams (and, with a process group, RCCL's
+        collectives) become a single graph launch per step - the host needs ~4 ms to enqueue a 6.3 ms bf16 step kernel by kernel,
+        and twice that once SyncBatchNorm adds its 104 messages.  See GraphedStep."""
+        return GraphedStep(self, x, targets, mask, warmup)
+
+    _adam_scalars = None       # device [8] floats while a captured step owns the optimizer's scalars (see capture())
+    force_collectives = False  # issue the SyncBatchNorm / gradient collectives on ONE rank too (a 1-rank RCCL group: preflight of their capture)
     fuse_optimizer = True
     use_arena = True           # step / forward_backward reuse last step's tensors request by request (see _take)
     kernel_events = None       # bench.py: a list collects (kind, layer, flops per image, start event, end event) per conv-family launch
@@ -1207,3 +1287,59 @@ class PoseTrainer:
         torch.cuda.synchronize()
         m = self._marks
         return {m[i][0]: m[i - 1][1].elapsed_time(m[i][1]) for i in range(1, len(m))}
+
+
+class GraphedStep:
+    """`PoseTrainer.step` of one batch shape as a hipGraph (HIP stream capture through torch.cuda.CUDAGraph).
+
+    What makes the step capturable: every tensor it touches has a fixed address (the step arena, the flat parameter / gradient / moment
+    buffers, the packed weights, static copies of the inputs); the three streams of the step fork from and join the capturing stream
+    through events; nothing in it synchronises with the host; and the only launch arguments that change from step to step - Adam's
+    bias-corrected step size - are read from device memory (`sp_adam_step_dev`), refreshed by one tiny launch in front of every replay.
+    With a process group the RCCL all-reduces (gradient buckets, SyncBatchNorm messages) are captured with the kernels.
+
+        g = trainer.capture(x, targets, mask)      # a few eager steps (tile tables, arena, streams), then the capture
+        loss = g.step(x, targets, mask)            # copies the batch into the static inputs, replays; same results as trainer.step
+
+    The eager steps taken here are real optimizer steps on the given batch (as torch's own graph warm-up recipes do)."""
+
+    def __init__(self, tr: PoseTrainer, x: torch.Tensor, targets: torch.Tensor, mask: torch.Tensor, warmup: int = 3):
+        if not tr.fuse_optimizer:
+            raise ValueError("capture() records the fused step (optimizer inside backward)")
+        if tr.profile or tr.kernel_events is not None:
+            raise ValueError("capture(): timing events (profile / kernel_events) cannot be recorded inside a graph")
+        self.tr = tr
+        dev = tr.flat.data.device
+        self.x = _lib.require_cuda_f32(x, "input").clone()
+        self.targets = _lib.require_cuda_f32(targets, "targets").clone()
+        self.mask = _lib.require_cuda_f32(mask, "mask").clone()
+        tr._adam_scalars = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.grad_scale = 1.0 / tr.world
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):                 # eager, on the stream the capture will use: streams, events, arena, tile opt-ins
+                tr._adam_scalars_for_step(self.grad_scale)
+                tr.step(self.x, self.targets, self.mask)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=side):
+            self.loss = tr.step(self.x, self.targets, self.mask)
+        self.launches = None
+
+    def step(self, x: torch.Tensor, targets: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        if x is not self.x:
+            self.x.copy_(x, non_blocking=True)
+        if targets is not self.targets:
+            self.targets.copy_(targets, non_blocking=True)
+        if mask is not self.mask:
+            self.mask.copy_(mask, non_blocking=True)
+        self.tr._adam_scalars_for_step(self.grad_scale)
+        self.graph.replay()
+        return self.loss
+
+    def release(self) -> None:
+        """Give the optimizer's scalars back to the eager path (`trainer.step` works as before)."""
+        self.tr._adam_scalars = None
+        self.graph = None

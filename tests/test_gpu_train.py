@@ -239,6 +239,57 @@ def test_two_rank_step_matches_single_rank(sync_bn, fused, head, tmp_path):
     assert agree > 0.99, agree                     # first Adam step = lr * sign(grad): the update direction agrees
 
 
+def _one_rank_rccl_worker(rank, port, out_dir):
+    """A 1-rank RCCL group on the GPU: every collective of the SyncBatchNorm + DDP step is issued for real (nothing to exchange, so the
+    results must equal the local step's), through torch.distributed and through the library's own communicator, eagerly and captured."""
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    x, t, w = _batch(4, 64, 64, 11)
+    xs, ts, ws = (torch.from_numpy(v).to(DEV) for v in (x, t, w))
+    res = {}
+    for mode in ("local", "torch", "native", "native_graph"):
+        model, _ = _model(3)
+        tr = PoseTrainer(model, in_h=64, in_w=64, lr=1e-3, bucket_mb=8.0, collectives=mode != "local", native_comm=False)
+        if mode != "local":
+            tr.force_collectives, tr.sync_bn = True, True
+        if mode.startswith("native"):
+            tr._native_comm_wanted = True
+            tr._open_native_comm()
+            assert tr._comm is not None
+        if mode == "native_graph":
+            g = tr.capture(xs, ts, ws, warmup=2)
+            losses = [g.step(xs, ts, ws).item() for _ in range(2)]
+        else:
+            losses = [tr.step(xs, ts, ws).item() for _ in range(4)][2:]
+        torch.cuda.synchronize()
+        res[mode] = (losses, tr.flat.data.cpu().numpy().copy(), tr.collective_count)
+        tr.close()
+    np.savez(os.path.join(out_dir, "one_rank.npz"), **{f"{m}_{k}": v for m, (l, p, c) in res.items() for k, v in (("loss", np.array(l)), ("param", p), ("n", np.array(c)))})
+    dist.destroy_process_group()
+
+
+def test_one_rank_rccl_collectives_leave_the_step_unchanged(tmp_path):
+    """Preflight of the RCCL leg on the one GPU there is: with a 1-rank nccl group every SyncBatchNorm message (104 per step) and every
+    gradient bucket really goes through RCCL - via torch.distributed (its own stream + events) and via sp_comm_allreduce_sum_f32 (on the
+    step's own streams; also inside a captured step) - and the three ways give the same parameters after four steps bit for bit
+    (the local-statistics step agrees to rounding)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_one_rank_rccl_worker, args=(port, str(tmp_path)), nprocs=1, join=True)
+    r = np.load(tmp_path / "one_rank.npz")
+    assert int(r["local_n"]) == 0 and int(r["torch_n"]) == 104 and int(r["native_n"]) == 104 and int(r["native_graph_n"]) == 104
+    for mode in ("native", "native_graph"):                      # the same SyncBatchNorm arithmetic, three ways of issuing the messages
+        np.testing.assert_array_equal(r[f"{mode}_loss"], r["torch_loss"])
+        np.testing.assert_array_equal(r[f"{mode}_param"], r["torch_param"])
+    # against the local-statistics step: the SyncBatchNorm path forms mean / variance from exchanged sums (another summation order)
+    np.testing.assert_allclose(r["torch_loss"], r["local_loss"], rtol=1e-3)
+    assert _l2(r["torch_param"], r["local_param"]) < 1e-3
+
+
 def _flat_init(seed, head="dconv"):
     from simple_pose_amd.train import FlatParams
     m, _ = _model(seed, head)
@@ -341,6 +392,41 @@ def test_streamed_schedule_equals_plain_schedule(dtype):
     (l0, p0, v0, r0, w0), (l1, p1, v1, r1, w1) = out
     assert l0 == l1 and l0[-1] < l0[0]
     assert torch.equal(p0, p1) and torch.equal(v0, v1) and torch.equal(r0, r1)
+    assert all(torch.equal(a, b) for a, b in zip(w0, w1))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("sync_bn_path", [False, True], ids=["local_bn", "sync_bn_path"])
+def test_captured_step_equals_eager_steps_bitwise(dtype, sync_bn_path):
+    """PoseTrainer.capture(): the whole step (three streams, optimizer inside backward, Adam's scalars from device memory) recorded into
+    one hipGraph and replayed with fresh batches gives the parameters, optimizer state, BN buffers, packed weights and losses of the
+    same steps run eagerly, bit for bit - a dependency that only stream order provided, or a pointer that moved between capture and
+    replay, would show here.  `sync_bn_path`: with the SyncBatchNorm message path switched on (a delay kernel on the message stream
+    stands in for the all-reduce on one rank), i.e. with a fourth stream inside the capture."""
+    batches = []
+    for seed in (3, 4, 5):
+        x, t, w = _batch(4, 128, 96, seed)
+        batches.append(tuple(torch.from_numpy(v).to(DEV) for v in (x, t, w)))
+    out = []
+    for graphed in (False, True):
+        model, _ = _model(3)
+        tr = PoseTrainer(model, in_h=128, in_w=96, lr=1e-3, dtype=dtype, bucket_mb=8.0, sync_bn_latency_us=2.0 if sync_bn_path else 0.0)
+        losses = []
+        if graphed:
+            g = tr.capture(*batches[0], warmup=2)                      # two eager steps on batch 0, then the capture
+            for b in batches[1:] + batches[:2]:
+                losses.append(g.step(*b).item())
+            assert tr.step_count == 2 + 4
+        else:
+            for b in [batches[0]] * 2 + batches[1:] + batches[:2]:
+                losses.append(tr.step(*b).item())
+            losses = losses[2:]
+        torch.cuda.synchronize()
+        out.append((losses, tr.flat.data.clone(), tr.exp_avg.clone(), tr.exp_avg_sq.clone(), model.bn1.running_var.clone(),
+                    model.bn1.num_batches_tracked.clone(), [l.w_fwd.clone() for l in tr.layers.values()]))
+    (l0, p0, m0, v0, r0, n0, w0), (l1, p1, m1, v1, r1, n1, w1) = out
+    assert l0 == l1, (l0, l1)
+    assert torch.equal(p0, p1) and torch.equal(m0, m1) and torch.equal(v0, v1) and torch.equal(r0, r1) and torch.equal(n0, n1)
     assert all(torch.equal(a, b) for a, b in zip(w0, w1))
 
 
