@@ -27,7 +27,7 @@ extern "C" {
 #define SP_EINVAL (-1)   /* bad argument / unsupported shape (message in sp_last_error) */
 #define SP_ELAUNCH (-2)  /* HIP launch or runtime failure */
 
-#define SP_ABI_VERSION 24
+#define SP_ABI_VERSION 25
 
 /* epilogue / layout flags of sp_conv_desc.flags */
 #define SP_CONV_RELU 0x1u          /* y = max(y, 0) after scale/shift (+ residual) */
@@ -76,6 +76,8 @@ typedef struct sp_conv_desc {
 #define SP_CONV_KERNEL_IGEMM 0 /* 4-wave workgroups, register-staged double buffer: every dtype / flag / tile listed at sp_conv2d_default_tile */
 #define SP_CONV_KERNEL_RING 1  /* bf16 only: persistent 8-wave workgroups fed by an LDS-DMA ring (buffer_load ... lds, counted vmcnt);
                                   tiles 256x256 256x128 128x256 256x64 128x128 192x128 192x256; needs sp_conv2d_ring_ok(desc) == 1 */
+#define SP_CONV_KERNEL_PW 2    /* fp32 1x1 stride-1 NHWC layers with c_in 64 / 128 and c_out % 256 == 0 (bottleneck conv3, projection shortcut):
+                                  one persistent workgroup per CU streams 64-row tiles, weights in registers (sp_conv2d_pw_ok); tile_m / tile_n unused */
 
 /* ---- library ---------------------------------------------------------------------------------- */
 int sp_abi_version(void);
@@ -131,6 +133,9 @@ int sp_bottleneck_c64(const sp_conv_desc* desc, const void* x, const void* w1_pa
 int sp_stem7_pool_ok(int batch, int h, int w);
 int sp_stem7_pool(const float* x, const void* w_packed, int k_pad, const float* scale, const float* shift, void* y, int bf16,
                   int batch, int h, int w, void* stream);
+
+/* 1 when `desc` can run with kernel = SP_CONV_KERNEL_PW (see there).  Same bits as the tiled kernel. */
+int sp_conv2d_pw_ok(const sp_conv_desc* desc);
 
 /* 1 when `desc` (flags, shapes, tile_m x tile_n) can run with kernel = SP_CONV_KERNEL_RING: bf16 NHWC in and out (ReLU, residual and
  * fused PixelShuffle allowed; no NCHW / fp32 output), c_in % 64 == 0, taps <= 32, k_pad / 64 >= the tile's ring depth, tile_n | n_pad. */

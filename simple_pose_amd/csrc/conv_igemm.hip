@@ -820,6 +820,8 @@ int launch(const ConvArgs& a, int phases, bool uniform, hipStream_t stream) {
 extern "C" int sp_conv2d_default_tile(const sp_conv_desc* d, int* tile_m, int* tile_n);
 int sp_conv_ring_launch(const sp_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift,
                         const void* residual, void* y, void* stream);   // conv_ring.hip
+int sp_conv_pw_launch(const sp_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift,
+                      const void* residual, void* y, void* stream);     // conv_pw.hip
 
 static int tile_rows_per_block(int bm, int bn) { return (bm == 256 && bn == 64) || (bm == 128 && bn == 32) ? 4 : 2; }   // WR of the tile
 
@@ -890,7 +892,12 @@ static int conv_fwd_impl(const sp_conv_desc* d, const void* x, const void* w_pac
     const int phases = d->phases_y * d->phases_x;
     hipStream_t s = (hipStream_t)stream;
 
-    SP_REQUIRE(d->kernel == SP_CONV_KERNEL_IGEMM || d->kernel == SP_CONV_KERNEL_RING, "sp_conv2d_fwd: unknown kernel id %d", d->kernel);
+    SP_REQUIRE(d->kernel == SP_CONV_KERNEL_IGEMM || d->kernel == SP_CONV_KERNEL_RING || d->kernel == SP_CONV_KERNEL_PW,
+               "sp_conv2d_fwd: unknown kernel id %d", d->kernel);
+    if (d->kernel == SP_CONV_KERNEL_PW) {
+        SP_REQUIRE(!stats_s && !bsrc, "sp_conv2d_fwd: the streaming 1x1 kernel has no statistics epilogue");
+        return sp_conv_pw_launch(d, x, w_packed, scale, shift, residual, y, stream);
+    }
     if (d->kernel == SP_CONV_KERNEL_RING) {
         SP_REQUIRE(!stats_s && !bsrc, "sp_conv2d_fwd: the LDS-DMA ring kernel has no statistics epilogue");
         return sp_conv_ring_launch(d, x, w_packed, scale, shift, residual, y, stream);

@@ -328,6 +328,8 @@ class Program:
                 if lib.sp_conv2d_ring_ok(d):
                     out.append((bm, bn, _lib.SP_CONV_KERNEL_RING))
         d.tile_m, d.tile_n, d.kernel = keep
+        if lib.sp_conv2d_pw_ok(d):
+            out.append((64, 256, _lib.SP_CONV_KERNEL_PW))
         if lib.sp_conv3x3_direct_ok(d):
             out.append((-1, -1, 0))
         return out

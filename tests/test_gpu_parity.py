@@ -1025,6 +1025,54 @@ def test_ring_kernel_matches_igemm_on_ragged_shapes():
     print(f"ring-vs-igemm: {ran} ring launches bit-identical to the implicit GEMM")
 
 
+@pytest.mark.parametrize("Cin,Cout,B,H,W,with_res,relu", [(64, 256, 3, 16, 12, True, True), (64, 256, 2, 9, 7, False, False), (128, 512, 5, 8, 6, True, True),
+                                                       (128, 256, 1, 5, 13, True, False), (64, 512, 40, 16, 12, False, True)])
+def test_streaming_pointwise_kernel_equals_the_tiled_gemm_bitwise(Cin, Cout, B, H, W, with_res, relu):
+    """kernel = SP_CONV_KERNEL_PW (csrc/conv_pw.hip: fp32 1x1, K = 64 / 128, c_out % 256 == 0 - the bottleneck's conv3 and the projection
+    shortcut of layer1 / layer2, pose_resnet_dconv.py:99-103,124-131): one persistent workgroup per CU, weights in registers.  Same bits
+    as every tile of the implicit GEMM, incl. row counts that are not multiples of its 64-row tile and more row tiles than workgroups;
+    against float64 within the fp32 bar of the other conv tests."""
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(Cin + Cout + B)
+    x = torch.randn((B, Cin, H, W), generator=g)
+    w = torch.randn((Cout, Cin, 1, 1), generator=g) / Cin ** 0.5
+    scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.2
+    r = torch.randn((B, Cout, H, W), generator=g) if with_res else None
+    b = engine.ProgramBuilder(H, W, "fp32")
+    b.p.shapes["input"] = (H, W, Cin)
+    if with_res:
+        b.p.shapes["res"] = (H, W, Cout)
+    out = b.conv("input", w.to(DEV), scale=scale.to(DEV), shift=shift.to(DEV), relu=relu, res="res" if with_res else None, name="c")
+    op = b.p.ops[-1]
+    op.desc.batch = B
+    assert lib.sp_conv2d_pw_ok(op.desc) == 1
+    cands = b.p._candidates(lib, op)
+    assert (64, 256, _lib.SP_CONV_KERNEL_PW) in cands
+    xin = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    rin = r.permute(0, 2, 3, 1).contiguous().to(DEV) if with_res else None
+    results = []
+    for cand in cands:
+        op.desc.tile_m, op.desc.tile_n, op.desc.kernel = cand
+        y = torch.full((B, H, W, Cout), float("nan"), device=DEV)
+        _lib.check(lib.sp_conv2d_fwd(op.desc, _lib.ptr(xin), _lib.ptr(op.w), _lib.ptr(op.scale), _lib.ptr(op.shift), _lib.ptr(rin), _lib.ptr(y),
+                                     _lib.current_stream()), str(cand))
+        torch.cuda.synchronize()
+        results.append((cand, y.view(torch.int32).cpu(), y.cpu()))
+    for cand, bits, _ in results[1:]:
+        assert torch.equal(bits, results[0][1]), (cand, int((bits != results[0][1]).sum()))
+    ref = torch.nn.functional.conv2d(x.double(), w.double()) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    if with_res:
+        ref = ref + r.double()
+    if relu:
+        ref = torch.relu(ref)
+    got = results[-1][2].permute(0, 3, 1, 2).double()
+    assert not torch.isnan(got).any()
+    assert float((got - ref).abs().max() / ref.abs().max()) < 2e-6
+    # a descriptor the kernel does not take is refused, not mis-run
+    op.desc.kernel, op.desc.stride = _lib.SP_CONV_KERNEL_PW, 2
+    assert lib.sp_conv2d_pw_ok(op.desc) == 0
+
+
 def test_hrnet_branches_on_separate_streams_match_single_stream(golden):
     """engine.Program lanes: the independent branches of every HRNet module run on their own HIP stream, ordered by events
     (RAW on activations, WAR/WAW on the planner's recycled storage).  The result must equal the one-stream schedule bit for bit,

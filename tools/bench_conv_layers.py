@@ -110,9 +110,9 @@ def main():
                "best_igemm_us": res[best_old]["us"], "cands": res}
         seen[key] = row
         rows.append(row)
-        ring = {k: v["us"] for k, v in res.items() if k.endswith("k1")}
+        ring = {k: v["us"] for k, v in res.items() if k.endswith("k1") or k.endswith("k2")}
         print(f"{op.name:26s} M={row['M']:7d} N={row['N']:5d} K={row['K']:5d}  igemm {best_old:>11s} {row['best_igemm_us']:7.1f} us | "
-              + " ".join(f"{k[:-3]}:{v:.1f}" for k, v in ring.items()) + f" | best {best} {res[best]['tflops']:.0f} TF", flush=True)
+              + " ".join(f"{k[:-3] + ('(pw)' if k.endswith('k2') else '')}:{v:.1f}" for k, v in ring.items()) + f" | best {best} {res[best]['tflops']:.0f} TF", flush=True)
     tot_old = sum(r["best_igemm_us"] for r in rows)
     tot_new = sum(r["best_us"] for r in rows)
     print(f"sum over {len(rows)} conv launches: best igemm {tot_old:.0f} us, best of all {tot_new:.0f} us; mismatching candidates: {bad}")
