@@ -27,7 +27,7 @@ extern "C" {
 #define SP_EINVAL (-1)   /* bad argument / unsupported shape (message in sp_last_error) */
 #define SP_ELAUNCH (-2)  /* HIP launch or runtime failure */
 
-#define SP_ABI_VERSION 25
+#define SP_ABI_VERSION 26
 
 /* epilogue / layout flags of sp_conv_desc.flags */
 #define SP_CONV_RELU 0x1u          /* y = max(y, 0) after scale/shift (+ residual) */
@@ -133,6 +133,11 @@ int sp_bottleneck_c64(const sp_conv_desc* desc, const void* x, const void* w1_pa
 int sp_stem7_pool_ok(int batch, int h, int w);
 int sp_stem7_pool(const float* x, const void* w_packed, int k_pad, const float* scale, const float* shift, void* y, int bf16,
                   int batch, int h, int w, void* stream);
+/* The same launch on uint8 BGR crops [batch,h,w,3] (what cv.warpAffine / sp_warp_affine_u8c3 produce): the collate normalisation of
+ * datasets/coco.py:136 (`x / 255 - mean`, BGR -> RGB; mean_rgb_host = {0.485, 0.456, 0.406}) happens while the patch is loaded - the
+ * arithmetic of sp_u8hwc_bgr_to_nhwc, same bits as that launch followed by sp_conv2d_fwd and sp_maxpool3x3s2_nhwc. */
+int sp_stem7_pool_u8(const unsigned char* crops_bgr, const float* mean_rgb_host, const void* w_packed, int k_pad, const float* scale,
+                     const float* shift, void* y, int bf16, int batch, int h, int w, void* stream);
 
 /* 1 when `desc` can run with kernel = SP_CONV_KERNEL_PW (see there).  Same bits as the tiled kernel. */
 int sp_conv2d_pw_ok(const sp_conv_desc* desc);

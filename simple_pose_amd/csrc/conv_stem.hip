@@ -55,7 +55,8 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 struct StemArgs {
-    const float* x;            // [B][3][H][W]
+    const void* x;             // fp32 [B][3][H][W], or (U8) BGR bytes [B][H][W][3] normalised on the fly: (v / 255 - mean) as datasets/coco.py:136
+    float mean[3];             // U8: RGB means
     const void* w;             // packed stem weights [64][k_pad]
     const float* scale;        // [64] folded BatchNorm
     const float* shift;
@@ -89,7 +90,7 @@ struct Cfg {
     static_assert(MT % 2 == 0 && TPH % 4 == 0, "fp32: the two row halves get MT / 2 MFMA tiles each; pooling: TPH / 4 pooled rows per wave");
 };
 
-template <bool BF16, int TPH, int TPW>
+template <bool BF16, int TPH, int TPW, bool U8 = false>
 __global__ __launch_bounds__(256, BF16 ? 2 : 1) void stem_pool_kernel(const StemArgs p) {
     extern __shared__ __align__(16) unsigned char smem[];
     using C = Cfg<BF16, TPH, TPW>;
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256, BF16 ? 2 : 1) void stem_pool_kernel(const Stem
     unsigned* const outd = reinterpret_cast<unsigned*>(smem + C::PATCH_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, fh = lane >> 5;
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), (short)0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), (short)0, p.x_bytes, 0x00020000);
     const int plane4 = p.H * p.W * 4;
 
     // ---- B fragments: this wave's share of the packed weights, loaded once ----
@@ -139,6 +140,7 @@ __global__ __launch_bounds__(256, BF16 ? 2 : 1) void stem_pool_kernel(const Stem
         prc[i] = idx < NPIX ? (unsigned)((r << 8) | c) : 0xffffff00u;     // a row that is outside every image
     }
     float pf[NPF][3];
+    unsigned okmask = 0;                                   // U8: which of this thread's pixels lie inside the image (a byte 0 is a black pixel, not padding)
     auto origin = [&](int t, int& b, int& py0, int& px0) {
         const int per = p.tiles_y * p.tiles_x;
         b = t / per;
@@ -147,28 +149,40 @@ __global__ __launch_bounds__(256, BF16 ? 2 : 1) void stem_pool_kernel(const Stem
         py0 = ty * TPH;
         px0 = (r - ty * p.tiles_x) * TPW;
     };
+    // one pixel's three values into pf[i]: fp32 planes, or the B, G, R bytes of an HWC pixel (kept as integers until park())
+    auto fetch = [&](int i, int pix, bool ok) {
+        if constexpr (U8) {
+            const unsigned off = ok ? (unsigned)(pix * 3) : OOB;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch)     // channel ch of the network's RGB input is byte 2 - ch
+                pf[i][ch] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b8(xr, off, 2 - ch, 0));
+        } else {
+            const unsigned off = ok ? (unsigned)(pix * 4) : OOB;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch)
+                pf[i][ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, off, ch * plane4, 0));
+        }
+    };
     auto prefetch = [&](int t) {
         int b, py0, px0;
         origin(t, b, py0, px0);
         const int iy0 = 4 * py0 - 5, ix0 = 4 * px0 - (BF16 ? 6 : 5);
-        const int base = (b * 3 * p.H + iy0) * p.W + ix0;
+        const int base = (b * (U8 ? 1 : 3) * p.H + iy0) * p.W + ix0;
+        okmask = 0;
         if (iy0 >= 0 && ix0 >= 0 && iy0 + C::PR <= p.H && ix0 + PC <= p.W) {      // the whole patch lies inside the image (uniform)
 #pragma unroll
             for (int i = 0; i < NPF; ++i) {
-                const unsigned off = (i + 1) * 256 <= NPIX || tid + 256 * i < NPIX ? (unsigned)((base + prel[i]) * 4) : OOB;
-#pragma unroll
-                for (int ch = 0; ch < 3; ++ch)
-                    pf[i][ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, off, ch * plane4, 0));
+                const bool ok = (i + 1) * 256 <= NPIX || tid + 256 * i < NPIX;
+                okmask |= (unsigned)ok << i;
+                fetch(i, base + prel[i], ok);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < NPF; ++i) {
                 const int gy = iy0 + (int)(prc[i] >> 8), gx = ix0 + (int)(prc[i] & 255);
                 const bool ok = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-                const unsigned off = ok ? (unsigned)((base + prel[i]) * 4) : OOB;
-#pragma unroll
-                for (int ch = 0; ch < 3; ++ch)
-                    pf[i][ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, off, ch * plane4, 0));
+                okmask |= (unsigned)ok << i;
+                fetch(i, base + prel[i], ok);
             }
         }
     };
@@ -177,12 +191,22 @@ __global__ __launch_bounds__(256, BF16 ? 2 : 1) void stem_pool_kernel(const Stem
         for (int i = 0; i < NPF; ++i) {
             const int idx = tid + 256 * i;
             if (idx < NPIX) {
+                float v3[3];
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    if constexpr (U8) {        // sp_u8hwc_bgr_to_nhwc's arithmetic; padding stays 0
+                        const float n = (float)__builtin_bit_cast(unsigned, pf[i][ch]) / 255.0f - p.mean[ch];
+                        v3[ch] = (okmask >> i) & 1 ? n : 0.f;
+                    } else {
+                        v3[ch] = pf[i][ch];
+                    }
+                }
                 if constexpr (BF16) {
-                    const bf16x4 v = {(__bf16)pf[i][0], (__bf16)pf[i][1], (__bf16)pf[i][2], (__bf16)0.f};
+                    const bf16x4 v = {(__bf16)v3[0], (__bf16)v3[1], (__bf16)v3[2], (__bf16)0.f};
                     *reinterpret_cast<u32x2*>(patch + idx * 8) = __builtin_bit_cast(u32x2, v);
                 } else {
 #pragma unroll
-                    for (int ch = 0; ch < 3; ++ch) reinterpret_cast<float*>(patch)[ch * NPIX + idx] = pf[i][ch];
+                    for (int ch = 0; ch < 3; ++ch) reinterpret_cast<float*>(patch)[ch * NPIX + idx] = v3[ch];
                 }
             }
         }
@@ -372,7 +396,7 @@ __global__ __launch_bounds__(256, BF16 ? 2 : 1) void stem_pool_kernel(const Stem
 #endif
 }
 
-template <bool BF16, int TPH, int TPW>
+template <bool BF16, int TPH, int TPW, bool U8 = false>
 int launch_stem(StemArgs a, hipStream_t stream) {
     using C = Cfg<BF16, TPH, TPW>;
     static bool opted[64] = {};
@@ -380,7 +404,7 @@ int launch_stem(StemArgs a, hipStream_t stream) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!opted[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pool_kernel<BF16, TPH, TPW>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pool_kernel<BF16, TPH, TPW, U8>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess) {
             sp_set_error("stem: hipFuncSetAttribute(max dynamic LDS = %d) failed on device %d", C::LDS_BYTES, dev);
             return SP_ELAUNCH;
         }
@@ -395,7 +419,7 @@ int launch_stem(StemArgs a, hipStream_t stream) {
     // whole rounds: every persistent workgroup gets the same number of tiles (4,096 tiles at bs = 128 on 256 CUs: 8 / 16 each)
     const int rounds = (a.n_tiles + slots - 1) / slots;
     const int grid = (a.n_tiles + rounds - 1) / rounds;
-    hipLaunchKernelGGL((stem_pool_kernel<BF16, TPH, TPW>), dim3(grid), dim3(256), C::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((stem_pool_kernel<BF16, TPH, TPW, U8>), dim3(grid), dim3(256), C::LDS_BYTES, stream, a);
     return sp_check_launch("stem_pool_kernel");
 }
 
@@ -406,19 +430,27 @@ extern "C" int sp_stem7_pool_ok(int batch, int h, int w) {
     return batch > 0 && h >= 8 && w >= 8 && (long long)batch * 3 * h * w * 4 < (1ll << 31) ? 1 : 0;
 }
 
-extern "C" int sp_stem7_pool(const float* x, const void* w_packed, int k_pad, const float* scale, const float* shift, void* y, int bf16,
-                             int batch, int h, int w, void* stream) {
+static int stem_args(StemArgs& a, const void* x, const void* w_packed, int k_pad, const float* scale, const float* shift, void* y, int batch, int h,
+                     int w, int bytes_per_pixel_plane) {
     SP_REQUIRE(x && w_packed && scale && shift && y, "sp_stem7_pool: null pointer");
     SP_REQUIRE(sp_stem7_pool_ok(batch, h, w), "sp_stem7_pool: batch %d of %d x %d images is outside the kernel's 32-bit offsets", batch, h, w);
     SP_REQUIRE(k_pad >= 224 && k_pad % 8 == 0, "sp_stem7_pool: k_pad %d (the packed 7x7 stem has K >= 224)", k_pad);
-    StemArgs a;
     a.x = x; a.w = w_packed; a.scale = scale; a.shift = shift; a.y = y;
+    a.mean[0] = a.mean[1] = a.mean[2] = 0.f;
     a.batch = batch; a.H = h; a.W = w;
     a.Hc = (h + 6 - 7) / 2 + 1; a.Wc = (w + 6 - 7) / 2 + 1;
     a.Hp = (a.Hc + 2 - 3) / 2 + 1; a.Wp = (a.Wc + 2 - 3) / 2 + 1;
     a.tiles_y = a.tiles_x = a.n_tiles = 0;                 // set by the launcher (tile shape)
     a.k_pad = k_pad;
-    a.x_bytes = (unsigned)((long long)batch * 3 * h * w * 4);
+    a.x_bytes = (unsigned)((long long)batch * 3 * h * w * bytes_per_pixel_plane);
+    return SP_OK;
+}
+
+extern "C" int sp_stem7_pool(const float* x, const void* w_packed, int k_pad, const float* scale, const float* shift, void* y, int bf16,
+                             int batch, int h, int w, void* stream) {
+    StemArgs a;
+    const int rc = stem_args(a, x, w_packed, k_pad, scale, shift, y, batch, h, w, 4);
+    if (rc != SP_OK) return rc;
     if (sp_name_query_active()) {
         sp_name_query_set("stem_pool_kernel<%s>", bf16 ? "true" : "false");
         return SP_OK;
@@ -428,4 +460,18 @@ extern "C" int sp_stem7_pool(const float* x, const void* w_packed, int k_pad, co
     static const int wide = [] { const char* e = getenv("SP_STEM_TILE_W"); return e ? atoi(e) : 12; }();
     if (wide == 8) return bf16 ? launch_stem<true, 8, 8>(a, (hipStream_t)stream) : launch_stem<false, 8, 8>(a, (hipStream_t)stream);
     return bf16 ? launch_stem<true, 8, 12>(a, (hipStream_t)stream) : launch_stem<false, 8, 12>(a, (hipStream_t)stream);
+}
+
+extern "C" int sp_stem7_pool_u8(const unsigned char* crops_bgr, const float* mean_rgb_host, const void* w_packed, int k_pad, const float* scale,
+                                const float* shift, void* y, int bf16, int batch, int h, int w, void* stream) {
+    SP_REQUIRE(mean_rgb_host, "sp_stem7_pool_u8: null pointer");
+    StemArgs a;
+    const int rc = stem_args(a, crops_bgr, w_packed, k_pad, scale, shift, y, batch, h, w, 1);
+    if (rc != SP_OK) return rc;
+    for (int c = 0; c < 3; ++c) a.mean[c] = mean_rgb_host[c];
+    if (sp_name_query_active()) {
+        sp_name_query_set("stem_pool_kernel<%s, u8>", bf16 ? "true" : "false");
+        return SP_OK;
+    }
+    return bf16 ? launch_stem<true, 8, 12, true>(a, (hipStream_t)stream) : launch_stem<false, 8, 12, true>(a, (hipStream_t)stream);
 }

@@ -220,13 +220,10 @@ class Program:
         elif op.kind == "stem7":
             h, w, k_pad, unfused = op.args
             src = bufs[op.src]
-            if src.dtype == torch.uint8:           # BGR crops: the three-launch lowering, whose first launch normalises them
-                tmp = dict(bufs)
-                for u in unfused[:-1]:
-                    uh, uw, uc = self.shapes[u.dst]
-                    tmp[u.dst] = torch.empty(B * uh * uw * uc, dtype=torch.bfloat16 if self.dtype == "bf16" else torch.float32, device=src.device)
-                for u in unfused:
-                    self._launch(lib, u, tmp, B, stream)
+            if src.dtype == torch.uint8:           # BGR crops [B,h,w,3]: normalised (coco.py:136) while the patch is loaded
+                mean = (ctypes.c_float * 3)(0.485, 0.456, 0.406)
+                _lib.check(lib.sp_stem7_pool_u8(P(src), mean, P(op.w), k_pad, P(op.scale), P(op.shift), P(bufs[op.dst]), int(self.dtype == "bf16"),
+                                                B, h, w, stream), op.name)
             else:
                 _lib.check(lib.sp_stem7_pool(P(src), P(op.w), k_pad, P(op.scale), P(op.shift), P(bufs[op.dst]), int(self.dtype == "bf16"),
                                              B, h, w, stream), op.name)
@@ -622,8 +619,8 @@ class ProgramBuilder:
 
     def stem_pool(self, src: str, weight: torch.Tensor, scale, shift, name: str = "conv1") -> str:
         """relu(bn(conv 7x7 s2 p3 (3 -> 64))) followed by maxpool 3x3 s2 p1 (pose_resnet_dconv.py:158-162).  With `fuse_stem` the three
-        launches (layout change, implicit GEMM, pooling) become one `stem7` op that reads the fp32 NCHW image directly; the three are
-        kept inside it for uint8 crop input, whose first launch also normalises the pixels."""
+        launches (layout change, implicit GEMM, pooling) become one `stem7` op that reads the fp32 NCHW image - or the uint8 BGR crops,
+        normalising them on the way - directly; the three stay inside the op as its definition (the CPU interpreter of the test suite reads them)."""
         first = len(self.p.ops)
         x4 = self.to_nhwc4(src)
         y = self.conv(x4, weight, stride=2, pad=3, scale=scale, shift=shift, relu=True, name=name)

@@ -486,6 +486,36 @@ def test_fused_stem_equals_the_three_launch_stem_bitwise(head, B, H, W, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("B,H,W", [(2, 70, 50), (1, 8, 8), (3, 34, 130), (2, 256, 192)])
+def test_fused_stem_on_uint8_crops_bitwise(B, H, W, dtype):
+    """sp_stem7_pool_u8: uint8 BGR crops [B,H,W,3] normalised (datasets/coco.py:136) while the patch is loaded, against
+    sp_u8hwc_bgr_to_nhwc -> sp_conv2d_fwd -> sp_maxpool3x3s2_nhwc on the same crops - bit for bit, incl. black pixels next to the zero
+    padding (a byte 0 normalises to -mean, padding stays 0) and sizes with ragged tiles."""
+    g = torch.Generator().manual_seed(H * 1000 + W + 1)
+    w = torch.randn((64, 3, 7, 7), generator=g).to(DEV) * 0.1
+    scale = (torch.rand(64, generator=g) + 0.5).to(DEV)
+    shift = (torch.randn(64, generator=g) * 0.3).to(DEV)
+    crops = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8)
+    crops[:, :3, :, :] = 0                                   # black rows at the border
+    crops = crops.to(DEV)
+    outs = []
+    for fuse in (False, True):
+        b = engine.ProgramBuilder(H, W, dtype)
+        b.fuse_stem = fuse
+        out = b.stem_pool("input", w, scale, shift)
+        prog = b.p
+        bufs = dict(prog._alloc(B, crops.device))
+        bufs["input"] = crops
+        for op in prog.ops:
+            prog._launch(_lib.lib(), op, bufs, B, _lib.current_stream())
+        torch.cuda.synchronize()
+        outs.append(bufs[out].clone())
+    view = torch.int16 if dtype == "bf16" else torch.int32
+    assert torch.equal(outs[0].view(view), outs[1].view(view))
+    assert float(outs[1].float().abs().max()) > 0
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("B,H,W", [(2, 70, 50), (1, 8, 8), (3, 34, 130), (1, 258, 62)])
 def test_fused_stem_kernel_on_ragged_sizes_bitwise(B, H, W, dtype):
     """sp_stem7_pool through the C ABI against sp_nchw_to_nhwc4 -> sp_conv2d_fwd -> sp_maxpool3x3s2_nhwc on sizes whose pooled maps are
