@@ -27,7 +27,7 @@ extern "C" {
 #define SP_EINVAL (-1)   /* bad argument / unsupported shape (message in sp_last_error) */
 #define SP_ELAUNCH (-2)  /* HIP launch or runtime failure */
 
-#define SP_ABI_VERSION 26
+#define SP_ABI_VERSION 27
 
 /* epilogue / layout flags of sp_conv_desc.flags */
 #define SP_CONV_RELU 0x1u          /* y = max(y, 0) after scale/shift (+ residual) */
@@ -393,6 +393,19 @@ int sp_permute4_batched(const float* src, const void* jobs_device, int n_jobs, i
 
 /* measurement aid: occupies `stream` for `us` microseconds (one idle wave on the 100 MHz constant clock) - bench.py's stand-in for the
  * latency of a SyncBatchNorm message (ddp...:89-90) on a box with a single GPU */
+/* SELayer backward (nets/commons.py:4-18 inside Bottleneck.forward, pose_resnet_dconv.py:124-131; `bf16`: dtype of the saved activations,
+ * gradients w.r.t. activations are fp32):  y = relu(u * sigmoid(g[b,c]) + identity), u = bn3(conv3(.)), g = fc2(relu(fc0(mean_hw u))).
+ *   sp_se_gate_bwd_reduce: da[b,c] = sum_hw (y > 0 ? dy : 0) * u
+ *   sp_se_sigmoid_bwd:     dg = da * a (1 - a), a = sigmoid(g) (written in the activation dtype: the FC layers' MFMA operand); dbias[c] = sum_b dg
+ *   sp_relu_bwd_rows:      out = dh (h > 0) on a [batch, c] map, dbias[c] = sum_b out (dbias may be null)
+ *   sp_se_gate_bwd_apply:  du = (y > 0 ? dy : 0) * a + ds[b,c] / hw;  dres (+)= (y > 0 ? dy : 0)
+ * The FC layers themselves run as 1x1 convolutions (sp_conv2d_fwd / dgrad re-packing / sp_conv2d_wgrad_batched). */
+int sp_se_gate_bwd_reduce(const float* dy, int bf16, const void* y, const void* u, int batch, int hw, int c, float* da, void* stream);
+int sp_se_sigmoid_bwd(const float* da, int bf16, const void* gate_logits, int batch, int c, void* dg, float* dbias, void* stream);
+int sp_relu_bwd_rows(const float* dh, int bf16, const void* h, int batch, int c, void* out, float* dbias, void* stream);
+int sp_se_gate_bwd_apply(const float* dy, int bf16, const void* y, const void* gate_logits, const float* ds, int batch, int hw, int c,
+                         float* du, float* dres, int dres_accumulate, void* stream);
+
 int sp_stream_delay_us(double us, void* stream);
 
 /* RCCL called directly, for the collectives that sit on the train step's critical path (replaces the `SyncBatchNorm` exchanges and the

@@ -822,6 +822,115 @@ extern "C" int sp_adam_step_dev(float* param, const float* grad, float* exp_avg,
     return sp_check_launch("adam_kernel");
 }
 
+// ---- SELayer backward (nets/commons.py:4-18 inside Bottleneck.forward, pose_resnet_dconv.py:124-131):
+//   forward  u = bn3(conv3(t)); s = mean_hw(u); h = relu(fc0 s + b0); g = fc2 h + b2; y = relu(u * sigmoid(g) + identity)
+//   backward dr = dy (y > 0);  d identity += dr;  da[b,c] = sum_hw dr u;  dg = da a (1 - a);  (fc2, relu, fc0 through the conv kernels)
+//            du = dr a + ds / HW
+// The two FC layers are 1x1 convolutions on a [B,1,1,C] map and go through the conv kernels (forward, dgrad, wgrad); the four small
+// kernels below are what is specific to the gate.  Not on any BASELINE config's path: written for clarity, deterministic (fixed-order
+// sums in fp64), coalesced along the channels.
+namespace {
+
+template <bool BF16> __device__ __forceinline__ float ld_act(const void* p, size_t i) {
+    if constexpr (BF16) return (float)reinterpret_cast<const __bf16*>(p)[i];
+    else return reinterpret_cast<const float*>(p)[i];
+}
+template <bool BF16> __device__ __forceinline__ void st_act(void* p, size_t i, float v) {
+    if constexpr (BF16) reinterpret_cast<__bf16*>(p)[i] = (__bf16)v;
+    else reinterpret_cast<float*>(p)[i] = v;
+}
+
+// da[b][c] = sum over pixels of (y > 0 ? dy : 0) * u; workgroup = (64 channels, image b), 4 row lanes per channel
+template <bool BF16>
+__global__ __launch_bounds__(256) void se_gate_bwd_reduce_kernel(const float* __restrict__ dy, const void* __restrict__ y, const void* __restrict__ u,
+                                                                 int HW, int C, float* __restrict__ da) {
+    __shared__ double sm[256];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6, b = blockIdx.y;
+    double acc = 0;
+    if (c < C)
+        for (int r = rl; r < HW; r += 4) {
+            const size_t i = ((size_t)b * HW + r) * C + c;
+            const float dr = ld_act<BF16>(y, i) > 0.f ? dy[i] : 0.f;
+            acc += (double)dr * (double)ld_act<BF16>(u, i);
+        }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    if (rl == 0 && c < C) da[(size_t)b * C + c] = (float)(((sm[threadIdx.x] + sm[threadIdx.x + 64]) + sm[threadIdx.x + 128]) + sm[threadIdx.x + 192]);
+}
+
+// MODE 0: out = da * a (1 - a) with a = sigmoid(gate logit);  MODE 1: out = dh (h > 0).  bias gradient db[c] = sum_b out[b][c] either way
+template <bool BF16, int MODE>
+__global__ void se_rows_bwd_kernel(const float* __restrict__ grad, const void* __restrict__ saved, int B, int C, void* __restrict__ out, float* __restrict__ db) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0;
+    for (int b = 0; b < B; ++b) {
+        const size_t i = (size_t)b * C + c;
+        const float x = ld_act<BF16>(saved, i);
+        float v;
+        if constexpr (MODE == 0) {
+            const float a = 1.f / (1.f + expf(-x));
+            v = grad[i] * a * (1.f - a);
+        } else {
+            v = x > 0.f ? grad[i] : 0.f;
+        }
+        st_act<BF16>(out, i, v);
+        s += (double)v;
+    }
+    if (db) db[c] = (float)s;
+}
+
+template <bool BF16>
+__global__ void se_gate_bwd_apply_kernel(const float* __restrict__ dy, const void* __restrict__ y, const void* __restrict__ g, const float* __restrict__ ds,
+                                         int HW, int C, float inv_hw, float* __restrict__ du, float* __restrict__ dres, int accumulate, long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long long b = i / ((long long)HW * C);
+        const float dr = ld_act<BF16>(y, (size_t)i) > 0.f ? dy[i] : 0.f;
+        const float a = 1.f / (1.f + expf(-ld_act<BF16>(g, (size_t)(b * C + c))));
+        du[i] = dr * a + ds[b * C + c] * inv_hw;
+        dres[i] = accumulate ? dres[i] + dr : dr;
+    }
+}
+
+}  // namespace
+
+extern "C" int sp_se_gate_bwd_reduce(const float* dy, int bf16, const void* y, const void* u, int batch, int hw, int c, float* da, void* stream) {
+    SP_REQUIRE(dy && y && u && da && batch > 0 && hw > 0 && c > 0, "sp_se_gate_bwd_reduce: bad argument");
+    const dim3 grid((c + 63) / 64, batch);
+    if (bf16) hipLaunchKernelGGL(se_gate_bwd_reduce_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dy, y, u, hw, c, da);
+    else hipLaunchKernelGGL(se_gate_bwd_reduce_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dy, y, u, hw, c, da);
+    return sp_check_launch("se_gate_bwd_reduce_kernel");
+}
+
+extern "C" int sp_se_sigmoid_bwd(const float* da, int bf16, const void* gate_logits, int batch, int c, void* dg, float* dbias, void* stream) {
+    SP_REQUIRE(da && gate_logits && dg && batch > 0 && c > 0, "sp_se_sigmoid_bwd: bad argument");
+    const dim3 grid((c + 255) / 256);
+    if (bf16) hipLaunchKernelGGL((se_rows_bwd_kernel<true, 0>), grid, dim3(256), 0, (hipStream_t)stream, da, gate_logits, batch, c, dg, dbias);
+    else hipLaunchKernelGGL((se_rows_bwd_kernel<false, 0>), grid, dim3(256), 0, (hipStream_t)stream, da, gate_logits, batch, c, dg, dbias);
+    return sp_check_launch("se_rows_bwd_kernel");
+}
+
+extern "C" int sp_relu_bwd_rows(const float* dh, int bf16, const void* h, int batch, int c, void* out, float* dbias, void* stream) {
+    SP_REQUIRE(dh && h && out && batch > 0 && c > 0, "sp_relu_bwd_rows: bad argument");
+    const dim3 grid((c + 255) / 256);
+    if (bf16) hipLaunchKernelGGL((se_rows_bwd_kernel<true, 1>), grid, dim3(256), 0, (hipStream_t)stream, dh, h, batch, c, out, dbias);
+    else hipLaunchKernelGGL((se_rows_bwd_kernel<false, 1>), grid, dim3(256), 0, (hipStream_t)stream, dh, h, batch, c, out, dbias);
+    return sp_check_launch("se_rows_bwd_kernel");
+}
+
+extern "C" int sp_se_gate_bwd_apply(const float* dy, int bf16, const void* y, const void* gate_logits, const float* ds, int batch, int hw, int c,
+                                    float* du, float* dres, int dres_accumulate, void* stream) {
+    SP_REQUIRE(dy && y && gate_logits && ds && du && dres && batch > 0 && hw > 0 && c > 0, "sp_se_gate_bwd_apply: bad argument");
+    const long long total = (long long)batch * hw * c;
+    SP_REQUIRE(total < (1ll << 31), "sp_se_gate_bwd_apply: tensor too large");
+    if (bf16) hipLaunchKernelGGL(se_gate_bwd_apply_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, dy, y, gate_logits, ds, hw,
+                                 c, 1.f / (float)hw, du, dres, dres_accumulate, total);
+    else hipLaunchKernelGGL(se_gate_bwd_apply_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, dy, y, gate_logits, ds, hw, c,
+                            1.f / (float)hw, du, dres, dres_accumulate, total);
+    return sp_check_launch("se_gate_bwd_apply_kernel");
+}
+
 // Measurement aid (bench.py --sync-bn-latency-us): keep `stream` busy for `us` microseconds of the 100 MHz constant clock - a stand-in
 // for the latency of a small cross-GPU message on a box with one GPU.  One wave, no memory traffic.
 __global__ void stream_delay_kernel(unsigned long long ticks) {

@@ -121,8 +121,6 @@ class PoseResNetBase(nn.Module):
         updated) records its tape; `loss.backward()` runs the HIP backward (dgrad / wgrad / BN backward) and hands every parameter
         gradient to autograd, so `.grad`, gradient hooks (DistributedDataParallel) and any torch optimizer work as in the reference.
         `simple_pose_amd.train.PoseTrainer.step` stays the faster fused path (loss, Adam and repack as kernels of the same tape)."""
-        if self.reduction:
-            raise NotImplementedError("training with SELayer (reduction=True) is not lowered; eval-mode forward is")
         from ..train import PoseTrainer
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and not getattr(self, "_warned_local_bn", False):

@@ -258,13 +258,20 @@ class ConvT:
         ke.append((kind, self.name, self.flops, e0, e1))
         return lambda: e1.record(st)
 
-    def forward(self, x: torch.Tensor, B: int, out: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, B: int, out: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
+                relu: bool = False) -> torch.Tensor:
         lib, d = _lib.lib(), self.d_fwd
         d.batch = B
         if out is None:
             out = self._new((B, d.out_h, d.out_w, d.out_c), self._wdt, x.device)
         done = self._timed("forward")
-        _lib.check(lib.sp_conv2d_fwd(d, P(x), P(self.w_fwd), None, P(shift), None, P(out), _lib.current_stream()), self.name)
+        keep = d.flags
+        if relu:
+            d.flags = keep | SP_CONV_RELU
+        try:
+            _lib.check(lib.sp_conv2d_fwd(d, P(x), P(self.w_fwd), None, P(shift), None, P(out), _lib.current_stream()), self.name)
+        finally:
+            d.flags = keep
         done()
         return out
 
@@ -393,8 +400,6 @@ class PoseTrainer:
         self.act_dtype = torch.bfloat16 if self.bf16 else torch.float32
         if getattr(model, "HEAD", None) not in ("dconv", "duc"):
             raise NotImplementedError("PoseTrainer lowers the ResNet DConv / DUC nets (the DDP solver's models, ddp...:65-68); HRNet pending")
-        if getattr(model, "reduction", False):
-            raise NotImplementedError("PoseTrainer: SELayer (reduction=True) backward is not lowered")
         self.head = model.HEAD
         self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
         self.pg = process_group
@@ -679,6 +684,9 @@ class PoseTrainer:
                 self._conv(p + ".conv3", h // s, w // s)
                 if bi == 0:
                     self._conv(p + ".downsample.0", h, w, stride=s)
+                if (p + ".se.fc.0.weight") in self.sd:          # SELayer (reduction=True): its two 1x1 convs act on the pooled [B,1,1,C] map
+                    self._conv(p + ".se.fc.0", 1, 1)
+                    self._conv(p + ".se.fc.2", 1, 1)
                 h, w = h // s, w // s
                 inpl = planes * 4
         if self.head == "dconv":
@@ -934,7 +942,7 @@ class PoseTrainer:
             # slabs.  The group goes out when a gradient bucket completes, when `wgrad_group_gflop` of work is queued, or at the end.
             self._wg_queue.append((layer, xin, dzt))
             self._wg_queued_flops += layer.flops * B
-            if self._wg_queued_flops >= self._group_gflop * 1e9:
+            if self._wg_queued_flops >= self._group_gflop * 1e9 or len(self._wg_queue) >= 64:     # (64 jobs: the batched call's limit)
                 self._wgrad_flush()
 
         self._pending = [set(b["names"]) for b in self.buckets]
@@ -993,7 +1001,8 @@ class PoseTrainer:
                 _lib.check(lib.sp_bn_train_finalize(P(pd["sums"]), pd["rows"] * W, pd["C"], BN_EPS, BN_MOMENTUM, P(pd["mean"]), P(pd["invstd"]),
                                                     rm, rv, stream), bn)
 
-        def conv_bn(xa: Act, cname: str, bname: str, relu: bool, res: Optional[Act] = None, pend: Optional[dict] = None) -> Act:
+        def conv_bn(xa: Act, cname: str, bname: str, relu: bool, res: Optional[Act] = None, pend: Optional[dict] = None,
+                    shortcut: bool = True) -> Act:
             if pend is None:
                 pend = conv_stats(xa, cname)
                 batch_stats([pend], [bname])
@@ -1009,7 +1018,7 @@ class PoseTrainer:
                 res.consumers += 1
             if relu:
                 ya.bn = (z, mean, invstd)      # y = relu(bn(z) [+ res]): backward masks with y > 0 either way
-            if not relu and res is None:
+            if not relu and res is None and shortcut:
                 ya.sibling = (z, mean, invstd, bname)      # a projection shortcut: its backward sums ride on its consumer's (message / epilogue)
             if relu and res is not None and res.sibling is not None and not sync and self.fuse_bn_bwd:
                 ya.bn2 = res.sibling                       # the shortcut's dy is this layer's g = dy * (y > 0): one more sum in the same epilogue
@@ -1089,6 +1098,48 @@ class PoseTrainer:
             tape.append(bwd)
             return ya
 
+        def se_gate(ua: Act, idn: Act, sname: str) -> Act:
+            """SELayer + the block tail (nets/commons.py:4-18, pose_resnet_dconv.py:124-131): y = relu(u * sigmoid(fc2(relu(fc0(mean_hw u)))) + identity).
+            The FC layers are 1x1 convs on the pooled [B,1,1,C] map (conv kernels forward, backward and for the weight gradients)."""
+            fc0, fc2 = L[sname + ".fc.0"], L[sname + ".fc.2"]
+            u, C, hw = ua.data, ua.c, ua.h * ua.w
+            ua.consumers += 1
+            idn.consumers += 1
+            sq = new((B, 1, 1, C))
+            _lib.check((lib.sp_global_avg_pool_nhwc_bf16 if self.bf16 else lib.sp_global_avg_pool_nhwc)(P(u), P(sq), B, hw, C, stream), sname + ".pool")
+            hid = fc0.forward(sq, B, shift=self.sd[sname + ".fc.0.bias"], relu=True)
+            gl = fc2.forward(hid, B, shift=self.sd[sname + ".fc.2.bias"])
+            y = new(u.shape)
+            _lib.check((lib.sp_se_gate_add_relu_nhwc_bf16 if self.bf16 else lib.sp_se_gate_add_relu_nhwc)(P(u), P(gl), P(idn.data), P(y), B, hw, C,
+                                                                                                         stream), sname + ".gate")
+            ya = Act(y, ua.h, ua.w, C)
+
+            def bwd():
+                dy = ya.grad
+                da = newf((B, C))
+                _lib.check(lib.sp_se_gate_bwd_reduce(P(dy), bf, P(y), P(u), B, hw, C, P(da), stream), sname + ".bwd")
+                dg = new((B, 1, 1, C))
+                _lib.check(lib.sp_se_sigmoid_bwd(P(da), bf, P(gl), B, C, P(dg), P(self.flat.view(sname + ".fc.2.bias", True)), stream), sname + ".bwd")
+                wgrad_async(fc2, hid, dg)
+                dh = fc2.dgrad(dg, B, None)
+                dhm = new((B, 1, 1, fc0.O))
+                _lib.check(lib.sp_relu_bwd_rows(P(dh), bf, P(hid), B, fc0.O, P(dhm), P(self.flat.view(sname + ".fc.0.bias", True)), stream), sname + ".bwd")
+                wgrad_async(fc0, sq, dhm)
+                ds = fc0.dgrad(dhm, B, None)
+                acc = 0
+                if idn.grad is None:
+                    idn.grad = newf(idn.data.shape)
+                else:
+                    acc = 1
+                ua.grad = newf(u.shape)
+                _lib.check(lib.sp_se_gate_bwd_apply(P(dy), bf, P(y), P(gl), P(ds), B, hw, C, P(ua.grad), P(idn.grad), acc, stream), sname + ".bwd")
+                ua.contrib += 1
+                idn.contrib += 1
+                ya.grad = None
+                self._grads_ready(sname + ".fc.0.weight", sname + ".fc.0.bias", sname + ".fc.2.weight", sname + ".fc.2.bias")
+            tape.append(bwd)
+            return ya
+
         # ---- forward ----
         cp = 8 if self.bf16 else 4
         x4 = new((B, self.in_h, self.in_w, cp))
@@ -1118,7 +1169,12 @@ class PoseTrainer:
                 t = conv_bn(a, p + ".conv1", p + ".bn1", True, pend=p1)
                 t = conv_bn(t, p + ".conv2", p + ".bn2", True)
                 idn = conv_bn(a, p + ".downsample.0", p + ".downsample.1", False, pend=pdn) if bi == 0 else a
-                a = conv_bn(t, p + ".conv3", p + ".bn3", True, res=idn)
+                if (p + ".se.fc.0") in L:
+                    if idn.sibling is not None:
+                        idn.sibling = None                 # the shortcut's consumer is the gate, not a BatchNorm epilogue: it reduces its own sums
+                    a = se_gate(conv_bn(t, p + ".conv3", p + ".bn3", False, shortcut=False), idn, p + ".se")
+                else:
+                    a = conv_bn(t, p + ".conv3", p + ".bn3", True, res=idn)
         def shuffle(xa: Act) -> Act:
             """nn.PixelShuffle(2) and, on the tape, its inverse permutation for the gradient."""
             xa.consumers += 1

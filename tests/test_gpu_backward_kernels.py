@@ -378,3 +378,60 @@ def test_bias_gradient_channel_sum_nchw_vs_float64(B, J, hw, measured):
         worst = max(worst, float(((out.double() - ref).abs() / torch.from_numpy(np.spacing(ref.float().abs().cpu().numpy())).double().to(DEV)).max()))
     measured("ulp_of_exact_sum", worst, 0.51)
     assert worst <= 0.51
+
+
+@pytest.mark.parametrize("bf16", [False, True], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("B,HW,C", [(3, 48, 256), (2, 192, 512), (5, 7, 64)])
+def test_selayer_gate_backward_vs_float64(B, HW, C, bf16, measured):
+    """The four kernels of the SELayer backward (sp_se_gate_bwd_reduce / sp_se_sigmoid_bwd / sp_relu_bwd_rows / sp_se_gate_bwd_apply) against
+    torch autograd in float64 on y = relu(u * sigmoid(g) + identity) and h = relu(.) with the saved activations rounded as the forward
+    stores them (bf16 mode); gradients w.r.t. activations are fp32."""
+    g_ = torch.Generator().manual_seed(B * 100 + C)
+    adt = torch.bfloat16 if bf16 else torch.float32
+    u = torch.randn((B, HW, C), generator=g_).to(adt)
+    idn = torch.randn((B, HW, C), generator=g_).to(adt)
+    gl = (torch.randn((B, C), generator=g_) * 1.5).to(adt)
+    dy = torch.randn((B, HW, C), generator=g_)
+    ds = torch.randn((B, C), generator=g_)
+    u64, i64, g64 = (t.double().requires_grad_(True) for t in (u, idn, gl))
+    a64 = torch.sigmoid(g64)
+    y64 = torch.relu(u64 * a64.view(B, 1, C) + i64)
+    y = y64.detach().to(adt)                                          # what the forward kernel stores
+    dr = torch.where(y.double() > 0, dy.double(), torch.zeros_like(dy.double()))
+    da_ref = (dr * u.double()).sum(1)
+    a = torch.sigmoid(gl.double())
+    dg_ref = da_ref * a * (1 - a)
+    du_ref = dr * a.view(B, 1, C) + ds.double().view(B, 1, C) / HW
+    lib, st = _lib.lib(), _lib.current_stream()
+    ud, yd, gd, dyd, dsd = (t.to(DEV).contiguous() for t in (u, y, gl, dy, ds))
+    da = torch.empty((B, C), device=DEV)
+    _lib.check(lib.sp_se_gate_bwd_reduce(P(dyd), int(bf16), P(yd), P(ud), B, HW, C, P(da), st), "reduce")
+    dg = torch.empty((B, C), dtype=adt, device=DEV)
+    db = torch.empty(C, device=DEV)
+    _lib.check(lib.sp_se_sigmoid_bwd(P(da), int(bf16), P(gd), B, C, P(dg), P(db), st), "sigmoid")
+    du = torch.empty((B, HW, C), device=DEV)
+    base = torch.randn((B, HW, C), generator=g_).to(DEV)
+    dres = base.clone()
+    _lib.check(lib.sp_se_gate_bwd_apply(P(dyd), int(bf16), P(yd), P(gd), P(dsd), B, HW, C, P(du), P(dres), 1, st), "apply")
+    dres0 = torch.empty_like(dres)
+    _lib.check(lib.sp_se_gate_bwd_apply(P(dyd), int(bf16), P(yd), P(gd), P(dsd), B, HW, C, P(du), P(dres0), 0, st), "apply")
+    torch.cuda.synchronize()
+    e_da = _rel(da.cpu().double(), da_ref)
+    e_dg = (_rel_bf16 if bf16 else _rel)(dg.float().cpu().double(), dg_ref)      # bf16: one rounding of the stored operand
+    e_du = _rel(du.cpu().double(), du_ref)
+    measured("da_rel", e_da, 1e-6)
+    measured("dg_rel", e_dg, 4e-3 if bf16 else 2e-6)
+    measured("du_rel", e_du, 2e-6)
+    assert e_da < 1e-6 and e_dg < (4e-3 if bf16 else 2e-6) and e_du < 2e-6
+    assert torch.equal(dres0.cpu(), dr.float()) and torch.allclose(dres.cpu(), base.cpu() + dr.float(), rtol=0, atol=1e-6)
+    assert _rel(db.cpu().double(), dg_ref.sum(0)) < 2e-6             # the bias gradient sums the UNROUNDED dg (fp64 accumulation)
+    # relu rows
+    h = torch.randn((B, C), generator=g_).to(adt)
+    dh = torch.randn((B, C), generator=g_)
+    out = torch.empty((B, C), dtype=adt, device=DEV)
+    db1 = torch.empty(C, device=DEV)
+    dhd, hd = dh.to(DEV), h.to(DEV)
+    _lib.check(lib.sp_relu_bwd_rows(P(dhd), int(bf16), P(hd), B, C, P(out), P(db1), st), "relu")
+    torch.cuda.synchronize()
+    ref = torch.where(h.float() > 0, dh, torch.zeros_like(dh))
+    assert torch.equal(out.cpu(), ref.to(adt)) and _rel(db1.cpu().double(), ref.double().sum(0)) < 1e-6

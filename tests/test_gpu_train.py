@@ -70,6 +70,59 @@ def test_train_step_vs_oracle_small(B, H, W, head):
     assert frac_close > 0.995, (frac_close, sorted(bad, reverse=True)[:5])
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (3, 96, 64)])
+def test_train_step_with_selayer_vs_oracle(B, H, W):
+    """`resnet50(reduction=True)` (SELayer in the first Bottleneck of every stage, nets/commons.py:4-18, pose_resnet_dconv.py:108-110,126-127;
+    enabled by configs/dp_fast_pose.yaml) in train mode: loss, heat maps, every gradient incl. the gate's FC weights and biases, and
+    one Adam step against the float64 oracle - same bars as the plain net (a tiny-batch BatchNorm net is chaotic at the 0.3 % level)."""
+    m = pose_resnet_dconv.resnet50(pretrained=False, num_classes=17, reduction=True)
+    sdn = synth.conditioned_state_dict(nets_oracle.state_dict_shapes_resnet50("dconv", se=True), 7)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sdn.items()}, strict=True)
+    model = m.to(DEV).train()
+    sd = {k: torch.from_numpy(v.copy()) for k, v in sdn.items()}
+    x, t, w = _batch(B, H, W, 7)
+    tr = PoseTrainer(model, in_h=H, in_w=W, lr=1e-3)
+    assert sum(".se.fc." in n for n in tr.layers) == 8
+    loss = tr.forward_backward(torch.from_numpy(x).to(DEV), torch.from_numpy(t).to(DEV), torch.from_numpy(w).to(DEV))
+    torch.cuda.synchronize()
+    oloss, ograds, oheat = train_oracle.forward_backward(sd, torch.from_numpy(x), torch.from_numpy(t), torch.from_numpy(w), arch="resnet50_dconv")
+    assert _rel(tr.last_heat.cpu().numpy(), oheat.numpy()) < 1e-3
+    assert abs(loss.item() - float(oloss)) <= 1e-4 * abs(float(oloss))
+    named = dict(model.named_parameters())
+    sd64 = {k: (torch.from_numpy(v.copy()).double() if v.dtype.kind == "f" else torch.from_numpy(v.copy())) for k, v in sdn.items()}
+    _, g64, _ = train_oracle.forward_backward(sd64, torch.from_numpy(x).double(), torch.from_numpy(t).double(), torch.from_numpy(w).double(),
+                                              arch="resnet50_dconv")
+    assert set(g64) == set(named)
+    l2 = sorted(((float((named[k].grad.cpu().double() - g64[k]).norm() / (g64[k].norm() + 1e-30)), k) for k in g64), reverse=True)
+    l2_torch = sorted((float((ograds[k].double() - g64[k]).norm() / (g64[k].norm() + 1e-30)) for k in g64), reverse=True)
+    assert l2[0][0] < max(3e-2, 8 * l2_torch[0]), (l2[:6], l2_torch[:3])
+    assert np.median([e for e, _ in l2]) < max(1e-2, 4 * np.median(l2_torch)), (np.median([e for e, _ in l2]), np.median(l2_torch))
+    se = [(e, k) for e, k in l2 if ".se." in k]
+    assert len(se) == 16 and max(e for e, _ in se) < max(3e-2, 8 * l2_torch[0]), se[:4]
+    # the streamed step (weight gradients / optimizer on their own streams) on the same net: bit-reproducible, loss goes down
+    losses = [tr.step(torch.from_numpy(x).to(DEV), torch.from_numpy(t).to(DEV), torch.from_numpy(w).to(DEV)).item() for _ in range(3)]
+    assert losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_selayer_train_step_is_bit_reproducible_and_bf16_tracks_fp32(dtype):
+    """The SELayer step twice from the same state: identical parameters (deterministic kernels); bf16 compute stays within the bf16 bar of
+    the plain net's loss."""
+    res = []
+    for _ in range(2):
+        m = pose_resnet_dconv.resnet50(pretrained=False, num_classes=17, reduction=True)
+        sdn = synth.conditioned_state_dict(nets_oracle.state_dict_shapes_resnet50("dconv", se=True), 9)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sdn.items()}, strict=True)
+        tr = PoseTrainer(m.to(DEV).train(), in_h=128, in_w=96, lr=1e-3, dtype=dtype)
+        x, t, w = _batch(4, 128, 96, 9)
+        xs, ts, ws = (torch.from_numpy(v).to(DEV) for v in (x, t, w))
+        losses = [tr.step(xs, ts, ws).item() for _ in range(3)]
+        torch.cuda.synchronize()
+        res.append((losses, tr.flat.data.clone()))
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
+    assert res[0][0][-1] < res[0][0][0]
+
+
 # pinned from gpurun_out/measured_parity.json, round 2: worst gradient slice 1.5e-2 of the per-element gradient scale (conv1.weight: the
 # longest fp32 chain of the net, where the reference's own oneDNN-vs-fp64 spread is 0.3-1 %); 99.86 % of the sliced parameters within
 # 2e-4 after one Adam step (lr 1e-3: a sign flip of a near-zero gradient moves a parameter by 2e-3); loss 7.8e-8 relative
@@ -579,8 +632,21 @@ def test_reference_training_loop_through_autograd(dtype):
     assert torch.allclose(pa[k].grad, g1[k], rtol=1e-5, atol=1e-12)
 
 
-def test_train_mode_forward_needs_no_trainer_object_and_refuses_what_is_not_lowered():
+def test_train_mode_forward_of_the_selayer_net_through_autograd():
+    """`resnet50(reduction=True)` in train() mode through the autograd surface (no trainer object in sight): loss.backward() fills every
+    parameter's .grad, the SELayer's FC weights and biases included, finite and non-zero."""
     from simple_pose_amd.nets import pose_resnet_dconv as prd
+    torch.manual_seed(0)
     m = prd.resnet50(pretrained=False, num_classes=17, reduction=True).to(DEV).train()
-    with pytest.raises(NotImplementedError):
-        m(torch.zeros(2, 3, 64, 64, device=DEV))
+    with torch.no_grad():
+        for p in m.parameters():                                  # the reference's init (std 1e-3) gives gradients too small to look at
+            if p.dim() == 4:
+                p.normal_(0, (2.0 / (p.shape[1] * p.shape[2] * p.shape[3])) ** 0.5)
+    out = m(torch.randn(2, 3, 64, 64, device=DEV))
+    assert out.shape == (2, 17, 16, 16) and out.requires_grad
+    out.square().mean().backward()
+    torch.cuda.synchronize()
+    grads = {k: p.grad for k, p in m.named_parameters()}
+    assert all(g is not None and torch.isfinite(g).all() for g in grads.values())
+    for k in ("layer1.0.se.fc.0.weight", "layer1.0.se.fc.0.bias", "layer3.0.se.fc.2.weight", "layer4.0.se.fc.2.bias"):
+        assert float(grads[k].abs().max()) > 0, k
