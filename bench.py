@@ -317,8 +317,8 @@ def main():
     x = torch.from_numpy(np.concatenate([base] * ((B + 7) // 8), 0)[:B]).to(dev)
     tinv = torch.from_numpy(synth.trans_inv_batch(B)).to(dev)
     if args.mode == "train":
-        if args.arch not in ("dconv", "duc"):
-            raise SystemExit("--mode train lowers the ResNet50 DConv / DUC nets")
+        if args.arch not in ("dconv", "duc", "hrnet_w32"):
+            raise SystemExit("--mode train lowers the ResNet50 DConv / DUC nets and HRNet-W32")
         from simple_pose_amd.commons.transforms import RefineSimpleTransform
         from simple_pose_amd.train import PoseTrainer
         model.train()
@@ -329,7 +329,7 @@ def main():
         # committed rocprofv3 summaries were taken with: no tuner launches in a profiled run, same launches on every rank and box);
         # --retune / a missing table: timed on rank 0 at this batch and shared
         tiles_src = "built-in heuristic"
-        tpath = args.tiles or (None if args.retune else tracked_tiles("train", args.dtype))
+        tpath = args.tiles or (None if (args.retune or args.arch != "dconv") else tracked_tiles("train", args.dtype))   # the tracked tables are ResNet50-DConv's
         if not args.no_train_autotune:
             if tpath and os.path.isfile(tpath) and B == 32:
                 with open(tpath) as fh:
@@ -447,7 +447,8 @@ def main():
     if rank == 0:
         name = ARCH_NAMES[args.arch]
         if args.mode == "train":
-            gflop = 3 * (10.8528 if args.arch == "dconv" else 11.7517)   # train step ~ 3 x forward (fwd + dgrad + wgrad) = 32.56 GFLOP / image
+            # train step ~ 3 x forward (fwd + dgrad + wgrad) = 32.56 GFLOP / image (HRNet: from the trainer's own layer table)
+            gflop = 3 * ({"dconv": 10.8528, "duc": 11.7517}.get(args.arch) or sum(L.flops for L in trainer.layers.values()) / 1e9)
             line = {
                 "metric": f"images/sec train step (fwd+bwd+Adam), {name} 256x192 bs={B}/GPU", "value": round(value, 1), "unit": "images/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),

@@ -27,7 +27,7 @@ extern "C" {
 #define SP_EINVAL (-1)   /* bad argument / unsupported shape (message in sp_last_error) */
 #define SP_ELAUNCH (-2)  /* HIP launch or runtime failure */
 
-#define SP_ABI_VERSION 27
+#define SP_ABI_VERSION 28
 
 /* epilogue / layout flags of sp_conv_desc.flags */
 #define SP_CONV_RELU 0x1u          /* y = max(y, 0) after scale/shift (+ residual) */
@@ -393,6 +393,13 @@ int sp_permute4_batched(const float* src, const void* jobs_device, int n_jobs, i
 
 /* measurement aid: occupies `stream` for `us` microseconds (one idle wave on the 100 MHz constant clock) - bench.py's stand-in for the
  * latency of a SyncBatchNorm message (ddp...:89-90) on a box with a single GPU */
+/* Backward of sp_upsample_add_nhwc (HRNet fuse layers, nets/pose_hrnet.py:192-202,250-257): dr = y_relu_src ? dy (y > 0) : dy (y in the
+ * activation dtype, null when the forward had no ReLU); dbase (+)= dr at the high resolution [batch, h*factor, w*factor, c]; dx (+)= the sum
+ * of dr over each factor x factor block [batch, h, w, c].  Gradients are fp32; the accumulate flags say whether the target already holds other
+ * consumers' shares. */
+int sp_upsample_add_bwd_nhwc(const float* dy, int bf16, const void* y_relu_src, int batch, int h, int w, int c, int factor, float* dbase,
+                             int dbase_accumulate, float* dx, int dx_accumulate, void* stream);
+
 /* SELayer backward (nets/commons.py:4-18 inside Bottleneck.forward, pose_resnet_dconv.py:124-131; `bf16`: dtype of the saved activations,
  * gradients w.r.t. activations are fp32):  y = relu(u * sigmoid(g[b,c]) + identity), u = bn3(conv3(.)), g = fc2(relu(fc0(mean_hw u))).
  *   sp_se_gate_bwd_reduce: da[b,c] = sum_hw (y > 0 ? dy : 0) * u

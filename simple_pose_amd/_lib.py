@@ -20,7 +20,7 @@ SP_CONV_PIXEL_SHUFFLE = 0x4
 SP_CONV_BF16 = 0x8
 SP_CONV_OUT_F32 = 0x10
 CONV_TILES = ((128, 128), (64, 128), (128, 64), (64, 64), (256, 64), (128, 32))
-ABI_VERSION = 27
+ABI_VERSION = 28
 SP_CONV_KERNEL_IGEMM, SP_CONV_KERNEL_RING, SP_CONV_KERNEL_PW = 0, 1, 2
 RING_TILES = ((256, 256), (256, 128), (128, 256), (256, 64), (128, 128), (192, 128), (192, 256))   # kernel = SP_CONV_KERNEL_RING (bf16)
 
@@ -82,6 +82,7 @@ SYMBOLS = {
     "sp_channel_sum_nhwc": (c_int, [_P, c_int64, c_int, _P, _P, _P]),
     "sp_maxpool3x3s2_bwd_nhwc": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "sp_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_double, c_double, c_double, c_double, c_int, c_float, _P]),
+    "sp_upsample_add_bwd_nhwc": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P]),
     "sp_se_gate_bwd_reduce": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, _P, _P]),
     "sp_se_sigmoid_bwd": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P, _P]),
     "sp_relu_bwd_rows": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P, _P]),

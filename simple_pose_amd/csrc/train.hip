@@ -931,6 +931,56 @@ extern "C" int sp_se_gate_bwd_apply(const float* dy, int bf16, const void* y, co
     return sp_check_launch("se_gate_bwd_apply_kernel");
 }
 
+// Backward of y = [relu](base + nearest_upsample(x, f)) (HRNet fuse layers, nets/pose_hrnet.py:192-202,250-257; f = 1: a plain add):
+// dr = relu ? dy (y > 0) : dy;  d base (+)= dr;  d x (+)= sum of dr over the f x f block above each low-resolution pixel.  One thread per
+// (low-resolution pixel, 4 channels); fixed summation order.
+template <bool BF16>
+__global__ void upsample_add_bwd_kernel(const f32x4* __restrict__ dy, const void* __restrict__ y, int h, int w, int C4, int f, f32x4* __restrict__ dbase,
+                                        int base_acc, f32x4* __restrict__ dx, int x_acc, long long total) {
+    const int W = w * f, H = h * f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long long r = i / C4;
+        const int X0 = (int)(r % w) * f; r /= w;
+        const int Y0 = (int)(r % h) * f;
+        const long long b = r / h;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int yy = 0; yy < f; ++yy)
+            for (int xx = 0; xx < f; ++xx) {
+                const long long I = ((b * H + Y0 + yy) * W + X0 + xx) * C4 + c;
+                f32x4 g = dy[I];
+                if (y) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float yv = BF16 ? (float)reinterpret_cast<const __bf16*>(y)[I * 4 + e] : reinterpret_cast<const float*>(y)[I * 4 + e];
+                        g[e] = yv > 0.f ? g[e] : 0.f;
+                    }
+                }
+                if (base_acc) { const f32x4 o = dbase[I]; dbase[I] = f32x4{o[0] + g[0], o[1] + g[1], o[2] + g[2], o[3] + g[3]}; }
+                else dbase[I] = g;
+                acc[0] += g[0]; acc[1] += g[1]; acc[2] += g[2]; acc[3] += g[3];
+            }
+        if (x_acc) { const f32x4 o = dx[i]; dx[i] = f32x4{o[0] + acc[0], o[1] + acc[1], o[2] + acc[2], o[3] + acc[3]}; }
+        else dx[i] = acc;
+    }
+}
+
+extern "C" int sp_upsample_add_bwd_nhwc(const float* dy, int bf16, const void* y_relu_src, int batch, int h, int w, int c, int factor, float* dbase,
+                                        int dbase_accumulate, float* dx, int dx_accumulate, void* stream) {
+    SP_REQUIRE(dy && dbase && dx, "sp_upsample_add_bwd_nhwc: null pointer");
+    SP_REQUIRE(batch > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0 && factor >= 1, "sp_upsample_add_bwd_nhwc: bad shape");
+    SP_REQUIRE(dbase != dx, "sp_upsample_add_bwd_nhwc: the two gradients must be different tensors");
+    const long long total = (long long)batch * h * w * (c / 4);
+    SP_REQUIRE(total * factor * factor * 4 < (1ll << 31), "sp_upsample_add_bwd_nhwc: tensor too large");
+    if (bf16) hipLaunchKernelGGL(upsample_add_bwd_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                                 reinterpret_cast<const f32x4*>(dy), y_relu_src, h, w, c / 4, factor, reinterpret_cast<f32x4*>(dbase), dbase_accumulate,
+                                 reinterpret_cast<f32x4*>(dx), dx_accumulate, total);
+    else hipLaunchKernelGGL(upsample_add_bwd_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                            reinterpret_cast<const f32x4*>(dy), y_relu_src, h, w, c / 4, factor, reinterpret_cast<f32x4*>(dbase), dbase_accumulate,
+                            reinterpret_cast<f32x4*>(dx), dx_accumulate, total);
+    return sp_check_launch("upsample_add_bwd_kernel");
+}
+
 // Measurement aid (bench.py --sync-bn-latency-us): keep `stream` busy for `us` microseconds of the 100 MHz constant clock - a stand-in
 // for the latency of a small cross-GPU message on a box with one GPU.  One wave, no memory traffic.
 __global__ void stream_delay_kernel(unsigned long long ticks) {

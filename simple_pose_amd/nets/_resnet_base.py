@@ -117,31 +117,35 @@ class PoseResNetBase(nn.Module):
 
     # -- train mode: the reference loop `predicts = model(x); loss = ...; loss.backward(); optimizer.step()` (ddp...:114-119) ------
     def _forward_train(self, x: torch.Tensor) -> torch.Tensor:
-        """Train-mode forward as one autograd node: the HIP train-mode forward (batch-statistics BatchNorm, running statistics
-        updated) records its tape; `loss.backward()` runs the HIP backward (dgrad / wgrad / BN backward) and hands every parameter
-        gradient to autograd, so `.grad`, gradient hooks (DistributedDataParallel) and any torch optimizer work as in the reference.
-        `simple_pose_amd.train.PoseTrainer.step` stays the faster fused path (loss, Adam and repack as kernels of the same tape)."""
-        from ..train import PoseTrainer
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and not getattr(self, "_warned_local_bn", False):
-            # the reference converts to SyncBatchNorm under DDP (ddp...:89-90); this surface computes LOCAL gradients and leaves the
-            # exchange to the caller's DistributedDataParallel wrapper, so its BatchNorm statistics are per rank
-            import warnings
-            warnings.warn("simple_pose_amd: model(x) in train() mode under an initialised process group uses per-rank BatchNorm statistics "
-                          "(sync_bn: False behaviour); PoseTrainer(model, process_group=..., sync_bn=True).step() is the SyncBatchNorm path")
-            self._warned_local_bn = True
-        key = (x.shape[2], x.shape[3], str(x.device), self.compute_dtype)
-        tr = getattr(self, "_trainer", None)
-        if tr is None or self._trainer_key != key or not tr.still_owns_parameters():
-            tr = PoseTrainer(self, in_h=x.shape[2], in_w=x.shape[3], dtype="bf16" if self.compute_dtype == "bf16" else "fp32",
-                             collectives=False)
-            self._trainer, self._trainer_key = tr, key
-        if not torch.is_grad_enabled():
-            return tr.forward_tape(x)[0]
-        return _TrainForward.apply(x, tr, *tr.sd.values())
+        return train_forward(self, x)
 
     def forward_crops(self, crops: torch.Tensor) -> torch.Tensor:
         return forward_uint8_crops(self, crops)
+
+
+def train_forward(self, x: torch.Tensor) -> torch.Tensor:
+    """Train-mode forward as one autograd node: the HIP train-mode forward (batch-statistics BatchNorm, running statistics
+    updated) records its tape; `loss.backward()` runs the HIP backward (dgrad / wgrad / BN backward) and hands every parameter
+    gradient to autograd, so `.grad`, gradient hooks (DistributedDataParallel) and any torch optimizer work as in the reference.
+    `simple_pose_amd.train.PoseTrainer.step` stays the faster fused path (loss, Adam and repack as kernels of the same tape)."""
+    from ..train import PoseTrainer
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and not getattr(self, "_warned_local_bn", False):
+        # the reference converts to SyncBatchNorm under DDP (ddp...:89-90); this surface computes LOCAL gradients and leaves the
+        # exchange to the caller's DistributedDataParallel wrapper, so its BatchNorm statistics are per rank
+        import warnings
+        warnings.warn("simple_pose_amd: model(x) in train() mode under an initialised process group uses per-rank BatchNorm statistics "
+                      "(sync_bn: False behaviour); PoseTrainer(model, process_group=..., sync_bn=True).step() is the SyncBatchNorm path")
+        self._warned_local_bn = True
+    key = (x.shape[2], x.shape[3], str(x.device), self.compute_dtype)
+    tr = getattr(self, "_trainer", None)
+    if tr is None or self._trainer_key != key or not tr.still_owns_parameters():
+        tr = PoseTrainer(self, in_h=x.shape[2], in_w=x.shape[3], dtype="bf16" if self.compute_dtype == "bf16" else "fp32",
+                         collectives=False)
+        self._trainer, self._trainer_key = tr, key
+    if not torch.is_grad_enabled():
+        return tr.forward_tape(x)[0]
+    return _TrainForward.apply(x, tr, *tr.sd.values())
 
 
 class _TrainForward(torch.autograd.Function):

@@ -110,6 +110,7 @@ class PoseHighResolutionNet(ParamTree):
             elif v.dim() == 4:
                 torch.nn.init.normal_(v, std=0.001)
 
+    HEAD = "hrnet"         # which network walk simple_pose_amd.train.PoseTrainer takes
     fuse_blocks = False    # True: bf16 32-channel BasicBlocks as one launch each (sp_basic_block_c32); same bits, measured no faster
 
     def hip_program(self, x: torch.Tensor) -> engine.Program:
@@ -128,8 +129,9 @@ class PoseHighResolutionNet(ParamTree):
         x = require_cuda_f32(x, "input")
         if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] % 32 or x.shape[3] % 32:
             raise ValueError(f"expected [B,3,H,W] with H,W multiples of 32, got {tuple(x.shape)}")
-        if self.training:
-            raise NotImplementedError("train-mode HRNet is not lowered to HIP yet; call .eval()")
+        if self.training:                       # one autograd node over the HIP tape, as the ResNets (PoseTrainer lowers pose_hrnet.py:419-454)
+            from ._resnet_base import train_forward
+            return train_forward(self, x)
         prog = self.hip_program(x)
         if self.autotune and x.shape[0] >= 16 and x.shape[0] >= 4 * prog.tuned_for_batch:
             prog.autotune(x)

@@ -96,7 +96,8 @@ class ConvT:
     """One conv / transposed-conv layer in training: forward launch, dgrad launches, wgrad, and its pack jobs."""
 
     def __init__(self, tr: "PoseTrainer", name: str, kind: str, weight: torch.Tensor, h: int, w: int, stride: int = 1, pad: int = 0,
-                 c_in_buf: Optional[int] = None, bias_name: Optional[str] = None, out_nchw: bool = False, need_dgrad: bool = True):
+                 c_in_buf: Optional[int] = None, bias_name: Optional[str] = None, out_nchw: bool = False, need_dgrad: bool = True,
+                 taps_w: Optional[int] = None):
         self.tr, self.name, self.kind, self.wname = tr, name, kind, name + ".weight"
         self.stride, self.pad, self.h, self.w = stride, pad, h, w
         self.bias_name, self.out_nchw, self.need_dgrad = bias_name, out_nchw, need_dgrad
@@ -112,14 +113,15 @@ class ConvT:
             self.O, self.I, self.kh, self.kw = O, I, kh, kw
             ci = c_in_buf or I                                     # stem: 3 -> NHWC4
             stem = c_in_buf is not None and c_in_buf > I
-            tw = (_round_up(kw, 8) if kw > 4 else 4) if stem else kw
+            tw = taps_w or ((_round_up(kw, 8) if kw > 4 else 4) if stem else kw)     # stem: tap rows padded so that K fills whole tiles
             self.ci, self.tw = ci, tw
-            k = kh * tw * ci
-            k_pad, n_pad = _round_up(k, kmul), n_pad_for(O)
-            assert k_pad == k, (name, k, k_pad)   # the pack job writes dense [n][kh][tw][ci] rows
+            # K = (tap rows) x tw x ci must fill whole 128-byte K tiles; where it does not (bf16 with 32 channels: 9 x 32 = 288) whole zero tap
+            # ROWS are appended - the pack job writes them as padding and the kernel's gather treats a tap row >= taps_h as out of range
+            khp = self._pad_rows(kh, tw * ci)
+            k_pad, n_pad = khp * tw * ci, n_pad_for(O)
             self.w_fwd = torch.zeros((n_pad, k_pad), dtype=wdt, device=dev)
-            # fwd pack: dst [n_pad][kh][tw][ci] <- W[o][c][ty][tx]
-            self.pack_jobs.append(PackJob(self.wname, self.w_fwd, (n_pad, kh, tw, ci), (I * kh * kw, kw, 1, kh * kw), (O, kh, kw, I), 0))
+            # fwd pack: dst [n_pad][khp][tw][ci] <- W[o][c][ty][tx]
+            self.pack_jobs.append(PackJob(self.wname, self.w_fwd, (n_pad, khp, tw, ci), (I * kh * kw, kw, 1, kh * kw), (O, kh, kw, I), 0))
             self.oh, self.ow = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
             d = ConvDesc()
             d.batch, d.in_h, d.in_w, d.c_in = 1, h, w, ci
@@ -185,24 +187,35 @@ class ConvT:
         else:
             raise ValueError(kind)
 
+    def _pad_rows(self, rows: int, row_elems: int) -> int:
+        """Smallest number of tap rows >= `rows` whose elements fill whole K tiles."""
+        r = rows
+        while (r * row_elems) % self._kmul:
+            r += 1
+        return r
+
     # dgrad of a Conv2d: stride 1 -> one conv with flipped taps; stride 2 -> one launch per output phase
     def _build_conv_dgrad(self, weight):
         O, I, kh, kw, s, p = self.O, self.I, self.kh, self.kw, self.stride, self.pad
         dev = weight.device
         wdt, kmul, fbf = self._wdt, self._kmul, self._fbf
         nd = n_pad_for(I)
-        Ob = _round_up(O, kmul) if O % kmul else O        # 17 heat-map channels -> one whole K tile (32 fp32 / 64 bf16)                    # channels of the incoming gradient buffer (17 -> 32)
+        # channels of the incoming gradient buffer: 17 heat-map channels -> one whole K tile (32 fp32 / 64 bf16); a channel count that is a
+        # whole number of 16-byte chunks stays as it is (32 channels in bf16) and zero tap rows fill the K tile instead (_pad_rows)
+        epc = 8 if self.bf16 else 4
+        Ob = O if (O % kmul == 0 or O % epc == 0) else _round_up(O, kmul)
         self.c_out_buf = Ob
         self.w_dgrad, self.d_dgrad = [], []
         if s == 1:
-            wd = torch.zeros((nd, kh * kw * Ob), dtype=wdt, device=dev)
+            khp = self._pad_rows(kh, kw * Ob)
+            wd = torch.zeros((nd, khp * kw * Ob), dtype=wdt, device=dev)
             # Wd[c][(ty,tx,o)] = W[o][c][kh-1-ty][kw-1-tx]
-            self.pack_jobs.append(PackJob(self.wname, wd, (nd, kh, kw, Ob), (kh * kw, -kw, -1, I * kh * kw), (I, kh, kw, O),
+            self.pack_jobs.append(PackJob(self.wname, wd, (nd, khp, kw, Ob), (kh * kw, -kw, -1, I * kh * kw), (I, kh, kw, O),
                                           (kh - 1) * kw + (kw - 1)))
             g = ConvDesc()
             g.batch, g.in_h, g.in_w, g.c_in = 1, self.oh, self.ow, Ob
             g.grid_h, g.grid_w, g.c_out, g.n_pad = self.h, self.w, I, nd
-            g.taps_h, g.taps_w, g.k_pad, g.stride = kh, kw, kh * kw * Ob, 1
+            g.taps_h, g.taps_w, g.k_pad, g.stride = kh, kw, khp * kw * Ob, 1
             pp = kh - 1 - p
             g.dy0, g.dy_step, g.dx0, g.dx_step = -pp, 1, -pp, 1
             g.out_h, g.out_w, g.out_c = self.h, self.w, I
@@ -224,13 +237,14 @@ class ConvT:
                     if th == 0 or tw == 0:
                         self.dgrad_full_cover = False             # 1x1 stride 2: only phase (0,0) receives gradient
                         continue
-                    wd = torch.zeros((nd, th * tw * Ob), dtype=wdt, device=dev)
-                    self.pack_jobs.append(PackJob(self.wname, wd, (nd, th, tw, Ob), (kh * kw, 2 * kw, 2, I * kh * kw), (I, th, tw, O),
+                    thp = self._pad_rows(th, tw * Ob)
+                    wd = torch.zeros((nd, thp * tw * Ob), dtype=wdt, device=dev)
+                    self.pack_jobs.append(PackJob(self.wname, wd, (nd, thp, tw, Ob), (kh * kw, 2 * kw, 2, I * kh * kw), (I, th, tw, O),
                                                   ky0 * kw + kx0))
                     g = ConvDesc()
                     g.batch, g.in_h, g.in_w, g.c_in = 1, self.oh, self.ow, Ob
                     g.grid_h, g.grid_w, g.c_out, g.n_pad = self.h // 2, self.w // 2, I, nd
-                    g.taps_h, g.taps_w, g.k_pad, g.stride = th, tw, th * tw * Ob, 1
+                    g.taps_h, g.taps_w, g.k_pad, g.stride = th, tw, thp * tw * Ob, 1
                     g.dy0, g.dy_step, g.dx0, g.dx_step = (py + p - ky0) // 2, -1, (px + p - kx0) // 2, -1
                     g.out_h, g.out_w, g.out_c = self.h, self.w, I
                     g.oy_mul, g.oy_add, g.ox_mul, g.ox_add = 2, py, 2, px
@@ -398,8 +412,8 @@ class PoseTrainer:
             raise ValueError(dtype)
         self.bf16 = dtype == "bf16"
         self.act_dtype = torch.bfloat16 if self.bf16 else torch.float32
-        if getattr(model, "HEAD", None) not in ("dconv", "duc"):
-            raise NotImplementedError("PoseTrainer lowers the ResNet DConv / DUC nets (the DDP solver's models, ddp...:65-68); HRNet pending")
+        if getattr(model, "HEAD", None) not in ("dconv", "duc", "hrnet"):
+            raise NotImplementedError("PoseTrainer lowers the ResNet DConv / DUC nets (the DDP solver's models, ddp...:65-68) and HRNet")
         self.head = model.HEAD
         self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
         self.pg = process_group
@@ -671,7 +685,55 @@ class PoseTrainer:
         self.layers[name] = layer
         return layer
 
+    def _build_hrnet(self, H, W):
+        """One ConvT per conv of PoseHighResolutionNet (nets/pose_hrnet.py:419-454), walked exactly as the forward walks it."""
+        extra = self.model.cfg["MODEL"]["EXTRA"]
+        cp = 8 if self.bf16 else 4
+        self._conv("conv1", H, W, stride=2, pad=1, c_in_buf=cp, need_dgrad=False, taps_w=8)      # K = 3 x 8 x cp: whole 128-byte tiles
+        self._conv("conv2", H // 2, W // 2, stride=2, pad=1)
+        h, w = H // 4, W // 4
+        for k in range(4):
+            p = f"layer1.{k}"
+            self._conv(p + ".conv1", h, w)
+            self._conv(p + ".conv2", h, w, pad=1)
+            self._conv(p + ".conv3", h, w)
+            if k == 0:
+                self._conv(p + ".downsample.0", h, w)
+        pre_n = 1
+        for si, st in enumerate((2, 3, 4)):
+            sc = extra[f"STAGE{st}"]
+            nb = sc["NUM_BRANCHES"]
+            t = f"transition{si + 1}"
+            for i in range(nb):
+                if i < pre_n:
+                    if (f"{t}.{i}.0.weight") in self.sd:
+                        self._conv(f"{t}.{i}.0", h >> i, w >> i, pad=1)
+                else:
+                    for j in range(i + 1 - pre_n):
+                        self._conv(f"{t}.{i}.{j}.0", h >> (pre_n - 1 + j), w >> (pre_n - 1 + j), stride=2, pad=1)
+            for m in range(sc["NUM_MODULES"]):
+                multi = not (st == 4 and m == sc["NUM_MODULES"] - 1)
+                base = f"stage{st}.{m}"
+                for i in range(nb):
+                    for k in range(sc["NUM_BLOCKS"][i]):
+                        self._conv(f"{base}.branches.{i}.{k}.conv1", h >> i, w >> i, pad=1)
+                        self._conv(f"{base}.branches.{i}.{k}.conv2", h >> i, w >> i, pad=1)
+                for i in range(nb if multi else 1):
+                    for j in range(nb):
+                        f = f"{base}.fuse_layers.{i}.{j}"
+                        if j > i:
+                            self._conv(f + ".0", h >> j, w >> j)
+                        elif j < i:
+                            for k in range(i - j):
+                                self._conv(f"{f}.{k}.0", h >> (j + k), w >> (j + k), stride=2, pad=1)
+            pre_n = nb
+        kf = extra["FINAL_CONV_KERNEL"]
+        self._conv("final_layer", h, w, pad=1 if kf == 3 else 0, bias_name="final_layer.bias", out_nchw=True)
+        self.heat_hw = (h, w)
+
     def _build(self, H, W):
+        if self.head == "hrnet":
+            return self._build_hrnet(H, W)
         self._conv("conv1", H, W, stride=2, pad=3, c_in_buf=8 if self.bf16 else 4, need_dgrad=False)
         h, w = H // 4, W // 4
         inpl = 64
@@ -1140,11 +1202,91 @@ class PoseTrainer:
             tape.append(bwd)
             return ya
 
+        def upsample_add(xa: Act, base: Act, f: int, relu: bool) -> Act:
+            """y = [relu](base + nearest_upsample(x, f)) (HRNet fuse layers, pose_hrnet.py:192-202,250-257; f = 1: the identity term)."""
+            xa.consumers += 1
+            base.consumers += 1
+            y = new(base.data.shape)
+            _lib.check((lib.sp_upsample_add_nhwc_bf16 if self.bf16 else lib.sp_upsample_add_nhwc)(P(xa.data), P(base.data), P(y), B, xa.h, xa.w, xa.c, f,
+                                                                                                 int(relu), stream), "fuse")
+            ya = Act(y, base.h, base.w, base.c)
+
+            def bwd():
+                accs = []
+                for t in (base, xa):
+                    accs.append(0 if t.grad is None else 1)
+                    if t.grad is None:
+                        t.grad = newf(t.data.shape)
+                _lib.check(lib.sp_upsample_add_bwd_nhwc(P(ya.grad), bf, P(y) if relu else None, B, xa.h, xa.w, xa.c, f, P(base.grad), accs[0],
+                                                        P(xa.grad), accs[1], stream), "fuse.bwd")
+                base.contrib += 1
+                xa.contrib += 1
+                ya.grad = None
+            tape.append(bwd)
+            return ya
+
+        def hrnet_forward(a: Act) -> Act:
+            """PoseHighResolutionNet.forward after the first stem conv (pose_hrnet.py:419-454, :241-259, :181-236, :327-366)."""
+            extra = self.model.cfg["MODEL"]["EXTRA"]
+            a = conv_bn(a, "conv2", "bn2", True)
+            for k in range(4):
+                p = f"layer1.{k}"
+                t = conv_bn(a, p + ".conv1", p + ".bn1", True)
+                t = conv_bn(t, p + ".conv2", p + ".bn2", True)
+                idn = conv_bn(a, p + ".downsample.0", p + ".downsample.1", False) if k == 0 else a
+                a = conv_bn(t, p + ".conv3", p + ".bn3", True, res=idn)
+            ys, pre_n = [a], 1
+            for si, st in enumerate((2, 3, 4)):
+                sc = extra[f"STAGE{st}"]
+                nb = sc["NUM_BRANCHES"]
+                tn = f"transition{si + 1}"
+                xs: List[Act] = []
+                for i in range(nb):
+                    if i < pre_n:
+                        xs.append(conv_bn(ys[i], f"{tn}.{i}.0", f"{tn}.{i}.1", True) if (f"{tn}.{i}.0") in L else ys[i])
+                    else:
+                        v = ys[-1]
+                        for j in range(i + 1 - pre_n):
+                            v = conv_bn(v, f"{tn}.{i}.{j}.0", f"{tn}.{i}.{j}.1", True)
+                        xs.append(v)
+                for m in range(sc["NUM_MODULES"]):
+                    multi = not (st == 4 and m == sc["NUM_MODULES"] - 1)
+                    base = f"stage{st}.{m}"
+                    for i in range(nb):
+                        for k in range(sc["NUM_BLOCKS"][i]):
+                            p = f"{base}.branches.{i}.{k}"
+                            t = conv_bn(xs[i], p + ".conv1", p + ".bn1", True)
+                            xs[i] = conv_bn(t, p + ".conv2", p + ".bn2", True, res=xs[i])
+                    outs = []
+                    for i in range(nb if multi else 1):
+                        y: Optional[Act] = None
+                        for j in range(nb):
+                            last = j == nb - 1
+                            f = f"{base}.fuse_layers.{i}.{j}"
+                            if j == i:
+                                y = xs[i] if y is None else upsample_add(xs[i], y, 1, last)
+                            elif j > i:
+                                t = conv_bn(xs[j], f + ".0", f + ".1", False, shortcut=False)
+                                y = upsample_add(t, y, 2 ** (j - i), last)
+                            else:
+                                t = xs[j]
+                                for k in range(i - j):
+                                    fin = k == i - j - 1
+                                    t = conv_bn(t, f"{f}.{k}.0", f"{f}.{k}.1", last if fin else True, res=y if fin else None, shortcut=False)
+                                y = t
+                        outs.append(y)
+                    xs = outs
+                ys, pre_n = xs, nb
+            return ys[0]
+
         # ---- forward ----
         cp = 8 if self.bf16 else 4
         x4 = new((B, self.in_h, self.in_w, cp))
         _lib.check((lib.sp_nchw_to_nhwc8_bf16 if self.bf16 else lib.sp_nchw_to_nhwc4)(P(x), P(x4), B, 3, self.in_h, self.in_w, stream), "to_nhwc")
         a = conv_bn(Act(x4, self.in_h, self.in_w, cp, needs_grad=False), "conv1", "bn1", True)
+        if self.head == "hrnet":
+            a = hrnet_forward(a)
+            return self._finish_forward(a, tape, nbt, B, wgrad_async, new, newf)
         pooled = new((B, a.h // 2, a.w // 2, a.c))
         pool_idx = self._take(tuple(pooled.shape), torch.uint8, dev)               # winning tap per output element
         _lib.check(lib.sp_maxpool3x3s2_idx_nhwc(P(a.data), bf, P(pooled), P(pool_idx), B, a.h, a.w, a.c, stream), "maxpool")
@@ -1199,10 +1341,14 @@ class PoseTrainer:
             a = shuffle(a)
             for idx in (1, 2):
                 a = shuffle(conv_bn(a, f"duc_layers.{idx}.conv", f"duc_layers.{idx}.bn", True))
-        fl = L["final_layer"]
+        return self._finish_forward(a, tape, nbt, B, wgrad_async, new, newf)
+
+    def _finish_forward(self, a: Act, tape, nbt, B, wgrad_async, new, newf):
+        """final_layer (+ bias, NCHW heat maps) on the last activation; returns (heat maps, backward closure)."""
+        fl = self.layers["final_layer"]
         J = fl.O
         hh, ww = self.heat_hw
-        heat = torch.empty((B, J, hh, ww), dtype=torch.float32, device=dev)
+        heat = torch.empty((B, J, hh, ww), dtype=torch.float32, device=a.data.device)
         a.consumers += 1
         fl.forward(a.data, B, out=heat, shift=self.sd["final_layer.bias"])
         self.last_heat = heat

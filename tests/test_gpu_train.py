@@ -104,6 +104,70 @@ def test_train_step_with_selayer_vs_oracle(B, H, W):
     assert losses[-1] < losses[0]
 
 
+def _hrnet(seed):
+    import functools
+    import os
+    from simple_pose_amd.nets.pose_hrnet import get_pose_net, hrnet_state_dict_shapes
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    net = get_pose_net(os.path.join(root, "simple_pose_amd", "nets", "hrnet_w32.yaml"), pretrained=None, joint_num=17)
+    sdn = synth.conditioned_state_dict(hrnet_state_dict_shapes(net.cfg, 17), seed=seed)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sdn.items()}, strict=True)
+    nets_oracle.FORWARDS["hrnet_w32"] = lambda sd, x, training=False: nets_oracle.hrnet_forward(sd, x, net.cfg, training=training)
+    return net.to(DEV).train(), sdn
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (3, 96, 64)])
+def test_hrnet_train_step_vs_oracle(B, H, W):
+    """PoseHighResolutionNet (nets/pose_hrnet.py:419-454) in train mode through PoseTrainer: stem, layer1 Bottlenecks, transitions, the
+    BasicBlock branches of every HighResolutionModule, the fuse layers (1x1 conv + BN + nearest upsample + add; chains of stride-2 3x3
+    convs; ReLU after the last term) and the final conv - loss, heat maps and all 1,148 parameter gradients against the float64 oracle
+    (torch autograd through oracle/nets_oracle.hrnet_forward), bars as for the ResNets."""
+    model, sdn = _hrnet(5)
+    sd = {k: torch.from_numpy(v.copy()) for k, v in sdn.items()}
+    x, t, w = _batch(B, H, W, 7)
+    tr = PoseTrainer(model, in_h=H, in_w=W, lr=1e-3)
+    loss = tr.forward_backward(torch.from_numpy(x).to(DEV), torch.from_numpy(t).to(DEV), torch.from_numpy(w).to(DEV))
+    torch.cuda.synchronize()
+    oloss, ograds, oheat = train_oracle.forward_backward(sd, torch.from_numpy(x), torch.from_numpy(t), torch.from_numpy(w), arch="hrnet_w32")
+    assert _rel(tr.last_heat.cpu().numpy(), oheat.numpy()) < 1e-3
+    assert abs(loss.item() - float(oloss)) <= 1e-4 * abs(float(oloss))
+    named = dict(model.named_parameters())
+    sd64 = {k: (torch.from_numpy(v.copy()).double() if v.dtype.kind == "f" else torch.from_numpy(v.copy())) for k, v in sdn.items()}
+    _, g64, _ = train_oracle.forward_backward(sd64, torch.from_numpy(x).double(), torch.from_numpy(t).double(), torch.from_numpy(w).double(),
+                                              arch="hrnet_w32")
+    assert set(g64) == set(named)
+    l2 = sorted(((float((named[k].grad.cpu().double() - g64[k]).norm() / (g64[k].norm() + 1e-30)), k) for k in g64), reverse=True)
+    l2_torch = sorted((float((ograds[k].double() - g64[k]).norm() / (g64[k].norm() + 1e-30)) for k in g64), reverse=True)
+    assert l2[0][0] < max(3e-2, 8 * l2_torch[0]), (l2[:6], l2_torch[:3])
+    assert np.median([e for e, _ in l2]) < max(1e-2, 4 * np.median(l2_torch)), (np.median([e for e, _ in l2]), np.median(l2_torch))
+    bufs = dict(model.named_buffers())
+    for k in ("bn1.running_mean", "stage3.1.branches.2.0.bn1.running_var", "stage4.2.fuse_layers.0.3.1.running_mean"):
+        assert _rel(bufs[k].cpu().numpy(), sd[k].numpy()) < 1e-4, k
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_hrnet_train_step_is_bit_reproducible_and_learns(dtype):
+    """The streamed HRNet step (weight gradients and optimizer on their own streams) twice from the same state: identical parameters;
+    the loss goes down; also through the autograd surface `model(x)` in train() mode."""
+    res = []
+    for _ in range(2):
+        model, _ = _hrnet(6)
+        tr = PoseTrainer(model, in_h=128, in_w=96, lr=1e-3, dtype=dtype)
+        x, t, w = _batch(4, 128, 96, 9)
+        xs, ts, ws = (torch.from_numpy(v).to(DEV) for v in (x, t, w))
+        losses = [tr.step(xs, ts, ws).item() for _ in range(3)]
+        torch.cuda.synchronize()
+        res.append((losses, tr.flat.data.clone()))
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
+    assert res[0][0][-1] < res[0][0][0]
+    if dtype == "fp32":
+        model, _ = _hrnet(6)
+        out = model(xs)
+        assert out.requires_grad and out.shape == (4, 17, 32, 24)
+        out.square().mean().backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_selayer_train_step_is_bit_reproducible_and_bf16_tracks_fp32(dtype):
     """The SELayer step twice from the same state: identical parameters (deterministic kernels); bf16 compute stays within the bf16 bar of
