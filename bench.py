@@ -60,9 +60,10 @@ def parse():
     ap.add_argument("--retune", action="store_true", help="ignore the tracked tile table: time every (tile, kernel) per layer shape on this GPU")
     ap.add_argument("--layers-out", default=None, help="write the per-layer timing table (JSON) here")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (roofline object)")
-    ap.add_argument("--fuse-bottlenecks", action="store_true",
-                    help="infer mode, bf16 ResNets: identity-shortcut Bottlenecks with 64 mid channels (layer1.1, layer1.2) as one launch each "
-                         "(sp_bottleneck_c64; same bits)")
+    ap.add_argument("--fuse-bottlenecks", action="store_true", help="(default since round 3; kept so that older command lines still parse)")
+    ap.add_argument("--no-fuse-bottlenecks", action="store_true",
+                    help="infer mode, bf16 ResNets: run the identity-shortcut Bottlenecks with 64 mid channels (layer1.1, layer1.2) conv by conv "
+                         "instead of as one launch each (sp_bottleneck_c64; same bits)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="preflight of the N-rank job without touching a GPU: start the N ranks exactly as a real run does, rendezvous over gloo, "
                          "check the rank -> device mapping, one barrier and the MAX/SUM reductions of the measurement, print ONE JSON line; "
@@ -307,8 +308,8 @@ def main():
     model = model.to(dev).eval()
     if args.dtype == "bf16" and args.mode == "infer":
         model.compute_dtype = "bf16"
-        if args.fuse_bottlenecks and args.arch in ("dconv", "duc"):
-            model.fuse_bottlenecks = True
+        if args.arch in ("dconv", "duc"):
+            model.fuse_bottlenecks = not args.no_fuse_bottlenecks
     decoder = GaussTaylorKeyPointDecoder(kernel_size=11, num_joints=17)
 
     B = args.batch

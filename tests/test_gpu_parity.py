@@ -441,7 +441,7 @@ def test_deeper_resnet_factories_vs_oracle(measured, factory, head):
 
 @pytest.mark.parametrize("head,B,H,W", [("dconv", 3, 256, 192), ("duc", 2, 128, 96), ("dconv", 1, 96, 160)])
 def test_fused_bottlenecks_equal_the_per_conv_program_bitwise(head, B, H, W):
-    """model.fuse_bottlenecks: layer1.1 / layer1.2 (identity shortcut, 256 -> 64 -> 64 -> 256) as ONE launch each (sp_bottleneck_c64) give
+    """model.fuse_bottlenecks (default on): layer1.1 / layer1.2 (identity shortcut, 256 -> 64 -> 64 -> 256) as ONE launch each (sp_bottleneck_c64) give
     the heat maps of the conv-by-conv bf16 program bit for bit - same accumulation chains, intermediates rounded to bf16 at the same
     places; incl. sizes whose 16x8 tiles are ragged (96x160 input: 24x40 maps)."""
     m = {"dconv": pose_resnet_dconv, "duc": pose_resnet_duc}[head].resnet50(pretrained=False, num_classes=17)
@@ -452,9 +452,11 @@ def test_fused_bottlenecks_equal_the_per_conv_program_bitwise(head, B, H, W):
     m.autotune = False
     x = _cuda(synth.input_images(B, 21, h=H, w=W))
     with torch.no_grad():
+        m.fuse_bottlenecks = False
         ref = m(x).clone()
         n_ref = len(m.hip_program(x).ops)
-        m.fuse_bottlenecks = True
+        assert not any(op.kind == "bneck64" for op in m.hip_program(x).ops)
+        m.fuse_bottlenecks = True                  # (the default)
         got = m(x)
         prog = m.hip_program(x)
     assert sum(op.kind == "bneck64" for op in prog.ops) == 2 and len(prog.ops) == n_ref - 4
