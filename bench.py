@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--layers-out", default=None, help="write the per-layer timing table (JSON) here")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (roofline object)")
     ap.add_argument("--fuse-bottlenecks", action="store_true", help="(default since round 3; kept so that older command lines still parse)")
+    ap.add_argument("--no-fuse-stem", action="store_true", help="infer mode: run the stem launch by launch (layout change, conv(s), pooling) instead of "
+                    "as one launch (sp_stem7_pool for the ResNets, sp_hrnet_stem for HRNet in bf16; same bits)")
     ap.add_argument("--no-fuse-bottlenecks", action="store_true",
                     help="infer mode, bf16 ResNets: run the identity-shortcut Bottlenecks with 64 mid channels (layer1.1, layer1.2) conv by conv "
                          "instead of as one launch each (sp_bottleneck_c64; same bits)")
@@ -306,6 +308,8 @@ def main():
         sd = synth.conditioned_state_dict(layout, seed=0)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     model = model.to(dev).eval()
+    if args.no_fuse_stem:
+        model.fuse_stem = False
     if args.dtype == "bf16" and args.mode == "infer":
         model.compute_dtype = "bf16"
         if args.arch in ("dconv", "duc"):
@@ -547,6 +551,8 @@ def _variant_name(op):
         return "basic_block_c32_kernel"
     if op.kind == "bneck64":
         return "bottleneck_c64_kernel"
+    if op.kind == "hstem":
+        return "hrnet_stem_kernel"
     if op.kind == "stem7":                        # conv1 + bn1 + relu + maxpool in one launch (its time includes the pooling)
         return "stem_pool_kernel<%s>" % ("true" if op.w.element_size() == 2 else "false")
     return _lib.conv_kernel_name(op.desc, op.res is not None, 3 if getattr(op, "direct", False) else 0)
@@ -617,7 +623,7 @@ def kernel_roofline(prog, x, steps: int, layers_out=None, peak=FP32_MATRIX_PEAK_
     bufs = dict(prog._alloc(B, x.device))
     bufs["input"] = x
     bufs[prog.out_name] = torch.empty((B,) + tuple(prog.out_shape), dtype=torch.float32, device=x.device)
-    FLOP_KINDS = ("conv", "bb32", "bneck64", "stem7")
+    FLOP_KINDS = ("conv", "bb32", "bneck64", "stem7", "hstem")
     conv_ops = [op for op in prog.ops if op.kind in FLOP_KINDS]            # every launch that carries algorithmic FLOPs
     ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in conv_ops]
           for _ in range(steps)]

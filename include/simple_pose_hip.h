@@ -27,7 +27,7 @@ extern "C" {
 #define SP_EINVAL (-1)   /* bad argument / unsupported shape (message in sp_last_error) */
 #define SP_ELAUNCH (-2)  /* HIP launch or runtime failure */
 
-#define SP_ABI_VERSION 28
+#define SP_ABI_VERSION 29
 
 /* epilogue / layout flags of sp_conv_desc.flags */
 #define SP_CONV_RELU 0x1u          /* y = max(y, 0) after scale/shift (+ residual) */
@@ -138,6 +138,14 @@ int sp_stem7_pool(const float* x, const void* w_packed, int k_pad, const float* 
  * arithmetic of sp_u8hwc_bgr_to_nhwc, same bits as that launch followed by sp_conv2d_fwd and sp_maxpool3x3s2_nhwc. */
 int sp_stem7_pool_u8(const unsigned char* crops_bgr, const float* mean_rgb_host, const void* w_packed, int k_pad, const float* scale,
                      const float* shift, void* y, int bf16, int batch, int h, int w, void* stream);
+
+/* HRNet's stem (nets/pose_hrnet.py:419-425: conv1 3x3 s2 + bn1 + relu, conv2 3x3 s2 + bn2 + relu) in ONE launch, bf16 compute:
+ * x fp32 NCHW [batch,3,h,w] -> y bf16 NHWC [batch,h/4,w/4,64].  w1_packed / k1_pad: conv1's weights as sp_conv2d_fwd takes them on the bf16
+ * NHWC4 image (sp_pack_conv_weights with c_in_packed 8, taps_w_packed 2, pair_s0 1 -> [64][64]); w2_packed: conv2's [64][576]; scale / shift:
+ * the folded bn1 / bn2.  conv1's map never reaches HBM: bit-identical to sp_nchw_to_nhwc4_bf16 -> sp_conv2d_fwd -> sp_conv2d_fwd. */
+int sp_hrnet_stem_ok(int batch, int h, int w);
+int sp_hrnet_stem(const float* x, const void* w1_packed, int k1_pad, const float* scale1, const float* shift1, const void* w2_packed,
+                  const float* scale2, const float* shift2, void* y, int batch, int h, int w, void* stream);
 
 /* 1 when `desc` can run with kernel = SP_CONV_KERNEL_PW (see there).  Same bits as the tiled kernel. */
 int sp_conv2d_pw_ok(const sp_conv_desc* desc);

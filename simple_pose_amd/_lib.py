@@ -20,7 +20,7 @@ SP_CONV_PIXEL_SHUFFLE = 0x4
 SP_CONV_BF16 = 0x8
 SP_CONV_OUT_F32 = 0x10
 CONV_TILES = ((128, 128), (64, 128), (128, 64), (64, 64), (256, 64), (128, 32))
-ABI_VERSION = 28
+ABI_VERSION = 29
 SP_CONV_KERNEL_IGEMM, SP_CONV_KERNEL_RING, SP_CONV_KERNEL_PW = 0, 1, 2
 RING_TILES = ((256, 256), (256, 128), (128, 256), (256, 64), (128, 128), (192, 128), (192, 256))   # kernel = SP_CONV_KERNEL_RING (bf16)
 
@@ -123,6 +123,8 @@ SYMBOLS = {
     "sp_basic_block_c32": (c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sp_bottleneck_c64_ok": (c_int, [ctypes.POINTER(ConvDesc)]),
     "sp_conv2d_pw_ok": (c_int, [ctypes.POINTER(ConvDesc)]),
+    "sp_hrnet_stem_ok": (c_int, [c_int, c_int, c_int]),
+    "sp_hrnet_stem": (c_int, [_P, _P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "sp_stem7_pool_ok": (c_int, [c_int, c_int, c_int]),
     "sp_stem7_pool": (c_int, [_P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "sp_stem7_pool_u8": (c_int, [_P, ctypes.POINTER(ctypes.c_float), _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -97,7 +97,7 @@ class HipPacker:
 # ------------------------------------------------------------------------------------------------
 @dataclass
 class Op:
-    kind: str                    # "conv" | "bb32" (fused BasicBlock) | "bneck64" (fused Bottleneck) | "stem7" (fused ResNet stem) | "maxpool" | "to_nhwc4" | ...
+    kind: str                    # "conv" | "bb32" (fused BasicBlock) | "bneck64" (fused Bottleneck) | "stem7" / "hstem" (fused ResNet / HRNet stem) | "maxpool" | ...
     src: str
     dst: str
     res: Optional[str] = None
@@ -227,6 +227,19 @@ class Program:
             else:
                 _lib.check(lib.sp_stem7_pool(P(src), P(op.w), k_pad, P(op.scale), P(op.shift), P(bufs[op.dst]), int(self.dtype == "bf16"),
                                              B, h, w, stream), op.name)
+        elif op.kind == "hstem":
+            h, w, k1_pad, w2, s2, h2, unfused = op.args
+            src = bufs[op.src]
+            if src.dtype == torch.uint8:           # BGR crops: the three-launch lowering, whose first launch normalises them
+                tmp = dict(bufs)
+                for u in unfused[:-1]:
+                    uh, uw, uc = self.shapes[u.dst]
+                    tmp[u.dst] = torch.empty(B * uh * uw * uc, dtype=torch.bfloat16, device=src.device)
+                for u in unfused:
+                    self._launch(lib, u, tmp, B, stream)
+            else:
+                _lib.check(lib.sp_hrnet_stem(P(src), P(op.w), k1_pad, P(op.scale), P(op.shift), P(w2), P(s2), P(h2), P(bufs[op.dst]), B, h, w,
+                                             stream), op.name)
         elif op.kind == "maxpool":
             h, w, c = op.args
             fn = lib.sp_maxpool3x3s2_nhwc_bf16 if self.dtype == "bf16" else lib.sp_maxpool3x3s2_nhwc
@@ -635,6 +648,24 @@ class ProgramBuilder:
                      flops=conv.flops))
         return out
 
+    def hrnet_stem(self, src: str, w1: torch.Tensor, s1, h1, w2: torch.Tensor, s2, h2) -> str:
+        """relu(bn2(conv2(relu(bn1(conv1(x)))))), both 3x3 stride 2 (pose_hrnet.py:419-425).  bf16 with `fuse_stem`: one `hstem` op on the fp32
+        NCHW image (sp_hrnet_stem; same bits); the three launches stay inside the op as its definition and for uint8 crop input."""
+        first = len(self.p.ops)
+        x4 = self.to_nhwc4(src)
+        y = self.conv(x4, w1, stride=2, pad=1, scale=s1, shift=h1, relu=True, name="conv1")
+        out = self.conv(y, w2, stride=2, pad=1, scale=s2, shift=h2, relu=True, name="conv2")
+        h, w, _ = self.p.shapes[src]
+        if not (self.bf16 and self.fuse_stem and tuple(w1.shape) == (64, 3, 3, 3) and tuple(w2.shape) == (64, 64, 3, 3)
+                and _lib.lib().sp_hrnet_stem_ok(1, h, w)):
+            return out
+        unfused = self.p.ops[first:]
+        del self.p.ops[first:]
+        c1, c2 = unfused[1], unfused[2]
+        self._add(Op("hstem", src, out, w=c1.w, scale=s1, shift=h1, args=(h, w, c1.desc.k_pad, c2.w, s2, h2, tuple(unfused)), name="stem",
+                     flops=c1.flops + c2.flops))
+        return out
+
     def maxpool(self, src: str) -> str:
         h, w, c = self.p.shapes[src]
         dst = self._fresh("pool")
@@ -930,18 +961,17 @@ def _hr_module(b: ProgramBuilder, sd, xs: List[str], base: str, num_blocks: List
 
 
 def hrnet_program(sd: Dict[str, torch.Tensor], cfg: dict, in_h: int = 256, in_w: int = 192, dtype: str = "fp32", packer=None,
-                  fuse_blocks: bool = False) -> Program:
+                  fuse_blocks: bool = False, fuse_stem: bool = True) -> Program:
     """Lower a reference-layout HRNet state_dict into a Program (PoseHighResolutionNet.forward, pose_hrnet.py:419-454).
     `fuse_blocks`: bf16 32-channel BasicBlocks as one launch each (sp_basic_block_c32; same bits as the two conv launches; opt-in,
     see ProgramBuilder.fuse_blocks)."""
     extra = cfg["MODEL"]["EXTRA"]
     b = ProgramBuilder(in_h, in_w, dtype, packer)
     b.fuse_blocks = fuse_blocks
-    x = b.to_nhwc4("input")
-    s, h = _bn(b, sd, "bn1")
-    x = b.conv(x, sd["conv1.weight"], stride=2, pad=1, scale=s, shift=h, relu=True, name="conv1")
-    s, h = _bn(b, sd, "bn2")
-    x = b.conv(x, sd["conv2.weight"], stride=2, pad=1, scale=s, shift=h, relu=True, name="conv2")
+    b.fuse_stem = fuse_stem
+    s1, h1 = _bn(b, sd, "bn1")
+    s2, h2 = _bn(b, sd, "bn2")
+    x = b.hrnet_stem("input", sd["conv1.weight"], s1, h1, sd["conv2.weight"], s2, h2)
     for k in range(4):
         x = _bottleneck(b, sd, x, f"layer1.{k}", 1)
     ys = [x]

@@ -487,6 +487,62 @@ def test_fused_stem_equals_the_three_launch_stem_bitwise(head, B, H, W, dtype):
     assert torch.equal(got, ref)
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 256, 192), (3, 64, 96), (1, 36, 52), (2, 4, 4), (1, 130, 34)])
+def test_fused_hrnet_stem_equals_the_three_launches_bitwise(B, H, W):
+    """sp_hrnet_stem (bf16: conv1 3x3 s2 + bn1 + relu + conv2 3x3 s2 + bn2 + relu, pose_hrnet.py:419-425, one launch on the fp32 NCHW image)
+    against sp_nchw_to_nhwc4_bf16 -> sp_conv2d_fwd -> sp_conv2d_fwd: bit for bit, incl. sizes whose 8 x 8 output tiles are ragged and
+    images smaller than a tile; conv2's zero padding is conv1 positions OUTSIDE conv1's output, not conv1 of a padded image."""
+    g = torch.Generator().manual_seed(H * 1000 + W + 7)
+    w1 = torch.randn((64, 3, 3, 3), generator=g).to(DEV) * 0.2
+    w2 = torch.randn((64, 64, 3, 3), generator=g).to(DEV) * 0.05
+    s1, h1 = (torch.rand(64, generator=g) + 0.5).to(DEV), (torch.randn(64, generator=g) * 0.3).to(DEV)
+    s2, h2 = (torch.rand(64, generator=g) + 0.5).to(DEV), (torch.randn(64, generator=g) * 0.3).to(DEV)
+    x = torch.randn((B, 3, H, W), generator=g).to(DEV)
+    outs = []
+    for fuse in (False, True):
+        b = engine.ProgramBuilder(H, W, "bf16")
+        b.fuse_stem = fuse
+        out = b.hrnet_stem("input", w1, s1, h1, w2, s2, h2)
+        prog = b.p
+        assert [op.kind for op in prog.ops] == (["hstem"] if fuse else ["to_nhwc4", "conv", "conv"])
+        bufs = dict(prog._alloc(B, x.device))
+        bufs["input"] = x
+        for op in prog.ops:
+            prog._launch(_lib.lib(), op, bufs, B, _lib.current_stream())
+        torch.cuda.synchronize()
+        outs.append(bufs[out].clone())
+    assert outs[0].numel() == B * ((H // 2 + 1) // 2) * ((W // 2 + 1) // 2) * 64
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    assert float(outs[1].float().abs().max()) > 0
+
+
+def test_hrnet_with_fused_stem_equals_the_per_conv_program_bitwise():
+    """model.fuse_stem on PoseHighResolutionNet (bf16, the default): same heat maps as the per-conv program, bit for bit; fp32 keeps the
+    per-conv stem; uint8 crops run the op's three-launch definition."""
+    import os
+    from simple_pose_amd.nets.pose_hrnet import get_pose_net, hrnet_state_dict_shapes
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    net = get_pose_net(os.path.join(root, "simple_pose_amd", "nets", "hrnet_w32.yaml"), pretrained=None, joint_num=17)
+    sd = synth.conditioned_state_dict(hrnet_state_dict_shapes(net.cfg, 17), seed=2)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    net = net.cuda().eval()
+    net.autotune = False
+    x = _cuda(synth.input_images(3, 5, h=128, w=96))
+    with torch.no_grad():
+        assert not any(op.kind == "hstem" for op in net.hip_program(x).ops)          # fp32
+        net.compute_dtype = "bf16"
+        net.fuse_stem = False
+        ref = net(x).clone()
+        net.fuse_stem = True
+        got = net(x)
+        assert net.hip_program(x).ops[0].kind == "hstem"
+        assert torch.equal(got, ref)
+        crops = torch.randint(0, 256, (2, 128, 96, 3), dtype=torch.uint8, device=DEV)
+        a = net.forward_crops(crops).clone()
+        net.fuse_stem = False
+        assert torch.equal(net.forward_crops(crops), a)
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("B,H,W", [(2, 70, 50), (1, 8, 8), (3, 34, 130), (2, 256, 192)])
 def test_fused_stem_on_uint8_crops_bitwise(B, H, W, dtype):
