@@ -1423,7 +1423,10 @@ class PoseTrainer:
                                                   P(self._adam_scalars), _lib.current_stream()), "adam scalars")
 
     def optimizer_step(self, grad_scale: float = 1.0):
-        self.step_count += 1
+        if self._adam_scalars is not None:
+            self._adam_scalars_for_step(grad_scale)
+        else:
+            self.step_count += 1
         self._adam(slice(0, self.flat.numel), grad_scale, _lib.current_stream())
         self.repack()
         if getattr(self.model, "_program", None) is not None:
@@ -1441,7 +1444,9 @@ class PoseTrainer:
             self._mark("adam_repack")
             return loss
         if self._adam_scalars is None:
-            self.step_count += 1                           # (a captured step is counted by GraphedStep, outside the graph)
+            self.step_count += 1
+        elif not self._adam_scalars_external:              # device-side scalars (a GraphedStep exists) but this step runs eagerly
+            self._adam_scalars_for_step(1.0 / self.world)  # (a captured / replayed step is counted by GraphedStep, outside the graph)
         self._opt_in_backward = True
         try:
             loss = self.forward_backward(x, targets, mask)
@@ -1460,6 +1465,7 @@ class PoseTrainer:
         return GraphedStep(self, x, targets, mask, warmup)
 
     _adam_scalars = None       # device [8] floats while a captured step owns the optimizer's scalars (see capture())
+    _adam_scalars_external = False   # True while GraphedStep captures: the scalars' launch then sits outside the recorded region
     force_collectives = False  # issue the SyncBatchNorm / gradient collectives on ONE rank too (a 1-rank RCCL group: preflight of their capture)
     fuse_optimizer = True
     use_arena = True           # step / forward_backward reuse last step's tensors request by request (see _take)
@@ -1521,13 +1527,16 @@ class GraphedStep:
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             for _ in range(max(1, warmup)):                 # eager, on the stream the capture will use: streams, events, arena, tile opt-ins
-                tr._adam_scalars_for_step(self.grad_scale)
-                tr.step(self.x, self.targets, self.mask)
+                tr.step(self.x, self.targets, self.mask)    # (counts itself and refreshes the device-side scalars)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=side):
-            self.loss = tr.step(self.x, self.targets, self.mask)
+        tr._adam_scalars_external = True
+        try:
+            with torch.cuda.graph(self.graph, stream=side):
+                self.loss = tr.step(self.x, self.targets, self.mask)
+        finally:
+            tr._adam_scalars_external = False
         self.launches = None
 
     def step(self, x: torch.Tensor, targets: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
