@@ -433,7 +433,7 @@ class PoseTrainer:
         self.sync_bn_inline = bool(sync_bn_inline)
         if self.sync_bn_latency_us > 0 and (sync_bn is None or sync_bn):
             self.sync_bn = True
-        self._comm = None
+        self._comm = self._comm_grad = None
         self._native_comm_wanted = native_comm
         self.flat = FlatParams(model, attach_grads=collectives)
         dev = self.flat.data.device
@@ -472,30 +472,38 @@ class PoseTrainer:
             raise _lib.HipLibraryError("native_comm=True needs an nccl-backed process group and librccl (sp_comm_available() == 1)")
         dev = self.flat.data.device
         world, rank = dist.get_world_size(self.pg), dist.get_rank(self.pg)
-        idt = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            buf = (ctypes.c_ubyte * 128)()
-            _lib.check(lib.sp_comm_unique_id(buf), "sp_comm_unique_id")
-            idt = torch.tensor(list(buf), dtype=torch.uint8)
-        idt = idt.to(dev)
-        if world > 1:
-            dist.broadcast(idt, src=dist.get_global_rank(self.pg, 0) if self.pg is not None else 0, group=self.pg)
-        raw = bytes(idt.cpu().tolist())
-        comm = ctypes.c_void_p()
-        with torch.cuda.device(dev):
-            _lib.check(lib.sp_comm_create(raw, world, rank, ctypes.byref(comm)), "sp_comm_create")
-        self._comm = comm
+
+        def make():
+            idt = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                buf = (ctypes.c_ubyte * 128)()
+                _lib.check(lib.sp_comm_unique_id(buf), "sp_comm_unique_id")
+                idt = torch.tensor(list(buf), dtype=torch.uint8)
+            idt = idt.to(dev)
+            if world > 1:
+                dist.broadcast(idt, src=dist.get_global_rank(self.pg, 0) if self.pg is not None else 0, group=self.pg)
+            raw = bytes(idt.cpu().tolist())
+            comm = ctypes.c_void_p()
+            with torch.cuda.device(dev):
+                _lib.check(lib.sp_comm_create(raw, world, rank, ctypes.byref(comm)), "sp_comm_create")
+            return comm
+        # TWO communicators: RCCL orders the operations of one communicator one after the other whatever stream they are issued to, so a
+        # SyncBatchNorm message (compute stream, on the critical chain) would queue behind a 32 MB gradient bucket (optimizer stream) of the
+        # same communicator - which is what happens to every collective of a torch.distributed process group (one communicator, one stream)
+        self._comm = make()
+        self._comm_grad = make()
 
     def close(self) -> None:
         """Release the RCCL communicator (if any); the trainer must not step afterwards."""
         if self._comm is not None:
             torch.cuda.synchronize(self.flat.data.device)
-            _lib.check(_lib.lib().sp_comm_destroy(self._comm), "sp_comm_destroy")
-            self._comm = None
+            for c in (self._comm, self._comm_grad):
+                _lib.check(_lib.lib().sp_comm_destroy(c), "sp_comm_destroy")
+            self._comm = self._comm_grad = None
 
-    def _all_reduce_sum(self, t: torch.Tensor, stream) -> None:
-        """In-place SUM over the ranks on `stream` through our own communicator."""
-        _lib.check(_lib.lib().sp_comm_allreduce_sum_f32(self._comm, P(t), t.numel(), stream), "all-reduce")
+    def _all_reduce_sum(self, t: torch.Tensor, stream, grad: bool = False) -> None:
+        """In-place SUM over the ranks on `stream` through our own communicators (`grad`: the gradient buckets' one)."""
+        _lib.check(_lib.lib().sp_comm_allreduce_sum_f32(self._comm_grad if grad else self._comm, P(t), t.numel(), stream), "all-reduce")
 
     # ---- gradient buckets (DDP reducer, reverse parameter order) ---------------------------------------------------------
     def _plan_buckets(self, bucket_mb: float):
@@ -554,7 +562,7 @@ class PoseTrainer:
                 opt.wait_event(self._wgrad_tail)
             with torch.cuda.stream(opt):
                 if self._comm is not None:
-                    self._all_reduce_sum(self.flat.grad[b["lo"]:b["hi"]], _lib.c_void_p(opt.cuda_stream))
+                    self._all_reduce_sum(self.flat.grad[b["lo"]:b["hi"]], _lib.c_void_p(opt.cuda_stream), grad=True)
                 elif self.world > 1 or self.force_collectives:
                     dist.all_reduce(self.flat.grad[b["lo"]:b["hi"]], op=dist.ReduceOp.SUM, group=self.pg)
                 self._adam(slice(b["lo"], b["hi"]), 1.0 / self.world, _lib.c_void_p(opt.cuda_stream))
