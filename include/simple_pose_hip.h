@@ -27,7 +27,7 @@ extern "C" {
 #define SP_EINVAL (-1)   /* bad argument / unsupported shape (message in sp_last_error) */
 #define SP_ELAUNCH (-2)  /* HIP launch or runtime failure */
 
-#define SP_ABI_VERSION 29
+#define SP_ABI_VERSION 30
 
 /* epilogue / layout flags of sp_conv_desc.flags */
 #define SP_CONV_RELU 0x1u          /* y = max(y, 0) after scale/shift (+ residual) */
@@ -327,6 +327,15 @@ int sp_bn_train_partial_nhwc(const void* z, int bf16, int64_t rows, int c, doubl
 int sp_bn_sums_from_conv(const float* stats_sum, const float* stats_sumsq, int partial_rows, int stride, int c, double* sums, void* stream);
 int sp_bn_train_finalize(const double* sums, int64_t total_rows, int c, float eps, float momentum, float* mean, float* invstd,
                          float* running_mean, float* running_var, void* stream);
+/* SyncBatchNorm with one launch less on each side of the exchange: sp_bn_apply_sums_nhwc = sp_bn_train_finalize + sp_bn_apply_nhwc (every thread
+ * finalises its own 4 channels from the all-reduced sums, the first row's threads publish mean / invstd / running statistics; same values);
+ * sp_bn_bwd_sums_from_conv2 = sp_bn_bwd_sums_from_conv that ALSO writes the two sums where the message is assembled (the parameter gradients keep
+ * this rank's sums, the message carries them to the other ranks: no concatenation launch). */
+int sp_bn_apply_sums_nhwc(const void* z, int bf16, const double* sums, int64_t total_rows, float eps, float momentum, const float* gamma,
+                          const float* beta, const void* residual, void* y, int64_t rows, int c, int relu, float* mean, float* invstd,
+                          float* running_mean, float* running_var, void* stream);
+int sp_bn_bwd_sums_from_conv2(const float* sum_g, const float* sum_g_xhat, int partial_rows, int stride, int c, float* dgamma, float* dbeta,
+                              float* dgamma_copy, float* dbeta_copy, void* stream);
 int sp_bn_train_bwd_reduce_nhwc(const void* dy, int bf16, const void* relu_src, const void* z, const float* mean, const float* invstd,
                                 int64_t rows, int c, float* dgamma, float* dbeta, void* workspace, void* stream);
 int sp_bn_train_bwd_apply_nhwc(const void* dy, int bf16, const void* relu_src, const void* z, const float* mean, const float* invstd,

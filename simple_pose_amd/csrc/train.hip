@@ -224,12 +224,17 @@ __global__ __launch_bounds__(1024) void bn_sums_from_conv_kernel(const float* __
 
 // dbeta = sum g, dgamma = sum g*xhat from the partial rows a BSTATS dgrad launch (or several: one per output phase) left
 __global__ __launch_bounds__(1024) void bn_bwd_sums_from_conv_kernel(const float* __restrict__ ps, const float* __restrict__ pq, int nrows, int stride, int C,
-                                             float* __restrict__ dbeta, float* __restrict__ dgamma) {
+                                             float* __restrict__ dbeta, float* __restrict__ dgamma, float* __restrict__ dbeta_copy,
+                                             float* __restrict__ dgamma_copy) {
     int c;
     double s0, s1;
     if (!fold_conv_rows(ps, pq, nrows, stride, C, c, s0, s1)) return;
     dbeta[c] = (float)s0;
     dgamma[c] = (float)s1;
+    if (dbeta_copy) {                  // SyncBatchNorm: the same sums again where the message is assembled (the parameter gradients keep the local ones)
+        dbeta_copy[c] = (float)s0;
+        dgamma_copy[c] = (float)s1;
+    }
 }
 
 // SyncBatchNorm halves: per-rank (sum, sum of squares) kept in fp64 so that the cross-rank SUM is order-insensitive to ~1e-16
@@ -252,6 +257,54 @@ __global__ void bn_apply_kernel(const void* __restrict__ z, const float* __restr
         const int c4 = (int)(i % C4);
         const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c4], is = reinterpret_cast<const f32x4*>(invstd)[c4];
         const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[c4], b = reinterpret_cast<const f32x4*>(beta)[c4];
+        f32x4 v = ld4<BF16>(z, i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (v[e] - mu[e]) * is[e] * g[e] + b[e];
+        if (res) { const f32x4 r = ld4<BF16>(res, i); v += r; }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+        st4<BF16>(y, i, v);
+    }
+}
+
+// The same with the statistics still as (sum, sum of squares) per channel in fp64 ([c][2], what the SyncBatchNorm all-reduce leaves): every
+// thread finalises the 4 channels it works on exactly as bn_stats_final_kernel does (its channel chunk only changes when the grid stride
+// is not a multiple of C / 4), and the threads of the first row also write mean / invstd (saved for backward) and the running statistics -
+// sp_bn_train_finalize's launch on the SyncBatchNorm critical chain disappears into the consumer
+template <bool BF16>
+__global__ void bn_apply_sums_kernel(const void* __restrict__ z, const double* __restrict__ sums, double M, float eps, float momentum,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta, const void* __restrict__ res, void* __restrict__ y,
+                                     int C4, int relu, long long total, float* __restrict__ mean, float* __restrict__ invstd,
+                                     float* __restrict__ run_mean, float* __restrict__ run_var) {
+    int have = -1;
+    f32x4 mu, is, g, b;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        if (c4 != have) {
+            have = c4;
+            g = reinterpret_cast<const f32x4*>(gamma)[c4];
+            b = reinterpret_cast<const f32x4*>(beta)[c4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 4 * c4 + e;
+                const double m = sums[2 * c] / M;
+                double var = sums[2 * c + 1] / M - m * m;
+                if (var < 0) var = 0;
+                mu[e] = (float)m;
+                is[e] = (float)(1.0 / sqrt(var + (double)eps));
+                if (i < C4) {                     // the first row's thread of this chunk publishes the layer's statistics
+                    mean[c] = mu[e];
+                    invstd[c] = is[e];
+                    if (run_mean) {
+                        const double unb = M > 1 ? var * M / (M - 1) : var;
+                        run_mean[c] = (float)((1.0 - momentum) * (double)run_mean[c] + (double)momentum * m);
+                        run_var[c] = (float)((1.0 - momentum) * (double)run_var[c] + (double)momentum * unb);
+                    }
+                }
+            }
+        }
         f32x4 v = ld4<BF16>(z, i);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (v[e] - mu[e]) * is[e] * g[e] + b[e];
@@ -611,7 +664,16 @@ extern "C" int sp_bn_bwd_sums_from_conv(const float* sum_g, const float* sum_g_x
                                         float* dbeta, void* stream) {
     SP_REQUIRE(sum_g && sum_g_xhat && dgamma && dbeta && partial_rows > 0 && stride >= c && c > 0, "sp_bn_bwd_sums_from_conv: bad argument");
     hipLaunchKernelGGL(bn_bwd_sums_from_conv_kernel, dim3((c + FC_CH - 1) / FC_CH), dim3(FC_CH * FC_RL), 0, (hipStream_t)stream, sum_g, sum_g_xhat, partial_rows, stride,
-                       c, dbeta, dgamma);
+                       c, dbeta, dgamma, nullptr, nullptr);
+    return sp_check_launch("bn_bwd_sums_from_conv_kernel");
+}
+
+extern "C" int sp_bn_bwd_sums_from_conv2(const float* sum_g, const float* sum_g_xhat, int partial_rows, int stride, int c, float* dgamma, float* dbeta,
+                                         float* dgamma_copy, float* dbeta_copy, void* stream) {
+    SP_REQUIRE(sum_g && sum_g_xhat && dgamma && dbeta && dgamma_copy && dbeta_copy && partial_rows > 0 && stride >= c && c > 0,
+               "sp_bn_bwd_sums_from_conv2: bad argument");
+    hipLaunchKernelGGL(bn_bwd_sums_from_conv_kernel, dim3((c + FC_CH - 1) / FC_CH), dim3(FC_CH * FC_RL), 0, (hipStream_t)stream, sum_g, sum_g_xhat, partial_rows, stride,
+                       c, dbeta, dgamma, dbeta_copy, dgamma_copy);
     return sp_check_launch("bn_bwd_sums_from_conv_kernel");
 }
 
@@ -625,6 +687,20 @@ extern "C" int sp_bn_apply_nhwc(const void* z, int bf16, const float* mean, cons
     else hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, z, mean, invstd, gamma, beta,
                             residual, y, c / 4, relu, total);
     return sp_check_launch("bn_apply_kernel");
+}
+
+extern "C" int sp_bn_apply_sums_nhwc(const void* z, int bf16, const double* sums, int64_t total_rows, float eps, float momentum, const float* gamma,
+                                     const float* beta, const void* residual, void* y, int64_t rows, int c, int relu, float* mean, float* invstd,
+                                     float* running_mean, float* running_var, void* stream) {
+    SP_REQUIRE(z && sums && gamma && beta && y && mean && invstd, "sp_bn_apply_sums_nhwc: null pointer");
+    SP_REQUIRE(rows > 0 && total_rows > 0 && c > 0 && c % 4 == 0, "sp_bn_apply_sums_nhwc: bad shape");
+    SP_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "sp_bn_apply_sums_nhwc: running stats come in pairs");
+    const long long total = rows * (c / 4);
+    if (bf16 & 1) hipLaunchKernelGGL(bn_apply_sums_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, z, sums, (double)total_rows, eps,
+                                     momentum, gamma, beta, residual, y, c / 4, relu, total, mean, invstd, running_mean, running_var);
+    else hipLaunchKernelGGL(bn_apply_sums_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, z, sums, (double)total_rows, eps,
+                            momentum, gamma, beta, residual, y, c / 4, relu, total, mean, invstd, running_mean, running_var);
+    return sp_check_launch("bn_apply_sums_kernel");
 }
 
 extern "C" int sp_bn_train_bwd_reduce_nhwc(const void* dy, int bf16, const void* relu_src, const void* z, const float* mean, const float* invstd,

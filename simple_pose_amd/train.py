@@ -1067,9 +1067,12 @@ class PoseTrainer:
                     _lib.check(lib.sp_bn_train_partial_nhwc(P(pd["z"]), bf, pd["rows"], pd["C"], P(pd["sums"]), P(ws), stream), bn)
             self._exchange_wait(self._exchange(sums))
             for pd, bn in zip(pends, bnames):
-                rm, rv = run(bn)
-                _lib.check(lib.sp_bn_train_finalize(P(pd["sums"]), pd["rows"] * W, pd["C"], BN_EPS, BN_MOMENTUM, P(pd["mean"]), P(pd["invstd"]),
-                                                    rm, rv, stream), bn)
+                if self.fuse_sync_finalize:
+                    pd["from_sums"] = True         # the consuming sp_bn_apply_sums_nhwc finalises (mean, invstd, running statistics) itself
+                else:
+                    rm, rv = run(bn)
+                    _lib.check(lib.sp_bn_train_finalize(P(pd["sums"]), pd["rows"] * W, pd["C"], BN_EPS, BN_MOMENTUM, P(pd["mean"]), P(pd["invstd"]),
+                                                        rm, rv, stream), bn)
 
         def conv_bn(xa: Act, cname: str, bname: str, relu: bool, res: Optional[Act] = None, pend: Optional[dict] = None,
                     shortcut: bool = True) -> Act:
@@ -1081,8 +1084,13 @@ class PoseTrainer:
             gamma, beta = self.sd[bname + ".weight"], self.sd[bname + ".bias"]
             nbt.append(self.buffers[bname + ".num_batches_tracked"])
             y = new(z.shape)
-            _lib.check(lib.sp_bn_apply_nhwc(P(z), bf, P(mean), P(invstd), P(gamma), P(beta), P(res.data) if res else None, P(y), rows, C,
-                                            int(relu), stream), bname)
+            if pend.get("from_sums"):
+                _lib.check(lib.sp_bn_apply_sums_nhwc(P(z), bf, P(pend["sums"]), rows * W, BN_EPS, BN_MOMENTUM, P(gamma), P(beta),
+                                                     P(res.data) if res else None, P(y), rows, C, int(relu), P(mean), P(invstd),
+                                                     P(self.buffers[bname + ".running_mean"]), P(self.buffers[bname + ".running_var"]), stream), bname)
+            else:
+                _lib.check(lib.sp_bn_apply_nhwc(P(z), bf, P(mean), P(invstd), P(gamma), P(beta), P(res.data) if res else None, P(y), rows, C,
+                                                int(relu), stream), bname)
             ya = Act(y, z.shape[1], z.shape[2], C)
             if res is not None:
                 res.consumers += 1
@@ -1116,8 +1124,15 @@ class PoseTrainer:
                         # the dgrad launch that completed ya.grad already reduced sum g and sum g*xhat (sp_conv2d_dgrad_bn_bwd_stats)
                         part, prow = ya.bstats
                         ya.bstats = None
-                        _lib.check(lib.sp_bn_bwd_sums_from_conv(P(part[0]), P(part[1]), prow, part.shape[2], C, P(dgamma), P(dbeta), stream),
-                                   bname + ".bwd")
+                        msg = None
+                        if sync and self.fuse_sync_finalize and not (res is not None and acc == 0 and res.sibling is not None):
+                            # SyncBatchNorm: the fold also writes the two sums into the message (no concatenation launch)
+                            msg = newf(2 * C)
+                            _lib.check(lib.sp_bn_bwd_sums_from_conv2(P(part[0]), P(part[1]), prow, part.shape[2], C, P(dgamma), P(dbeta),
+                                                                     P(msg[:C]), P(msg[C:]), stream), bname + ".bwd")
+                        else:
+                            _lib.check(lib.sp_bn_bwd_sums_from_conv(P(part[0]), P(part[1]), prow, part.shape[2], C, P(dgamma), P(dbeta), stream),
+                                       bname + ".bwd")
                         if part.shape[0] == 3 and res is not None and acc == 0:
                             # the projection shortcut's sums came out of the same epilogue: d beta = sum g (shared), d gamma = sum g * xhat2
                             sname = ya.bn2[3]
@@ -1126,10 +1141,16 @@ class PoseTrainer:
                                        sname + ".bwd")
                             res.presums = (dgs, dbs)
                     else:
+                        msg = None
                         _lib.check(lib.sp_bn_train_bwd_reduce_nhwc(P(ya.grad), bf, rs, P(z), P(mean), P(invstd), rows, C, P(dgamma), P(dbeta),
                                                                    P(ws), stream), bname + ".bwd")
                     sg, sb, tot = dgamma, dbeta, rows
-                    if sync:
+                    if sync and msg is not None:
+                        token = self._exchange(msg)
+                        self._wgrad_flush_if(0.5)            # queued weight gradients go out under the message rather than after it
+                        self._exchange_wait(token)
+                        sg, sb, tot = msg[:C], msg[C:], rows * W
+                    elif sync:
                         # local sums are this rank's parameter gradients (DDP averages them later); dz needs the global ones
                         parts = [dgamma, dbeta]
                         sib = res.sibling if (res is not None and acc == 0) else None
@@ -1482,6 +1503,7 @@ class PoseTrainer:
     _opt_stream = None
     _wgrad_stream = None
     _wgrad_tail = None
+    fuse_sync_finalize = True  # SyncBatchNorm: finalise inside the consuming bn_apply, message assembled by the backward fold (one launch less each way)
     fuse_bn_bwd = True         # BN backward sums from the epilogue of the dgrad launch that produces dy (single-consumer BN+ReLU outputs)
     fuse_bn_stats = True       # BN batch statistics from the conv epilogue (sp_conv2d_fwd_bn_stats), SyncBN included (sp_bn_sums_from_conv)
     collective_count = 0
