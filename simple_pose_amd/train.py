@@ -1098,7 +1098,7 @@ class PoseTrainer:
                 ya.bn = (z, mean, invstd)      # y = relu(bn(z) [+ res]): backward masks with y > 0 either way
             if not relu and res is None and shortcut:
                 ya.sibling = (z, mean, invstd, bname)      # a projection shortcut: its backward sums ride on its consumer's (message / epilogue)
-            if relu and res is not None and res.sibling is not None and not sync and self.fuse_bn_bwd:
+            if relu and res is not None and res.sibling is not None and self.fuse_bn_bwd and (not sync or self.fuse_sync_finalize):
                 ya.bn2 = res.sibling                       # the shortcut's dy is this layer's g = dy * (y > 0): one more sum in the same epilogue
 
             def bwd():
@@ -1125,15 +1125,23 @@ class PoseTrainer:
                         part, prow = ya.bstats
                         ya.bstats = None
                         msg = None
-                        if sync and self.fuse_sync_finalize and not (res is not None and acc == 0 and res.sibling is not None):
-                            # SyncBatchNorm: the fold also writes the two sums into the message (no concatenation launch)
-                            msg = newf(2 * C)
+                        three = part.shape[0] == 3 and res is not None and acc == 0
+                        if sync and self.fuse_sync_finalize and (three or not (res is not None and acc == 0 and res.sibling is not None)):
+                            # SyncBatchNorm: the fold also writes the sums into the message (no concatenation launch); with the projection
+                            # shortcut's sum g * xhat2 out of the same dgrad epilogue its pair travels in the same message
+                            msg = newf((4 if three else 2) * C)
                             _lib.check(lib.sp_bn_bwd_sums_from_conv2(P(part[0]), P(part[1]), prow, part.shape[2], C, P(dgamma), P(dbeta),
-                                                                     P(msg[:C]), P(msg[C:]), stream), bname + ".bwd")
+                                                                     P(msg[:C]), P(msg[C:2 * C]), stream), bname + ".bwd")
+                            if three:
+                                sname = ya.bn2[3]
+                                dgs, dbs = self.flat.view(sname + ".weight", True), self.flat.view(sname + ".bias", True)
+                                _lib.check(lib.sp_bn_bwd_sums_from_conv2(P(part[0]), P(part[2]), prow, part.shape[2], C, P(dgs), P(dbs),
+                                                                         P(msg[2 * C:3 * C]), P(msg[3 * C:]), stream), sname + ".bwd")
+                                res.presums = (msg[2 * C:3 * C], msg[3 * C:])       # (global after the exchange below)
                         else:
                             _lib.check(lib.sp_bn_bwd_sums_from_conv(P(part[0]), P(part[1]), prow, part.shape[2], C, P(dgamma), P(dbeta), stream),
                                        bname + ".bwd")
-                        if part.shape[0] == 3 and res is not None and acc == 0:
+                        if msg is None and part.shape[0] == 3 and res is not None and acc == 0:
                             # the projection shortcut's sums came out of the same epilogue: d beta = sum g (shared), d gamma = sum g * xhat2
                             sname = ya.bn2[3]
                             dgs, dbs = self.flat.view(sname + ".weight", True), self.flat.view(sname + ".bias", True)
@@ -1149,7 +1157,7 @@ class PoseTrainer:
                         token = self._exchange(msg)
                         self._wgrad_flush_if(0.5)            # queued weight gradients go out under the message rather than after it
                         self._exchange_wait(token)
-                        sg, sb, tot = msg[:C], msg[C:], rows * W
+                        sg, sb, tot = msg[:C], msg[C:2 * C], rows * W
                     elif sync:
                         # local sums are this rank's parameter gradients (DDP averages them later); dz needs the global ones
                         parts = [dgamma, dbeta]
