@@ -953,6 +953,32 @@ def test_captured_hip_graph_replays_forward_and_decode_bitwise(golden):
     assert rel <= 1e-4, rel
 
 
+def test_captured_graph_survives_the_eviction_of_its_activation_pool():
+    """Program._alloc keeps MAX_POOLS activation pools; a captured hipGraph has the pointers of ITS pool baked in, so it must keep that
+    pool alive: capture at one batch size, run more other batch sizes than pools are kept (which evicts the captured size from the
+    program's table), scribble over freed memory, replay - still bit-identical to the stream launches."""
+    net = pose_resnet_dconv.resnet50(pretrained=False, num_classes=17)
+    sd = synth.conditioned_state_dict(nets_oracle.state_dict_shapes_resnet50("dconv"), 4)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net = net.cuda().eval()
+    net.autotune = False
+    x = _cuda(synth.input_images(4, 12, h=128, w=96))
+    prog = net.hip_program(x)
+    ref = prog.run(x).clone()
+    graphed = prog.capture(x)
+    assert (4, str(x.device)) in prog._pools
+    for b in (2, 6, 3):                                        # MAX_POOLS = 2: the pool of batch 4 leaves the table
+        prog.run(_cuda(synth.input_images(b, b, h=128, w=96)))
+    assert (4, str(x.device)) not in prog._pools and len(prog._pools) <= prog.MAX_POOLS
+    junk = [torch.full((1 << 22,), float("nan"), device="cuda") for _ in range(8)]       # whatever the allocator hands out now is poisoned
+    torch.cuda.synchronize()
+    out = graphed(x)
+    out = out[0] if isinstance(out, tuple) else out
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    del junk
+
+
 def test_gpu_person_crops_vs_reference_glue_golden(golden):
     """crop_boxes (one launch for all boxes of an image) == the crops / trans_inv the reference's BasicTransform
     produced through the restated OpenCV primitives, bit for bit; feeds normalize_crops -> model as eval.py's loader would."""
