@@ -61,6 +61,10 @@ def parse():
     ap.add_argument("--layers-out", default=None, help="write the per-layer timing table (JSON) here")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (roofline object)")
     ap.add_argument("--fuse-bottlenecks", action="store_true", help="(default since round 3; kept so that older command lines still parse)")
+    ap.add_argument("--pipeline-decode", action="store_true", help="infer mode: decode of step i on its own stream while the forward of step i + 1 runs "
+                    "(engine.PipelinedForward; same results).  Default for hrnet_w32 (+4 %: its forward ends in low-occupancy launches); "
+                    "measured -2 % on the ResNets in bf16, neutral in fp32")
+    ap.add_argument("--no-pipeline-decode", action="store_true", help="hrnet_w32: decode in line, on the forward's stream")
     ap.add_argument("--no-fuse-stem", action="store_true", help="infer mode: run the stem launch by launch (layout change, conv(s), pooling) instead of "
                     "as one launch (sp_stem7_pool for the ResNets, sp_hrnet_stem for HRNet in bf16; same bits)")
     ap.add_argument("--no-fuse-bottlenecks", action="store_true",
@@ -395,11 +399,18 @@ def main():
                 _, kps, mv = graphed()                  # inputs already sit in the graph's static buffers (resident in HBM)
                 return kps, mv
         else:
-            hm_buf = torch.empty((B,) + tuple(prog.out_shape), dtype=torch.float32, device=dev)   # steady state: one resident result buffer
+            if args.pipeline_decode or (args.arch == "hrnet_w32" and not args.no_pipeline_decode):
+                from simple_pose_amd.engine import PipelinedForward
+                piped = PipelinedForward(prog, decoder)     # decode of step i on its own stream under the forward of step i + 1
 
-            def step():
-                hm = prog.run(x, out=hm_buf)
-                return decoder(hm, tinv)
+                def step():
+                    return piped(x, tinv)
+            else:
+                hm_buf = torch.empty((B,) + tuple(prog.out_shape), dtype=torch.float32, device=dev)   # steady state: one resident result buffer
+
+                def step():
+                    hm = prog.run(x, out=hm_buf)
+                    return decoder(hm, tinv)
 
     with torch.no_grad():
         for _ in range(args.warmup):
@@ -482,6 +493,7 @@ def main():
                            "images_per_gpu": B, "global_batch": B * world, "parallelism": f"replicas x{world} (no collective)",
                            "ranks": f"{world} process(es), one per GPU" + (f", {args.dist_backend} for the barrier / MAX only" if world > 1 else ""),
                            "launch": "one hipGraph per step" if args.graph else "stream launches", "tile_table": tiles_src,
+                           "decode": "own stream, under the next step's forward (engine.PipelinedForward)" if (not args.graph and (args.pipeline_decode or (args.arch == "hrnet_w32" and not args.no_pipeline_decode))) else "in line",
                            "HSA_ENABLE_IPC_MODE_LEGACY": ipc_mode},
                 "gflop_per_image": round(prog.flops_per_image / 1e9, 4),
                 "network_tflops": round(value * prog.flops_per_image / 1e12, 2),

@@ -953,6 +953,30 @@ def test_captured_hip_graph_replays_forward_and_decode_bitwise(golden):
     assert rel <= 1e-4, rel
 
 
+def test_pipelined_decode_equals_the_in_line_decode_bitwise():
+    """engine.PipelinedForward: the decode of batch i on its own stream under the forward of batch i + 1, two alternating heat-map buffers -
+    key points and scores of five consecutive (different) batches equal the in-line forward + decode bit for bit."""
+    net = pose_resnet_dconv.resnet50(pretrained=False, num_classes=17)
+    sd = synth.conditioned_state_dict(nets_oracle.state_dict_shapes_resnet50("dconv"), 4)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net = net.cuda().eval()
+    net.autotune = False
+    dec = GaussTaylorKeyPointDecoder()
+    xs = [_cuda(synth.input_images(6, 30 + i, h=128, w=96)) for i in range(5)]
+    tinv = _cuda(synth.trans_inv_batch(6))
+    prog = net.hip_program(xs[0])
+    ref = []
+    for x in xs:
+        k, m = dec(prog.run(x), tinv)
+        ref.append((k.clone(), m.clone()))
+    piped = engine.PipelinedForward(prog, dec)
+    got = [piped(x, tinv) for x in xs]
+    piped.sync()
+    torch.cuda.synchronize()
+    for (k, m), (rk, rm) in zip(got, ref):
+        assert torch.equal(k, rk) and torch.equal(m, rm)
+
+
 def test_captured_graph_survives_the_eviction_of_its_activation_pool():
     """Program._alloc keeps MAX_POOLS activation pools; a captured hipGraph has the pointers of ITS pool baked in, so it must keep that
     pool alive: capture at one batch size, run more other batch sizes than pools are kept (which evicts the captured size from the
