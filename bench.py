@@ -64,6 +64,10 @@ def parse():
     ap.add_argument("--pipeline-decode", action="store_true", help="infer mode: decode of step i on its own stream while the forward of step i + 1 runs "
                     "(engine.PipelinedForward; same results).  Default for hrnet_w32 (+4 %: its forward ends in low-occupancy launches); "
                     "measured -2 % on the ResNets in bf16, neutral in fp32")
+    ap.add_argument("--interleave", type=int, default=None, help="infer mode: consecutive steps on this many independent streams, each with its own "
+                    "activation pool (engine.InterleavedForward; same results).  Default 2 for the ResNets (two batches in flight fill the launch "
+                    "boundaries and partial last rounds of each other's kernels: +2.7 %% fp32, +10 %% bf16), 1 for hrnet_w32 (its forward already "
+                    "runs on four streams; it pipelines the decode instead)")
     ap.add_argument("--no-pipeline-decode", action="store_true", help="hrnet_w32: decode in line, on the forward's stream")
     ap.add_argument("--no-fuse-stem", action="store_true", help="infer mode: run the stem launch by launch (layout change, conv(s), pooling) instead of "
                     "as one launch (sp_stem7_pool for the ResNets, sp_hrnet_stem for HRNet in bf16; same bits)")
@@ -399,7 +403,15 @@ def main():
                 _, kps, mv = graphed()                  # inputs already sit in the graph's static buffers (resident in HBM)
                 return kps, mv
         else:
-            if args.pipeline_decode or (args.arch == "hrnet_w32" and not args.no_pipeline_decode):
+            if args.interleave is None:
+                args.interleave = 1 if args.arch == "hrnet_w32" else 2
+            if args.interleave > 1:
+                from simple_pose_amd.engine import InterleavedForward
+                inter = InterleavedForward(prog, decoder, depth=args.interleave)   # consecutive steps on independent streams / activation pools
+
+                def step():
+                    return inter(x, tinv)
+            elif args.pipeline_decode or (args.arch == "hrnet_w32" and not args.no_pipeline_decode):
                 from simple_pose_amd.engine import PipelinedForward
                 piped = PipelinedForward(prog, decoder)     # decode of step i on its own stream under the forward of step i + 1
 
@@ -493,7 +505,8 @@ def main():
                            "images_per_gpu": B, "global_batch": B * world, "parallelism": f"replicas x{world} (no collective)",
                            "ranks": f"{world} process(es), one per GPU" + (f", {args.dist_backend} for the barrier / MAX only" if world > 1 else ""),
                            "launch": "one hipGraph per step" if args.graph else "stream launches", "tile_table": tiles_src,
-                           "decode": "own stream, under the next step's forward (engine.PipelinedForward)" if (not args.graph and (args.pipeline_decode or (args.arch == "hrnet_w32" and not args.no_pipeline_decode))) else "in line",
+                           "batches_in_flight": 1 if args.graph else (args.interleave or 1),
+                           "decode": "in line" if (args.graph or (args.interleave or 1) > 1) else ("own stream, under the next step's forward (engine.PipelinedForward)" if (args.pipeline_decode or (args.arch == "hrnet_w32" and not args.no_pipeline_decode)) else "in line"),
                            "HSA_ENABLE_IPC_MODE_LEGACY": ipc_mode},
                 "gflop_per_image": round(prog.flops_per_image / 1e9, 4),
                 "network_tflops": round(value * prog.flops_per_image / 1e12, 2),

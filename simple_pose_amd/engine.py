@@ -133,13 +133,16 @@ class Program:
     # -- buffer planning: greedy reuse of dead activations (keeps the working set small for L2 / MALL) --
     MAX_POOLS = 2     # activation pools kept alive (distinct batch sizes / devices); older ones are dropped with their sync plans
 
-    def _alloc(self, batch: int, device) -> Dict[str, torch.Tensor]:
-        key = (batch, str(device))
+    def _alloc(self, batch: int, device, slot: int = 0) -> Dict[str, torch.Tensor]:
+        """Activation pool of (batch, device).  `slot` > 0: a further, independent pool of the same shape (engine.InterleavedForward runs
+        consecutive batches on different streams: each needs its own activations); those are owned by whoever asked and never evicted."""
+        key = (batch, str(device)) if slot == 0 else (batch, str(device), slot)
         if key in self._pools:
-            self._pools[key] = self._pools.pop(key)          # most recently used last
+            if slot == 0:
+                self._pools[key] = self._pools.pop(key)      # most recently used last
             return self._pools[key]
-        while len(self._pools) >= self.MAX_POOLS:            # a detector-driven caller sees a new person count per image: do not
-            old = next(iter(self._pools))                    # let every batch size keep a full activation pool forever
+        while slot == 0 and sum(len(k) == 2 for k in self._pools) >= self.MAX_POOLS:   # a detector-driven caller sees a new person count per
+            old = next(k for k in self._pools if len(k) == 2)                          # image: do not let every batch size keep a full pool forever
             del self._pools[old]
             self._sync.pop(old, None)
         last_use: Dict[str, int] = {}
@@ -194,10 +197,10 @@ class Program:
         self._sync[key] = (waits, set(records), tails)
         return self._sync[key]
 
-    def _lane_streams(self, device, n_lanes: int) -> list:
-        pool = self._streams.setdefault(str(device), [])
+    def _lane_streams(self, key, n_lanes: int, device=None) -> list:
+        pool = self._streams.setdefault(str(key), [])
         while len(pool) < n_lanes - 1:
-            pool.append(torch.cuda.Stream(device=device))
+            pool.append(torch.cuda.Stream(device=device if device is not None else key))
         return pool
 
     def _launch(self, lib, op: Op, bufs, B: int, stream) -> None:
@@ -272,7 +275,7 @@ class Program:
         else:
             raise ValueError(op.kind)
 
-    def run(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def run(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, slot: int = 0) -> torch.Tensor:
         """`out`: optional preallocated fp32 [B,J,H/4,W/4] result (a steady-state caller reuses one; default: a fresh tensor per call,
         which the caller may keep - torch's caching allocator makes that a pointer bump, no hipMalloc).
         x: fp32 NCHW [B,3,H,W] on the GPU (or uint8 BGR crops [B,H,W,3], normalised on the fly as datasets/coco.py:136 does) ->
@@ -280,7 +283,7 @@ class Program:
         different lanes (independent HRNet branches) go to different HIP streams and overlap on the GPU, ordered by events."""
         lib = _lib.lib()
         B = x.shape[0]
-        bufs = dict(self._alloc(B, x.device))
+        bufs = dict(self._alloc(B, x.device, slot))       # (slot: engine.InterleavedForward - own activations, lane streams and events)
         bufs["input"] = x
         if out is None:
             out = torch.empty((B,) + tuple(self.out_shape), dtype=torch.float32, device=x.device)
@@ -297,14 +300,14 @@ class Program:
             return out
         waits, records, tails = self._plan_sync(B, x.device)
         main = torch.cuda.current_stream(x.device)
-        side = self._lane_streams(x.device, n_lanes)
+        side = self._lane_streams(x.device if slot == 0 else f"{x.device}/{slot}", n_lanes, x.device)
         streams = [main] + side[: n_lanes - 1]
         fork = torch.cuda.Event()
         fork.record(main)                                   # inputs are ready / the previous run has drained (it joined on `main`)
         for st in streams[1:]:
             st.wait_event(fork)
         handles = [ctypes.c_void_p(st.cuda_stream) for st in streams]
-        events = self._events.setdefault(str(x.device), {})
+        events = self._events.setdefault(str(x.device) if slot == 0 else f"{x.device}/{slot}", {})
         for i, op in enumerate(self.ops):
             st = streams[op.lane]
             for j in waits[i]:
@@ -632,6 +635,54 @@ class PipelinedForward:
     def sync(self) -> None:
         """The caller's stream waits for every decode issued so far."""
         for ev in self._dec_done:
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+
+
+class InterleavedForward:
+    """Consecutive batches on `depth` independent streams, each with its own activation pool, lane streams and events: the forward (+ decode)
+    of batch i + 1 starts while batch i is still in its low-occupancy tail.  For programs whose launches do not fill the chip (HRNet: 2-4
+    branches of small convolutions, a last module that only produces one branch) this is where throughput is; the ResNets' launches fill
+    the chip on their own.  Results are those of Program.run (+ decoder) bit for bit.
+
+        run = InterleavedForward(program, decoder, depth=2)
+        for x, tinv in batches: kps, score = run(x, tinv)      # valid after run.sync()
+    """
+
+    def __init__(self, prog: "Program", decoder=None, depth: int = 2):
+        self.prog, self.decoder, self.depth = prog, decoder, depth
+        self._streams: list = []
+        self._hm: list = [None] * depth
+        self._done: list = [None] * depth
+        self._ready = None
+        self._i = 0
+
+    def __call__(self, x: torch.Tensor, trans_inv: Optional[torch.Tensor] = None):
+        dev = x.device
+        while len(self._streams) < self.depth:
+            self._streams.append(torch.cuda.Stream(device=dev))
+        k = self._i % self.depth
+        self._i += 1
+        st = self._streams[k]
+        if self._ready is None:
+            self._ready = torch.cuda.Event()
+        self._ready.record(torch.cuda.current_stream(dev))    # the inputs are ready on the caller's stream
+        st.wait_event(self._ready)
+        shape = (x.shape[0],) + tuple(self.prog.out_shape)
+        if self._hm[k] is None or tuple(self._hm[k].shape) != shape:
+            self._hm[k] = torch.empty(shape, dtype=torch.float32, device=dev)
+        with torch.cuda.stream(st):
+            out = self.prog.run(x, out=self._hm[k], slot=k + 1)
+            if self.decoder is not None:
+                out = self.decoder(out, trans_inv)
+            if self._done[k] is None:
+                self._done[k] = torch.cuda.Event()
+            self._done[k].record(st)
+        return out
+
+    def sync(self) -> None:
+        """The caller's stream waits for everything issued so far."""
+        for ev in self._done:
             if ev is not None:
                 torch.cuda.current_stream().wait_event(ev)
 

@@ -977,6 +977,36 @@ def test_pipelined_decode_equals_the_in_line_decode_bitwise():
         assert torch.equal(k, rk) and torch.equal(m, rm)
 
 
+def test_interleaved_forward_equals_run_bitwise():
+    """engine.InterleavedForward: consecutive batches on independent streams with their own activation pools, lane streams and events (HRNet:
+    the forward of batch i + 1 under the low-occupancy tail of batch i) - key points and scores of seven different batches equal
+    Program.run + decoder bit for bit, for depth 2 and 3."""
+    import os
+    from simple_pose_amd.nets.pose_hrnet import get_pose_net, hrnet_state_dict_shapes
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    net = get_pose_net(os.path.join(root, "simple_pose_amd", "nets", "hrnet_w32.yaml"), pretrained=None, joint_num=17)
+    sd = synth.conditioned_state_dict(hrnet_state_dict_shapes(net.cfg, 17), seed=3)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    net = net.cuda().eval()
+    net.autotune = False
+    net.compute_dtype = "bf16"
+    dec = GaussTaylorKeyPointDecoder()
+    xs = [_cuda(synth.input_images(4, 50 + i, h=128, w=96)) for i in range(7)]
+    tinv = _cuda(synth.trans_inv_batch(4))
+    prog = net.hip_program(xs[0])
+    ref = []
+    for x in xs:
+        k, m = dec(prog.run(x), tinv)
+        ref.append((k.clone(), m.clone()))
+    for depth in (2, 3):
+        inter = engine.InterleavedForward(prog, dec, depth=depth)
+        got = [inter(x, tinv) for x in xs]
+        inter.sync()
+        torch.cuda.synchronize()
+        for (k, m), (rk, rm) in zip(got, ref):
+            assert torch.equal(k, rk) and torch.equal(m, rm)
+
+
 def test_captured_graph_survives_the_eviction_of_its_activation_pool():
     """Program._alloc keeps MAX_POOLS activation pools; a captured hipGraph has the pointers of ITS pool baked in, so it must keep that
     pool alive: capture at one batch size, run more other batch sizes than pools are kept (which evicts the captured size from the

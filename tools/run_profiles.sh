@@ -16,7 +16,9 @@ for cfg in $CONFIGS; do
   D=$OUT/${arch}_${dt}
   mkdir -p $D
   TILES=$ROOT/profiles/${TAG}_${arch}_${dt}_tiles.json      # the tracked table (what bench.py loads by default); picked if missing
-  BENCH="python3 $ROOT/bench.py --arch $arch --dtype $dt --steps 10 --warmup 3 --no-cpu-baseline --tiles $TILES"
+  # kernel statistics and counters with ONE batch in flight (the per-kernel durations then mean what the roofline's HIP events mean); the
+  # unprofiled line below is the default command: two batches in flight on the ResNets
+  BENCH="python3 $ROOT/bench.py --arch $arch --dtype $dt --steps 10 --warmup 3 --no-cpu-baseline --tiles $TILES --interleave 1"
   # untimed: the tile table is pinned so that the tuner's trial launches stay out of the statistics (tools/pick_tiles.py: the
   # fastest of several tuner runs on the whole forward)
   [ -f $TILES ] || timeout 300 python3 $ROOT/tools/pick_tiles.py --arch $arch --dtype $dt --out $TILES > $D/pick_tiles.log 2>&1
