@@ -66,9 +66,11 @@ def parse():
                     "measured -2 % on the ResNets in bf16, neutral in fp32")
     ap.add_argument("--interleave", type=int, default=None, help="infer mode: consecutive steps on this many independent streams, each with its own "
                     "activation pool (engine.InterleavedForward; same results).  Default 2 for the ResNets (two batches in flight fill the launch "
-                    "boundaries and partial last rounds of each other's kernels: +2.7 %% fp32, +10 %% bf16), 1 for hrnet_w32 (its forward already "
-                    "runs on four streams; it pipelines the decode instead)")
+                    "boundaries and partial last rounds of each other's kernels: +2.7 %% fp32, +10 %% bf16), 3 for hrnet_w32 with every forward on "
+                    "ONE stream (+20 %% over one forward spread over four branch streams)")
+    ap.add_argument("--multi-stream", action="store_true", help="hrnet_w32 with --interleave > 1: keep the per-branch streams inside each forward")
     ap.add_argument("--no-pipeline-decode", action="store_true", help="hrnet_w32: decode in line, on the forward's stream")
+    ap.add_argument("--fuse-blocks", action="store_true", help="hrnet_w32 bf16: 32-channel BasicBlocks as one launch each (sp_basic_block_c32; same bits)")
     ap.add_argument("--no-fuse-stem", action="store_true", help="infer mode: run the stem launch by launch (layout change, conv(s), pooling) instead of "
                     "as one launch (sp_stem7_pool for the ResNets, sp_hrnet_stem for HRNet in bf16; same bits)")
     ap.add_argument("--no-fuse-bottlenecks", action="store_true",
@@ -318,6 +320,8 @@ def main():
     model = model.to(dev).eval()
     if args.no_fuse_stem:
         model.fuse_stem = False
+    if args.fuse_blocks and args.arch == "hrnet_w32":
+        model.fuse_blocks = True
     if args.dtype == "bf16" and args.mode == "infer":
         model.compute_dtype = "bf16"
         if args.arch in ("dconv", "duc"):
@@ -404,7 +408,9 @@ def main():
                 return kps, mv
         else:
             if args.interleave is None:
-                args.interleave = 1 if args.arch == "hrnet_w32" else 2
+                args.interleave = 3 if args.arch == "hrnet_w32" else 2
+            if args.arch == "hrnet_w32" and args.interleave > 1 and not args.multi_stream:
+                prog.multi_stream = False      # batches on three streams beat branches on four: 24.0 -> 29.0 k img/s (the two do not add up: 4 hardware queues)
             if args.interleave > 1:
                 from simple_pose_amd.engine import InterleavedForward
                 inter = InterleavedForward(prog, decoder, depth=args.interleave)   # consecutive steps on independent streams / activation pools
