@@ -84,7 +84,7 @@ def one_config(src, dst, cfg, fh):
     prof = bench_line(os.path.join(d, "bench_trace.log"))
     fh.write(f"\n## {cfg}: `python3 bench.py --arch {cfg.rsplit('_', 1)[0]} --dtype {cfg.rsplit('_', 1)[1]} --steps 10 --warmup 3 --interleave 1` under rocprofv3 --kernel-trace --stats\n\n")
     fh.write("(kernel statistics and counters: ONE batch in flight, so that a kernel's duration means what the roofline's HIP events mean; the unprofiled "
-             "line is the default command - on the ResNets two batches in flight on independent streams, engine.InterleavedForward)\n\n")
+             "line is the default command - engine.InterleavedForward: two batches in flight on independent streams on the ResNets, three single-stream forwards on HRNet)\n\n")
     if line:
         r = line.get("roofline") or {}
         fh.write(f"unprofiled: **{line['value']} img/s**, {line['ms_per_step']} ms/step; dominant kernel `{r.get('kernel')}` "
