@@ -649,8 +649,14 @@ class InterleavedForward:
         for x, tinv in batches: kps, score = run(x, tinv)      # valid after run.sync()
     """
 
+    _next_slot = 1      # slots are unique per instance: two InterleavedForward objects on one Program never share activations
+
     def __init__(self, prog: "Program", decoder=None, depth: int = 2):
+        if depth < 1:
+            raise ValueError("depth >= 1")
         self.prog, self.decoder, self.depth = prog, decoder, depth
+        self._slot0 = InterleavedForward._next_slot
+        InterleavedForward._next_slot += depth
         self._streams: list = []
         self._hm: list = [None] * depth
         self._done: list = [None] * depth
@@ -672,7 +678,7 @@ class InterleavedForward:
         if self._hm[k] is None or tuple(self._hm[k].shape) != shape:
             self._hm[k] = torch.empty(shape, dtype=torch.float32, device=dev)
         with torch.cuda.stream(st):
-            out = self.prog.run(x, out=self._hm[k], slot=k + 1)
+            out = self.prog.run(x, out=self._hm[k], slot=self._slot0 + k)
             if self.decoder is not None:
                 out = self.decoder(out, trans_inv)
             if self._done[k] is None:
@@ -685,6 +691,17 @@ class InterleavedForward:
         for ev in self._done:
             if ev is not None:
                 torch.cuda.current_stream().wait_event(ev)
+
+    def close(self) -> None:
+        """Wait for the work in flight and give this object's activation pools, lane streams and events back."""
+        torch.cuda.synchronize()
+        mine = range(self._slot0, self._slot0 + self.depth)
+        for key in [k for k in self.prog._pools if len(k) == 3 and k[2] in mine]:
+            del self.prog._pools[key]
+        for table in (self.prog._streams, self.prog._events):
+            for key in [k for k in table if "/" in k and k.rsplit("/", 1)[1].isdigit() and int(k.rsplit("/", 1)[1]) in mine]:
+                del table[key]
+        self._hm = [None] * self.depth
 
 
 class ProgramBuilder:

@@ -1005,6 +1005,10 @@ def test_interleaved_forward_equals_run_bitwise():
         torch.cuda.synchronize()
         for (k, m), (rk, rm) in zip(got, ref):
             assert torch.equal(k, rk) and torch.equal(m, rm)
+        n_slots = sum(len(key) == 3 for key in prog._pools)
+        assert n_slots == depth
+        inter.close()
+        assert not any(len(key) == 3 for key in prog._pools)
 
 
 def test_captured_graph_survives_the_eviction_of_its_activation_pool():
