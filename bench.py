@@ -80,6 +80,13 @@ def parse():
                     help="preflight of the N-rank job without touching a GPU: start the N ranks exactly as a real run does, rendezvous over gloo, "
                          "check the rank -> device mapping, one barrier and the MAX/SUM reductions of the measurement, print ONE JSON line; "
                          "non-zero exit when any rank dies")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default run (N = 1, infer, dconv f32 bs=128) only: skip the other BASELINE configs that are otherwise timed after the "
+                         "headline with the same --steps / --warmup and appended as `other_configs` (DUC bf16 bs=128, HRNet-W32 bf16 bs=128, the "
+                         "32-image bf16 train step)")
+    ap.add_argument("--by-kernel", action="store_true", help="keep the per-instantiation table (`roofline.by_kernel`) in the JSON line")
+    ap.add_argument("--native-comm", action="store_true", help="train mode, N > 1: the step's collectives through our own RCCL communicators on the "
+                    "step's streams (sp_comm_*) instead of torch.distributed; opt-in until it has run on a multi-GPU box")
     ap.add_argument("--hsa-ipc-legacy", default="0", choices=["0", "1", "inherit"],
                     help="HSA_ENABLE_IPC_MODE_LEGACY for the ranks (recorded in config): 0 = dmabuf IPC, what this pool's host driver supports "
                          "(RCCL / tensor sharing across processes fails with hipIpcGetMemHandle otherwise); inherit = leave the environment alone")
@@ -300,7 +307,60 @@ def main():
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
     red_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")   # where the measurement's scalar reductions live
+    ctx = {"rank": rank, "world": world, "dev": dev, "red_dev": red_dev, "ipc_mode": ipc_mode, "rccl": None}
+    if dist.is_initialized() and dist.get_backend() == "nccl":
+        # N > 1 over RCCL (or the 1-rank preflight group): ask RCCL itself who is in the job
+        try:
+            ctx["rccl"] = rccl_census(dev, rank, world)
+        except Exception as e:                               # reported in the line, never fatal for the measurement
+            ctx["rccl"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    # the default command (what the driver runs: N = 1, the headline config) also times the other single-GPU BASELINE configs, after the
+    # headline, with the same --steps / --warmup and the tracked tile tables, and appends them as the LAST key of the one JSON line
+    default_cmd = (world == 1 and args.mode == "infer" and args.arch == "dconv" and args.dtype == "f32" and args.batch == 128 and
+                   not args.graph and args.tiles is None and not args.retune and args.interleave is None and not args.no_other_configs)
+    line = run_once(args, ctx)
+    if default_cmd and line is not None:
+        others = []
+        for over in OTHER_CONFIGS:
+            a2 = argparse.Namespace(**vars(args))
+            for k, v in over["args"].items():
+                setattr(a2, k, v)
+            a2.no_cpu_baseline, a2.layers_out = True, None
+            t0 = time.perf_counter()
+            try:
+                ln = run_once(a2, ctx)
+                rf = ln.get("roofline") or {}
+                others.append({"config": over["config"], "value": ln["value"], "unit": ln["unit"], "ms_per_step": ln["ms_per_step"],
+                               "dtype": ln["dtype"], "steps": ln["steps"], "warmup": ln["warmup"], "roofline_frac": rf.get("frac"),
+                               "roofline_kernel": rf.get("kernel"), "network_frac_of_matrix_peak": ln.get("network_frac_of_matrix_peak"),
+                               "batches_in_flight": ln["config"].get("batches_in_flight", 1), "tile_table": ln["config"].get("tile_table"),
+                               "wall_s": round(time.perf_counter() - t0, 1)})
+            except Exception as e:       # the headline line must still go out; a failed extra config is reported, not hidden
+                others.append({"config": over["config"], "error": f"{type(e).__name__}: {e}"[:300]})
+        line["other_configs"] = others
+    if rank == 0 and line is not None:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
+
+# the other single-GPU BASELINE configs (BASELINE.json configs[2], [4] and the per-GPU shard of configs[3]) as overrides of the default
+# arguments; `interleave: None` = each architecture's default number of batches in flight
+OTHER_CONFIGS = [
+    {"config": "ResNet50-DUC 256x192 bs=128 bf16 forward+decode", "args": {"arch": "duc", "dtype": "bf16", "mode": "infer", "batch": 128, "interleave": None}},
+    {"config": "HRNet-W32 256x192 bs=128 bf16 forward+decode", "args": {"arch": "hrnet_w32", "dtype": "bf16", "mode": "infer", "batch": 128, "interleave": None}},
+    {"config": "ResNet50-DConv 256x192 bs=32/GPU bf16 train step (fwd+bwd+Adam), 1-GPU shard of the bs=256 DDP config",
+     "args": {"arch": "dconv", "dtype": "bf16", "mode": "train", "batch": 32, "interleave": None}},
+]
+
+
+def run_once(args, ctx):
+    """One measurement (warm-up, timed region, per-kernel events) of the configuration `args` describes, in this process; returns the
+    JSON line as a dict on rank 0 (None elsewhere)."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world, dev, red_dev, ipc_mode = ctx["rank"], ctx["world"], ctx["dev"], ctx["red_dev"], ctx["ipc_mode"]
     from simple_pose_amd import _lib, synth
     from simple_pose_amd.metrics import GaussTaylorKeyPointDecoder
     from simple_pose_amd.nets import pose_resnet_dconv, pose_resnet_duc
@@ -341,7 +401,8 @@ def main():
         model.train()
         trainer = PoseTrainer(model, lr=1e-3, dtype="bf16" if args.dtype == "bf16" else "fp32", sync_bn=not args.no_sync_bn,
                               bucket_mb=args.bucket_mb, sync_bn_latency_us=args.sync_bn_latency_us,
-                              native_comm=False if args.torch_collectives else None, sync_bn_inline=not args.torch_collectives)
+                              native_comm=False if args.torch_collectives else (True if (args.native_comm and world > 1) else None),
+                              sync_bn_inline=not args.torch_collectives)
         # untimed setup: the tile of every forward / dgrad launch.  Default: the tracked table of this dtype under profiles/ (the one the
         # committed rocprofv3 summaries were taken with: no tuner launches in a profiled run, same launches on every rank and box);
         # --retune / a missing table: timed on rank 0 at this batch and shared
@@ -355,7 +416,7 @@ def main():
             else:
                 table = trainer.autotune_shared(B)
                 tiles_src = "autotuned on rank 0 (untimed setup)"
-                if args.tiles and rank == 0:
+                if args.tiles and rank == 0 and not os.path.isfile(args.tiles):    # never overwrite a table tuned at another batch
                     with open(args.tiles, "w") as fh:
                         json.dump(table, fh)
         joints = torch.from_numpy(synth.joints_batch(B, 17, seed=200 + rank)).to(dev)
@@ -461,6 +522,11 @@ def main():
                                    peak=FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else BF16_MATRIX_PEAK_TFLOPS,
                                    arch=args.arch, dtype=args.dtype)
 
+    if roofline is not None:
+        roofline["mode"] = "one batch in flight, one stream (per-kernel HIP events; `value` above: config.batches_in_flight)"
+        if not args.by_kernel:
+            roofline.pop("by_kernel", None)                   # (kept in --layers-out / --by-kernel; profiles/*_kernel_stats.csv has the same table)
+
     step_split = None
     if args.mode == "train":                                  # untimed extra steps with phase events (every rank: collectives inside)
         if graphed_step is not None:                          # (timing events cannot live inside a graph: these steps run eagerly)
@@ -520,9 +586,63 @@ def main():
                 "roofline": roofline,
                 "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args.arch),   # rank 0 at N = 1 only
             }
-        print(json.dumps(line), flush=True)
+        if ctx.get("rccl") is not None:
+            line["config"]["rccl"] = ctx["rccl"]
+    else:
+        line = None
+    # give this configuration's pools / streams back before the next one is built in the same process
+    for obj in ("inter", "piped"):
+        o = locals().get(obj)
+        if o is not None and hasattr(o, "close"):
+            o.close()
+    if args.mode == "train":
+        trainer.close()
+    del step, out
+    prog = trainer = model = None
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    return line
+
+
+def rccl_census(dev, rank: int, world: int):
+    """What RCCL itself reports for a communicator of our own over the job's ranks (ncclCommCount / ncclCommUserRank / ncclCommCuDevice
+    through sp_comm_info), gathered over all ranks: an N-GPU line then carries proof that N ranks on N devices met."""
+    import ctypes
+
+    import torch
+    import torch.distributed as dist
+
+    from simple_pose_amd import _lib
+    lib = _lib.lib()
+    if not lib.sp_comm_available():
+        return {"error": "librccl not resolvable (sp_comm_available() == 0)"}
+    idt = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        buf = (ctypes.c_ubyte * 128)()
+        _lib.check(lib.sp_comm_unique_id(buf), "sp_comm_unique_id")
+        idt = torch.tensor(list(buf), dtype=torch.uint8)
+    idt = idt.to(dev)
     if world > 1:
-        dist.destroy_process_group()
+        dist.broadcast(idt, src=0)
+    comm = ctypes.c_void_p()
+    with torch.cuda.device(dev):
+        _lib.check(lib.sp_comm_create(bytes(idt.cpu().tolist()), world, rank, ctypes.byref(comm)), "sp_comm_create")
+    n, r, d = ctypes.c_int(-1), ctypes.c_int(-1), ctypes.c_int(-1)
+    _lib.check(lib.sp_comm_info(comm, ctypes.byref(n), ctypes.byref(r), ctypes.byref(d)), "sp_comm_info")
+    # one real exchange through it: every rank contributes (rank + 1), the sum must be world (world + 1) / 2
+    probe = torch.full((4,), float(rank + 1), dtype=torch.float32, device=dev)
+    _lib.check(lib.sp_comm_allreduce_sum_f32(comm, _lib.ptr(probe), 4, _lib.current_stream(dev)), "census all-reduce")
+    torch.cuda.synchronize(dev)
+    mine = torch.tensor([n.value, r.value, d.value, int(round(float(probe[0].item())))], dtype=torch.int64, device=dev)
+    table = [torch.zeros_like(mine) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(table, mine)
+    else:
+        table = [mine]
+    _lib.check(lib.sp_comm_destroy(comm), "sp_comm_destroy")
+    rows = [[int(v) for v in t.cpu().tolist()] for t in table]
+    return {"ncclCommCount": sorted({row[0] for row in rows}), "ranks": [row[1] for row in rows], "devices": [row[2] for row in rows],
+            "allreduce_sum_of_rank_plus_1": sorted({row[3] for row in rows}), "expected_sum": world * (world + 1) // 2}
 
 
 def train_roofline(trainer, step, B: int, peak: float, steps: int = 3, layers_out=None):

@@ -27,7 +27,7 @@ extern "C" {
 #define SP_EINVAL (-1)   /* bad argument / unsupported shape (message in sp_last_error) */
 #define SP_ELAUNCH (-2)  /* HIP launch or runtime failure */
 
-#define SP_ABI_VERSION 30
+#define SP_ABI_VERSION 31
 
 /* epilogue / layout flags of sp_conv_desc.flags */
 #define SP_CONV_RELU 0x1u          /* y = max(y, 0) after scale/shift (+ residual) */
@@ -281,7 +281,7 @@ int sp_masked_mse(const float* pred, const float* target, const float* mask, int
 int sp_bn_train_stats_nhwc(const void* z, int bf16, int64_t rows, int c, float eps, float momentum, float* mean, float* invstd,
                            float* running_mean, float* running_var, void* workspace, void* stream);
 /* The same statistics without a pass over z: sp_conv2d_fwd_bn_stats is sp_conv2d_fwd (no scale/shift/residual/ReLU, NHWC store in
- * the conv's dtype) whose epilogue also writes, per (phase, M tile, wave row) of the launch, the per-channel sum and sum of squares
+ * the conv's dtype) whose epilogue also writes, per (phase, M tile) of the launch (the tile's wave rows are added inside the launch), the per-channel sum and sum of squares
  * of the values it stores ([partial_rows][n_pad] fp32 each; sp_conv2d_bn_stats_rows gives partial_rows for the tile the launch
  * will use); sp_bn_train_stats_from_conv folds them in index order in fp64 and finishes like sp_bn_train_stats_nhwc. */
 int sp_conv2d_bn_stats_rows(const sp_conv_desc* desc, int* partial_rows);
@@ -292,7 +292,7 @@ int sp_bn_train_stats_from_conv(const float* stats_sum, const float* stats_sumsq
                                 void* stream);
 /* Backward counterpart: a dgrad launch (sp_conv2d_fwd on the dgrad packing, fp32 NHWC store, optional in-place accumulate) whose
  * output IS dy of a BatchNorm+ReLU layer.  Given that layer's saved output bn_y (ReLU mask), input bn_z and statistics, the
- * epilogue also writes the partial sums of g = dy*(bn_y > 0) and g*xhat, one row per (phase, M tile, wave row) as above;
+ * epilogue also writes the partial sums of g = dy*(bn_y > 0) and g*xhat, one row per (phase, M tile) as above;
  * several launches that together cover dy (the phases of a stride-2 dgrad) fill consecutive row ranges of the same buffers.
  * sp_bn_bwd_sums_from_conv folds them (index order, fp64) into dbeta / dgamma; sp_bn_train_bwd_apply_nhwc finishes the layer. */
 int sp_conv2d_dgrad_bn_bwd_stats(const sp_conv_desc* desc, const void* dz, const void* w_packed, const void* accumulate, void* dx,
@@ -307,6 +307,19 @@ int sp_conv2d_dgrad_bn_bwd_stats2(const sp_conv_desc* desc, const void* dz, cons
                                   const void* bn_y, const void* bn_z, const float* bn_mean, const float* bn_invstd, float* sum_g,
                                   float* sum_g_xhat, const void* bn2_z, const float* bn2_mean, const float* bn2_invstd,
                                   float* sum_g_xhat2, int stats_rows_capacity, void* stream);
+/* The fold as the prologue of the pass that consumes it (round 4): sp_bn_fold_apply_nhwc = sp_bn_train_stats_from_conv + sp_bn_apply_nhwc
+ * in ONE launch - every workgroup folds the partial rows of its 64-channel slab itself (same order as the stand-alone fold: same bits),
+ * the first row stripe publishes mean / invstd / running statistics; sp_bn_fold_bwd_apply_nhwc = sp_bn_bwd_sums_from_conv (+ the same for
+ * a second BatchNorm sharing g: sum_g_xhat2 -> dgamma2, sum g -> dbeta2; all three NULL when there is none) + sp_bn_train_bwd_apply_nhwc.
+ * Meant for tensors with few partial rows (the caller decides: layer3 / layer4 of a ResNet at 32 images have 24-96); replaces
+ * `nn.BatchNorm2d` forward / backward of processors/ddp_pose_resnet_solver.py:115,118 together with the conv launch that left the rows. */
+int sp_bn_fold_apply_nhwc(const void* z, int bf16, const float* stats_sum, const float* stats_sumsq, int partial_rows, int stride,
+                          int64_t total_rows, float eps, float momentum, const float* gamma, const float* beta, const void* residual, void* y,
+                          int64_t rows, int c, int relu, float* mean, float* invstd, float* running_mean, float* running_var, void* stream);
+int sp_bn_fold_bwd_apply_nhwc(const void* dy, int bf16, const void* relu_src, const void* z, const float* sum_g, const float* sum_g_xhat,
+                              const float* sum_g_xhat2, int partial_rows, int stride, const float* mean, const float* invstd,
+                              const float* gamma, int64_t total_rows, int64_t rows, int c, float* dgamma, float* dbeta, float* dgamma2,
+                              float* dbeta2, void* dz, void* dres, int dres_accumulate, void* stream);
 /* y = [relu]((z - mean) * invstd * gamma + beta [+ residual])   (Bottleneck.forward tail, pose_resnet_dconv.py:124-131) */
 int sp_bn_apply_nhwc(const void* z, int bf16, const float* mean, const float* invstd, const float* gamma, const float* beta,
                      const void* residual, void* y, int64_t rows, int c, int relu, void* stream);
@@ -441,6 +454,10 @@ int sp_comm_available(void);
 int sp_comm_unique_id(void* id128);
 int sp_comm_create(const void* id128, int world, int rank, void** comm);
 int sp_comm_allreduce_sum_f32(void* comm, float* buf, int64_t n, void* stream);
+/* the same for fp64 buffers (the SyncBatchNorm forward message: per-channel (sum, sum of squares) in double); n = number of doubles */
+int sp_comm_allreduce_sum_f64(void* comm, double* buf, int64_t n, void* stream);
+/* what RCCL reports for a communicator: ncclCommCount / ncclCommUserRank / ncclCommCuDevice */
+int sp_comm_info(void* comm, int* world, int* rank, int* device);
 int sp_comm_destroy(void* comm);
 
 /* ---- parameter packing: the reference's tensors -> what the launches above read ------------------------------------------

@@ -20,7 +20,7 @@ SP_CONV_PIXEL_SHUFFLE = 0x4
 SP_CONV_BF16 = 0x8
 SP_CONV_OUT_F32 = 0x10
 CONV_TILES = ((128, 128), (64, 128), (128, 64), (64, 64), (256, 64), (128, 32))
-ABI_VERSION = 30
+ABI_VERSION = 31
 SP_CONV_KERNEL_IGEMM, SP_CONV_KERNEL_RING, SP_CONV_KERNEL_PW = 0, 1, 2
 RING_TILES = ((256, 256), (256, 128), (128, 256), (256, 64), (128, 128), (192, 128), (192, 256))   # kernel = SP_CONV_KERNEL_RING (bf16)
 
@@ -95,6 +95,8 @@ SYMBOLS = {
     "sp_comm_unique_id": (c_int, [_P]),
     "sp_comm_create": (c_int, [_P, c_int, c_int, ctypes.POINTER(ctypes.c_void_p)]),
     "sp_comm_allreduce_sum_f32": (c_int, [_P, _P, c_int64, _P]),
+    "sp_comm_allreduce_sum_f64": (c_int, [_P, _P, c_int64, _P]),
+    "sp_comm_info": (c_int, [_P, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "sp_comm_destroy": (c_int, [_P]),
     "sp_conv2d_wgrad": (c_int, [ctypes.POINTER(ConvDesc), _P, c_int, _P, c_int, c_int, c_int, c_int64, c_int64, _P, _P, c_int64, _P]),
     "sp_conv2d_wgrad_workspace": (c_int, [ctypes.POINTER(WgradJob), c_int, ctypes.POINTER(c_int64)]),
@@ -116,6 +118,8 @@ SYMBOLS = {
     "sp_conv2d_dgrad_bn_bwd_stats": (c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "sp_conv2d_dgrad_bn_bwd_stats2": (c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "sp_bn_sums_from_conv": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
+    "sp_bn_fold_apply_nhwc": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int64, c_float, c_float, _P, _P, _P, _P, c_int64, c_int, c_int, _P, _P, _P, _P, _P]),
+    "sp_bn_fold_bwd_apply_nhwc": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, c_int64, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "sp_bn_bwd_sums_from_conv": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "sp_u8hwc_bgr_to_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "sp_nchw_to_nhwc4_bf16": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -22,6 +22,9 @@ struct Rccl {
     decltype(&ncclCommInitRank) comm_init_rank = nullptr;
     decltype(&ncclAllReduce) all_reduce = nullptr;
     decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclCommCount) comm_count = nullptr;
+    decltype(&ncclCommUserRank) comm_user_rank = nullptr;
+    decltype(&ncclCommCuDevice) comm_device = nullptr;
     decltype(&ncclGetErrorString) error_string = nullptr;
     bool tried = false;
 };
@@ -43,7 +46,12 @@ Rccl& rccl() {
     r.all_reduce = reinterpret_cast<decltype(r.all_reduce)>(dlsym(r.handle, "ncclAllReduce"));
     r.comm_destroy = reinterpret_cast<decltype(r.comm_destroy)>(dlsym(r.handle, "ncclCommDestroy"));
     r.error_string = reinterpret_cast<decltype(r.error_string)>(dlsym(r.handle, "ncclGetErrorString"));
-    if (!(r.get_unique_id && r.comm_init_rank && r.all_reduce && r.comm_destroy && r.error_string)) r.handle = nullptr;
+    r.comm_count = reinterpret_cast<decltype(r.comm_count)>(dlsym(r.handle, "ncclCommCount"));
+    r.comm_user_rank = reinterpret_cast<decltype(r.comm_user_rank)>(dlsym(r.handle, "ncclCommUserRank"));
+    r.comm_device = reinterpret_cast<decltype(r.comm_device)>(dlsym(r.handle, "ncclCommCuDevice"));
+    if (!(r.get_unique_id && r.comm_init_rank && r.all_reduce && r.comm_destroy && r.error_string && r.comm_count && r.comm_user_rank &&
+          r.comm_device))
+        r.handle = nullptr;
     return r;
 }
 
@@ -92,6 +100,30 @@ extern "C" int sp_comm_allreduce_sum_f32(void* comm, float* buf, int64_t n, void
     SP_NEED_RCCL();
     const ncclResult_t rc = rccl().all_reduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, (ncclComm_t)comm, (hipStream_t)stream);
     if (rc != ncclSuccess) return fail("ncclAllReduce", rc);
+    return SP_OK;
+}
+
+// The SyncBatchNorm forward message is (sum, sum of squares) per channel in fp64 (train.hip: bn_sums_from_conv_kernel): summed as
+// ncclFloat64.  (Round 3 sent these buffers through the f32 entry point with the fp64 element count - wrong for world > 1.)
+extern "C" int sp_comm_allreduce_sum_f64(void* comm, double* buf, int64_t n, void* stream) {
+    SP_REQUIRE(comm && buf && n > 0, "sp_comm_allreduce_sum_f64: bad argument");
+    SP_NEED_RCCL();
+    const ncclResult_t rc = rccl().all_reduce(buf, buf, (size_t)n, ncclFloat64, ncclSum, (ncclComm_t)comm, (hipStream_t)stream);
+    if (rc != ncclSuccess) return fail("ncclAllReduce", rc);
+    return SP_OK;
+}
+
+// What RCCL itself says about a communicator: ranks in it, this process's rank, the HIP device it was created on (bench.py prints
+// these per rank so that an N-GPU line proves N ranks met).
+extern "C" int sp_comm_info(void* comm, int* world, int* rank, int* device) {
+    SP_REQUIRE(comm && world && rank && device, "sp_comm_info: null pointer");
+    SP_NEED_RCCL();
+    ncclResult_t rc = rccl().comm_count((ncclComm_t)comm, world);
+    if (rc != ncclSuccess) return fail("ncclCommCount", rc);
+    rc = rccl().comm_user_rank((ncclComm_t)comm, rank);
+    if (rc != ncclSuccess) return fail("ncclCommUserRank", rc);
+    rc = rccl().comm_device((ncclComm_t)comm, device);
+    if (rc != ncclSuccess) return fail("ncclCommCuDevice", rc);
     return SP_OK;
 }
 

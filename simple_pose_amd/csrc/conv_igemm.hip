@@ -76,7 +76,7 @@ struct ConvArgs {
     unsigned flags;
     int tiles_m, tiles_n;
     int x_bytes, w_bytes, y_bytes;  // buffer-descriptor extents (w: one phase slab)
-    // STATS instantiations (train-mode BatchNorm): per (phase, M tile, wave row) partial sums of the stored values, per channel
+    // STATS instantiations (train-mode BatchNorm): per (phase, M tile) partial sums of the stored values, per channel
     float* stats_s;      // [rows][stats_stride] sum
     float* stats_q;      // [rows][stats_stride] sum of squares
     int stats_stride;
@@ -662,8 +662,8 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
             __builtin_amdgcn_raw_buffer_store_b128(o, yr, off[it], 0, 0);
         }
         if constexpr (STATS || BSTATS) {
-            // lanes chunk, chunk + CPR, ... hold the same channels for different rows: fixed butterfly, then one partial row per
-            // (phase, M tile, wave row); the host-side fold adds the rows in index order -> deterministic statistics
+            // lanes chunk, chunk + CPR, ... hold the same channels for different rows: fixed butterfly, then (below) one partial row per
+            // (phase, M tile); the fold adds the rows in a fixed order -> deterministic statistics
 #pragma unroll
             for (int o = CPR; o < 64; o <<= 1) {
 #pragma unroll
@@ -675,21 +675,31 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
                     }
                 }
             }
-            if (rsub == 0 && col_ok) {
-                const size_t base = ((size_t)(phase * p.tiles_m + tm) * WR + wr) * p.stats_stride + col;
+            // the WR wave rows of the tile meet in LDS (a slice behind the row table, reserved for these instantiations) and are added in
+            // wave-row order: ONE partial row per (phase, M tile) - the fold that follows (a launch of its own, or the prologue of the
+            // consuming BatchNorm pass: train.hip) reads WR times fewer rows
+            float* sred = reinterpret_cast<float*>(rowtab + BM * 4);          // [3][WR][BN]
+            constexpr int NARR = BSTATS ? 3 : 2;
+            if (rsub == 0) {
+                const int cl = wc * WN + chunk * CPL;
 #pragma unroll
-                for (int e4 = 0; e4 < CPL / 4; ++e4) {
-                    const f32x4 a4 = {st_s[4 * e4], st_s[4 * e4 + 1], st_s[4 * e4 + 2], st_s[4 * e4 + 3]};
-                    const f32x4 b4 = {st_q[4 * e4], st_q[4 * e4 + 1], st_q[4 * e4 + 2], st_q[4 * e4 + 3]};
-                    *reinterpret_cast<f32x4*>(p.stats_s + base + 4 * e4) = a4;
-                    *reinterpret_cast<f32x4*>(p.stats_q + base + 4 * e4) = b4;
-                    if constexpr (BSTATS) {
-                        if (p.bz2) {
-                            const f32x4 c4 = {st_q2[4 * e4], st_q2[4 * e4 + 1], st_q2[4 * e4 + 2], st_q2[4 * e4 + 3]};
-                            *reinterpret_cast<f32x4*>(p.stats_q2 + base + 4 * e4) = c4;
-                        }
-                    }
+                for (int e = 0; e < CPL; ++e) {
+                    sred[(0 * WR + wr) * BN + cl + e] = st_s[e];
+                    sred[(1 * WR + wr) * BN + cl + e] = st_q[e];
+                    if constexpr (BSTATS) sred[(2 * WR + wr) * BN + cl + e] = st_q2[e];
                 }
+            }
+            __syncthreads();
+            for (int i = tid; i < NARR * BN; i += 256) {
+                const int arr = i / BN, cl = i - arr * BN;
+                const int c = n0 + cl;
+                if (c >= p.c_out) continue;
+                if (BSTATS && arr == 2 && !p.bz2) continue;
+                float v = sred[(arr * WR) * BN + cl];
+#pragma unroll
+                for (int w = 1; w < WR; ++w) v += sred[(arr * WR + w) * BN + cl];
+                float* dst = arr == 0 ? p.stats_s : (arr == 1 ? p.stats_q : p.stats_q2);
+                dst[(size_t)(phase * p.tiles_m + tm) * p.stats_stride + c] = v;
             }
         }
     } else {
@@ -773,7 +783,8 @@ int launch_t(const ConvArgs& a, int phases, bool uniform, hipStream_t stream) {
     ConvArgs p = a;
     p.tiles_m = (a.M + BM - 1) / BM;
     p.tiles_n = a.n_pad / BN;
-    const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float) + (size_t)BM * 4 * sizeof(int);
+    const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float) + (size_t)BM * 4 * sizeof(int) +
+                       ((STATS || BSTATS) ? (size_t)3 * WR * BN * sizeof(float) : 0);     // + the wave rows' column sums (statistics epilogue)
     dim3 grid(p.tiles_m * p.tiles_n, phases, 1), block(256, 1, 1);
     // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel instantiation AND per device (the attribute belongs to the
     // function on the device that is current: a process driving several GPUs must not inherit device 0's opt-in)
@@ -823,7 +834,7 @@ int sp_conv_ring_launch(const sp_conv_desc* d, const void* x, const void* w_pack
 int sp_conv_pw_launch(const sp_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift,
                       const void* residual, void* y, void* stream);     // conv_pw.hip
 
-static int tile_rows_per_block(int bm, int bn) { return (bm == 256 && bn == 64) || (bm == 128 && bn == 32) ? 4 : 2; }   // WR of the tile
+static int tile_rows_per_block(int, int) { return 1; }   // partial rows per (phase, M tile): the wave rows are added inside the launch
 
 struct BnBwdSrc { const void* y; const void* z; const float* mean; const float* invstd; const void* z2; const float* mean2; const float* invstd2; float* q2; };
 

@@ -29,6 +29,26 @@ __device__ __forceinline__ void st4(void* p, long long i4, f32x4 v) {
     }
 }
 
+// BatchNorm element maps shared by the plain and the fused (fold-in-prologue) passes.  Contraction is switched off inside them: the
+// compiler's choice of fused multiply-adds depends on the surrounding code, and the two ways of running a layer must give the same bits.
+__device__ __forceinline__ f32x4 bn_fwd_elem(f32x4 v, const f32x4 mu, const f32x4 is, const f32x4 g, const f32x4 b) {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (v[e] - mu[e]) * is[e] * g[e] + b[e];
+    return v;
+}
+__device__ __forceinline__ f32x4 bn_bwd_elem(const f32x4 g, const f32x4 zz, const f32x4 mu, const f32x4 is, const f32x4 ga, const f32x4 dg,
+                                             const f32x4 db, const float inv_m) {
+#pragma clang fp contract(off)
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float xh = (zz[e] - mu[e]) * is[e];
+        o[e] = ga[e] * is[e] * (g[e] - db[e] * inv_m - xh * dg[e] * inv_m);
+    }
+    return o;
+}
+
 // partial-sum workgroups of a channel reduction: enough to fill the chip (>= 4 rows per thread), bounded by the 4 MB workspace
 // ([blocks][C][2] doubles)
 static int red_blocks(long long rows, int c) {
@@ -150,90 +170,259 @@ __global__ void pair_sum_final_kernel(const double* __restrict__ part, int nblk,
     if (o1) o1[c] = (float)s1;
 }
 
-// Fold of the per-(phase, M tile, wave row) partial rows a STATS / BSTATS conv epilogue wrote ([nrows][stride] fp32, two arrays): a
-// workgroup of 1,024 threads takes 16 channels x 64 row lanes, so a wave reads four 64-byte row segments per load (one wave per channel
-// with the lanes over the rows touched 64 lines per load, 16x the bytes through L2: 12-14 us on layer1's 1,536 rows); thread (row lane
-// rl, channel) adds rows rl, rl + 64, ... in fp64 (two chains), the 64 row lanes of a channel are then added in index order through
-// LDS (8 x 8): every order is fixed by the shape -> deterministic.  Returns true on the one thread per channel that holds the sums.
-constexpr int FC_CH = 16, FC_RL = 64;
-__device__ __forceinline__ bool fold_conv_rows(const float* __restrict__ ps, const float* __restrict__ pq, int nrows, int stride, int C, int& c,
-                                               double& s0, double& s1) {
-    __shared__ double sh[2][FC_RL][FC_CH];
-    const int ch = threadIdx.x & (FC_CH - 1), rl = threadIdx.x >> 4;
-    c = blockIdx.x * FC_CH + ch;
-    double a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+// Fold of the per-(phase, M tile) partial rows a STATS / BSTATS conv epilogue wrote ([nrows][stride] fp32, two arrays) for ONE slab of 64
+// channels, by a workgroup of 1,024 threads = 16 channel quads x 64 row lanes: thread (quad q, row lane rl) adds rows rl, rl + 64, ... of
+// its four channels in fp64 (two chains: even and odd trips), the 4 row lanes of a wave meet through two xor shuffles, the 16 waves
+// through LDS in wave order.  Every order is fixed by the shape -> deterministic; and the SAME function is the prologue of the fused
+// BatchNorm passes below and the body of the stand-alone fold kernels, so the two ways of running a layer agree bit for bit.
+// Result: threads tid < 64 hold (sum0, sum1) of channel c0 + tid; returns whether that channel exists.
+constexpr int SLAB = 64, FOLD_THREADS = 1024;
+__device__ __forceinline__ bool fold_slab64(const float* __restrict__ ps, const float* __restrict__ pq, int nrows, int stride, int C, int c0,
+                                            double& s0, double& s1) {
+    __shared__ double sh[16][SLAB][2];                  // [wave][channel][stat]: 16 KB
+    const int tid = threadIdx.x, q = tid & 15, rl = tid >> 4, wave = tid >> 6;
+    const int c = c0 + 4 * q;
+    double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0}, b0[4] = {0, 0, 0, 0}, b1[4] = {0, 0, 0, 0};
     if (c < C) {
         int r = rl;
-        for (; r + FC_RL < nrows; r += 2 * FC_RL) {
-            a0 += (double)ps[(size_t)r * stride + c]; a1 += (double)pq[(size_t)r * stride + c];
-            b0 += (double)ps[(size_t)(r + FC_RL) * stride + c]; b1 += (double)pq[(size_t)(r + FC_RL) * stride + c];
+        for (; r + 64 < nrows; r += 128) {
+            const f32x4 u0 = *reinterpret_cast<const f32x4*>(ps + (size_t)r * stride + c), u1 = *reinterpret_cast<const f32x4*>(pq + (size_t)r * stride + c);
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(ps + (size_t)(r + 64) * stride + c), v1 = *reinterpret_cast<const f32x4*>(pq + (size_t)(r + 64) * stride + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a0[e] += (double)u0[e]; a1[e] += (double)u1[e]; b0[e] += (double)v0[e]; b1[e] += (double)v1[e]; }
         }
-        for (; r < nrows; r += FC_RL) { a0 += (double)ps[(size_t)r * stride + c]; a1 += (double)pq[(size_t)r * stride + c]; }
-    }
-    sh[0][rl][ch] = a0 + b0;
-    sh[1][rl][ch] = a1 + b1;
-    __syncthreads();
-    if (rl < 8) {
-        double t0 = 0, t1 = 0;
+        for (; r < nrows; r += 64) {
+            const f32x4 u0 = *reinterpret_cast<const f32x4*>(ps + (size_t)r * stride + c), u1 = *reinterpret_cast<const f32x4*>(pq + (size_t)r * stride + c);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { t0 += sh[0][rl * 8 + i][ch]; t1 += sh[1][rl * 8 + i][ch]; }
-        __syncthreads();            // (all 8 x 16 readers are done before the slots are overwritten)
-        sh[0][rl][ch] = t0;
-        sh[1][rl][ch] = t1;
-    } else {
-        __syncthreads();
+            for (int e = 0; e < 4; ++e) { a0[e] += (double)u0[e]; a1[e] += (double)u1[e]; }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        double t0 = a0[e] + b0[e], t1 = a1[e] + b1[e];
+        t0 += __shfl_xor(t0, 16, SP_WAVE); t1 += __shfl_xor(t1, 16, SP_WAVE);     // row lanes 4w+0/1 and 4w+2/3
+        t0 += __shfl_xor(t0, 32, SP_WAVE); t1 += __shfl_xor(t1, 32, SP_WAVE);
+        if ((tid & 63) < 16) { sh[wave][4 * q + e][0] = t0; sh[wave][4 * q + e][1] = t1; }
     }
     __syncthreads();
-    if (rl != 0 || c >= C) return false;
-    s0 = 0; s1 = 0;
+    bool have = false;
+    if (tid < SLAB) {
+        s0 = 0; s1 = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { s0 += sh[0][i][ch]; s1 += sh[1][i][ch]; }
-    return true;
+        for (int w = 0; w < 16; ++w) { s0 += sh[w][tid][0]; s1 += sh[w][tid][1]; }
+        have = c0 + tid < C;
+    }
+    __syncthreads();                                    // (the slab's LDS may be folded into again: second array pair of a BSTATS2 launch)
+    return have;
 }
 
-// BN forward statistics from the partial sums of the STATS conv epilogue (fp32 sums of <= 64 values each), then the same finalisation
-// as bn_stats_final_kernel
-__global__ __launch_bounds__(1024) void bn_stats_from_conv_kernel(const float* __restrict__ ps, const float* __restrict__ pq, int nrows, int stride, int C, double M,
-                                          float eps, float momentum, float* __restrict__ mean, float* __restrict__ invstd,
-                                          float* __restrict__ run_mean, float* __restrict__ run_var) {
-    int c;
-    double s0, s1;
-    if (!fold_conv_rows(ps, pq, nrows, stride, C, c, s0, s1)) return;
+__device__ __forceinline__ void bn_finalize(double s0, double s1, double M, float eps, float momentum, int c, float& mu_f, float& is_f,
+                                            float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ run_mean,
+                                            float* __restrict__ run_var, bool publish) {
     const double mu = s0 / M;
     double var = s1 / M - mu * mu;
     if (var < 0) var = 0;
-    mean[c] = (float)mu;
-    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (run_mean) {
-        const double unb = M > 1 ? var * M / (M - 1) : var;
-        run_mean[c] = (float)((1.0 - momentum) * (double)run_mean[c] + (double)momentum * mu);
-        run_var[c] = (float)((1.0 - momentum) * (double)run_var[c] + (double)momentum * unb);
+    mu_f = (float)mu;
+    is_f = (float)(1.0 / sqrt(var + (double)eps));
+    if (publish) {
+        mean[c] = mu_f;
+        invstd[c] = is_f;
+        if (run_mean) {
+            const double unb = M > 1 ? var * M / (M - 1) : var;
+            run_mean[c] = (float)((1.0 - momentum) * (double)run_mean[c] + (double)momentum * mu);
+            run_var[c] = (float)((1.0 - momentum) * (double)run_var[c] + (double)momentum * unb);
+        }
     }
+}
+
+// BN forward statistics from the partial sums of the STATS conv epilogue (fp32 sums of one M tile's rows each), then the same
+// finalisation as bn_stats_final_kernel.  One workgroup per 64-channel slab.
+__global__ __launch_bounds__(FOLD_THREADS) void bn_stats_from_conv_kernel(const float* __restrict__ ps, const float* __restrict__ pq, int nrows, int stride, int C,
+                                          double M, float eps, float momentum, float* __restrict__ mean, float* __restrict__ invstd,
+                                          float* __restrict__ run_mean, float* __restrict__ run_var) {
+    double s0, s1;
+    const int c0 = blockIdx.x * SLAB;
+    if (!fold_slab64(ps, pq, nrows, stride, C, c0, s0, s1)) return;
+    float mu, is;
+    bn_finalize(s0, s1, M, eps, momentum, c0 + threadIdx.x, mu, is, mean, invstd, run_mean, run_var, true);
 }
 
 // SyncBatchNorm on the fused statistics: the same fold, stopped before the finalisation - this rank's (sum, sum of squares) per channel
 // in fp64, the [c][2] layout sp_bn_train_finalize consumes after the cross-rank SUM
-__global__ __launch_bounds__(1024) void bn_sums_from_conv_kernel(const float* __restrict__ ps, const float* __restrict__ pq, int nrows, int stride, int C,
+__global__ __launch_bounds__(FOLD_THREADS) void bn_sums_from_conv_kernel(const float* __restrict__ ps, const float* __restrict__ pq, int nrows, int stride, int C,
                                          double* __restrict__ sums) {
-    int c;
     double s0, s1;
-    if (!fold_conv_rows(ps, pq, nrows, stride, C, c, s0, s1)) return;
-    sums[2 * c] = s0;
-    sums[2 * c + 1] = s1;
+    const int c0 = blockIdx.x * SLAB;
+    if (!fold_slab64(ps, pq, nrows, stride, C, c0, s0, s1)) return;
+    sums[2 * (c0 + threadIdx.x)] = s0;
+    sums[2 * (c0 + threadIdx.x) + 1] = s1;
 }
 
 // dbeta = sum g, dgamma = sum g*xhat from the partial rows a BSTATS dgrad launch (or several: one per output phase) left
-__global__ __launch_bounds__(1024) void bn_bwd_sums_from_conv_kernel(const float* __restrict__ ps, const float* __restrict__ pq, int nrows, int stride, int C,
+__global__ __launch_bounds__(FOLD_THREADS) void bn_bwd_sums_from_conv_kernel(const float* __restrict__ ps, const float* __restrict__ pq, int nrows, int stride, int C,
                                              float* __restrict__ dbeta, float* __restrict__ dgamma, float* __restrict__ dbeta_copy,
                                              float* __restrict__ dgamma_copy) {
-    int c;
     double s0, s1;
-    if (!fold_conv_rows(ps, pq, nrows, stride, C, c, s0, s1)) return;
+    const int c0 = blockIdx.x * SLAB;
+    if (!fold_slab64(ps, pq, nrows, stride, C, c0, s0, s1)) return;
+    const int c = c0 + threadIdx.x;
     dbeta[c] = (float)s0;
     dgamma[c] = (float)s1;
     if (dbeta_copy) {                  // SyncBatchNorm: the same sums again where the message is assembled (the parameter gradients keep the local ones)
         dbeta_copy[c] = (float)s0;
         dgamma_copy[c] = (float)s1;
+    }
+}
+
+// ---- the fold as the PROLOGUE of the consuming BatchNorm pass (round 4) -------------------------------------------------------------------
+// At 32 images per GPU the step is a chain of ~400 dependent launches and the 111 stand-alone folds (5-9 us each, plus a launch boundary
+// and ~10 us of host time) were a seventh of it.  With one partial row per (phase, M tile) a 64-channel slab of a layer3 / layer4 /
+// deconv0 tensor has 24-96 rows of 512 bytes to fold: every workgroup of the consuming pass does that itself (same order everywhere,
+// so all workgroups of a slab hold the same bits) and then streams its stripe of rows.  Grid = (slabs of 64 channels) x (row stripes);
+// thread = (channel quad, row lane).  The workgroups of stripe 0 publish mean / invstd (saved for backward) and the running statistics.
+// Host side: used while nrows stays small (PoseTrainer.fold_in_consumer_rows); layer1 / the stem keep the stand-alone fold.
+template <bool BF16>
+__global__ __launch_bounds__(FOLD_THREADS) void bn_fold_apply_kernel(const void* __restrict__ z, const float* __restrict__ ps, const float* __restrict__ pq,
+                                                                     int nrows, int stride, double M, float eps, float momentum,
+                                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                     const void* __restrict__ res, void* __restrict__ y, int C, int relu, long long rows,
+                                                                     float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ run_mean,
+                                                                     float* __restrict__ run_var) {
+    __shared__ float st[2][SLAB];
+    const int slab = blockIdx.x, stripe = blockIdx.y, stripes = gridDim.y;
+    const int c0 = slab * SLAB, tid = threadIdx.x, q = tid & 15, rl = tid >> 4;
+    const int c = c0 + 4 * q, C4 = C >> 2, c4 = c >> 2;
+    const bool live = c < C;
+    const long long step = (long long)stripes * 64;
+    long long r = (long long)stripe * 64 + rl;
+    // the first four rows of this thread (and gamma / beta) are requested BEFORE the fold: their latency and the prologue's overlap
+    f32x4 v[4], rr[4];
+    f32x4 g = {0.f, 0.f, 0.f, 0.f}, b = g;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long long row = r + u * step;
+        const bool ok = live && row < rows;
+        v[u] = ok ? ld4<BF16>(z, row * C4 + c4) : g;
+        rr[u] = (ok && res) ? ld4<BF16>(res, row * C4 + c4) : g;
+    }
+    if (live) { g = *reinterpret_cast<const f32x4*>(gamma + c); b = *reinterpret_cast<const f32x4*>(beta + c); }
+    double s0, s1;
+    if (fold_slab64(ps, pq, nrows, stride, C, c0, s0, s1)) {
+        float mu, is;
+        bn_finalize(s0, s1, M, eps, momentum, c0 + tid, mu, is, mean, invstd, run_mean, run_var, stripe == 0);
+        st[0][tid] = mu; st[1][tid] = is;
+    }
+    __syncthreads();
+    if (!live) return;
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(&st[0][4 * q]), is = *reinterpret_cast<const f32x4*>(&st[1][4 * q]);
+    auto one = [&](f32x4 x, f32x4 rx, long long row) {
+        x = bn_fwd_elem(x, mu, is, g, b);
+        if (res) x += rx;
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = x[e] > 0.f ? x[e] : 0.f;
+        }
+        st4<BF16>(y, row * C4 + c4, x);
+    };
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (r + u * step < rows) one(v[u], rr[u], r + u * step);
+    r += 4 * step;
+    for (; r + 3 * step < rows; r += 4 * step) {          // four rows in flight per thread
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = ld4<BF16>(z, (r + u * step) * C4 + c4);
+        if (res) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rr[u] = ld4<BF16>(res, (r + u * step) * C4 + c4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) one(v[u], rr[u], r + u * step);
+    }
+    for (; r < rows; r += step) {
+        const f32x4 x = ld4<BF16>(z, r * C4 + c4);
+        f32x4 rx = {0.f, 0.f, 0.f, 0.f};
+        if (res) rx = ld4<BF16>(res, r * C4 + c4);
+        one(x, rx, r);
+    }
+}
+
+// Backward counterpart: dbeta = sum g and dgamma = sum g * xhat folded from the BSTATS partial rows in the prologue of the pass that
+// needs them (bn_bwd_apply_kernel's body follows); stripe 0 writes the two parameter gradients.  pq2 != null: the projection shortcut's
+// BatchNorm shares this g (its d beta is the same sum g, its d gamma = sum g * xhat2 from the third array): stripe 0 folds and writes those too.
+template <bool BF16, bool G16>
+__global__ __launch_bounds__(FOLD_THREADS) void bn_fold_bwd_apply_kernel(const void* __restrict__ dy, const void* __restrict__ relu_src, const void* __restrict__ z,
+                                                                         const float* __restrict__ ps, const float* __restrict__ pq, const float* __restrict__ pq2,
+                                                                         int nrows, int stride, const float* __restrict__ mean,
+                                                                         const float* __restrict__ invstd, const float* __restrict__ gamma, float inv_m,
+                                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dgamma2,
+                                                                         float* __restrict__ dbeta2, void* __restrict__ dz, void* dres, int dres_accumulate,
+                                                                         int C, long long rows) {
+    __shared__ float st[2][SLAB];
+    const int slab = blockIdx.x, stripe = blockIdx.y, stripes = gridDim.y;
+    const int c0 = slab * SLAB, tid = threadIdx.x, q = tid & 15, rl = tid >> 4;
+    const int c = c0 + 4 * q, C4 = C >> 2, c4 = c >> 2;
+    const bool live = c < C;
+    const long long step = (long long)stripes * 64;
+    long long r = (long long)stripe * 64 + rl;
+    // first four rows (dy, z, ReLU source) and the per-channel constants requested before the fold
+    f32x4 g4[4], yy[4], zz[4];
+    f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = mu, ga = mu;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long long row = r + u * step;
+        const bool ok = live && row < rows;
+        const long long i = row * C4 + c4;
+        g4[u] = ok ? ld4<G16>(dy, i) : mu;
+        zz[u] = ok ? ld4<BF16>(z, i) : mu;
+        yy[u] = (ok && relu_src) ? ld4<BF16>(relu_src, i) : zz[u];
+    }
+    if (live) {
+        mu = *reinterpret_cast<const f32x4*>(mean + c); is = *reinterpret_cast<const f32x4*>(invstd + c);
+        ga = *reinterpret_cast<const f32x4*>(gamma + c);
+    }
+    double s0, s1;
+    if (fold_slab64(ps, pq, nrows, stride, C, c0, s0, s1)) {
+        const float db = (float)s0, dg = (float)s1;
+        st[0][tid] = db; st[1][tid] = dg;
+        if (stripe == 0) { dbeta[c0 + tid] = db; dgamma[c0 + tid] = dg; }
+    }
+    if (pq2 && stripe == 0) {                             // (uniform per workgroup)
+        double t0, t1;
+        if (fold_slab64(ps, pq2, nrows, stride, C, c0, t0, t1)) { dbeta2[c0 + tid] = (float)t0; dgamma2[c0 + tid] = (float)t1; }
+    }
+    __syncthreads();
+    if (!live) return;
+    const f32x4 db = *reinterpret_cast<const f32x4*>(&st[0][4 * q]), dg = *reinterpret_cast<const f32x4*>(&st[1][4 * q]);
+    auto one = [&](f32x4 g, f32x4 ys, f32x4 zs, long long row) {
+        if (relu_src) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = ys[e] > 0.f ? g[e] : 0.f;
+        }
+        const f32x4 o = bn_bwd_elem(g, zs, mu, is, ga, dg, db, inv_m);
+        st4<BF16>(dz, row * C4 + c4, o);
+        if (dres) {
+            if (dres_accumulate) { f32x4 t = ld4<G16>(dres, row * C4 + c4); t += g; st4<G16>(dres, row * C4 + c4, t); } else st4<G16>(dres, row * C4 + c4, g);
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (r + u * step < rows) one(g4[u], yy[u], zz[u], r + u * step);
+    r += 4 * step;
+    for (; r + 3 * step < rows; r += 4 * step) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long i = (r + u * step) * C4 + c4;
+            g4[u] = ld4<G16>(dy, i);
+            zz[u] = ld4<BF16>(z, i);
+            yy[u] = relu_src ? ld4<BF16>(relu_src, i) : zz[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) one(g4[u], yy[u], zz[u], r + u * step);
+    }
+    for (; r < rows; r += step) {
+        const long long i = r * C4 + c4;
+        const f32x4 g = ld4<G16>(dy, i), zs = ld4<BF16>(z, i);
+        one(g, relu_src ? ld4<BF16>(relu_src, i) : zs, zs, r);
     }
 }
 
@@ -257,9 +446,7 @@ __global__ void bn_apply_kernel(const void* __restrict__ z, const float* __restr
         const int c4 = (int)(i % C4);
         const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c4], is = reinterpret_cast<const f32x4*>(invstd)[c4];
         const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[c4], b = reinterpret_cast<const f32x4*>(beta)[c4];
-        f32x4 v = ld4<BF16>(z, i);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (v[e] - mu[e]) * is[e] * g[e] + b[e];
+        f32x4 v = bn_fwd_elem(ld4<BF16>(z, i), mu, is, g, b);
         if (res) { const f32x4 r = ld4<BF16>(res, i); v += r; }
         if (relu) {
 #pragma unroll
@@ -305,9 +492,7 @@ __global__ void bn_apply_sums_kernel(const void* __restrict__ z, const double* _
                 }
             }
         }
-        f32x4 v = ld4<BF16>(z, i);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (v[e] - mu[e]) * is[e] * g[e] + b[e];
+        f32x4 v = bn_fwd_elem(ld4<BF16>(z, i), mu, is, g, b);
         if (res) { const f32x4 r = ld4<BF16>(res, i); v += r; }
         if (relu) {
 #pragma unroll
@@ -335,12 +520,7 @@ __global__ void bn_bwd_apply_kernel(const void* __restrict__ dy, const void* __r
             for (int e = 0; e < 4; ++e) g[e] = y[e] > 0.f ? g[e] : 0.f;
         }
         const f32x4 zz = ld4<BF16>(z, i);
-        f32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float xh = (zz[e] - mu[e]) * is[e];
-            o[e] = ga[e] * is[e] * (g[e] - db[e] * inv_m - xh * dg[e] * inv_m);
-        }
+        const f32x4 o = bn_bwd_elem(g, zz, mu, is, ga, dg, db, inv_m);
         st4<BF16>(dz, i, o);
         if (dres) {
             if (dres_accumulate) { f32x4 r = ld4<G16>(dres, i); r += g; st4<G16>(dres, i, r); } else st4<G16>(dres, i, g);
@@ -647,7 +827,7 @@ extern "C" int sp_bn_train_stats_from_conv(const float* stats_sum, const float* 
     SP_REQUIRE(stats_sum && stats_sumsq && mean && invstd, "sp_bn_train_stats_from_conv: null pointer");
     SP_REQUIRE(partial_rows > 0 && stride >= c && c > 0 && rows > 0, "sp_bn_train_stats_from_conv: bad shape");
     SP_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "sp_bn_train_stats_from_conv: running stats come in pairs");
-    hipLaunchKernelGGL(bn_stats_from_conv_kernel, dim3((c + FC_CH - 1) / FC_CH), dim3(FC_CH * FC_RL), 0, (hipStream_t)stream, stats_sum, stats_sumsq, partial_rows, stride,
+    hipLaunchKernelGGL(bn_stats_from_conv_kernel, dim3((c + SLAB - 1) / SLAB), dim3(FOLD_THREADS), 0, (hipStream_t)stream, stats_sum, stats_sumsq, partial_rows, stride,
                        c, (double)rows, eps, momentum, mean, invstd, running_mean, running_var);
     return sp_check_launch("bn_stats_from_conv_kernel");
 }
@@ -655,7 +835,7 @@ extern "C" int sp_bn_train_stats_from_conv(const float* stats_sum, const float* 
 extern "C" int sp_bn_sums_from_conv(const float* stats_sum, const float* stats_sumsq, int partial_rows, int stride, int c, double* sums,
                                     void* stream) {
     SP_REQUIRE(stats_sum && stats_sumsq && sums && partial_rows > 0 && stride >= c && c > 0, "sp_bn_sums_from_conv: bad argument");
-    hipLaunchKernelGGL(bn_sums_from_conv_kernel, dim3((c + FC_CH - 1) / FC_CH), dim3(FC_CH * FC_RL), 0, (hipStream_t)stream, stats_sum, stats_sumsq, partial_rows, stride,
+    hipLaunchKernelGGL(bn_sums_from_conv_kernel, dim3((c + SLAB - 1) / SLAB), dim3(FOLD_THREADS), 0, (hipStream_t)stream, stats_sum, stats_sumsq, partial_rows, stride,
                        c, sums);
     return sp_check_launch("bn_sums_from_conv_kernel");
 }
@@ -663,7 +843,7 @@ extern "C" int sp_bn_sums_from_conv(const float* stats_sum, const float* stats_s
 extern "C" int sp_bn_bwd_sums_from_conv(const float* sum_g, const float* sum_g_xhat, int partial_rows, int stride, int c, float* dgamma,
                                         float* dbeta, void* stream) {
     SP_REQUIRE(sum_g && sum_g_xhat && dgamma && dbeta && partial_rows > 0 && stride >= c && c > 0, "sp_bn_bwd_sums_from_conv: bad argument");
-    hipLaunchKernelGGL(bn_bwd_sums_from_conv_kernel, dim3((c + FC_CH - 1) / FC_CH), dim3(FC_CH * FC_RL), 0, (hipStream_t)stream, sum_g, sum_g_xhat, partial_rows, stride,
+    hipLaunchKernelGGL(bn_bwd_sums_from_conv_kernel, dim3((c + SLAB - 1) / SLAB), dim3(FOLD_THREADS), 0, (hipStream_t)stream, sum_g, sum_g_xhat, partial_rows, stride,
                        c, dbeta, dgamma, nullptr, nullptr);
     return sp_check_launch("bn_bwd_sums_from_conv_kernel");
 }
@@ -672,9 +852,59 @@ extern "C" int sp_bn_bwd_sums_from_conv2(const float* sum_g, const float* sum_g_
                                          float* dgamma_copy, float* dbeta_copy, void* stream) {
     SP_REQUIRE(sum_g && sum_g_xhat && dgamma && dbeta && dgamma_copy && dbeta_copy && partial_rows > 0 && stride >= c && c > 0,
                "sp_bn_bwd_sums_from_conv2: bad argument");
-    hipLaunchKernelGGL(bn_bwd_sums_from_conv_kernel, dim3((c + FC_CH - 1) / FC_CH), dim3(FC_CH * FC_RL), 0, (hipStream_t)stream, sum_g, sum_g_xhat, partial_rows, stride,
+    hipLaunchKernelGGL(bn_bwd_sums_from_conv_kernel, dim3((c + SLAB - 1) / SLAB), dim3(FOLD_THREADS), 0, (hipStream_t)stream, sum_g, sum_g_xhat, partial_rows, stride,
                        c, dbeta, dgamma, dbeta_copy, dgamma_copy);
     return sp_check_launch("bn_bwd_sums_from_conv_kernel");
+}
+
+// Row stripes of the fused passes: enough workgroups of 1,024 threads to fill the chip twice over, each with >= 4 x 64 rows to stream (the
+// prologue's fold is repeated per workgroup)
+static int fold_stripes(long long rows, int slabs) {
+    long long want = (512 + slabs - 1) / slabs;
+    const long long cap = (rows + 255) / 256;
+    if (want > cap) want = cap;
+    return (int)(want < 1 ? 1 : want);
+}
+
+extern "C" int sp_bn_fold_apply_nhwc(const void* z, int bf16, const float* stats_sum, const float* stats_sumsq, int partial_rows, int stride,
+                                     int64_t total_rows, float eps, float momentum, const float* gamma, const float* beta, const void* residual,
+                                     void* y, int64_t rows, int c, int relu, float* mean, float* invstd, float* running_mean, float* running_var,
+                                     void* stream) {
+    SP_REQUIRE(z && stats_sum && stats_sumsq && gamma && beta && y && mean && invstd, "sp_bn_fold_apply_nhwc: null pointer");
+    SP_REQUIRE(rows > 0 && total_rows >= rows && c > 0 && c % 4 == 0 && partial_rows > 0 && stride >= c && stride % 4 == 0 && rows < (1ll << 31),
+               "sp_bn_fold_apply_nhwc: bad shape");
+    SP_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "sp_bn_fold_apply_nhwc: running stats come in pairs");
+    const int slabs = (c + SLAB - 1) / SLAB;
+    const dim3 grid(slabs, fold_stripes(rows, slabs));
+    if (bf16 & 1) hipLaunchKernelGGL(bn_fold_apply_kernel<true>, grid, dim3(FOLD_THREADS), 0, (hipStream_t)stream, z, stats_sum, stats_sumsq, partial_rows, stride,
+                                     (double)total_rows, eps, momentum, gamma, beta, residual, y, c, relu, (long long)rows, mean, invstd, running_mean, running_var);
+    else hipLaunchKernelGGL(bn_fold_apply_kernel<false>, grid, dim3(FOLD_THREADS), 0, (hipStream_t)stream, z, stats_sum, stats_sumsq, partial_rows, stride,
+                            (double)total_rows, eps, momentum, gamma, beta, residual, y, c, relu, (long long)rows, mean, invstd, running_mean, running_var);
+    return sp_check_launch("bn_fold_apply_kernel");
+}
+
+extern "C" int sp_bn_fold_bwd_apply_nhwc(const void* dy, int bf16, const void* relu_src, const void* z, const float* sum_g, const float* sum_g_xhat,
+                                         const float* sum_g_xhat2, int partial_rows, int stride, const float* mean, const float* invstd,
+                                         const float* gamma, int64_t total_rows, int64_t rows, int c, float* dgamma, float* dbeta, float* dgamma2,
+                                         float* dbeta2, void* dz, void* dres, int dres_accumulate, void* stream) {
+    SP_REQUIRE(dy && z && sum_g && sum_g_xhat && mean && invstd && gamma && dgamma && dbeta && dz, "sp_bn_fold_bwd_apply_nhwc: null pointer");
+    SP_REQUIRE(!sum_g_xhat2 || (dgamma2 && dbeta2), "sp_bn_fold_bwd_apply_nhwc: the second BatchNorm's gradients are missing");
+    SP_REQUIRE(rows > 0 && total_rows >= rows && c > 0 && c % 4 == 0 && partial_rows > 0 && stride >= c && stride % 4 == 0 && rows < (1ll << 31),
+               "sp_bn_fold_bwd_apply_nhwc: bad shape");
+    const bool a16 = bf16 & 1, g16 = bf16 & 2;
+    SP_REQUIRE(a16 || !g16, "sp_bn_fold_bwd_apply_nhwc: bf16 gradients with fp32 activations is not a supported mix");
+    const int slabs = (c + SLAB - 1) / SLAB;
+    const dim3 grid(slabs, fold_stripes(rows, slabs));
+    hipStream_t s = (hipStream_t)stream;
+#define SP_FBA(A, G)                                                                                                                         \
+    hipLaunchKernelGGL((bn_fold_bwd_apply_kernel<A, G>), grid, dim3(FOLD_THREADS), 0, s, dy, relu_src, z, sum_g, sum_g_xhat, sum_g_xhat2, partial_rows, \
+                       stride, mean, invstd, gamma, (float)(1.0 / (double)total_rows), dgamma, dbeta, dgamma2, dbeta2, dz, dres, dres_accumulate, c,  \
+                       (long long)rows)
+    if (a16 && g16) SP_FBA(true, true);
+    else if (a16) SP_FBA(true, false);
+    else SP_FBA(false, false);
+#undef SP_FBA
+    return sp_check_launch("bn_fold_bwd_apply_kernel");
 }
 
 extern "C" int sp_bn_apply_nhwc(const void* z, int bf16, const float* mean, const float* invstd, const float* gamma, const float* beta,

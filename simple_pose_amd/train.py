@@ -402,8 +402,8 @@ class PoseTrainer:
             backward sums of every BN layer are summed over ranks (one [2C] all-reduce each way per layer);
           * the flat gradient buffer is all-reduced in `bucket_mb`-sized contiguous slices, each launched (async, on RCCL's
             own stream) as soon as backward has produced its last gradient - final_layer's end of the buffer first.
-        `native_comm` (default: on when the group's backend is nccl and librccl resolves): the step's collectives go to RCCL directly
-        (`sp_comm_allreduce_sum_f32`, csrc/comm.hip) - a SyncBatchNorm message is then ONE host call that enqueues the all-reduce on the
+        `native_comm` (opt-in: True, or SP_NATIVE_COMM=1; needs an nccl group and librccl): the step's collectives go to RCCL directly
+        (`sp_comm_allreduce_sum_f32` / `_f64`, csrc/comm.hip) - a SyncBatchNorm message is then ONE host call that enqueues the all-reduce on the
         compute stream (the chain of dependent launches leaves nothing to run under it; through torch.distributed each message costs
         five stream / event calls from Python and the step becomes host-bound), a gradient bucket one call on the optimizer stream.
         `sync_bn_inline`: where the emulated message latency (`sync_bn_latency_us`) is spent - on the compute stream (as the native
@@ -465,7 +465,10 @@ class PoseTrainer:
         lib = _lib.lib()
         usable = dist.get_backend(self.pg) == "nccl" and bool(lib.sp_comm_available())
         if want is None:
-            want = usable
+            # opt-in (native_comm=True, or SP_NATIVE_COMM=1 in the environment) until the two private communicators have met a peer on a
+            # multi-GPU box: `tests/test_gpu_train.py::test_two_rank_rccl_*` is that test and skips on one GPU
+            import os
+            want = usable and os.environ.get("SP_NATIVE_COMM", "0") == "1"
         if not want:
             return
         if not usable:
@@ -502,8 +505,18 @@ class PoseTrainer:
             self._comm = self._comm_grad = None
 
     def _all_reduce_sum(self, t: torch.Tensor, stream, grad: bool = False) -> None:
-        """In-place SUM over the ranks on `stream` through our own communicators (`grad`: the gradient buckets' one)."""
-        _lib.check(_lib.lib().sp_comm_allreduce_sum_f32(self._comm_grad if grad else self._comm, P(t), t.numel(), stream), "all-reduce")
+        """In-place SUM over the ranks on `stream` through our own communicators (`grad`: the gradient buckets' one).  The element type
+        of the RCCL call follows the tensor: fp32 (gradient buckets, backward SyncBatchNorm sums) or fp64 (the forward SyncBatchNorm
+        message: per-channel (sum, sum of squares) in double); anything else is refused."""
+        lib, comm = _lib.lib(), (self._comm_grad if grad else self._comm)
+        if not t.is_contiguous():
+            raise ValueError("native all-reduce needs a contiguous buffer")
+        if t.dtype == torch.float32:
+            _lib.check(lib.sp_comm_allreduce_sum_f32(comm, P(t), t.numel(), stream), "all-reduce f32")
+        elif t.dtype == torch.float64:
+            _lib.check(lib.sp_comm_allreduce_sum_f64(comm, P(t), t.numel(), stream), "all-reduce f64")
+        else:
+            raise TypeError(f"native all-reduce: unsupported dtype {t.dtype} (fp32 and fp64 buffers only)")
 
     # ---- gradient buckets (DDP reducer, reverse parameter order) ---------------------------------------------------------
     def _plan_buckets(self, bucket_mb: float):
@@ -1047,6 +1060,9 @@ class PoseTrainer:
             if not sync:
                 for pd, bn in zip(pends, bnames):
                     rm, rv = run(bn)
+                    if pd["part"] is not None and pd["prow"] <= self.fold_in_consumer_rows:
+                        pd["fold_in_apply"] = True      # few partial rows: the consuming sp_bn_fold_apply_nhwc folds them in its prologue
+                        continue
                     if pd["part"] is not None:
                         part = pd["part"]
                         _lib.check(lib.sp_bn_train_stats_from_conv(P(part[0]), P(part[1]), pd["prow"], part.shape[2], pd["rows"], pd["C"], BN_EPS,
@@ -1084,7 +1100,12 @@ class PoseTrainer:
             gamma, beta = self.sd[bname + ".weight"], self.sd[bname + ".bias"]
             nbt.append(self.buffers[bname + ".num_batches_tracked"])
             y = new(z.shape)
-            if pend.get("from_sums"):
+            if pend.get("fold_in_apply"):
+                part = pend["part"]
+                _lib.check(lib.sp_bn_fold_apply_nhwc(P(z), bf, P(part[0]), P(part[1]), pend["prow"], part.shape[2], rows, BN_EPS, BN_MOMENTUM, P(gamma),
+                                                     P(beta), P(res.data) if res else None, P(y), rows, C, int(relu), P(mean), P(invstd),
+                                                     P(self.buffers[bname + ".running_mean"]), P(self.buffers[bname + ".running_var"]), stream), bname)
+            elif pend.get("from_sums"):
                 _lib.check(lib.sp_bn_apply_sums_nhwc(P(z), bf, P(pend["sums"]), rows * W, BN_EPS, BN_MOMENTUM, P(gamma), P(beta),
                                                      P(res.data) if res else None, P(y), rows, C, int(relu), P(mean), P(invstd),
                                                      P(self.buffers[bname + ".running_mean"]), P(self.buffers[bname + ".running_var"]), stream), bname)
@@ -1119,6 +1140,20 @@ class PoseTrainer:
                     ya.presums = None
                     _lib.check(lib.sp_bn_train_bwd_apply_nhwc(P(ya.grad), bf, rs, P(z), P(mean), P(invstd), P(gamma), P(sg), P(sb),
                                                               rows * W, rows, C, P(dz), P(dres), acc, stream), bname + ".bwd")
+                elif ya.bstats is not None and not sync and ya.bstats[1] <= self.fold_in_consumer_rows:
+                    # few partial rows: ONE launch folds them (d beta, d gamma - and the projection shortcut's pair when its sum rode on the
+                    # same dgrad epilogue) in its prologue and applies the BatchNorm backward
+                    part, prow = ya.bstats
+                    ya.bstats = None
+                    three = part.shape[0] == 3 and res is not None and acc == 0
+                    dgs = dbs = None
+                    if three:
+                        sname = ya.bn2[3]
+                        dgs, dbs = self.flat.view(sname + ".weight", True), self.flat.view(sname + ".bias", True)
+                        res.presums = (dgs, dbs)
+                    _lib.check(lib.sp_bn_fold_bwd_apply_nhwc(P(ya.grad), bf, rs, P(z), P(part[0]), P(part[1]), P(part[2]) if three else None, prow,
+                                                             part.shape[2], P(mean), P(invstd), P(gamma), rows, rows, C, P(dgamma), P(dbeta), P(dgs),
+                                                             P(dbs), P(dz), P(dres), acc, stream), bname + ".bwd")
                 elif ya.bstats is not None or sync:
                     if ya.bstats is not None:
                         # the dgrad launch that completed ya.grad already reduced sum g and sum g*xhat (sp_conv2d_dgrad_bn_bwd_stats)
@@ -1471,7 +1506,10 @@ class PoseTrainer:
 
     def step(self, x, targets, mask) -> torch.Tensor:
         """optimizer.zero_grad(); loss = ...; loss.backward(); optimizer.step()  (ddp...:114-119).  The optimizer runs inside
-        backward, bucket by bucket (see `_grads_ready`); `fuse_optimizer = False` gives the three separate phases."""
+        backward, bucket by bucket (see `_grads_ready`); `fuse_optimizer = False` gives the three separate phases.
+        Tried in round 4 and dropped: the main chain on a HIGH-priority HIP stream (so that the weight-gradient / optimizer streams only get
+        the CUs the chain leaves free at dispatch): 6.32 vs 6.30 ms in a same-box A/B - queue priority orders dispatch, it does not preempt
+        the 50 us weight-gradient workgroups that are already resident when a chain kernel arrives."""
         self._mark("start")
         if not self.fuse_optimizer:
             loss = self.forward_backward(x, targets, mask)
@@ -1511,6 +1549,7 @@ class PoseTrainer:
     _opt_stream = None
     _wgrad_stream = None
     _wgrad_tail = None
+    fold_in_consumer_rows = 192  # partial rows (one per phase and M tile) up to which the BatchNorm pass folds them itself (sp_bn_fold_*): above, a stand-alone fold
     fuse_sync_finalize = True  # SyncBatchNorm: finalise inside the consuming bn_apply, message assembled by the backward fold (one launch less each way)
     fuse_bn_bwd = True         # BN backward sums from the epilogue of the dgrad launch that produces dy (single-consumer BN+ReLU outputs)
     fuse_bn_stats = True       # BN batch statistics from the conv epilogue (sp_conv2d_fwd_bn_stats), SyncBN included (sp_bn_sums_from_conv)

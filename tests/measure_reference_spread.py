@@ -1,0 +1,33 @@
+"""Not a test (run by hand in the build container: `python tests/measure_reference_spread.py`): how far the reference's OWN fp32 train
+step moves on the gradient-slice metric of test_gpu_train.py::test_train_step_vs_reference_golden when only its summation order changes
+(oneDNN with 1 thread instead of the 8 the golden was generated with), and how far fp64 is from it.  Round 4, this container:
+conv1.weight 0.0184 / 0.0182, layer1.0.conv1.weight 0.0208 / 0.0193, bn1.weight 0.0194 / 0.0198, layer1.0.bn3.weight 0.0200 / 0.0120 -
+a B = 2 BatchNorm net is chaotic at the 2e-2 level of this metric, so GRAD_SLICE_BAR cannot sit below ~2x that.  (The 8-thread oracle
+reproduces the golden exactly: 0.0000 on every slice.)"""
+# how far apart are two fp32 CPU evaluations (1 vs 8 threads, oneDNN summation order) and fp64 on G6's gradient-slice metric?
+import numpy as np, torch, sys
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
+from oracle import nets_oracle, train_oracle, pose_oracle
+from simple_pose_amd import synth
+g = np.load(__import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), 'golden', 'g6_train_step.npz'))
+shapes = nets_oracle.state_dict_shapes_resnet50("dconv")
+x = torch.from_numpy(synth.input_images(2, 0))
+t, w = pose_oracle.encode_refine(g["joints"], 2.0, (48, 64))
+t, w = torch.from_numpy(t), torch.from_numpy(w)
+res = {}
+for tag, dt, nt in (("f32_t8", torch.float32, 8), ("f32_t1", torch.float32, 1), ("f64", torch.float64, 8)):
+    torch.set_num_threads(nt)
+    sd = {k: torch.from_numpy(v).to(dt if v.dtype == np.float32 else torch.from_numpy(v).dtype) for k, v in synth.conditioned_state_dict(shapes, seed=0).items()}
+    loss, grads, heat = train_oracle.forward_backward(sd, x.to(dt), t.to(dt), w.to(dt))
+    res[tag] = grads
+    print(tag, float(loss))
+for key in [k for k in g.files if k.startswith("grad/")]:
+    k = key[5:]
+    ref = g[key]
+    sl = tuple(slice(0, s) for s in ref.shape)
+    scale = float(g["gradnorm/" + k]) / np.sqrt(res["f64"][k].numel())
+    row = [k]
+    for tag in ("f32_t8", "f32_t1", "f64"):
+        got = res[tag][k].double().numpy()[sl]
+        row.append("%s %.4f" % (tag, np.abs(got - ref).max() / scale))
+    print("  ".join(row))

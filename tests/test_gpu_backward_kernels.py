@@ -466,3 +466,152 @@ def test_upsample_add_backward_vs_float64(B, h, w, C, f, relu, bf16):
         ref_x = nhwc(dx_ref) + (prev_x.cpu().double() if acc else 0)
         assert torch.allclose(db.cpu(), ref_b, rtol=0, atol=1e-6)
         assert float((dx.cpu().double() - ref_x).abs().max()) <= 1e-5 * max(1.0, float(ref_x.abs().max()))
+
+
+# ---- round 4: BatchNorm sums out of the conv epilogues, folded by a stand-alone launch or in the prologue of the consuming pass ----------
+# (sp_conv2d_fwd_bn_stats -> sp_bn_train_stats_from_conv + sp_bn_apply_nhwc  ==  sp_bn_fold_apply_nhwc, bit for bit;
+#  sp_conv2d_dgrad_bn_bwd_stats[2] -> sp_bn_bwd_sums_from_conv + sp_bn_train_bwd_apply_nhwc  ==  sp_bn_fold_bwd_apply_nhwc, bit for bit;
+#  both against float64 on the tensors the launches themselves stored.)  Reference: nn.BatchNorm2d in train mode behind nn.Conv2d,
+#  nets/pose_resnet_dconv.py:112-133, and its backward.
+STATS_CASES = [
+    # name, I, O, k, stride, pad, H, W, B
+    ("1x1_64_128", 64, 128, 1, 1, 0, 16, 12, 4),
+    ("3x3_64_64", 64, 64, 3, 1, 1, 9, 7, 2),           # ragged last M tile
+    ("1x1_256_1024", 256, 1024, 1, 1, 0, 8, 6, 3),
+    ("3x3_s2_128_128", 128, 128, 3, 2, 1, 16, 12, 2),  # stride-2: dgrad = 4 phase launches filling consecutive partial rows
+    ("1x1_wide_m", 64, 256, 1, 1, 0, 64, 48, 2),       # 6,144 pixels: 48-96 partial rows per slab
+]
+
+
+@pytest.mark.parametrize("bf16", [False, True], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("case", STATS_CASES, ids=[c[0] for c in STATS_CASES])
+def test_conv_epilogue_statistics_and_fused_fold_forward(case, bf16, measured):
+    name, I, O, k, s, p, H, W, B = case
+    g = torch.Generator().manual_seed(5 + I + O)
+    x = torch.randn(B, I, H, W, generator=g, dtype=torch.float64)
+    w = (torch.randn(O, I, k, k, generator=g, dtype=torch.float64) / np.sqrt(I * k * k)).float()
+    adt = torch.bfloat16 if bf16 else torch.float32
+    one = _OneLayer("conv", w, H, W, bf16, stride=s, pad=p)
+    L = one.layer
+    xd = _nhwc(x, dtype=adt)
+    z, part, prow = L.forward_bn_stats(xd, B)
+    rows, C = z.shape[0] * z.shape[1] * z.shape[2], O
+    torch.cuda.synchronize()
+    assert part.shape[1] == prow and prow > 0
+    z64 = z.double().cpu().reshape(rows, C)
+    # the partial rows add up to the column sums of the STORED tensor
+    s0, s1 = part[0].double().sum(0).cpu()[:C], part[1].double().sum(0).cpu()[:C]
+    e0 = float((s0 - z64.sum(0)).abs().max() / z64.abs().sum(0).max())
+    e1 = float((s1 - (z64 * z64).sum(0)).abs().max() / (z64 * z64).sum(0).max())
+    measured("partial_rows_sum_rel", e0, 2e-6)
+    measured("partial_rows_sumsq_rel", e1, 2e-6)
+    assert e0 <= 2e-6 and e1 <= 2e-6
+    lib, st = _lib.lib(), _lib.current_stream()
+    gamma = (0.75 + 0.5 * torch.rand(C, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(C, generator=g)).to(DEV)
+    res = torch.randn(rows, C, generator=g).to(adt).to(DEV)
+    for relu, use_res in ((1, False), (1, True), (0, False)):
+        rd = res if use_res else None
+        m_a, i_a = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        rm_a, rv_a = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        y_a = torch.empty((rows, C), dtype=adt, device=DEV)
+        _lib.check(lib.sp_bn_train_stats_from_conv(P(part[0]), P(part[1]), prow, part.shape[2], rows, C, 1e-5, 0.1, P(m_a), P(i_a), P(rm_a), P(rv_a), st), "fold")
+        _lib.check(lib.sp_bn_apply_nhwc(P(z), int(bf16), P(m_a), P(i_a), P(gamma), P(beta), P(rd), P(y_a), rows, C, relu, st), "apply")
+        m_b, i_b = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        rm_b, rv_b = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        y_b = torch.empty((rows, C), dtype=adt, device=DEV)
+        _lib.check(lib.sp_bn_fold_apply_nhwc(P(z), int(bf16), P(part[0]), P(part[1]), prow, part.shape[2], rows, 1e-5, 0.1, P(gamma), P(beta), P(rd),
+                                             P(y_b), rows, C, relu, P(m_b), P(i_b), P(rm_b), P(rv_b), st), "fold+apply")
+        torch.cuda.synchronize()
+        assert torch.equal(m_a, m_b) and torch.equal(i_a, i_b) and torch.equal(rm_a, rm_b) and torch.equal(rv_a, rv_b)
+        assert torch.equal(y_a, y_b)
+        m64, v64 = z64.mean(0), z64.var(0, unbiased=False)
+        em, ei = _rel(m_b, m64), _rel(i_b, 1 / torch.sqrt(v64 + 1e-5))
+        measured("mean_rel", em, 1e-6)
+        measured("invstd_rel", ei, 1e-6)
+        assert em <= 1e-6 and ei <= 1e-6
+        assert _rel(rm_b, 0.1 * m64) <= 2e-6 and _rel(rv_b, 0.9 + 0.1 * z64.var(0, unbiased=True)) <= 2e-6
+        pre = (z64 - m64) / torch.sqrt(v64 + 1e-5) * gamma.double().cpu() + beta.double().cpu()
+        if use_res:
+            pre = pre + res.double().cpu()
+        ref = torch.relu(pre) if relu else pre
+        e = (_rel_bf16 if bf16 else _rel)(y_b.float(), ref)
+        measured("y_rel", e, 4e-3 if bf16 else 3e-6)
+        assert e <= (4e-3 if bf16 else 3e-6)
+
+
+@pytest.mark.parametrize("bf16", [False, True], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("two", [False, True], ids=["one_bn", "with_shortcut_bn"])
+@pytest.mark.parametrize("case", STATS_CASES, ids=[c[0] for c in STATS_CASES])
+def test_dgrad_epilogue_sums_and_fused_fold_backward(case, two, bf16, measured):
+    """dy = dgrad(dz_next) of a conv whose INPUT came out of BatchNorm + ReLU: the BSTATS epilogue's partial rows, folded by the stand-alone
+    launch and by the fused pass, give the same (d gamma, d beta, dz, dres) bit for bit, and match float64 on the stored dy."""
+    from simple_pose_amd.train import Act
+    name, I, O, k, s, p, H, W, B = case
+    g = torch.Generator().manual_seed(9 + I + O)
+    w = (torch.randn(O, I, k, k, generator=g, dtype=torch.float64) / np.sqrt(I * k * k)).float()
+    adt = torch.bfloat16 if bf16 else torch.float32
+    one = _OneLayer("conv", w, H, W, bf16, stride=s, pad=p)
+    L = one.layer
+    if not L.dgrad_full_cover and two:
+        pytest.skip("stride-2 1x1: not a full-cover family")
+    rows, C = B * H * W, I
+    # the BatchNorm layer in front of this conv: saved z, its statistics, its output y (ReLU mask)
+    zb = (torch.randn(rows, C, generator=g) * (0.5 + torch.rand(C, generator=g)) + torch.randn(C, generator=g)).to(adt)
+    z64 = zb.double()
+    mean, invstd = z64.mean(0).float().to(DEV), (1 / torch.sqrt(z64.var(0, unbiased=False) + 1e-5)).float().to(DEV)
+    gamma = (0.75 + 0.5 * torch.rand(C, generator=g)).to(DEV)
+    yb = torch.relu((z64 - z64.mean(0)) * invstd.double().cpu() * gamma.double().cpu() + 0.1 * torch.randn(C, generator=g).double()).to(adt)
+    z2 = (torch.randn(rows, C, generator=g) * 0.7 + 0.2).to(adt)
+    mean2, invstd2 = z2.double().mean(0).float().to(DEV), (1 / torch.sqrt(z2.double().var(0, unbiased=False) + 1e-5)).float().to(DEV)
+    zd, yd, z2d = zb.to(DEV).reshape(B, H, W, C), yb.to(DEV).reshape(B, H, W, C), z2.to(DEV).reshape(B, H, W, C)
+    oh, ow = L.oh, L.ow
+    dzn = torch.randn(B, oh, ow, L.c_out_buf, generator=g).to(adt).to(DEV)
+    src = Act(yd, H, W, C)
+    src.bn = (zd, mean, invstd)
+    if two:
+        src.bn2 = (z2d, mean2, invstd2, "shortcut")
+    dy = L.dgrad(dzn, B, None, bn_src=src)
+    part, prow = src.bstats
+    torch.cuda.synchronize()
+    dy64 = dy.double().cpu().reshape(rows, C)
+    g64 = dy64 * (yb.double() > 0)
+    xh = (z64 - mean.double().cpu()) * invstd.double().cpu()
+    sg, sgx = g64.sum(0), (g64 * xh).sum(0)
+    lib, st = _lib.lib(), _lib.current_stream()
+    # stand-alone fold + apply
+    dga, dba = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    _lib.check(lib.sp_bn_bwd_sums_from_conv(P(part[0]), P(part[1]), prow, part.shape[2], C, P(dga), P(dba), st), "fold")
+    dg2a = db2a = None
+    if two:
+        dg2a, db2a = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        _lib.check(lib.sp_bn_bwd_sums_from_conv(P(part[0]), P(part[2]), prow, part.shape[2], C, P(dg2a), P(db2a), st), "fold2")
+    base = torch.randn(rows, C, generator=torch.Generator().manual_seed(3)).to(DEV)
+    dz_a, dres_a = torch.empty((rows, C), dtype=adt, device=DEV), base.clone()
+    _lib.check(lib.sp_bn_train_bwd_apply_nhwc(P(dy), int(bf16), P(yd), P(zd), P(mean), P(invstd), P(gamma), P(dga), P(dba), rows, rows, C, P(dz_a),
+                                              P(dres_a), 1, st), "apply")
+    # fused
+    dgb, dbb = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    dg2b = torch.empty(C, device=DEV) if two else None
+    db2b = torch.empty(C, device=DEV) if two else None
+    dz_b, dres_b = torch.empty((rows, C), dtype=adt, device=DEV), base.clone()
+    _lib.check(lib.sp_bn_fold_bwd_apply_nhwc(P(dy), int(bf16), P(yd), P(zd), P(part[0]), P(part[1]), P(part[2]) if two else None, prow, part.shape[2],
+                                             P(mean), P(invstd), P(gamma), rows, rows, C, P(dgb), P(dbb), P(dg2b), P(db2b), P(dz_b), P(dres_b), 1, st),
+               "fold+bwd apply")
+    torch.cuda.synchronize()
+    assert torch.equal(dga, dgb) and torch.equal(dba, dbb) and torch.equal(dz_a, dz_b) and torch.equal(dres_a, dres_b)
+    if two:
+        assert torch.equal(dg2a, dg2b) and torch.equal(db2a, db2b)
+        xh2 = (z2.double() - mean2.double().cpu()) * invstd2.double().cpu()
+        e2 = _rel(dg2b, (g64 * xh2).sum(0))
+        measured("dgamma2_rel", e2, 3e-6)
+        assert e2 <= 3e-6 and _rel(db2b, sg) <= 3e-6
+    eg, eb = _rel(dgb, sgx), _rel(dbb, sg)
+    measured("dgamma_rel", eg, 3e-6)
+    measured("dbeta_rel", eb, 3e-6)
+    assert eg <= 3e-6 and eb <= 3e-6
+    ref_dz = gamma.double().cpu() * invstd.double().cpu() * (g64 - sg / rows - xh * sgx / rows)
+    e = (_rel_bf16 if bf16 else _rel)(dz_b.float(), ref_dz)
+    measured("dz_rel", e, 4e-3 if bf16 else 4e-6)
+    assert e <= (4e-3 if bf16 else 4e-6)
+    assert _rel(dres_b - base, g64) <= 2e-6
