@@ -273,6 +273,7 @@ def main():
     ipc_mode = apply_ipc_mode(args, os.environ)         # before the first HIP call (default 0: dmabuf IPC, the only mode this pool's driver has)
     if args.dry_launch:
         raise SystemExit(dry_rank(args))
+    others = measure_other_configs(args) if is_default_command(args) else None     # child processes: before torch / the GPU is touched here
     if args.mode == "micro":                           # the HBM-bound kernels of the path one by one (tools/bench_micro.py)
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_micro
@@ -314,44 +315,59 @@ def main():
             ctx["rccl"] = rccl_census(dev, rank, world)
         except Exception as e:                               # reported in the line, never fatal for the measurement
             ctx["rccl"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-    # the default command (what the driver runs: N = 1, the headline config) also times the other single-GPU BASELINE configs, after the
-    # headline, with the same --steps / --warmup and the tracked tile tables, and appends them as the LAST key of the one JSON line
-    default_cmd = (world == 1 and args.mode == "infer" and args.arch == "dconv" and args.dtype == "f32" and args.batch == 128 and
-                   not args.graph and args.tiles is None and not args.retune and args.interleave is None and not args.no_other_configs)
     line = run_once(args, ctx)
-    if default_cmd and line is not None:
-        others = []
-        for over in OTHER_CONFIGS:
-            a2 = argparse.Namespace(**vars(args))
-            for k, v in over["args"].items():
-                setattr(a2, k, v)
-            a2.no_cpu_baseline, a2.layers_out = True, None
-            t0 = time.perf_counter()
-            try:
-                ln = run_once(a2, ctx)
-                rf = ln.get("roofline") or {}
-                others.append({"config": over["config"], "value": ln["value"], "unit": ln["unit"], "ms_per_step": ln["ms_per_step"],
-                               "dtype": ln["dtype"], "steps": ln["steps"], "warmup": ln["warmup"], "roofline_frac": rf.get("frac"),
-                               "roofline_kernel": rf.get("kernel"), "network_frac_of_matrix_peak": ln.get("network_frac_of_matrix_peak"),
-                               "batches_in_flight": ln["config"].get("batches_in_flight", 1), "tile_table": ln["config"].get("tile_table"),
-                               "wall_s": round(time.perf_counter() - t0, 1)})
-            except Exception as e:       # the headline line must still go out; a failed extra config is reported, not hidden
-                others.append({"config": over["config"], "error": f"{type(e).__name__}: {e}"[:300]})
-        line["other_configs"] = others
+    if others is not None and line is not None:
+        line["other_configs"] = others                    # LAST key of the one JSON line
     if rank == 0 and line is not None:
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
-# the other single-GPU BASELINE configs (BASELINE.json configs[2], [4] and the per-GPU shard of configs[3]) as overrides of the default
-# arguments; `interleave: None` = each architecture's default number of batches in flight
+# the other single-GPU BASELINE configs (BASELINE.json configs[2], [4] and the per-GPU shard of configs[3]) as command lines of this file
 OTHER_CONFIGS = [
-    {"config": "ResNet50-DUC 256x192 bs=128 bf16 forward+decode", "args": {"arch": "duc", "dtype": "bf16", "mode": "infer", "batch": 128, "interleave": None}},
-    {"config": "HRNet-W32 256x192 bs=128 bf16 forward+decode", "args": {"arch": "hrnet_w32", "dtype": "bf16", "mode": "infer", "batch": 128, "interleave": None}},
+    {"config": "ResNet50-DUC 256x192 bs=128 bf16 forward+decode", "argv": ["--arch", "duc", "--dtype", "bf16"]},
+    {"config": "HRNet-W32 256x192 bs=128 bf16 forward+decode", "argv": ["--arch", "hrnet_w32", "--dtype", "bf16"]},
     {"config": "ResNet50-DConv 256x192 bs=32/GPU bf16 train step (fwd+bwd+Adam), 1-GPU shard of the bs=256 DDP config",
-     "args": {"arch": "dconv", "dtype": "bf16", "mode": "train", "batch": 32, "interleave": None}},
+     "argv": ["--mode", "train", "--dtype", "bf16", "--batch", "32"]},
 ]
+
+
+def is_default_command(args) -> bool:
+    """The command the driver runs: N = 1, the headline config, nothing overridden."""
+    return (args.gpus == 1 and os.environ.get("WORLD_SIZE", "1") == "1" and args.mode == "infer" and args.arch == "dconv" and args.dtype == "f32" and
+            args.batch == 128 and not args.graph and args.tiles is None and not args.retune and args.interleave is None and
+            not args.no_other_configs and not args.dry_launch)
+
+
+def measure_other_configs(args):
+    """The default command also times the other single-GPU BASELINE configs with the same --steps / --warmup and the tracked tile tables:
+    each as a fresh interpreter of this file (its own process: its own memory pools, streams and clocks - run in the headline's process
+    after it, DUC bf16 read 8 % low), one after the other, BEFORE this process imports torch or touches the GPU (a process that has
+    initialised HIP must not start children).  Returns the compact records appended to the line as `other_configs`."""
+    import subprocess
+    env = dict(os.environ)
+    apply_ipc_mode(args, env)
+    out = []
+    for oc in OTHER_CONFIGS:
+        cmd = [sys.executable, os.path.abspath(__file__)] + oc["argv"] + ["--steps", str(args.steps), "--warmup", str(args.warmup),
+                                                                        "--no-cpu-baseline", "--no-other-configs"]
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+            lines = [ln for ln in r.stdout.splitlines() if ln.lstrip().startswith("{")]
+            if r.returncode != 0 or not lines:
+                raise RuntimeError(f"exit code {r.returncode}: {(r.stderr or '').strip().splitlines()[-1:] or ['no output']}")
+            ln = json.loads(lines[-1])
+            rf = ln.get("roofline") or {}
+            out.append({"config": oc["config"], "value": ln["value"], "unit": ln["unit"], "ms_per_step": ln["ms_per_step"], "dtype": ln["dtype"],
+                        "steps": ln["steps"], "warmup": ln["warmup"], "roofline_frac": rf.get("frac"), "roofline_kernel": rf.get("kernel"),
+                        "network_frac_of_matrix_peak": ln.get("network_frac_of_matrix_peak"),
+                        "batches_in_flight": ln["config"].get("batches_in_flight", 1), "tile_table": ln["config"].get("tile_table"),
+                        "command": "python3 bench.py " + " ".join(cmd[2:-1]), "wall_s": round(time.perf_counter() - t0, 1)})
+        except Exception as e:       # the headline line must still go out; a failed extra config is reported, not hidden
+            out.append({"config": oc["config"], "error": f"{type(e).__name__}: {e}"[:300]})
+    return out
 
 
 def run_once(args, ctx):
