@@ -135,11 +135,31 @@ def dry_rank(args) -> int:
     one_per_device = n_dev >= world and devs == list(range(world))
     covered = sorted(i for r in range(world) for i in rank_indices(args.batch * world, r, world))
     ok = ok and covered == list(range(args.batch * world))      # DistributedSampler rule: every sample on exactly one rank
+    # the train step's exchange plan (BASELINE config 4: ResNet50-DConv, 32 images per GPU, SyncBatchNorm as the reference's yaml has it),
+    # computed on every rank from the model's own parameter table - host arithmetic only - and compared across the ranks
+    from simple_pose_amd.nets import pose_resnet_dconv
+    from simple_pose_amd.train import flat_layout, plan_gradient_buckets, sync_bn_messages_per_step
+    net = pose_resnet_dconv.resnet50(pretrained=False, num_classes=17)
+    offsets, numel = flat_layout([(n, tuple(p.shape)) for n, p in net.named_parameters()])
+    buckets = plan_gradient_buckets(offsets, numel, args.bucket_mb)
+    msgs = sync_bn_messages_per_step(list(net.state_dict().keys()))
+    plan = {"gradient_buckets": len(buckets), "bucket_mbytes": [round(4 * (b["hi"] - b["lo"]) / (1 << 20), 1) for b in buckets],
+            "gradient_floats": numel, "sync_bn_messages_per_step": msgs["per_step"], "batchnorm_layers": msgs["batchnorm_layers"],
+            "communicators": 2 if args.native_comm else 1,
+            "collective_path": "sp_comm_* (two RCCL communicators of our own)" if args.native_comm else "torch.distributed (nccl)"}
+    sig = torch.tensor([len(buckets), msgs["per_step"], numel] + [b["lo"] for b in buckets], dtype=torch.int64)
+    sigs = [torch.zeros_like(sig) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(sigs, sig)
+    else:
+        sigs = [sig]
+    plan["same_on_every_rank"] = all(torch.equal(t, sig) for t in sigs)
+    ok = ok and plan["same_on_every_rank"]
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"dry_launch": True, "n_ranks": world, "rendezvous": "gloo, env:// on 127.0.0.1", "ranks_seen": ranks,
+        print(json.dumps({"dry_launch": True, "train_step_plan": plan, "n_ranks": world, "rendezvous": "gloo, env:// on 127.0.0.1", "ranks_seen": ranks,
                           "visible_devices": n_dev, "rank_to_device": devs, "one_device_per_rank": one_per_device,
                           "reductions_ok": ok, "config": {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "unset")}}),
               flush=True)

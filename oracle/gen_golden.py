@@ -13,6 +13,7 @@ is committed - never reference source.  Fixture inventory
   g1s_dconv_se_fwd.npz  ResNet50-DConv + SELayer (reduction=True) eval forward, B=1, + key list
   g3_hrnet_w32_fwd.npz  HRNet-W32 eval forward, B=1, + the reference's state_dict key/shape list
   g7_next.npz        HeatMapAcc values and collate_fn normalisation
+  g10_fwd_wide.npz   8 / 8 / 4 / 4 distinct images through DConv / DUC / HRNet-W32 / DConv+SE (sub-sampled maps, per-joint sums, key points)
   g6_train_step.npz  one reference training step (B=2): loss, gradient slices, BN running stats, params after Adam
   g5_encode.npz      encoders (Refine + Basic) incl. out-of-range / trunc-toward-zero / vis=0 cases
 """
@@ -377,10 +378,50 @@ def gen_crop(ns):
     print("g9_crop.npz", np.stack(crops).shape, "mean", np.stack(crops).mean())
 
 
+WIDE_W_SEED, WIDE_X_SEED = 1, 7
+
+
+def gen_forward_wide(ns):
+    """g10_fwd_wide.npz (round 4: more DISTINCT reference inputs than G1-G3's one or two images, other weights too): eval forward of the
+    real reference on 8 images (ResNet50-DConv, -DUC) / 4 images (HRNet-W32, DConv with SELayer), conditioned weights of seed 1, inputs of
+    seed 7.  To stay small the heat maps are stored sub-sampled (every 4th row and column: [B,17,16,12] fp32) next to per-(image, joint)
+    sum / L2 norm (fp64 of the fp32 maps), maximum and arg-max, plus the reference's own GaussTaylor key points on the full maps."""
+    torch.set_num_threads(8)
+    pm = ns.pose_metrics
+    gt = pm.GaussTaylorKeyPointDecoder(kernel_size=11, num_joints=17)
+    out = {"w_seed": WIDE_W_SEED, "x_seed": WIDE_X_SEED}
+    nets = (("dconv", lambda: ns.dconv.resnet50(pretrained=False, num_classes=17), 8),
+            ("duc", lambda: ns.duc.resnet50(pretrained=False, num_classes=17), 8),
+            ("hrnet_w32", lambda: ns.hrnet.get_pose_net(ns.hrnet_w32_yaml, pretrained=None, joint_num=17), 4),
+            ("dconv_se", lambda: ns.dconv.resnet50(pretrained=False, num_classes=17, reduction=True), 4))
+    for tag, make, B in nets:
+        net = make()
+        synth.load_conditioned(net, WIDE_W_SEED)
+        net.eval()
+        x = torch.from_numpy(synth.input_images(B, WIDE_X_SEED))
+        with torch.no_grad():
+            hm = net(x)
+        kps, mv = gt(hm.clone(), torch.from_numpy(synth.trans_inv_batch(B)))
+        h = hm.numpy()
+        flat = h.reshape(B, 17, -1)
+        out[f"{tag}/heat_sub"] = h[:, :, ::4, ::4].copy()
+        out[f"{tag}/heat_sum"] = flat.astype(np.float64).sum(-1)
+        out[f"{tag}/heat_l2"] = np.sqrt((flat.astype(np.float64) ** 2).sum(-1))
+        out[f"{tag}/heat_max"] = flat.max(-1)
+        out[f"{tag}/heat_argmax"] = flat.argmax(-1).astype(np.int64)
+        out[f"{tag}/gt_kps"] = kps.numpy()
+        out[f"{tag}/gt_max"] = mv.numpy()
+        print("g10", tag, h.shape, "absmax", np.abs(h).max(), "std", h.std())
+    np.savez_compressed(os.path.join(GOLD, "g10_fwd_wide.npz"), **out)
+
+
 def main():
     assert ref_import.available(), "needs /root/reference (build container only)"
     os.makedirs(GOLD, exist_ok=True)
     ns = ref_import.load()
+    if "--only-wide" in sys.argv:          # (round 4 addition; the other files regenerate bit for bit and were left as committed)
+        gen_forward_wide(ns)
+        return
     hm = gen_forward(ns)  # returns the DUC maps last; reload dconv maps for the decoder set
     net_maps = np.load(os.path.join(GOLD, "g1_dconv_fwd.npz"))["heat_maps"]
     gen_decode(ns, net_maps)
@@ -391,6 +432,7 @@ def main():
     gen_train(ns)
     gen_nms(ns)
     gen_crop(ns)
+    gen_forward_wide(ns)
     del hm
 
 

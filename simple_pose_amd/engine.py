@@ -141,6 +141,11 @@ class Program:
             if slot == 0:
                 self._pools[key] = self._pools.pop(key)      # most recently used last
             return self._pools[key]
+        if slot != 0:
+            # a slot holds ONE batch shape at a time: a caller whose batch size varies (detector-driven person counts) would otherwise
+            # pile up `depth` full activation pools per distinct size until close()
+            for old in [k for k in self._pools if len(k) == 3 and k[1] == str(device) and k[2] == slot and k[0] != batch]:
+                del self._pools[old]
         while slot == 0 and sum(len(k) == 2 for k in self._pools) >= self.MAX_POOLS:   # a detector-driven caller sees a new person count per
             old = next(k for k in self._pools if len(k) == 2)                          # image: do not let every batch size keep a full pool forever
             del self._pools[old]
@@ -166,7 +171,7 @@ class Program:
         return bufs
 
     # -- cross-lane ordering: which earlier ops (on OTHER lanes) an op has to wait for -----------------------------------
-    def _plan_sync(self, batch: int, device) -> tuple:
+    def _plan_sync(self, batch: int, device, slot: int = 0) -> tuple:
         """Ops of one lane are ordered by their stream.  Across lanes an op waits (HIP event) for: the producers of what it reads
         (RAW), and every earlier reader / writer of the STORAGE it writes (WAR / WAW - the buffer planner hands dead storage to
         later ops, and on another lane "later" is no longer implied).  Per (waiting lane, signalling lane) only the latest op is
@@ -174,7 +179,7 @@ class Program:
         key = (batch, str(device))
         if key in self._sync:
             return self._sync[key]
-        bufs = self._alloc(batch, device)
+        bufs = self._alloc(batch, device, slot)             # (the slot's own pool: the aliasing structure is the same for every slot)
         store = lambda name: bufs[name].data_ptr() if name in bufs else ("@" + name)     # "input" / output: their own storage
         last_writer: Dict[str, int] = {}
         touched: Dict[object, List[int]] = {}
@@ -298,7 +303,7 @@ class Program:
             for op in self.ops:
                 self._launch(lib, op, bufs, B, stream)
             return out
-        waits, records, tails = self._plan_sync(B, x.device)
+        waits, records, tails = self._plan_sync(B, x.device, slot)
         main = torch.cuda.current_stream(x.device)
         side = self._lane_streams(x.device if slot == 0 else f"{x.device}/{slot}", n_lanes, x.device)
         streams = [main] + side[: n_lanes - 1]

@@ -37,6 +37,53 @@ def _i64(*v):
     return (ctypes.c_int64 * len(v))(*v)
 
 
+def flat_layout(named_shapes) -> Tuple[Dict[str, Tuple[int, int]], int]:
+    """Offsets of the parameters in the flat buffers (FlatParams' rule: parameter order, every view 16-byte aligned) from (name, shape)
+    pairs alone: (offsets {name: (offset, numel)}, total floats)."""
+    offsets: Dict[str, Tuple[int, int]] = {}
+    off = 0
+    for n, shape in named_shapes:
+        k = 1
+        for d in shape:
+            k *= int(d)
+        offsets[n] = (off, k)
+        off += _round_up(k, 4)
+    return offsets, _round_up(off, 4)
+
+
+def plan_gradient_buckets(offsets: Dict[str, Tuple[int, int]], numel: int, bucket_mb: float) -> List[dict]:
+    """Contiguous slices of the flat gradient buffer, cut at parameter boundaries walking from the END of the buffer (backward produces
+    final_layer first); each bucket knows which parameter gradients it waits for.  Pure host arithmetic (no device): PoseTrainer uses it
+    at construction, `bench.py --dry-launch` to print the plan of a world-8 job on the CPU."""
+    names = list(offsets.keys())
+    cap = max(1, int(bucket_mb * (1 << 20) / 4))
+    buckets: List[dict] = []
+    hi = numel
+    cur: List[str] = []
+    lo = hi
+    for n in reversed(names):
+        o, _ = offsets[n]
+        cur.append(n)
+        lo = o
+        if hi - lo >= cap:
+            buckets.append({"lo": lo, "hi": hi, "names": set(cur)})
+            hi, cur = lo, []
+    if cur or hi > 0:
+        buckets.append({"lo": 0, "hi": hi, "names": set(cur)})
+    return buckets
+
+
+def sync_bn_messages_per_step(state_keys) -> Dict[str, int]:
+    """SyncBatchNorm all-reduces per train step of a ResNet pose net, from its state_dict keys: one message per BatchNorm layer and
+    direction, except that conv1 and the projection shortcut of a stage's first bottleneck share one forward message (same input: both
+    convs are launched first) and bn3 and that shortcut share one backward message (the shortcut's dy is bn3's g).  52 + 52 for
+    ResNet50-DConv (56 BatchNorm layers, 4 shortcuts), 51 + 51 for the DUC head - the numbers `PoseTrainer.collective_count` reaches."""
+    bn = [k[:-len(".running_mean")] for k in state_keys if k.endswith(".running_mean")]
+    shortcuts = [k for k in bn if ".downsample." in k]
+    return {"batchnorm_layers": len(bn), "forward": len(bn) - len(shortcuts), "backward": len(bn) - len(shortcuts),
+            "per_step": 2 * (len(bn) - len(shortcuts))}
+
+
 class FlatParams:
     """All parameters of `model` as views into one flat fp32 buffer (+ a flat gradient buffer of the same layout)."""
 
@@ -522,21 +569,7 @@ class PoseTrainer:
     def _plan_buckets(self, bucket_mb: float):
         """Contiguous slices of the flat gradient buffer, cut at parameter boundaries walking from the END of the buffer (backward
         produces final_layer first).  Each bucket knows which parameter gradients it waits for."""
-        names = list(self.flat.offsets.keys())
-        cap = max(1, int(bucket_mb * (1 << 20) / 4))
-        self.buckets: List[dict] = []
-        hi = self.flat.numel
-        cur: List[str] = []
-        lo = hi
-        for n in reversed(names):
-            o, _ = self.flat.offsets[n]
-            cur.append(n)
-            lo = o
-            if hi - lo >= cap:
-                self.buckets.append({"lo": lo, "hi": hi, "names": set(cur)})
-                hi, cur = lo, []
-        if cur or hi > 0:
-            self.buckets.append({"lo": 0, "hi": hi, "names": set(cur)})
+        self.buckets: List[dict] = plan_gradient_buckets(self.flat.offsets, self.flat.numel, bucket_mb)
         self._bucket_of = {n: i for i, b in enumerate(self.buckets) for n in b["names"]}
 
     def _grads_ready(self, *names: str):
@@ -1614,6 +1647,9 @@ class GraphedStep:
                 self.loss = tr.step(self.x, self.targets, self.mask)
         finally:
             tr._adam_scalars_external = False
+        # the graph has the addresses of the step arena's tensors and of the weight-gradient slabs baked in: keep them alive whatever the
+        # trainer does afterwards (an eager step at another batch size truncates the arena, _wgrad_flush may re-allocate the slabs)
+        self._pinned = (list(tr._arena), tr.wgrad_ws)
         self.launches = None
 
     def step(self, x: torch.Tensor, targets: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
@@ -1631,3 +1667,4 @@ class GraphedStep:
         """Give the optimizer's scalars back to the eager path (`trainer.step` works as before)."""
         self.tr._adam_scalars = None
         self.graph = None
+        self._pinned = None

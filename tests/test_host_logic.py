@@ -255,6 +255,13 @@ def test_bench_dry_launch_eight_ranks_over_gloo():
     d = json.loads(lines[0])
     assert d["dry_launch"] and d["n_ranks"] == 8 and d["ranks_seen"] == list(range(8)) and d["reductions_ok"]
     assert d["config"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"                 # the explicit default, recorded
+    # the world-8 train step's exchange plan, built on every rank without a GPU: 4 gradient buckets of >= 32 MiB cut at parameter
+    # boundaries (40.0 / 34.0 / 32.6 / 23.1 MiB = the 136 MB of fp32 gradients, ddp...:91-93; the round-3 text said "5": it counted a
+    # 25 MB-style cut) and 52 + 52 SyncBatchNorm messages (ddp...:89-90; what PoseTrainer.collective_count reaches on the GPU)
+    plan = d["train_step_plan"]
+    assert plan["gradient_buckets"] == 4 and plan["sync_bn_messages_per_step"] == 104 and plan["batchnorm_layers"] == 56
+    assert plan["same_on_every_rank"] and abs(sum(plan["bucket_mbytes"]) - 4 * plan["gradient_floats"] / (1 << 20)) < 0.5
+    assert plan["communicators"] == 1
     n_dev = torch.cuda.device_count()
     assert d["one_device_per_rank"] == (n_dev >= 8)
     r = subprocess.run(cmd + ["--hsa-ipc-legacy", "1"], env=dict(env, SP_BENCH_DRY_FAIL_RANK="5"), capture_output=True, text=True, timeout=600)

@@ -209,3 +209,42 @@ def test_crop_geometry_and_warp_restatement(golden):
         inside = (sx > 0) & (sx < img.shape[1] - 1) & (sy > 0) & (sy < img.shape[0] - 1)
         assert np.abs(crop.astype(float) - ref)[inside].max() <= 1.0
         assert (crop[(sx < -1) | (sy < -1) | (sx > img.shape[1]) | (sy > img.shape[0])] == 0).all()      # BORDER_CONSTANT 0
+
+
+WIDE_NETS = [("dconv", 8), ("duc", 8), ("hrnet_w32", 4), ("dconv_se", 4)]
+
+
+def _wide_state_dict(tag, seed):
+    """(state_dict of torch tensors, forward callable) of one g10 net - shapes from the build's own tables."""
+    import os
+    if tag == "hrnet_w32":
+        from simple_pose_amd.nets.pose_hrnet import hrnet_state_dict_shapes, load_cfg
+        cfg = load_cfg(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "simple_pose_amd", "nets", "hrnet_w32.yaml"))
+        sd = {k: torch.from_numpy(v) for k, v in synth.conditioned_state_dict(hrnet_state_dict_shapes(cfg, 17), seed).items()}
+        return sd, lambda sd_, x: nets_oracle.hrnet_forward(sd_, x, cfg)
+    head = "duc" if tag == "duc" else "dconv"
+    shapes = nets_oracle.state_dict_shapes_resnet50(head, se=True) if tag == "dconv_se" else nets_oracle.state_dict_shapes_resnet50(head)
+    sd = {k: torch.from_numpy(v) for k, v in synth.conditioned_state_dict(shapes, seed).items()}
+    return sd, nets_oracle.FORWARDS["resnet50_" + head]
+
+
+@pytest.mark.parametrize("tag,B", WIDE_NETS, ids=[t for t, _ in WIDE_NETS])
+def test_forward_oracle_matches_reference_on_the_wide_set(golden, tag, B):
+    """g10_fwd_wide.npz (round 4): 8 / 8 / 4 / 4 DISTINCT images through the real reference with a second set of weights - the forward
+    oracle reproduces the sub-sampled maps, the per-joint sums / norms / maxima and arg-max cells, and the C decoder the key points."""
+    g = golden("g10_fwd_wide.npz")
+    sd, fwd = _wide_state_dict(tag, int(g["w_seed"]))
+    x = torch.from_numpy(synth.input_images(B, int(g["x_seed"])))
+    with torch.no_grad():
+        hm = fwd(sd, x).numpy()
+    ref = g[f"{tag}/heat_sub"]
+    scale = np.abs(g[f"{tag}/heat_max"]).max()
+    assert np.abs(hm[:, :, ::4, ::4] - ref).max() / scale <= 1e-5
+    flat = hm.reshape(B, 17, -1)
+    assert np.abs(flat.astype(np.float64).sum(-1) - g[f"{tag}/heat_sum"]).max() <= 1e-5 * scale * flat.shape[-1] ** 0.5
+    assert np.abs(np.sqrt((flat.astype(np.float64) ** 2).sum(-1)) - g[f"{tag}/heat_l2"]).max() <= 1e-5 * g[f"{tag}/heat_l2"].max()
+    assert np.abs(flat.max(-1) - g[f"{tag}/heat_max"]).max() <= 1e-5 * scale
+    assert (flat.argmax(-1) == g[f"{tag}/heat_argmax"]).mean() >= 0.99
+    kps, mv = pose_oracle.decode_gauss_taylor(hm, synth.trans_inv_batch(B))
+    err = np.abs(kps - g[f"{tag}/gt_kps"]).max(-1) / 4.0
+    assert (err <= 1e-3).mean() >= 0.9, (err <= 1e-3).mean()        # noise-like maps: the tail is the ill-conditioned -H^-1 g (SURVEY 7)
