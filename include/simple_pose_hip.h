@@ -182,6 +182,12 @@ int sp_se_gate_add_relu_nhwc(const float* x, const float* gate_logits, const flo
  * factor 1 = plain add).  HighResolutionModule fuse sum, nets/pose_hrnet.py:192-202,250-257 */
 int sp_upsample_add_nhwc(const float* x, const float* base, float* y, int batch, int h, int w, int c, int factor, int relu,
                          void* stream);
+/* All upsampled terms of one HRNet fuse output in one pass (pose_hrnet.py:250-257, `y = y + fuse_layers[i][j](x[j])` for j >= i):
+ * y = [relu](((base + up(xs[0], f0)) + up(xs[1], f1)) + up(xs[2], f2)), 1..3 terms, factor 1 = the identity term; xs[k] is
+ * [batch, out_h / fk, out_w / fk, c] of the tensors' dtype (bf16 != 0: bf16, else fp32).  fp32: the bits of the chained sp_upsample_add_nhwc
+ * launches; bf16: the sum is formed in fp32 and rounded once (the chain rounded after every term).  xs / factors: host arrays. */
+int sp_upsample_add_n_nhwc(const void* base, int bf16, int n_terms, const void* const* xs, const int32_t* factors, void* y, int batch,
+                           int out_h, int out_w, int c, int relu, void* stream);
 
 /* bf16 NHWC (8 channels = 16 B per lane) variants of the layout / pooling / fuse kernels, for SP_CONV_BF16 networks.
  * The network input stays the reference's fp32 NCHW tensor; channels are padded to 8. */

@@ -91,6 +91,7 @@ SYMBOLS = {
     "sp_se_gate_bwd_apply": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, c_int, _P, _P, c_int, _P]),
     "sp_adam_set_scalars": (c_int, [c_double, c_double, c_double, c_double, c_int, c_float, _P, _P]),
     "sp_adam_step_dev": (c_int, [_P, _P, _P, _P, c_int64, _P, _P]),
+    "sp_upsample_add_n_nhwc": (c_int, [_P, c_int, c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(c_int32), _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "sp_comm_available": (c_int, []),
     "sp_comm_unique_id": (c_int, [_P]),
     "sp_comm_create": (c_int, [_P, c_int, c_int, ctypes.POINTER(ctypes.c_void_p)]),

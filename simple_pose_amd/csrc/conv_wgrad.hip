@@ -60,6 +60,7 @@ struct WgLayer {
 struct WgArgs {
     WgLayer L[WG_MAXJ];
     int n_layers;
+    int units;           // units of the launch (>= gridDim.x: a workgroup walks units blockIdx.x, blockIdx.x + gridDim.x, ...)
 };
 
 __device__ __forceinline__ u32x4 make_rsrc(const void* base, unsigned bytes) {
@@ -317,11 +318,14 @@ __device__ __forceinline__ void wgrad_unit(const WgLayer& p, const int tg, const
 template <bool BF16>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_group_kernel(const WgArgs args) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-    // blocks b and b + 8 share an XCD (and its L2): every XCD takes a contiguous run of units - the tiles of one pixel range
-    const int G = gridDim.x;
+    // blocks b and b + 8 share an XCD (and its L2): every XCD takes a contiguous run of units - the tiles of one pixel range.
+    // The grid may be smaller than the number of units (args.units; a capped grid leaves CUs to the launches of the step's main chain):
+    // a workgroup then walks units k, k + gridDim.x, ...
+    const int G = args.units;
+  for (int orig = blockIdx.x; orig < G; orig += gridDim.x) {
+    if (orig != (int)blockIdx.x) __syncthreads();          // the previous unit's last LDS reads are done before the next unit's DMA lands
     int u;
     {
-        const int orig = blockIdx.x;
         const int xcd = orig & 7, q = G >> 3, r = G & 7;
         u = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     }
@@ -341,6 +345,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_group_kernel(const WgArgs a
         case 3: wgrad_unit<BF16, 256, 64, 4, 2, 64 / H, 3>(p, tg, ta, split, m_begin, m_end, smem); break;
         default: wgrad_unit<BF16, 64, 256, 1, 8, 64 / H, 3>(p, tg, ta, split, m_begin, m_end, smem); break;
     }
+  }
 }
 
 // ---- fold: dst[n*s_n + c*s_c + (ty*kw + tx)] = sum_s slab[s][n][(ty*taps_w + tx)*c_in + c]   for n < n_valid, c < c_valid, tx < kw,
@@ -512,7 +517,10 @@ int launch_group(const WgArgs& a, int units, hipStream_t s) {
         sp_set_error("conv_wgrad: hipFuncSetAttribute(max dynamic LDS = %zu) failed: %s", lds, hipGetErrorString(e));
         return SP_ELAUNCH;
     }
-    hipLaunchKernelGGL((conv_wgrad_group_kernel<BF16>), dim3(units), dim3(512), lds, s, a);
+    static const int cap = getenv("SP_WGRAD_GRID_CAP") ? atoi(getenv("SP_WGRAD_GRID_CAP")) : 0;      // (env: development knob; 0 = one workgroup per unit)
+    WgArgs b = a;
+    b.units = units;
+    hipLaunchKernelGGL((conv_wgrad_group_kernel<BF16>), dim3(cap > 0 && cap < units ? cap : units), dim3(512), lds, s, b);
     return sp_check_launch("conv_wgrad_group_kernel");
 }
 

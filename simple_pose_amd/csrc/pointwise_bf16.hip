@@ -110,6 +110,66 @@ __global__ void upsample_add_bf16_kernel(const u32x4* __restrict__ x, const u32x
     }
 }
 
+// HRNet fuse stage, all upsampled terms of one output in ONE pass (round 4):  y = [relu]( ((base + up(x0, f0)) + up(x1, f1)) + up(x2, f2) )
+// - `y = y + fuse_layers[i][j](x[j])` for j >= i of HighResolutionModule.forward (pose_hrnet.py:250-257), f = 1 being the identity term.
+// The chained form ran one launch per term, each reading and re-writing the high-resolution sum (and, in bf16, rounding it every time);
+// here base and every term are read once, the sum is formed in fp32 in the reference's order and rounded once.  fp32: same bits as the chain.
+struct UpTerms {
+    const void* x[3];
+    int h[3], w[3], f[3];
+    int n;
+};
+template <bool BF16>
+__global__ void upsample_add_n_kernel(const void* __restrict__ base, const UpTerms t, void* __restrict__ y, int H, int W, int CV, int relu,
+                                      long long total) {
+    constexpr int V = BF16 ? 8 : 4;                     // channels per 16-byte vector
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % CV);
+        long long r = i / CV;
+        const int X = (int)(r % W); r /= W;
+        const int Y = (int)(r % H);
+        const long long b = r / H;
+        float v[V];
+        u32x4 raw[4];
+        raw[0] = reinterpret_cast<const u32x4*>(base)[i];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (k < t.n) raw[k + 1] = reinterpret_cast<const u32x4*>(t.x[k])[((b * t.h[k] + Y / t.f[k]) * t.w[k] + X / t.f[k]) * CV + c];
+        auto unpack = [&](const u32x4 q, float* o) {
+            if constexpr (BF16) {
+                const bf16x8 a = __builtin_bit_cast(bf16x8, q);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (float)a[e];
+            } else {
+                const f32x4 a = __builtin_bit_cast(f32x4, q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = a[e];
+            }
+        };
+        unpack(raw[0], v);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (k < t.n) {
+                float a[V];
+                unpack(raw[k + 1], a);
+#pragma unroll
+                for (int e = 0; e < V; ++e) v[e] += a[e];
+            }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+        if constexpr (BF16) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+            reinterpret_cast<u32x4*>(y)[i] = __builtin_bit_cast(u32x4, o);
+        } else {
+            reinterpret_cast<f32x4*>(y)[i] = f32x4{v[0], v[1], v[2], v[3]};
+        }
+    }
+}
+
 // SELayer in bf16 (nets/commons.py:4-18): squeeze = mean over the pixels of one image, 8 channels per lane, fp64 sums, bf16 result (the
 // two FCs run as bf16 1x1 convolutions on the [B,1,1,C] tensor)
 __global__ __launch_bounds__(256) void global_avg_pool_bf16_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ y, int HW, int C8) {
@@ -232,4 +292,27 @@ extern "C" int sp_upsample_add_nhwc_bf16(const void* x, const void* base, void* 
                        reinterpret_cast<const u32x4*>(x), reinterpret_cast<const u32x4*>(base), reinterpret_cast<u32x4*>(y), h, w, c / 8, factor,
                        relu, total);
     return sp_check_launch("upsample_add_bf16_kernel");
+}
+
+extern "C" int sp_upsample_add_n_nhwc(const void* base, int bf16, int n_terms, const void* const* xs, const int32_t* factors, void* y, int batch,
+                                      int out_h, int out_w, int c, int relu, void* stream) {
+    SP_REQUIRE(base && xs && factors && y, "sp_upsample_add_n_nhwc: null pointer");
+    const int vec = bf16 ? 8 : 4;
+    SP_REQUIRE(n_terms >= 1 && n_terms <= 3 && batch > 0 && out_h > 0 && out_w > 0 && c > 0 && c % vec == 0,
+               "sp_upsample_add_n_nhwc: bad shape (1..3 terms, c %% %d == 0)", vec);
+    UpTerms t;
+    t.n = n_terms;
+    for (int k = 0; k < 3; ++k) { t.x[k] = nullptr; t.h[k] = t.w[k] = t.f[k] = 1; }
+    for (int k = 0; k < n_terms; ++k) {
+        const int f = factors[k];
+        SP_REQUIRE(xs[k] && f >= 1 && out_h % f == 0 && out_w % f == 0, "sp_upsample_add_n_nhwc: term %d: factor %d must divide %dx%d", k, f, out_h, out_w);
+        t.x[k] = xs[k]; t.f[k] = f; t.h[k] = out_h / f; t.w[k] = out_w / f;
+    }
+    const long long total = (long long)batch * out_h * out_w * (c / vec);
+    SP_REQUIRE(total * 16 < (1ll << 33), "sp_upsample_add_n_nhwc: tensor too large");
+    if (bf16) hipLaunchKernelGGL(upsample_add_n_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, base, t, y, out_h, out_w, c / vec,
+                                 relu, total);
+    else hipLaunchKernelGGL(upsample_add_n_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, base, t, y, out_h, out_w, c / vec,
+                            relu, total);
+    return sp_check_launch("upsample_add_n_kernel");
 }

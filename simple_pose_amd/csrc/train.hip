@@ -2,6 +2,7 @@
 // train-mode BatchNorm forward/backward on NHWC fp32, max-pool backward, fused Adam, weight (re)packing, layout helpers.
 // All reductions accumulate in double and are deterministic (fixed grid, per-block partials, ordered final sum).
 #include "sp_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -859,10 +860,16 @@ extern "C" int sp_bn_bwd_sums_from_conv2(const float* sum_g, const float* sum_g_
 
 // Row stripes of the fused passes: enough workgroups of 1,024 threads to fill the chip twice over, each with >= 4 x 64 rows to stream (the
 // prologue's fold is repeated per workgroup)
-static int fold_stripes(long long rows, int slabs) {
+static int fold_stripes(long long rows, int slabs, int partial_rows) {
     long long want = (512 + slabs - 1) / slabs;
     const long long cap = (rows + 255) / 256;
     if (want > cap) want = cap;
+    // every workgroup repeats the fold: (workgroups) x (partial rows) x 512 B of L2 reads.  Bounded to ~64 MB per launch: tensors with many
+    // partial rows get fewer, fatter workgroups (each thread keeps four rows of every operand in flight, so a few hundred workgroups of
+    // 1,024 threads still cover the HBM latency)
+    static const long long budget = getenv("SP_FOLD_BUDGET") ? atoll(getenv("SP_FOLD_BUDGET")) : 131072;      // (workgroups x partial rows; env: development knob)
+    const long long capf = budget / ((long long)partial_rows * slabs);
+    if (want > capf) want = capf;
     return (int)(want < 1 ? 1 : want);
 }
 
@@ -875,7 +882,7 @@ extern "C" int sp_bn_fold_apply_nhwc(const void* z, int bf16, const float* stats
                "sp_bn_fold_apply_nhwc: bad shape");
     SP_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "sp_bn_fold_apply_nhwc: running stats come in pairs");
     const int slabs = (c + SLAB - 1) / SLAB;
-    const dim3 grid(slabs, fold_stripes(rows, slabs));
+    const dim3 grid(slabs, fold_stripes(rows, slabs, partial_rows));
     if (bf16 & 1) hipLaunchKernelGGL(bn_fold_apply_kernel<true>, grid, dim3(FOLD_THREADS), 0, (hipStream_t)stream, z, stats_sum, stats_sumsq, partial_rows, stride,
                                      (double)total_rows, eps, momentum, gamma, beta, residual, y, c, relu, (long long)rows, mean, invstd, running_mean, running_var);
     else hipLaunchKernelGGL(bn_fold_apply_kernel<false>, grid, dim3(FOLD_THREADS), 0, (hipStream_t)stream, z, stats_sum, stats_sumsq, partial_rows, stride,
@@ -894,7 +901,7 @@ extern "C" int sp_bn_fold_bwd_apply_nhwc(const void* dy, int bf16, const void* r
     const bool a16 = bf16 & 1, g16 = bf16 & 2;
     SP_REQUIRE(a16 || !g16, "sp_bn_fold_bwd_apply_nhwc: bf16 gradients with fp32 activations is not a supported mix");
     const int slabs = (c + SLAB - 1) / SLAB;
-    const dim3 grid(slabs, fold_stripes(rows, slabs));
+    const dim3 grid(slabs, fold_stripes(rows, slabs, partial_rows));
     hipStream_t s = (hipStream_t)stream;
 #define SP_FBA(A, G)                                                                                                                         \
     hipLaunchKernelGGL((bn_fold_bwd_apply_kernel<A, G>), grid, dim3(FOLD_THREADS), 0, s, dy, relu_src, z, sum_g, sum_g_xhat, sum_g_xhat2, partial_rows, \

@@ -111,9 +111,16 @@ class Op:
     lane: int = 0                # HIP stream the op is issued on (0 = the caller's stream); independent branches get their own
     direct: bool = False         # conv: use sp_conv3x3_direct (bf16 3x3, 32 -> 32 channels) instead of the implicit GEMM; same bits
 
+    def extra_inputs(self) -> Tuple[str, ...]:
+        """Input buffers beyond src / res (the SELayer's gate logits; the further terms of a multi-term fuse)."""
+        if self.kind == "se_gate":
+            return (self.args[2],)
+        if self.kind == "upsample_add_n":
+            return tuple(self.args[4])
+        return ()
+
     def reads(self) -> Tuple[str, ...]:
-        extra = (self.args[2],) if self.kind == "se_gate" else ()
-        return tuple(n for n in (self.src, self.res) + extra if n)
+        return tuple(n for n in (self.src, self.res) + self.extra_inputs() if n)
 
 
 @dataclass
@@ -152,7 +159,7 @@ class Program:
             self._sync.pop(old, None)
         last_use: Dict[str, int] = {}
         for i, op in enumerate(self.ops):
-            for nm in (op.src, op.res, op.dst) + ((op.args[2],) if op.kind == "se_gate" else ()):
+            for nm in (op.src, op.res, op.dst) + op.extra_inputs():
                 if nm:
                     last_use[nm] = i
         free: Dict[int, List[torch.Tensor]] = {}
@@ -164,7 +171,7 @@ class Program:
                 pool = free.get(n)
                 bufs[op.dst] = pool.pop() if pool else torch.empty(
                     n, dtype=torch.bfloat16 if self.dtype == "bf16" else torch.float32, device=device)
-            for nm in (op.src, op.res) + ((op.args[2],) if op.kind == "se_gate" else ()):
+            for nm in (op.src, op.res) + op.extra_inputs():
                 if nm and nm in bufs and last_use[nm] == i and nm != "input":
                     free.setdefault(bufs[nm].numel(), []).append(bufs[nm])
         self._pools[key] = bufs
@@ -273,6 +280,13 @@ class Program:
             hw, c, gate = op.args
             fn = lib.sp_se_gate_add_relu_nhwc_bf16 if self.dtype == "bf16" else lib.sp_se_gate_add_relu_nhwc
             _lib.check(fn(P(bufs[op.src]), P(bufs[gate]), P(bufs[op.res]), P(bufs[op.dst]), B, hw, c, stream), op.name)
+        elif op.kind == "upsample_add_n":
+            H, W, c, relu, more, factors = op.args
+            srcs = (op.src,) + tuple(more)
+            xs = (ctypes.c_void_p * len(srcs))(*[bufs[n].data_ptr() for n in srcs])
+            fs = (ctypes.c_int32 * len(srcs))(*factors)
+            _lib.check(lib.sp_upsample_add_n_nhwc(P(bufs[op.res]), int(self.dtype == "bf16"), len(srcs), xs, fs, P(bufs[op.dst]), B, H, W, c, relu,
+                                                  stream), op.name)
         elif op.kind == "upsample_add":
             h, w, c, f, relu = op.args
             fn = lib.sp_upsample_add_nhwc_bf16 if self.dtype == "bf16" else lib.sp_upsample_add_nhwc
@@ -726,6 +740,9 @@ class ProgramBuilder:
         # the ResNet stem (conv1 7x7 s2 + bn1 + relu + maxpool) as one launch on the fp32 NCHW image (sp_stem7_pool: same bits, the
         # 128 x 96 x 64 map between conv and pooling never reaches HBM, K is not padded to a GEMM tile)
         self.fuse_stem = True
+        # HRNet fuse stage: the identity and upsampled terms of one output summed by ONE launch (sp_upsample_add_n_nhwc) instead of one
+        # launch per term that re-reads and re-writes the running sum (43 -> 23 launches per HRNet-W32 forward; fp32: same bits)
+        self.fuse_terms = True
         self.p = Program(dtype=dtype)
         self.bf16 = dtype == "bf16"
         self.cpad = 8 if self.bf16 else 4           # channels per 16-byte chunk
@@ -954,6 +971,21 @@ class ProgramBuilder:
         return dst
 
 
+    def upsample_add_n(self, base: str, terms: List[Tuple[str, int]], relu: bool = False) -> str:
+        """dst = [relu](((base + up(t0, f0)) + up(t1, f1)) + up(t2, f2)): every term of an HRNet fuse output that is added AFTER the
+        stride-2 chains, in ONE launch (sp_upsample_add_n_nhwc; factor 1 = the identity term).  1..3 terms."""
+        assert 1 <= len(terms) <= 3
+        H, W, c = self.p.shapes[base]
+        for src, f in terms:
+            h, w, cc = self.p.shapes[src]
+            assert (h * f, w * f, cc) == (H, W, c), (self.p.shapes[src], f, (H, W, c))
+        dst = self._fresh("fuse")
+        self.p.shapes[dst] = (H, W, c)
+        self._add(Op("upsample_add_n", terms[0][0], dst, res=base,
+                     args=(H, W, c, int(relu), tuple(t for t, _ in terms[1:]), tuple(f for _, f in terms)), name="upsample_add_n"))
+        return dst
+
+
 # ------------------------------------------------------------------------------------------------
 # ResNet-50 (+ DConv / DUC head)
 # ------------------------------------------------------------------------------------------------
@@ -1053,6 +1085,7 @@ def _hr_module(b: ProgramBuilder, sd, xs: List[str], base: str, num_blocks: List
     for i in range(nb if multi else 1):
         b.lane = i                                         # output i of the fuse stage is assembled on branch i's stream
         y: Optional[str] = None
+        pending: List[Tuple[str, int]] = []                # terms j >= i: summed in ONE launch once the last one exists (fuse_terms)
         for j in range(nb):
             last = (j == nb - 1)
             f = f"{base}.fuse_layers.{i}.{j}"
@@ -1061,12 +1094,22 @@ def _hr_module(b: ProgramBuilder, sd, xs: List[str], base: str, num_blocks: List
                     y = xs[i]
                     if last:       # single term: cannot happen (nb >= 2), kept for completeness
                         raise NotImplementedError
+                elif b.fuse_terms:
+                    pending.append((xs[i], 1))
                 else:
                     y = b.upsample_add(xs[i], y, 1, relu=last)
             elif j > i:            # 1x1 conv + bn at the low resolution, nearest upsample, add (:192-202)
                 s, h = _bn(b, sd, f + ".1")
                 t = b.conv(xs[j], sd[f + ".0.weight"], scale=s, shift=h, name=f)
-                y = b.upsample_add(t, y, 2 ** (j - i), relu=last)
+                if b.fuse_terms:
+                    pending.append((t, 2 ** (j - i)))
+                else:
+                    y = b.upsample_add(t, y, 2 ** (j - i), relu=last)
+            if last and pending:   # (j < i never is the last j: the identity term j == i follows it)
+                y = b.upsample_add_n(y, pending, relu=True)
+                pending = []
+            if j >= i:
+                continue
             else:                  # chain of 3x3 stride-2 convs (+bn, +relu except the last) (:205-233)
                 t = xs[j]
                 for k in range(i - j):
@@ -1081,13 +1124,14 @@ def _hr_module(b: ProgramBuilder, sd, xs: List[str], base: str, num_blocks: List
 
 
 def hrnet_program(sd: Dict[str, torch.Tensor], cfg: dict, in_h: int = 256, in_w: int = 192, dtype: str = "fp32", packer=None,
-                  fuse_blocks: bool = False, fuse_stem: bool = True) -> Program:
+                  fuse_blocks: bool = False, fuse_stem: bool = True, fuse_terms: bool = True) -> Program:
     """Lower a reference-layout HRNet state_dict into a Program (PoseHighResolutionNet.forward, pose_hrnet.py:419-454).
     `fuse_blocks`: bf16 32-channel BasicBlocks as one launch each (sp_basic_block_c32; same bits as the two conv launches; opt-in,
     see ProgramBuilder.fuse_blocks)."""
     extra = cfg["MODEL"]["EXTRA"]
     b = ProgramBuilder(in_h, in_w, dtype, packer)
     b.fuse_blocks = fuse_blocks
+    b.fuse_terms = fuse_terms
     b.fuse_stem = fuse_stem
     s1, h1 = _bn(b, sd, "bn1")
     s2, h2 = _bn(b, sd, "bn2")

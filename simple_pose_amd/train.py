@@ -465,6 +465,9 @@ class PoseTrainer:
         self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
         self.pg = process_group
         self.overlap_wgrad = overlap_wgrad
+        import os
+        if os.environ.get("SP_FOLD_ROWS"):                              # (development knob)
+            self.fold_in_consumer_rows = int(os.environ["SP_FOLD_ROWS"])
         self._wgrad_stream = None
         self._opt_stream = None
         self._opt_in_backward = False
@@ -1582,7 +1585,7 @@ class PoseTrainer:
     _opt_stream = None
     _wgrad_stream = None
     _wgrad_tail = None
-    fold_in_consumer_rows = 192  # partial rows (one per phase and M tile) up to which the BatchNorm pass folds them itself (sp_bn_fold_*): above, a stand-alone fold
+    fold_in_consumer_rows = 1536  # partial rows (one per phase and M tile) up to which the BatchNorm pass folds them itself (sp_bn_fold_*): above, a stand-alone fold
     fuse_sync_finalize = True  # SyncBatchNorm: finalise inside the consuming bn_apply, message assembled by the backward fold (one launch less each way)
     fuse_bn_bwd = True         # BN backward sums from the epilogue of the dgrad launch that produces dy (single-consumer BN+ReLU outputs)
     fuse_bn_stats = True       # BN batch statistics from the conv epilogue (sp_conv2d_fwd_bn_stats), SyncBN included (sp_bn_sums_from_conv)

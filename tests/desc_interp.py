@@ -88,6 +88,12 @@ def run_program_cpu(prog, x):
             up = bufs[op.src].float().repeat_interleave(f, 1).repeat_interleave(f, 2)
             t = bufs[op.res].float() + up
             bufs[op.dst] = (t.clamp(min=0) if relu else t).to(act_dt)
+        elif op.kind == "upsample_add_n":
+            H, W, c, relu, more, factors = op.args
+            t = bufs[op.res].float()
+            for name, f in zip((op.src,) + tuple(more), factors):                # the reference's order of additions, fp32, one rounding
+                t = t + bufs[name].float().repeat_interleave(f, 1).repeat_interleave(f, 2)
+            bufs[op.dst] = (t.clamp(min=0) if relu else t).to(act_dt)
         elif op.kind == "conv":
             d = op.desc
             d.batch = B

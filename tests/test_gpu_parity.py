@@ -1107,6 +1107,82 @@ def test_interleaved_forward_in_the_modes_bench_defaults_to(mode):
     inter.close()
 
 
+@pytest.mark.parametrize("bf16", [False, True], ids=["fp32", "bf16"])
+def test_multi_term_fuse_kernel_vs_torch_and_the_chain(bf16):
+    """sp_upsample_add_n_nhwc (HighResolutionModule.forward's `y = y + fuse_layers[i][j](x[j])` for j >= i, pose_hrnet.py:250-257, as one
+    launch): fp32 = the chained sp_upsample_add_nhwc launches bit for bit; bf16 = the fp32 sum of the same operands rounded once."""
+    import ctypes
+    lib, st = _lib.lib(), _lib.current_stream()
+    B, H, W, C = 3, 16, 24, 32
+    dt = torch.bfloat16 if bf16 else torch.float32
+    g = torch.Generator().manual_seed(5)
+    base = torch.randn(B, H, W, C, generator=g).to(dt).to(DEV)
+    for factors, relu in (((1,), 1), ((2,), 0), ((2, 4, 8), 1), ((1, 2, 4), 1), ((1, 2), 0)):
+        terms = [torch.randn(B, H // f, W // f, C, generator=g).to(dt).to(DEV) for f in factors]
+        y = torch.empty_like(base)
+        xs = (ctypes.c_void_p * len(terms))(*[t.data_ptr() for t in terms])
+        fs = (ctypes.c_int32 * len(terms))(*factors)
+        _lib.check(lib.sp_upsample_add_n_nhwc(_lib.ptr(base), int(bf16), len(terms), xs, fs, _lib.ptr(y), B, H, W, C, relu, st), "fuse")
+        ref = base.float()
+        for t, f in zip(terms, factors):
+            ref = ref + t.float().repeat_interleave(f, 1).repeat_interleave(f, 2)
+        if relu:
+            ref = ref.clamp(min=0)
+        torch.cuda.synchronize()
+        assert torch.equal(y, ref.to(dt))
+        if not bf16:                                   # the chain it replaces: one launch per term
+            cur = base
+            for k, (t, f) in enumerate(zip(terms, factors)):
+                nxt = torch.empty_like(base)
+                _lib.check(lib.sp_upsample_add_nhwc(_lib.ptr(t), _lib.ptr(cur), _lib.ptr(nxt), B, H // f, W // f, C, f, int(relu and k == len(terms) - 1), st), "chain")
+                cur = nxt
+            torch.cuda.synchronize()
+            assert torch.equal(cur, y)
+    bad = (ctypes.c_int32 * 1)(3)                      # a factor that does not divide the output is refused, nothing is launched
+    xs = (ctypes.c_void_p * 1)(base.data_ptr())
+    assert lib.sp_upsample_add_n_nhwc(_lib.ptr(base), int(bf16), 1, xs, bad, _lib.ptr(base), B, H, W, C, 0, st) != 0
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_hrnet_with_one_launch_per_fuse_output_vs_the_chained_program(dtype, measured):
+    """HRNet-W32 with `fuse_terms` (23 fuse launches per forward instead of 43): fp32 heat maps equal the chained program's bit for bit;
+    in bf16 the fused sums are rounded once instead of after every term - no further from the fp32 program than the chained one."""
+    import os
+    from simple_pose_amd.nets.pose_hrnet import get_pose_net, hrnet_state_dict_shapes
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    net = get_pose_net(os.path.join(root, "simple_pose_amd", "nets", "hrnet_w32.yaml"), pretrained=None, joint_num=17)
+    sd = synth.conditioned_state_dict(hrnet_state_dict_shapes(net.cfg, 17), seed=3)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    net = net.cuda().eval()
+    net.autotune = False
+    net.compute_dtype = dtype
+    x = _cuda(synth.input_images(3, 60))
+    with torch.no_grad():
+        net.fuse_terms = True
+        prog = net.hip_program(x)
+        n_fused = sum(op.kind == "upsample_add_n" for op in prog.ops)
+        assert n_fused == 23 and not any(op.kind == "upsample_add" for op in prog.ops)
+        a = net(x).clone()
+        net.fuse_terms = False
+        prog = net.hip_program(x)
+        assert sum(op.kind == "upsample_add" for op in prog.ops) == 43
+        b = net(x).clone()
+    if dtype == "fp32":
+        assert torch.equal(a, b)
+    else:
+        # two bf16 programs differ from each other by up to the sum of their own rounding noise (measured 2.7e-2 of the maximum); the
+        # meaningful comparison is each against the fp32 program: rounding the fused sums once must not be worse than rounding per term
+        with torch.no_grad():
+            net.compute_dtype = "fp32"
+            net.fuse_terms = True
+            ref = net(x).clone()
+        err_f = float((a - ref).abs().max() / ref.abs().max())
+        err_c = float((b - ref).abs().max() / ref.abs().max())
+        measured("bf16_fused_rel_err_vs_fp32", err_f, 2.5e-2)          # measured 2.01e-2 (chained: 2.21e-2) on these weights / images
+        measured("bf16_chained_rel_err_vs_fp32", err_c)
+        assert 1e-5 < err_f <= 2.5e-2 and err_f <= 1.05 * err_c, (err_f, err_c)
+
+
 def test_captured_graph_survives_the_eviction_of_its_activation_pool():
     """Program._alloc keeps MAX_POOLS activation pools; a captured hipGraph has the pointers of ITS pool baked in, so it must keep that
     pool alive: capture at one batch size, run more other batch sizes than pools are kept (which evicts the captured size from the
