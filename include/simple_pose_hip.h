@@ -143,6 +143,14 @@ int sp_stem7_pool_u8(const unsigned char* crops_bgr, const float* mean_rgb_host,
  * x fp32 NCHW [batch,3,h,w] -> y bf16 NHWC [batch,h/4,w/4,64].  w1_packed / k1_pad: conv1's weights as sp_conv2d_fwd takes them on the bf16
  * NHWC4 image (sp_pack_conv_weights with c_in_packed 8, taps_w_packed 2, pair_s0 1 -> [64][64]); w2_packed: conv2's [64][576]; scale / shift:
  * the folded bn1 / bn2.  conv1's map never reaches HBM: bit-identical to sp_nchw_to_nhwc4_bf16 -> sp_conv2d_fwd -> sp_conv2d_fwd. */
+/* HRNet transition1 as ONE launch (bf16; nets/pose_hrnet.py:327-366, used at :431-437): y_hi = relu(bn(conv3x3(x, 256 -> 32, stride 1, pad 1))),
+ * y_lo = relu(bn(conv3x3(x, 256 -> 64, stride 2, pad 1))) from one staging of x [batch, h, w, 256] (h, w even).  wa_packed / wb_packed:
+ * sp_pack_conv_weights layouts [32][k_pad] / [64][k_pad] with k_pad = 2304 = (tap, channel); scale / shift: folded BatchNorm (sp_fold_bn).
+ * Replaces the two sp_conv2d_fwd launches of those layers; reduction order (64-channel chunk, tap, channel): equal to them up to fp32
+ * summation order.  sp_hrnet_transition1_ok: whether (c_in, h, w) is a shape the kernel takes. */
+int sp_hrnet_transition1_ok(int c_in, int h, int w);
+int sp_hrnet_transition1(const void* x, int batch, int h, int w, const void* wa_packed, int k_pad, const float* scale_a, const float* shift_a,
+                         const void* wb_packed, const float* scale_b, const float* shift_b, void* y_hi, void* y_lo, void* stream);
 int sp_hrnet_stem_ok(int batch, int h, int w);
 int sp_hrnet_stem(const float* x, const void* w1_packed, int k1_pad, const float* scale1, const float* shift1, const void* w2_packed,
                   const float* scale2, const float* shift2, void* y, int batch, int h, int w, void* stream);

@@ -132,6 +132,8 @@ SYMBOLS = {
     "sp_conv2d_pw_ok": (c_int, [ctypes.POINTER(ConvDesc)]),
     "sp_hrnet_stem_ok": (c_int, [c_int, c_int, c_int]),
     "sp_hrnet_stem": (c_int, [_P, _P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "sp_hrnet_transition1_ok": (c_int, [c_int, c_int, c_int]),
+    "sp_hrnet_transition1": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sp_stem7_pool_ok": (c_int, [c_int, c_int, c_int]),
     "sp_stem7_pool": (c_int, [_P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "sp_stem7_pool_u8": (c_int, [_P, ctypes.POINTER(ctypes.c_float), _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),

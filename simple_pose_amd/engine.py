@@ -97,7 +97,7 @@ class HipPacker:
 # ------------------------------------------------------------------------------------------------
 @dataclass
 class Op:
-    kind: str                    # "conv" | "bb32" (fused BasicBlock) | "bneck64" (fused Bottleneck) | "stem7" / "hstem" (fused ResNet / HRNet stem) | "maxpool" | ...
+    kind: str                    # "conv" | "bb32" (fused BasicBlock) | "bneck64" (fused Bottleneck) | "stem7" / "hstem" (fused ResNet / HRNet stem) | "htrans" (HRNet transition1) | "maxpool" | ...
     src: str
     dst: str
     res: Optional[str] = None
@@ -110,6 +110,10 @@ class Op:
     name: str = ""
     lane: int = 0                # HIP stream the op is issued on (0 = the caller's stream); independent branches get their own
     direct: bool = False         # conv: use sp_conv3x3_direct (bf16 3x3, 32 -> 32 channels) instead of the implicit GEMM; same bits
+    dst2: Optional[str] = None   # second output ("htrans": HRNet's transition1 writes the high- and the half-resolution branch in one launch)
+
+    def writes(self) -> Tuple[str, ...]:
+        return (self.dst,) + ((self.dst2,) if self.dst2 else ())
 
     def extra_inputs(self) -> Tuple[str, ...]:
         """Input buffers beyond src / res (the SELayer's gate logits; the further terms of a multi-term fuse)."""
@@ -159,18 +163,19 @@ class Program:
             self._sync.pop(old, None)
         last_use: Dict[str, int] = {}
         for i, op in enumerate(self.ops):
-            for nm in (op.src, op.res, op.dst) + op.extra_inputs():
+            for nm in (op.src, op.res) + op.writes() + op.extra_inputs():
                 if nm:
                     last_use[nm] = i
         free: Dict[int, List[torch.Tensor]] = {}
         bufs: Dict[str, torch.Tensor] = {}
         for i, op in enumerate(self.ops):
-            if op.dst not in bufs and op.dst != self.out_name:
-                h, w, c = self.shapes[op.dst]
-                n = batch * h * w * c
-                pool = free.get(n)
-                bufs[op.dst] = pool.pop() if pool else torch.empty(
-                    n, dtype=torch.bfloat16 if self.dtype == "bf16" else torch.float32, device=device)
+            for dn in op.writes():
+                if dn not in bufs and dn != self.out_name:
+                    h, w, c = self.shapes[dn]
+                    n = batch * h * w * c
+                    pool = free.get(n)
+                    bufs[dn] = pool.pop() if pool else torch.empty(
+                        n, dtype=torch.bfloat16 if self.dtype == "bf16" else torch.float32, device=device)
             for nm in (op.src, op.res) + op.extra_inputs():
                 if nm and nm in bufs and last_use[nm] == i and nm != "input":
                     free.setdefault(bufs[nm].numel(), []).append(bufs[nm])
@@ -193,14 +198,15 @@ class Program:
         waits: List[List[int]] = []
         for i, op in enumerate(self.ops):
             need: Dict[int, int] = {}                       # signalling lane -> latest op index
-            cand = [last_writer[n] for n in op.reads() if n in last_writer] + touched.get(store(op.dst), [])
+            cand = [last_writer[n] for n in op.reads() if n in last_writer] + [j for dn in op.writes() for j in touched.get(store(dn), [])]
             for j in cand:
                 lj = self.ops[j].lane
                 if lj != op.lane and need.get(lj, -1) < j:
                     need[lj] = j
             waits.append(sorted(need.values()))
-            last_writer[op.dst] = i
-            for n in op.reads() + (op.dst,):
+            for dn in op.writes():
+                last_writer[dn] = i
+            for n in op.reads() + op.writes():
                 touched.setdefault(store(n), []).append(i)
         records = sorted({j for w in waits for j in w})
         tails: Dict[int, int] = {}
@@ -242,6 +248,10 @@ class Program:
             else:
                 _lib.check(lib.sp_stem7_pool(P(src), P(op.w), k_pad, P(op.scale), P(op.shift), P(bufs[op.dst]), int(self.dtype == "bf16"),
                                              B, h, w, stream), op.name)
+        elif op.kind == "htrans":
+            h, w, k_pad, wb, sb, hb, _ = op.args
+            _lib.check(lib.sp_hrnet_transition1(P(bufs[op.src]), B, h, w, P(op.w), k_pad, P(op.scale), P(op.shift), P(wb), P(sb), P(hb),
+                                                P(bufs[op.dst]), P(bufs[op.dst2]), stream), op.name)
         elif op.kind == "hstem":
             h, w, k1_pad, w2, s2, h2, unfused = op.args
             src = bufs[op.src]
@@ -743,6 +753,10 @@ class ProgramBuilder:
         # HRNet fuse stage: the identity and upsampled terms of one output summed by ONE launch (sp_upsample_add_n_nhwc) instead of one
         # launch per term that re-reads and re-writes the running sum (43 -> 23 launches per HRNet-W32 forward; fp32: same bits)
         self.fuse_terms = True
+        # bf16 HRNet: transition1's two 3x3 convolutions on layer1's 256-channel output (-> 32 channels at stride 1, -> 64 at stride 2) as
+        # ONE launch (sp_hrnet_transition1: the halo staged once per 64-channel chunk serves both; 308 -> ~100 us and 1.4 GB -> 0.3 GB of
+        # traffic at bs=128).  Reduction order (chunk, tap, channel): equal to the two conv launches up to fp32 summation order
+        self.fuse_transition = True
         self.p = Program(dtype=dtype)
         self.bf16 = dtype == "bf16"
         self.cpad = 8 if self.bf16 else 4           # channels per 16-byte chunk
@@ -1123,8 +1137,28 @@ def _hr_module(b: ProgramBuilder, sd, xs: List[str], base: str, num_blocks: List
     return outs
 
 
+def _fuse_transition1(b: "ProgramBuilder") -> None:
+    """The last two ops, if they are transition1's pair - conv3x3(256 -> 32, s1) and conv3x3(256 -> 64, s2) of the same input, BN + ReLU,
+    bf16 - become one `htrans` op (sp_hrnet_transition1).  The two conv ops stay inside it as its definition."""
+    if not (b.bf16 and b.fuse_transition and len(b.p.ops) >= 2):
+        return
+    a, c = b.p.ops[-2], b.p.ops[-1]
+    if not (a.kind == "conv" and c.kind == "conv" and a.src == c.src and a.res is None and c.res is None):
+        return
+    da, dc = a.desc, c.desc
+    ok = (da.c_in == 256 and dc.c_in == 256 and da.taps_h == 3 and da.taps_w == 3 and dc.taps_h == 3 and dc.taps_w == 3 and da.stride == 1 and
+          dc.stride == 2 and da.c_out == 32 and dc.c_out == 64 and da.n_pad == 32 and dc.n_pad == 64 and da.k_pad == 2304 and dc.k_pad == 2304 and
+          (da.flags & SP_CONV_RELU) and (dc.flags & SP_CONV_RELU) and da.dy0 == -1 and dc.dy0 == -1 and
+          a.scale is not None and c.scale is not None and _lib.lib().sp_hrnet_transition1_ok(256, da.in_h, da.in_w))
+    if not ok:
+        return
+    del b.p.ops[-2:]
+    b._add(Op("htrans", a.src, a.dst, dst2=c.dst, w=a.w, scale=a.scale, shift=a.shift, args=(da.in_h, da.in_w, da.k_pad, c.w, c.scale, c.shift, (a, c)),
+              name="transition1", flops=a.flops + c.flops))
+
+
 def hrnet_program(sd: Dict[str, torch.Tensor], cfg: dict, in_h: int = 256, in_w: int = 192, dtype: str = "fp32", packer=None,
-                  fuse_blocks: bool = False, fuse_stem: bool = True, fuse_terms: bool = True) -> Program:
+                  fuse_blocks: bool = False, fuse_stem: bool = True, fuse_terms: bool = True, fuse_transition: bool = True) -> Program:
     """Lower a reference-layout HRNet state_dict into a Program (PoseHighResolutionNet.forward, pose_hrnet.py:419-454).
     `fuse_blocks`: bf16 32-channel BasicBlocks as one launch each (sp_basic_block_c32; same bits as the two conv launches; opt-in,
     see ProgramBuilder.fuse_blocks)."""
@@ -1132,6 +1166,7 @@ def hrnet_program(sd: Dict[str, torch.Tensor], cfg: dict, in_h: int = 256, in_w:
     b = ProgramBuilder(in_h, in_w, dtype, packer)
     b.fuse_blocks = fuse_blocks
     b.fuse_terms = fuse_terms
+    b.fuse_transition = fuse_transition
     b.fuse_stem = fuse_stem
     s1, h1 = _bn(b, sd, "bn1")
     s2, h2 = _bn(b, sd, "bn2")
@@ -1160,6 +1195,8 @@ def hrnet_program(sd: Dict[str, torch.Tensor], cfg: dict, in_h: int = 256, in_w:
                     v = b.conv(v, sd[f"{t}.{i}.{j}.0.weight"], stride=2, pad=1, scale=s_, shift=h_, relu=True, name=f"{t}.{i}.{j}")
                 xs.append(v)
         b.lane = 0
+        if si == 0:
+            _fuse_transition1(b)
         for m in range(sc["NUM_MODULES"]):
             multi = not (st == 4 and m == sc["NUM_MODULES"] - 1)
             xs = _hr_module(b, sd, xs, f"stage{st}.{m}", list(sc["NUM_BLOCKS"]), multi)

@@ -64,7 +64,7 @@ def run_program_cpu(prog, x):
     bufs = {"input": x}
     # a fused stem (`stem7`) is defined as its three-launch lowering (kept in the op for uint8 input; the GPU tests hold the fused
     # kernel to that lowering bit for bit): interpret those descriptors
-    ops = [u for op in prog.ops for u in (op.args[-1] if op.kind in ("stem7", "hstem") else (op,))]
+    ops = [u for op in prog.ops for u in (op.args[-1] if op.kind in ("stem7", "hstem", "htrans") else (op,))]
     for op in ops:
         if op.kind == "to_nhwc4":
             c, h, w = op.args

@@ -1183,6 +1183,80 @@ def test_hrnet_with_one_launch_per_fuse_output_vs_the_chained_program(dtype, mea
         assert 1e-5 < err_f <= 2.5e-2 and err_f <= 1.05 * err_c, (err_f, err_c)
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 64, 48), (3, 34, 18), (1, 8, 6), (5, 32, 16)])
+def test_hrnet_transition1_kernel_vs_float64(B, H, W, measured):
+    """sp_hrnet_transition1 (transition1.0 = conv3x3 256 -> 32 stride 1 and transition1.1 = conv3x3 256 -> 64 stride 2, both + BN + ReLU, of
+    the SAME input: nets/pose_hrnet.py:327-366, :431-437) in one launch against float64 on the same bf16-rounded operands - the bar of
+    every other bf16 conv (output rounding) - on the network's 64x48 map, ragged tiles (34x18: one row / two columns past a tile) and
+    maps smaller than one tile."""
+    import ctypes
+    lib, st = _lib.lib(), _lib.current_stream()
+    assert lib.sp_hrnet_transition1_ok(256, H, W) == 1 and lib.sp_hrnet_transition1_ok(128, H, W) == 0
+    x = torch.from_numpy(synth.tensor_normal(31, "t1/x", (B, 256, H, W))).to(torch.bfloat16)
+    outs, refs = [], []
+    packed = []
+    for tag, cout, stride in (("a", 32, 1), ("b", 64, 2)):
+        w = torch.from_numpy(synth.tensor_normal(31, f"t1/w{tag}", (cout, 256, 3, 3), std=(2.0 / 2304) ** 0.5)).to(torch.bfloat16)
+        g, b_ = (torch.from_numpy(synth.tensor_uniform(31, f"t1/{n}{tag}", (cout,), 0.5, 1.5)) for n in "gb")
+        m = torch.from_numpy(synth.tensor_normal(31, f"t1/m{tag}", (cout,), std=0.3))
+        v = torch.from_numpy(synth.tensor_uniform(31, f"t1/v{tag}", (cout,), 0.2, 2.0))
+        ref = torch.nn.functional.conv2d(x.double(), w.double(), stride=stride, padding=1)
+        refs.append(torch.relu(torch.nn.functional.batch_norm(ref, m.double(), v.double(), g.double(), b_.double(), False, 0.0, 1e-5)))
+        n_pad, k_pad = ctypes.c_int(0), ctypes.c_int(0)
+        assert lib.sp_conv_packed_dims(cout, 2304, 1, ctypes.byref(n_pad), ctypes.byref(k_pad)) == 0 and (n_pad.value, k_pad.value) == (cout, 2304)
+        pk = torch.empty((cout, 2304), dtype=torch.bfloat16, device=DEV)
+        _lib.check(lib.sp_pack_conv_weights(_lib.ptr(w.float().to(DEV)), cout, 256, 3, 3, 256, 3, 0, -1, cout, 2304, _lib.ptr(pk), 1, st))
+        scale, shift = torch.empty(cout, device=DEV), torch.empty(cout, device=DEV)
+        dg, db, dm, dv = (t.to(DEV) for t in (g, b_, m, v))
+        _lib.check(lib.sp_fold_bn(_lib.ptr(dg), _lib.ptr(db), _lib.ptr(dm), _lib.ptr(dv), cout, 1e-5, 0, _lib.ptr(scale), _lib.ptr(shift), st))
+        packed.append((pk, scale, shift))
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    ya = torch.full((B, H, W, 32), float("nan"), dtype=torch.bfloat16, device=DEV)
+    yb = torch.full((B, H // 2, W // 2, 64), float("nan"), dtype=torch.bfloat16, device=DEV)
+    (pa, sa, ha), (pb, sb, hb) = packed
+    _lib.check(lib.sp_hrnet_transition1(_lib.ptr(xn), B, H, W, _lib.ptr(pa), 2304, _lib.ptr(sa), _lib.ptr(ha), _lib.ptr(pb), _lib.ptr(sb), _lib.ptr(hb),
+                                        _lib.ptr(ya), _lib.ptr(yb), st), "transition1")
+    torch.cuda.synchronize()
+    for tag, y, ref in (("hi", ya, refs[0]), ("lo", yb, refs[1])):
+        got = y.float().cpu().permute(0, 3, 1, 2).double()
+        assert not torch.isnan(got).any(), tag                          # every output element written
+        err = float((got - ref).abs().max() / ref.abs().max())
+        measured(f"transition1_{tag}_rel_err", err, 6e-3)
+        assert err <= 6e-3, (tag, err)
+    assert lib.sp_hrnet_transition1(_lib.ptr(xn), B, H + 1, W, _lib.ptr(pa), 2304, _lib.ptr(sa), _lib.ptr(ha), _lib.ptr(pb), _lib.ptr(sb), _lib.ptr(hb),
+                                    _lib.ptr(ya), _lib.ptr(yb), st) != 0          # odd sizes are refused
+
+
+def test_hrnet_with_the_fused_transition_vs_the_two_conv_launches(measured):
+    """HRNet-W32 bf16 with transition1 as one `htrans` op against the program with its two conv launches: the heat maps agree to bf16
+    noise (another fp32 summation order in two layers), each within the bf16 bar of the fp32 program."""
+    import os
+    from simple_pose_amd.nets.pose_hrnet import get_pose_net, hrnet_state_dict_shapes
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    net = get_pose_net(os.path.join(root, "simple_pose_amd", "nets", "hrnet_w32.yaml"), pretrained=None, joint_num=17)
+    sd = synth.conditioned_state_dict(hrnet_state_dict_shapes(net.cfg, 17), seed=3)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    net = net.cuda().eval()
+    net.autotune = False
+    x = _cuda(synth.input_images(3, 60))
+    with torch.no_grad():
+        net.compute_dtype = "fp32"
+        ref = net(x).clone()
+        net.compute_dtype = "bf16"
+        net.fuse_transition = True
+        prog = net.hip_program(x)
+        assert sum(op.kind == "htrans" for op in prog.ops) == 1 and not any(op.name.startswith("transition1") and op.kind == "conv" for op in prog.ops)
+        a = net(x).clone()
+        net.fuse_transition = False
+        assert not any(op.kind == "htrans" for op in net.hip_program(x).ops)
+        b = net(x).clone()
+    err_f = float((a - ref).abs().max() / ref.abs().max())
+    err_c = float((b - ref).abs().max() / ref.abs().max())
+    measured("bf16_fused_transition_rel_err_vs_fp32", err_f, 2.5e-2)
+    measured("bf16_two_launch_rel_err_vs_fp32", err_c)
+    assert 1e-5 < err_f <= 2.5e-2 and err_f <= 1.15 * err_c, (err_f, err_c)
+
+
 def test_captured_graph_survives_the_eviction_of_its_activation_pool():
     """Program._alloc keeps MAX_POOLS activation pools; a captured hipGraph has the pointers of ITS pool baked in, so it must keep that
     pool alive: capture at one batch size, run more other batch sizes than pools are kept (which evicts the captured size from the
