@@ -159,10 +159,9 @@ def dry_rank(args) -> int:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"dry_launch": True, "train_step_plan": plan, "n_ranks": world, "rendezvous": "gloo, env:// on 127.0.0.1", "ranks_seen": ranks,
+        emit(({"dry_launch": True, "train_step_plan": plan, "n_ranks": world, "rendezvous": "gloo, env:// on 127.0.0.1", "ranks_seen": ranks,
                           "visible_devices": n_dev, "rank_to_device": devs, "one_device_per_rank": one_per_device,
-                          "reductions_ok": ok, "config": {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "unset")}}),
-              flush=True)
+                          "reductions_ok": ok, "config": {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "unset")}}))
     return 0 if ok else 1
 
 
@@ -286,10 +285,31 @@ def launch_ranks(args) -> int:
     return rc
 
 
+_JSON_FD = None
+
+
+def claim_stdout() -> None:
+    """The contract is ONE JSON line on stdout.  Libraries print there too (RCCL's version banner at communicator creation goes to the C
+    stdout): from here on file descriptor 1 IS stderr for everything in this process, and only `emit` writes to the real stdout."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj) -> None:
+    data = (json.dumps(obj) + "\n").encode()
+    fd = _JSON_FD if _JSON_FD is not None else 1
+    while data:
+        data = data[os.write(fd, data):]
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args))        # before torch is imported or the GPU is touched
+    claim_stdout()
     ipc_mode = apply_ipc_mode(args, os.environ)         # before the first HIP call (default 0: dmabuf IPC, the only mode this pool's driver has)
     if args.dry_launch:
         raise SystemExit(dry_rank(args))
@@ -328,18 +348,39 @@ def main():
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
     red_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")   # where the measurement's scalar reductions live
-    ctx = {"rank": rank, "world": world, "dev": dev, "red_dev": red_dev, "ipc_mode": ipc_mode, "rccl": None}
-    if dist.is_initialized() and dist.get_backend() == "nccl":
-        # N > 1 over RCCL (or the 1-rank preflight group): ask RCCL itself who is in the job
-        try:
-            ctx["rccl"] = rccl_census(dev, rank, world)
-        except Exception as e:                               # reported in the line, never fatal for the measurement
-            ctx["rccl"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    ctx = {"rank": rank, "world": world, "dev": dev, "red_dev": red_dev, "ipc_mode": ipc_mode}
     line = run_once(args, ctx)
     if others is not None and line is not None:
         line["other_configs"] = others                    # LAST key of the one JSON line
+    abandoned = False
+    if dist.is_initialized() and dist.get_backend() == "nccl":
+        # N > 1 over RCCL (or the 1-rank preflight group): ask RCCL itself who is in the job - AFTER the measurement, on a helper thread
+        # with a deadline: a census that never answers must not cost the line (the process then leaves without tearing the group down)
+        import threading
+        box = {}
+
+        def work():
+            try:
+                torch.cuda.set_device(dev)
+                box["rccl"] = rccl_census(dev, rank, world)
+            except Exception as e:
+                box["rccl"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        th.join(120.0)
+        abandoned = th.is_alive()
+        info = {"error": "no answer from the communicator census within 120 s (abandoned; the measurement above is complete)"} if abandoned else box.get("rccl")
+        if line is not None and info is not None:
+            cfg = dict(line["config"])
+            cfg["rccl"] = info
+            line["config"] = cfg
+            if "other_configs" in line:                  # keep it the last key
+                line["other_configs"] = line.pop("other_configs")
     if rank == 0 and line is not None:
-        print(json.dumps(line), flush=True)
+        emit(line)
+    if abandoned:
+        sys.stderr.flush()
+        os._exit(0)
     if world > 1:
         dist.destroy_process_group()
 
@@ -551,6 +592,26 @@ def run_once(args, ctx):
 
     ms_per_step = 1e3 * elapsed / args.steps
 
+    # ---- the same steps with ONE batch in flight on one stream (rank 0, untimed extra: the mode of rounds 1-2 and of the per-kernel events,
+    #      kept in every line so that rounds stay comparable whatever the default number of batches in flight becomes) ----
+    one_in_flight = None
+    if prog is not None and not args.graph and (args.interleave or 1) > 1:
+        keep_ms = prog.multi_stream
+        prog.multi_stream = False
+        hm1 = torch.empty((B,) + tuple(prog.out_shape), dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for _ in range(max(2, args.warmup // 2)):
+                o1 = decoder(prog.run(x, out=hm1), tinv)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                o1 = decoder(prog.run(x, out=hm1), tinv)
+            torch.cuda.synchronize()
+        dt1 = time.perf_counter() - t1
+        prog.multi_stream = keep_ms
+        one_in_flight = {"value": round(B * args.steps / dt1, 1), "unit": "images/s", "ms_per_step": round(1e3 * dt1 / args.steps, 3),
+                         "note": "this rank, one batch in flight, one stream, decode in line"}
+
     # ---- per-kernel roofline: HIP events around every conv launch, on the launch stream, same inputs ----
     roofline = None
     if rank == 0 and not args.no_kernel_events and prog is not None:
@@ -620,10 +681,9 @@ def run_once(args, ctx):
                 "network_tflops": round(value * prog.flops_per_image / 1e12, 2),
                 "network_frac_of_matrix_peak": round(value * prog.flops_per_image / 1e12 / (peak * world), 4),
                 "roofline": roofline,
+                "one_batch_in_flight": one_in_flight,
                 "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args.arch),   # rank 0 at N = 1 only
             }
-        if ctx.get("rccl") is not None:
-            line["config"]["rccl"] = ctx["rccl"]
     else:
         line = None
     # give this configuration's pools / streams back before the next one is built in the same process
