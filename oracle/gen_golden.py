@@ -13,6 +13,7 @@ is committed - never reference source.  Fixture inventory
   g1s_dconv_se_fwd.npz  ResNet50-DConv + SELayer (reduction=True) eval forward, B=1, + key list
   g3_hrnet_w32_fwd.npz  HRNet-W32 eval forward, B=1, + the reference's state_dict key/shape list
   g7_next.npz        HeatMapAcc values and collate_fn normalisation
+  g11_resnet_variants.npz  resnet18-dconv, resnet34-duc, wide_resnet50_2-dconv, resnet18-dconv+SE (2 images; key lists, sub-sampled maps, key points)
   g10_fwd_wide.npz   8 / 8 / 4 / 4 distinct images through DConv / DUC / HRNet-W32 / DConv+SE (sub-sampled maps, per-joint sums, key points)
   g6_train_step.npz  one reference training step (B=2): loss, gradient slices, BN running stats, params after Adam
   g5_encode.npz      encoders (Refine + Basic) incl. out-of-range / trunc-toward-zero / vis=0 cases
@@ -415,12 +416,49 @@ def gen_forward_wide(ns):
     np.savez_compressed(os.path.join(GOLD, "g10_fwd_wide.npz"), **out)
 
 
+VARIANTS = (("resnet18", "dconv", False), ("resnet34", "duc", False), ("wide_resnet50_2", "dconv", False), ("resnet18", "dconv", True))
+
+
+def gen_variants(ns):
+    """g11_resnet_variants.npz (round 4): the reference's other ResNet factories (nets/pose_resnet_dconv.py:282-403, pose_resnet_duc.py) - the
+    BasicBlock nets and a wide Bottleneck net, one with SELayers - eval forward on 2 images (weight seed 1, input seed 7): state_dict key
+    lists + shapes, sub-sampled heat maps, per-joint sums / norms / arg-max, the reference's GaussTaylor key points."""
+    torch.set_num_threads(8)
+    gt = ns.pose_metrics.GaussTaylorKeyPointDecoder(kernel_size=11, num_joints=17)
+    out = {"w_seed": WIDE_W_SEED, "x_seed": WIDE_X_SEED}
+    x = torch.from_numpy(synth.input_images(2, WIDE_X_SEED))
+    for arch, head, se in VARIANTS:
+        tag = f"{arch}_{head}" + ("_se" if se else "")
+        net = getattr(ns.dconv if head == "dconv" else ns.duc, arch)(pretrained=False, num_classes=17, reduction=se)
+        synth.load_conditioned(net, WIDE_W_SEED)
+        net.eval()
+        with torch.no_grad():
+            hm = net(x)
+        kps, mv = gt(hm.clone(), torch.from_numpy(synth.trans_inv_batch(2)))
+        h = hm.numpy()
+        flat = h.reshape(2, 17, -1)
+        sd = net.state_dict()
+        out[f"{tag}/keys"] = np.array(list(sd.keys()))
+        out[f"{tag}/shapes"] = np.array([",".join(str(d) for d in v.shape) for v in sd.values()])
+        out[f"{tag}/heat_sub"] = h[:, :, ::4, ::4].copy()
+        out[f"{tag}/heat_sum"] = flat.astype(np.float64).sum(-1)
+        out[f"{tag}/heat_l2"] = np.sqrt((flat.astype(np.float64) ** 2).sum(-1))
+        out[f"{tag}/heat_max"] = flat.max(-1)
+        out[f"{tag}/heat_argmax"] = flat.argmax(-1).astype(np.int64)
+        out[f"{tag}/gt_kps"] = kps.numpy()
+        print("g11", tag, h.shape, "absmax", np.abs(h).max(), "std", h.std(), "keys", len(sd))
+    np.savez_compressed(os.path.join(GOLD, "g11_resnet_variants.npz"), **out)
+
+
 def main():
     assert ref_import.available(), "needs /root/reference (build container only)"
     os.makedirs(GOLD, exist_ok=True)
     ns = ref_import.load()
-    if "--only-wide" in sys.argv:          # (round 4 addition; the other files regenerate bit for bit and were left as committed)
+    if "--only-wide" in sys.argv:          # (round 4 additions; the other files regenerate bit for bit and were left as committed)
         gen_forward_wide(ns)
+        return
+    if "--only-variants" in sys.argv:
+        gen_variants(ns)
         return
     hm = gen_forward(ns)  # returns the DUC maps last; reload dconv maps for the decoder set
     net_maps = np.load(os.path.join(GOLD, "g1_dconv_fwd.npz"))["heat_maps"]
@@ -433,6 +471,7 @@ def main():
     gen_nms(ns)
     gen_crop(ns)
     gen_forward_wide(ns)
+    gen_variants(ns)
     del hm
 
 

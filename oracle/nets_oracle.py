@@ -50,6 +50,17 @@ def _bottleneck(x, sd, p, stride, training=False):
     return F.relu(out + x)
 
 
+def _res_basic_block(x, sd, p, stride, training=False):
+    # nets/pose_resnet_dconv.py:61-80 (BasicBlock of resnet18 / resnet34: the stride sits on conv1)
+    out = F.relu(_bn(F.conv2d(x, sd[p + ".conv1.weight"], stride=stride, padding=1), sd, p + ".bn1", training))
+    out = _bn(F.conv2d(out, sd[p + ".conv2.weight"], padding=1), sd, p + ".bn2", training)
+    if (p + ".se.fc.0.weight") in sd:
+        out = _se(out, sd, p + ".se")
+    if (p + ".downsample.0.weight") in sd:
+        x = _bn(F.conv2d(x, sd[p + ".downsample.0.weight"], stride=stride), sd, p + ".downsample.1", training)
+    return F.relu(out + x)
+
+
 def blocks_of(sd) -> tuple:
     """Bottlenecks per stage, read off the state_dict keys ((3, 4, 6, 3) for resnet50, (3, 4, 23, 3) resnet101, (3, 8, 36, 3) resnet152:
     nets/pose_resnet_dconv.py:306-339)."""
@@ -63,9 +74,10 @@ def resnet_trunk(sd: Dict[str, torch.Tensor], x: torch.Tensor, training=False,
     x = F.max_pool2d(x, 3, 2, 1)
     if tap:
         tap("maxpool", x)
+    block = _bottleneck if "layer1.0.conv3.weight" in sd else _res_basic_block
     for li, n in enumerate(blocks, start=1):
         for bi in range(n):
-            x = _bottleneck(x, sd, f"layer{li}.{bi}", 2 if (bi == 0 and li > 1) else 1, training)
+            x = block(x, sd, f"layer{li}.{bi}", 2 if (bi == 0 and li > 1) else 1, training)
         if tap:
             tap(f"layer{li}", x)
     return x

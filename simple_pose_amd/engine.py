@@ -1038,6 +1038,25 @@ def _bottleneck(b: ProgramBuilder, sd, x: str, p: str, stride: int) -> str:
     return b.conv(t, sd[p + ".conv3.weight"], scale=s3, shift=h3, relu=True, res=idn, name=p + ".conv3")
 
 
+def _res_basic_block(b: ProgramBuilder, sd, x: str, p: str, stride: int) -> str:
+    """BasicBlock.forward of resnet18 / resnet34 (pose_resnet_dconv.py:61-80): conv3x3 (stride) - bn - relu, conv3x3 - bn [- SELayer],
+    + identity (or the 1x1 projection shortcut), relu."""
+    s1, h1 = _bn(b, sd, p + ".bn1")
+    t = b.conv(x, sd[p + ".conv1.weight"], stride=stride, pad=1, scale=s1, shift=h1, relu=True, name=p + ".conv1")
+    idn = x
+    if (p + ".downsample.0.weight") in sd:
+        sdn, hdn = _bn(b, sd, p + ".downsample.1")
+        idn = b.conv(x, sd[p + ".downsample.0.weight"], stride=stride, scale=sdn, shift=hdn, name=p + ".downsample")
+    s2, h2 = _bn(b, sd, p + ".bn2")
+    if (p + ".se.fc.0.weight") in sd:
+        z = b.conv(t, sd[p + ".conv2.weight"], pad=1, scale=s2, shift=h2, name=p + ".conv2")
+        g = b.gap(z)
+        g = b.conv(g, sd[p + ".se.fc.0.weight"], shift=b.packer.bias(sd[p + ".se.fc.0.bias"]), relu=True, name=p + ".se.fc.0")
+        g = b.conv(g, sd[p + ".se.fc.2.weight"], shift=b.packer.bias(sd[p + ".se.fc.2.bias"]), name=p + ".se.fc.2")
+        return b.se_gate(z, g, idn)
+    return b.conv(t, sd[p + ".conv2.weight"], pad=1, scale=s2, shift=h2, relu=True, res=idn, name=p + ".conv2")
+
+
 def resnet_program(sd: Dict[str, torch.Tensor], head: str, in_h: int = 256, in_w: int = 192,
                    blocks=(3, 4, 6, 3), dtype: str = "fp32", packer=None, fuse_bottlenecks: bool = False, fuse_stem: bool = True) -> Program:
     """Lower a reference-layout state_dict into a Program.  `sd` tensors must be on the GPU.
@@ -1047,9 +1066,10 @@ def resnet_program(sd: Dict[str, torch.Tensor], head: str, in_h: int = 256, in_w
     b.fuse_stem = fuse_stem
     s, h = _bn(b, sd, "bn1")
     x = b.stem_pool("input", sd["conv1.weight"], s, h, name="conv1")
+    basic = "layer1.0.conv3.weight" not in sd            # resnet18 / resnet34: BasicBlocks (two 3x3 convs, no conv3)
     for li, n in enumerate(blocks, start=1):
         for bi in range(n):
-            x = _bottleneck(b, sd, x, f"layer{li}.{bi}", 2 if (bi == 0 and li > 1) else 1)
+            x = (_res_basic_block if basic else _bottleneck)(b, sd, x, f"layer{li}.{bi}", 2 if (bi == 0 and li > 1) else 1)
     J = sd["final_layer.weight"].shape[0]
     if head == "dconv":
         for idx in (0, 3, 6):

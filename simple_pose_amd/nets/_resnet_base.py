@@ -22,13 +22,14 @@ class _Bottleneck(nn.Module):
     optional `downsample` = Sequential(conv1x1, bn).  Keys as in nets/pose_resnet_dconv.py:83-110."""
     expansion = 4
 
-    def __init__(self, inplanes: int, planes: int, stride: int, with_downsample: bool, with_se: bool = False):
+    def __init__(self, inplanes: int, planes: int, stride: int, with_downsample: bool, with_se: bool = False, width: int = 0):
         super().__init__()
-        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes)
-        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
-        self.bn2 = nn.BatchNorm2d(planes)
-        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        width = width or planes          # wide_resnet*_2: width = 2 * planes (`int(planes * (base_width / 64.)) * groups`, pose_resnet_dconv.py:97)
+        self.conv1 = nn.Conv2d(inplanes, width, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(width)
+        self.conv2 = nn.Conv2d(width, width, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(width)
+        self.conv3 = nn.Conv2d(width, planes * 4, 1, bias=False)
         self.bn3 = nn.BatchNorm2d(planes * 4)
         if with_downsample:
             self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False),
@@ -41,13 +42,42 @@ class _Bottleneck(nn.Module):
             self.se = SELayer(planes * 4)
 
 
+class _BasicBlock(nn.Module):
+    """Parameter holder for one BasicBlock (resnet18 / resnet34; pose_resnet_dconv.py:38-80): conv1/bn1 (3x3, carries the stride),
+    conv2/bn2 (3x3), optional `downsample` = Sequential(conv1x1, bn), optional SELayer(planes)."""
+    expansion = 1
+
+    def __init__(self, inplanes: int, planes: int, stride: int, with_downsample: bool, with_se: bool = False, width: int = 0):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        if with_downsample:
+            self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes, 1, stride=stride, bias=False), nn.BatchNorm2d(planes))
+        else:
+            self.downsample = None
+        self.stride = stride
+        if with_se:
+            from .commons import SELayer
+            self.se = SELayer(planes)
+
+
 class PoseResNetBase(nn.Module):
-    """ResNet-50 trunk (conv1, bn1, layer1..4) + a head defined by the subclass (`_build_head`, `HEAD`)."""
+    """ResNet trunk (conv1, bn1, layer1..4 of Bottlenecks - resnet50 / 101 / 152, wide_resnet*_2 - or BasicBlocks - resnet18 / 34) + a
+    head defined by the subclass (`_build_head`, `HEAD`)."""
     HEAD = ""
     BLOCKS = (3, 4, 6, 3)
+    BLOCK = "bottleneck"       # or "basic"
+    WIDTH_PER_GROUP = 64       # 128: wide_resnet50_2 / wide_resnet101_2 (pose_resnet_dconv.py:370-403)
 
-    def __init__(self, num_classes: int = 17, reduction: bool = False, blocks=None):
+    def __init__(self, num_classes: int = 17, reduction: bool = False, blocks=None, block: str = "bottleneck", width_per_group: int = 64):
         super().__init__()
+        if block not in ("bottleneck", "basic"):
+            raise ValueError(block)
+        if block == "basic" and width_per_group != 64:
+            raise ValueError("BasicBlock only supports groups=1 and base_width=64")      # (the reference's own check, :46-47)
+        self.BLOCK, self.WIDTH_PER_GROUP = block, width_per_group
         if blocks is not None:           # resnet101 / resnet152: same bottleneck trunk, other depths (pose_resnet_dconv.py:318-339)
             self.BLOCKS = tuple(blocks)
         self.reduction = reduction     # SELayer on the first block of every layer (pose_resnet_dconv.py:215-218)
@@ -55,12 +85,17 @@ class PoseResNetBase(nn.Module):
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         inplanes = 64
+        Block = _Bottleneck if block == "bottleneck" else _BasicBlock
         for li, (planes, n) in enumerate(zip((64, 128, 256, 512), self.BLOCKS), start=1):
             blocks = []
             for bi in range(n):
                 stride = 2 if (bi == 0 and li > 1) else 1
-                blocks.append(_Bottleneck(inplanes, planes, stride, with_downsample=(bi == 0), with_se=(reduction and bi == 0)))
-                inplanes = planes * 4
+                # `_make_layer` (pose_resnet_dconv.py:205-221): a projection shortcut where the shape changes (always for a stage's first
+                # Bottleneck; NOT for layer1.0 of the BasicBlock nets), and the SELayer only on blocks that have one
+                down = bi == 0 and (stride != 1 or inplanes != planes * Block.expansion)
+                blocks.append(Block(inplanes, planes, stride, with_downsample=down, with_se=(reduction and down),
+                                    width=planes * width_per_group // 64))
+                inplanes = planes * Block.expansion
             setattr(self, f"layer{li}", nn.Sequential(*blocks))
         self._build_head(inplanes, num_classes)
         self._init_like_reference()

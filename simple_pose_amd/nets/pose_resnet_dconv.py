@@ -11,7 +11,8 @@ from torch import nn
 
 from ._resnet_base import PoseResNetBase, load_pretrained_like_reference
 
-__all__ = ["ResNet", "resnet50", "resnet101", "resnet152"]
+__all__ = ["ResNet", "resnet18", "resnet34", "resnet50", "resnet101", "resnet152", "wide_resnet50_2", "wide_resnet101_2",
+           "resnext50_32x4d", "resnext101_32x8d"]
 
 
 class ResNet(PoseResNetBase):
@@ -27,8 +28,9 @@ class ResNet(PoseResNetBase):
         self.final_layer = nn.Conv2d(256, num_classes, 1)  # :173-178
 
 
-def _resnet(arch: str, blocks, pretrained: bool, kwargs) -> ResNet:
-    model = ResNet(num_classes=kwargs.pop("num_classes", 1000), reduction=kwargs.pop("reduction", False), blocks=blocks)
+def _resnet(arch: str, blocks, pretrained: bool, kwargs, block: str = "bottleneck", width_per_group: int = 64) -> ResNet:
+    model = ResNet(num_classes=kwargs.pop("num_classes", 1000), reduction=kwargs.pop("reduction", False), blocks=blocks, block=block,
+                   width_per_group=width_per_group)
     if kwargs:
         raise TypeError(f"unsupported arguments for the HIP {arch}: {sorted(kwargs)}")
     if pretrained:
@@ -49,3 +51,37 @@ def resnet101(pretrained: bool = False, progress: bool = True, **kwargs) -> ResN
 def resnet152(pretrained: bool = False, progress: bool = True, **kwargs) -> ResNet:
     """Bottleneck depths [3, 8, 36, 3] (reference factory of the same name, pose_resnet_dconv.py:306-339)."""
     return _resnet("resnet152", (3, 8, 36, 3), pretrained, kwargs)
+
+
+def resnet18(pretrained: bool = False, progress: bool = True, **kwargs) -> ResNet:
+    """BasicBlock depths [2, 2, 2, 2] (reference factory of the same name, pose_resnet_dconv.py:282-403); the head starts from 512 channels."""
+    return _resnet("resnet18", (2, 2, 2, 2), pretrained, kwargs, block="basic")
+
+
+def resnet34(pretrained: bool = False, progress: bool = True, **kwargs) -> ResNet:
+    """BasicBlock depths [3, 4, 6, 3] (reference factory of the same name)."""
+    return _resnet("resnet34", (3, 4, 6, 3), pretrained, kwargs, block="basic")
+
+
+def wide_resnet50_2(pretrained: bool = False, progress: bool = True, **kwargs) -> ResNet:
+    """Bottlenecks [3, 4, 6, 3] with twice the inner width (`width_per_group = 128`; reference factory of the same name)."""
+    return _resnet("wide_resnet50_2", (3, 4, 6, 3), pretrained, kwargs, width_per_group=128)
+
+
+def wide_resnet101_2(pretrained: bool = False, progress: bool = True, **kwargs) -> ResNet:
+    """Bottlenecks [3, 4, 23, 3] with twice the inner width (reference factory of the same name)."""
+    return _resnet("wide_resnet101_2", (3, 4, 23, 3), pretrained, kwargs, width_per_group=128)
+
+
+def _grouped(arch: str):
+    raise NotImplementedError(f"{arch}: grouped 3x3 convolutions (groups = 32) are not lowered to the HIP kernels - the implicit GEMM is a dense "
+                              "contraction per launch; the reference's resnext factories have no counterpart here (DESIGN.md section 7)")
+
+
+def resnext50_32x4d(pretrained: bool = False, progress: bool = True, **kwargs):
+    """Refused with a message (see `_grouped`): the factory name exists so that a caller of the reference's API fails loudly, not with AttributeError."""
+    _grouped("resnext50_32x4d")
+
+
+def resnext101_32x8d(pretrained: bool = False, progress: bool = True, **kwargs):
+    _grouped("resnext101_32x8d")

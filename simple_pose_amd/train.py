@@ -462,6 +462,9 @@ class PoseTrainer:
         if getattr(model, "HEAD", None) not in ("dconv", "duc", "hrnet"):
             raise NotImplementedError("PoseTrainer lowers the ResNet DConv / DUC nets (the DDP solver's models, ddp...:65-68) and HRNet")
         self.head = model.HEAD
+        if getattr(model, "BLOCK", "bottleneck") != "bottleneck":
+            raise NotImplementedError("PoseTrainer lowers the Bottleneck ResNets (resnet50 / 101 / 152, wide_resnet*_2) and HRNet; the BasicBlock "
+                                      "nets (resnet18 / resnet34) run the eval-mode forward only")
         self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
         self.pg = process_group
         self.overlap_wgrad = overlap_wgrad

@@ -49,6 +49,46 @@ def test_packing_and_descriptors_reproduce_oracle_forward(head):
     assert abs(full.flops_per_image - expect) / expect < 1e-4, full.flops_per_image
 
 
+VARIANTS = [("resnet18", "dconv", False), ("resnet34", "duc", False), ("wide_resnet50_2", "dconv", False), ("resnet18", "dconv", True)]
+
+
+def _variant_model(arch, head, se):
+    return getattr(pose_resnet_dconv if head == "dconv" else pose_resnet_duc, arch)(pretrained=False, num_classes=17, reduction=se)
+
+
+@pytest.mark.parametrize("arch,head,se", VARIANTS, ids=[f"{a}_{h}" + ("_se" if s else "") for a, h, s in VARIANTS])
+def test_resnet_variant_layout_and_lowering(golden, arch, head, se):
+    """The reference's other ResNet factories (nets/pose_resnet_dconv.py:282-403: BasicBlock nets resnet18 / 34, wide_resnet*_2): the module
+    tree has the reference's state_dict keys and shapes in the reference's order (key lists frozen in g11 from the real reference), and the
+    lowered program interpreted on the CPU equals the oracle forward."""
+    g = golden("g11_resnet_variants.npz")
+    tag = f"{arch}_{head}" + ("_se" if se else "")
+    m = _variant_model(arch, head, se)
+    sd0 = m.state_dict()
+    assert list(sd0.keys()) == list(g[f"{tag}/keys"])
+    assert [",".join(str(d) for d in v.shape) for v in sd0.values()] == list(g[f"{tag}/shapes"])
+    layout = [(k, tuple(v.shape), str(v.dtype)) for k, v in sd0.items()]
+    sd = {k: torch.from_numpy(v) for k, v in synth.conditioned_state_dict(layout, seed=3).items()}
+    x = torch.from_numpy(synth.input_images(2, seed=3, h=64, w=64))
+    prog = engine.resnet_program(sd, head, in_h=64, in_w=64, blocks=m.BLOCKS, packer=TorchPacker())
+    with torch.no_grad():
+        ref = nets_oracle.FORWARDS["resnet50_" + head](sd, x)
+        got, _ = run_program_cpu(prog, x)
+    assert got.shape == ref.shape == (2, 17, 16, 16)
+    rel = (got - ref).abs().max() / ref.abs().max()
+    assert rel < 1e-5, rel
+
+
+def test_grouped_factories_and_basic_block_training_fail_loudly():
+    with pytest.raises(NotImplementedError, match="grouped"):
+        pose_resnet_dconv.resnext50_32x4d(num_classes=17)
+    with pytest.raises(NotImplementedError, match="grouped"):
+        pose_resnet_duc.resnext101_32x8d(num_classes=17)
+    from simple_pose_amd.train import PoseTrainer
+    with pytest.raises(NotImplementedError, match="BasicBlock"):
+        PoseTrainer(pose_resnet_dconv.resnet18(num_classes=17))
+
+
 def test_buffer_plan_never_aliases_live_tensors():
     shapes = nets_oracle.state_dict_shapes_resnet50("dconv")
     sd = {k: torch.from_numpy(v) for k, v in synth.conditioned_state_dict(shapes, seed=1).items()}

@@ -248,3 +248,26 @@ def test_forward_oracle_matches_reference_on_the_wide_set(golden, tag, B):
     kps, mv = pose_oracle.decode_gauss_taylor(hm, synth.trans_inv_batch(B))
     err = np.abs(kps - g[f"{tag}/gt_kps"]).max(-1) / 4.0
     assert (err <= 1e-3).mean() >= 0.9, (err <= 1e-3).mean()        # noise-like maps: the tail is the ill-conditioned -H^-1 g
+
+
+VARIANTS = [("resnet18", "dconv", False), ("resnet34", "duc", False), ("wide_resnet50_2", "dconv", False), ("resnet18", "dconv", True)]
+
+
+@pytest.mark.parametrize("arch,head,se", VARIANTS, ids=[f"{a}_{h}" + ("_se" if s else "") for a, h, s in VARIANTS])
+def test_forward_oracle_matches_reference_on_the_resnet_variants(golden, arch, head, se):
+    """g11_resnet_variants.npz: the BasicBlock nets, a wide Bottleneck net and an SELayer variant through the real reference - the forward oracle
+    (driven by the state_dict alone) reproduces the sub-sampled maps, norms and arg-max cells."""
+    from simple_pose_amd.nets import pose_resnet_dconv, pose_resnet_duc
+    g = golden("g11_resnet_variants.npz")
+    tag = f"{arch}_{head}" + ("_se" if se else "")
+    m = getattr(pose_resnet_dconv if head == "dconv" else pose_resnet_duc, arch)(pretrained=False, num_classes=17, reduction=se)
+    layout = [(k, tuple(v.shape), str(v.dtype)) for k, v in m.state_dict().items()]
+    sd = {k: torch.from_numpy(v) for k, v in synth.conditioned_state_dict(layout, int(g["w_seed"])).items()}
+    x = torch.from_numpy(synth.input_images(2, int(g["x_seed"])))
+    with torch.no_grad():
+        hm = nets_oracle.FORWARDS["resnet50_" + head](sd, x).numpy()
+    scale = np.abs(g[f"{tag}/heat_max"]).max()
+    assert np.abs(hm[:, :, ::4, ::4] - g[f"{tag}/heat_sub"]).max() / scale <= 1e-5
+    flat = hm.reshape(2, 17, -1)
+    assert np.abs(np.sqrt((flat.astype(np.float64) ** 2).sum(-1)) - g[f"{tag}/heat_l2"]).max() <= 1e-5 * g[f"{tag}/heat_l2"].max()
+    assert (flat.argmax(-1) == g[f"{tag}/heat_argmax"]).mean() >= 0.97
