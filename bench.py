@@ -682,6 +682,7 @@ def run_once(args, ctx):
                 "network_frac_of_matrix_peak": round(value * prog.flops_per_image / 1e12 / (peak * world), 4),
                 "roofline": roofline,
                 "one_batch_in_flight": one_in_flight,
+                "host_enqueue_ms_per_step": round(host_enqueue_ms, 3),
                 "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args.arch),   # rank 0 at N = 1 only
             }
     else:
