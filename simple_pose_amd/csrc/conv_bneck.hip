@@ -6,7 +6,7 @@
 // (x is read by conv1 and again as conv3's residual, the two 64-channel intermediates are written and read) against 402 MB for x in and
 // y out; layer1 and layer2 already sit on the HBM roofline conv by conv (profiles/r02_dconv_bf16_floors.md), so only fewer bytes move them.
 //
-// One persistent 8-wave workgroup per CU, 16x8-pixel output tiles (the 3x3 stage is conv3x3_c64_direct_kernel's):
+// One persistent 8-wave workgroup per CU, 16x8-pixel output tiles (the 3x3 stage is the round-2 64-channel direct kernel's):
 //   A  t1 = relu(bn1(x . W1^T)) on the 18x10-pixel halo (192-row GEMM, K = 256): A fragments straight from the NHWC rows of x (a lane's
 //      8 channels are 16 contiguous bytes), W1's fragments from L2; t1 -> LDS as bf16 (zero outside the image: the 3x3's padding
 //      applies to t1);
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_c64_kernel(const BneckArgs 
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) rv[m][nb][it] = __builtin_amdgcn_raw_buffer_load_b128(xr, o == OOB ? OOB : o + (unsigned)(nb * 64), 0, 0);
             }
-        // =================== stage B: 3x3 from the LDS halo tile (conv3x3_c64_direct_kernel's loop) ===================
+        // =================== stage B: 3x3 from the LDS halo tile (the round-2 64-channel direct kernel's loop) ===================
         {
             f32x16 acc0, acc1;
 #pragma unroll

@@ -6,6 +6,7 @@
 // GEMM (tap-major, channel-minor, one v_mfma_f32_32x32x16_bf16 chain per output tile) -> bit-identical results, which is how it
 // is tested.  Replaces nets/pose_hrnet.py BasicBlock convs (conv3x3 + BN [+ residual] + ReLU) on 32-channel branches.
 #include "sp_common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -150,168 +151,158 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_direct_kernel(const Direct
     }
 }
 
-// ---- 64 -> 64 channels --------------------------------------------------------------------------------------------------------------
-// (HRNet's second branch: 64 of its 293 convs at 32x24; ResNet-50 layer1.*.conv2 at 64x48.)  Same idea, different budget: the filter is
-// 72 KiB, too large for registers, so it lives in LDS for the whole (persistent, one per CU) workgroup in fragment order - the B
-// operand of every MFMA is ONE conflict-free ds_read_b128 - next to a double-buffered halo tile of the 16x8-pixel output tile
-// (18 x 10 pixels x 128 B).  A wave owns 32 pixels x 64 channels: per (tap, 16-channel K step) one A fragment feeds two MFMAs.  The
-// implicit GEMM spends 26 us on such a layer at bs=128 (9 short K tiles per workgroup, every input pixel gathered nine times) against
-// ~8 us of HBM time and ~7 us of MFMA time.
-constexpr int T6H = 16, T6W = 8;                   // output tile: 16 rows x 8 columns; wave w = rows 4w..4w+3
-constexpr int H6W = T6W + 2, H6H = T6H + 2;        // halo tile 18 x 10 = 180 pixels
-constexpr int C6 = 64, PIX6 = C6 * 2;              // 128 B per pixel = 8 chunks of 16 B
-constexpr int W6_BYTES = 9 * 4 * 2 * 2 * 32 * 16;  // [tap][k step][column block][k half][column] 16-B fragments = 73,728 B
-constexpr int X6_BYTES = H6H * H6W * PIX6;         // 23,040 B per halo buffer
-constexpr int TR6_BYTES = 32 * 64 * 4;             // epilogue transpose, per wave
-constexpr int LDS6 = W6_BYTES + 2 * X6_BYTES + 4 * TR6_BYTES;
+// ---- 64 -> 64 channels (HRNet's second branch: 64 of its 293 convs at 32x24; ResNet-50 layer1.*.conv2 at 64x48) -------------------------------
+// Round 4 structure: 8 waves, 16 x 24 pixel tiles.  (The round-2 kernel - 16 x 8 tiles, ONE wave per SIMD: 72 KB filter + two halo buffers = one
+// 4-wave workgroup per CU, 300 registers, 1.5 LDS reads per MFMA - was LDS- and latency-bound: 26 us per HRNet layer at bs=128 against an 8 us
+// HBM floor; this one measures 19.8 us, same bits.)  The implicit GEMM spends 26 us on such a layer (9 short K tiles per workgroup, every
+// input pixel gathered nine times).  A workgroup of 8 waves owns 16 rows x 24
+// columns (HRNet's second branch is 32 x 24 per image: two tiles; ResNet's layer1 64 x 48: eight): wave (g, h) multiplies rows 4g..4g+3 - three
+// row tiles of 4 x 8 pixels - with channels 32h..32h+31: one B fragment feeds three MFMAs, 1.33 reads per MFMA at two waves per SIMD.  The halo
+// (18 x 26 pixels) sits in LDS as LINEAR 144-byte pixel rows (a tap = a compile-time offset; 128 B + 16 B of padding spreads 8 consecutive
+// pixels over the banks) with the row stride padded to 128 mod 256 bytes so that the two pixel rows of a 16-lane read beat interleave; the
+// whole filter [tap][n][128 B] (XOR-swizzled 16-byte pieces, 72 KB) is loaded once per persistent workgroup; the next tile's halo waits in
+// registers.  Same reduction order as the implicit GEMM (one MFMA chain per output, tap-major, channel-minor): bit-identical results.
+constexpr int C6 = 64;
+constexpr int T7R = 16, T7C = 24;
+constexpr int H7R = T7R + 2, H7C = T7C + 2;              // 18 x 26 halo
+constexpr int PX7 = 144;                                  // bytes per halo pixel
+constexpr int RS7 = H7C * PX7 + 224;                      // 3,968 = 128 (mod 256) bytes per halo row
+constexpr int X7_BYTES = H7R * RS7;                       // 71,424
+constexpr int W7_BYTES = 9 * 64 * 128;                    // 73,728
+constexpr int LDS7 = X7_BYTES + W7_BYTES;                 // 145,152
+constexpr int NH7 = (H7R * H7C * 8 + 511) / 512;          // 16-byte halo pieces per thread (8)
+__device__ __forceinline__ int w7off(int n, int pc) { return (n << 7) + ((pc ^ ((n >> 1) & 7)) << 4); }
 
-// chunk c (0..7) of halo pixel (hy, hx) -> byte offset.  Sixteen lanes of one ds_read_b128 beat hold four rows x four consecutive
-// columns reading the same chunk: (hx & 1) picks the half of a 256-byte bank row (180 pixels x 128 B: pixel parity = column parity),
-// ((hx >> 1) & 1) | ((hy & 3) << 1) spreads the rest over its eight 16-byte slots.
-__device__ __forceinline__ int x6off(int hy, int hx, int c) {
-    return (hy * H6W + hx) * PIX6 + ((c ^ (((hx >> 1) & 1) | ((hy & 3) << 1))) << 4);
-}
-
-__global__ __launch_bounds__(256, 1) void conv3x3_c64_direct_kernel(const DirectArgs p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem6[];
-    unsigned char* const Ws = smem6;
-    unsigned char* const Xs0 = smem6 + W6_BYTES;
-    float* const Tr = reinterpret_cast<float*>(smem6 + W6_BYTES + 2 * X6_BYTES);
+__global__ __launch_bounds__(512, 2) void conv3x3_c64_tile_kernel(const DirectArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem7[];
+    unsigned char* const Xs = smem7;
+    unsigned char* const Ws = smem7 + X7_BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 31, fh = lane >> 5;
-    const int ntiles = p.tiles_x * p.tiles_y * p.batch;
+    const int per_img = p.tiles_x * p.tiles_y;
+    const int ntiles = per_img * p.batch;
 
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), (short)0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), (short)0, p.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, (short)0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res ? p.res : p.y), (short)0, p.x_bytes, 0x00020000);
 
-    // this thread's six halo chunks (180 pixels x 8 chunks = 1,440 = 5.6 per thread): pixel q >> 3, chunk q & 7 - fixed for the launch
-    constexpr int NH = (H6H * H6W * 8 + 255) / 256;
-    int hy[NH], hx[NH], hc[NH];
+    const int h_pc = tid & 7;
+    u32x4 hv[NH7];
+    auto req_halo = [&](int tile) {
+        const int b = tile / per_img, rem = tile - b * per_img;
+        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
 #pragma unroll
-    for (int i = 0; i < NH; ++i) {
-        const int q = tid + 256 * i, P = q >> 3;
-        hc[i] = q & 7;
-        hy[i] = P / H6W; hx[i] = P - hy[i] * H6W;
-    }
-    // TWO tiles' operands in flight in registers (one wave per SIMD: nothing else hides a loaded-HBM round trip of several us, and
-    // one tile of MFMAs is only ~1.2 us): set S holds tile i, i+2, ... of this workgroup
-    u32x4 hv[2][NH], rvn[2][4];
-    unsigned noff[2][4];
-    auto request = [&](auto slot, int tile) __attribute__((always_inline)) {
-        constexpr int S = decltype(slot)::value;
-        int t = tile;
-        const int tx = t % p.tiles_x; t /= p.tiles_x;
-        const int ty = t % p.tiles_y;
-        const int b = t / p.tiles_y;
-#pragma unroll
-        for (int i = 0; i < NH; ++i) {
-            const int iy = ty * T6H - 1 + hy[i], ix = tx * T6W - 1 + hx[i];
-            const bool ok = tile < ntiles && tid + 256 * i < H6H * H6W * 8 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            hv[S][i] = __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? (unsigned)((((b * p.H + iy) * p.W + ix) * C6 + hc[i] * 8) * 2) : OOB, 0, 0);
-        }
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int row = it * 8 + (lane >> 3), chunk = lane & 7;       // 8 pixels x 8 chunks of 8 channels per pass
-            const int oy = ty * T6H + 4 * wave + (row >> 3), ox = tx * T6W + (row & 7);
-            noff[S][it] = (tile < ntiles && oy < p.H && ox < p.W) ? (unsigned)((((b * p.H + oy) * p.W + ox) * C6 + chunk * 8) * 2) : OOB;
-            rvn[S][it] = u32x4{0u, 0u, 0u, 0u};
-            if (p.res) rvn[S][it] = __builtin_amdgcn_raw_buffer_load_b128(rr, noff[S][it], 0, 0);
+        for (int i = 0; i < NH7; ++i) {
+            const int q = tid + 512 * i, P = q >> 3;
+            const int hy = (P * 2521) >> 16, hx = P - hy * H7C;          // P / 26 for P < 512
+            const int iy = ty * T7R - 1 + hy, ix = tx * T7C - 1 + hx;
+            const bool ok = tile < ntiles && q < H7R * H7C * 8 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            hv[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? (unsigned)((((b * p.H + iy) * p.W + ix) * C6 + h_pc * 8) * 2) : OOB, 0, 0);
         }
     };
-    const int G = gridDim.x;
-    request(std::integral_constant<int, 0>{}, blockIdx.x);
-    request(std::integral_constant<int, 1>{}, blockIdx.x + G);
-    // ---- filter -> LDS in fragment order, once per workgroup: fragment (f = tap*4 + ks, nb, kh, n) = W[nb*32 + n][f*16 + kh*8 .. +8] ----
-    for (int q = tid; q < W6_BYTES / 16; q += 256) {
-        const int n = q & 31, kh = (q >> 5) & 1, nb = (q >> 6) & 1, f = q >> 7;
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wr, (unsigned)(((nb * 32 + n) * p.k_pad + f * 16 + kh * 8) * 2), 0, 0);
-        *reinterpret_cast<u32x4*>(Ws + q * 16) = v;
-    }
-    float sc[8], sh[8];                                       // this lane's 8 output channels in the epilogue
-    {
-        const int chunk = lane & 7;
+    auto put_halo = [&]() {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { sc[e] = p.scale ? p.scale[chunk * 8 + e] : 1.f; sh[e] = p.shift ? p.shift[chunk * 8 + e] : 0.f; }
-    }
-    const int py = 4 * wave + (fr >> 3), px = fr & 7;        // output pixel of this lane's A row inside the tile
-    const unsigned char* const wfrag = Ws + (fh * 32 + fr) * 16;
-    float* tr = Tr + wave * (32 * 64);
-    auto body = [&](auto slot, int tile) __attribute__((always_inline)) {
-        constexpr int S = decltype(slot)::value;
-        unsigned char* X = Xs0 + S * X6_BYTES;                 // tiles alternate between the two halo buffers as between the register sets
+        for (int i = 0; i < NH7; ++i) {
+            const int q = tid + 512 * i, P = q >> 3;
+            const int hy = (P * 2521) >> 16, hx = P - hy * H7C;
+            if (q < H7R * H7C * 8) *reinterpret_cast<u32x4*>(Xs + hy * RS7 + hx * PX7 + (h_pc << 4)) = hv[i];
+        }
+    };
+    int tile = blockIdx.x;
+    req_halo(tile);
+    // ---- the whole filter -> LDS, once per workgroup: piece q = (tap, n, pc) <- W[n][tap * 64 + pc * 8 .. + 8] ----
+    {   // (512 threads x 9 = the 4,608 pieces: thread t takes piece (pc, n) = (t & 7, t >> 3) of every tap; all nine loads in flight at once -
+        //  a load -> store loop paid nine HBM / L2 round trips one after the other, and with one tile per workgroup at bs=128 nothing hid them)
+        const int pc = tid & 7, n = tid >> 3;
+        u32x4 wv[9];
 #pragma unroll
-        for (int i = 0; i < NH; ++i)
-            if (tid + 256 * i < H6H * H6W * 8) *reinterpret_cast<u32x4*>(X + x6off(hy[i], hx[i], hc[i])) = hv[S][i];
-        const unsigned ooff[4] = {noff[S][0], noff[S][1], noff[S][2], noff[S][3]};
-        const u32x4 rv[4] = {rvn[S][0], rvn[S][1], rvn[S][2], rvn[S][3]};
-        __syncthreads();                                      // tile `tile` (and, first time round, the filter) is in LDS; the other buffer is free
-        request(slot, tile + 2 * G);                          // the tile after next: its operands fly during two tiles of MFMAs and stores
+        for (int tap = 0; tap < 9; ++tap) wv[tap] = __builtin_amdgcn_raw_buffer_load_b128(wr, (unsigned)((n * p.k_pad + tap * 64 + pc * 8) * 2), 0, 0);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) *reinterpret_cast<u32x4*>(Ws + tap * 8192 + w7off(n, pc)) = wv[tap];
+    }
+    const int g = wave >> 1, h = wave & 1;
+    const int a_r = 4 * g + (fr >> 3), a_c = fr & 7;              // this lane's pixel of a row tile: tile row a_r, column 8 m + a_c
+    const int x_a = a_r * RS7 + a_c * PX7 + (fh << 4);             // + tap offset + 8 m pixels + 32 j
+    int w_f[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w_f[j] = w7off(32 * h + fr, 2 * j + fh);
+    float sc[8], sh[8];                                            // this lane's 8 output channels in the epilogue: 32 h + 8 chunk + e
+    const int chunk = lane & 3;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = p.scale ? p.scale[32 * h + chunk * 8 + e] : 1.f; sh[e] = p.shift ? p.shift[32 * h + chunk * 8 + e] : 0.f; }
+    float* const tr = reinterpret_cast<float*>(smem7) + wave * 1024;   // epilogue transpose: 4 KB per wave inside the (then idle) halo
 
-        f32x16 acc0, acc1;
+    for (; tile < ntiles; tile += gridDim.x) {
+        put_halo();
+        __syncthreads();                                          // halo (and, first time round, the filter) visible; last tile's transposes done
+        req_halo(tile + gridDim.x);
+        const int b = tile / per_img, rem = tile - b * per_img;
+        const int tyy = rem / p.tiles_x, txx = rem - tyy * p.tiles_x;
+        // output offsets and residual of this lane's 6 stores (3 row tiles x 2 passes of 16 pixels x 4 chunks), in flight under the MFMAs
+        unsigned ooff[3][2];
+        u32x4 rv[3][2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-        // 36 steps (tap, 16-channel K step), each one A fragment + two B fragments -> two MFMAs.  One wave per SIMD issues in order, so the
-        // fragments of step s+PF are requested before the MFMAs of step s (a ring of PF+1 register sets; without it every step waits a
-        // full LDS round trip: measured 3.5x the MFMA time).
-        constexpr int PF = 3, NSTEP = 36;
-        u32x4 fa[PF + 1], fb0[PF + 1], fb1[PF + 1];
-        auto frags = [&](int st) __attribute__((always_inline)) {
-            const int tap = st >> 2, ks = st & 3;
-            const int ay = py + tap / 3, ax = px + tap % 3;
-            fa[st % (PF + 1)] = *reinterpret_cast<const u32x4*>(X + x6off(ay, ax, ks * 2 + fh));
-            const unsigned char* wb = wfrag + st * 2048;
-            fb0[st % (PF + 1)] = *reinterpret_cast<const u32x4*>(wb);
-            fb1[st % (PF + 1)] = *reinterpret_cast<const u32x4*>(wb + 1024);
-        };
+        for (int m = 0; m < 3; ++m)
 #pragma unroll
-        for (int st = 0; st < PF; ++st) frags(st);
-#pragma unroll
-        for (int st = 0; st < NSTEP; ++st) {
-            if (st + PF < NSTEP) frags(st + PF);
-            __builtin_amdgcn_sched_barrier(0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[st % (PF + 1)]), __builtin_bit_cast(bf16x8, fb0[st % (PF + 1)]), acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[st % (PF + 1)]), __builtin_bit_cast(bf16x8, fb1[st % (PF + 1)]), acc1, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // ---- epilogue: through the wave's private LDS slice so that a lane owns 8 consecutive channels of one pixel (16-byte stores) ----
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
-            tr[row * 64 + fr] = acc0[r];
-            tr[row * 64 + 32 + fr] = acc1[r];
-        }
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int row = it * 8 + (lane >> 3), chunk = lane & 7;
-            float v[8];
-#pragma unroll
-            for (int e4 = 0; e4 < 2; ++e4) {
-                const f32x4 tt = *reinterpret_cast<const f32x4*>(tr + row * 64 + chunk * 8 + 4 * e4);
-                v[4 * e4] = tt[0]; v[4 * e4 + 1] = tt[1]; v[4 * e4 + 2] = tt[2]; v[4 * e4 + 3] = tt[3];
+            for (int it = 0; it < 2; ++it) {
+                const int row = it * 16 + (lane >> 2);                  // pixel of the 32-pixel row tile
+                const int oy = tyy * T7R + 4 * g + (row >> 3), ox = txx * T7C + 8 * m + (row & 7);
+                ooff[m][it] = (oy < p.H && ox < p.W) ? (unsigned)((((b * p.H + oy) * p.W + ox) * C6 + 32 * h + chunk * 8) * 2) : OOB;
+                rv[m][it] = u32x4{0u, 0u, 0u, 0u};
+                if (p.res) rv[m][it] = __builtin_amdgcn_raw_buffer_load_b128(rr, ooff[m][it], 0, 0);
             }
+        f32x16 acc[3];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
-            if (p.res) {
-                const bf16x8 r8 = __builtin_bit_cast(bf16x8, rv[it]);
+        for (int m = 0; m < 3; ++m)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int toff = (tap / 3) * RS7 + (tap % 3) * PX7;           // compile-time
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u32x4 wb = *reinterpret_cast<const u32x4*>(Ws + tap * 8192 + w_f[j]);
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    const u32x4 xa = *reinterpret_cast<const u32x4*>(Xs + x_a + toff + m * 8 * PX7 + j * 32);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xa), __builtin_bit_cast(bf16x8, wb), acc[m], 0, 0, 0);
+                }
             }
-            if (p.relu) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-            }
-            bf16x8 o8;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o8[e] = (__bf16)v[e];
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o8), yr, ooff[it], 0, 0);
         }
-    };
-    for (int tile = blockIdx.x; tile < ntiles; tile += 2 * G) {
-        body(std::integral_constant<int, 0>{}, tile);
-        if (tile + G < ntiles) body(std::integral_constant<int, 1>{}, tile + G);
+        __syncthreads();                                          // every wave is done with the halo: it becomes the transpose scratch
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + 4 * fh) * 32 + fr] = acc[m][r];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int row = it * 16 + (lane >> 2);
+                float v[8];
+#pragma unroll
+                for (int e4 = 0; e4 < 2; ++e4) {
+                    const f32x4 tt = *reinterpret_cast<const f32x4*>(tr + row * 32 + chunk * 8 + 4 * e4);
+                    v[4 * e4] = tt[0]; v[4 * e4 + 1] = tt[1]; v[4 * e4 + 2] = tt[2]; v[4 * e4 + 3] = tt[3];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+                if (p.res) {
+                    const bf16x8 r8 = __builtin_bit_cast(bf16x8, rv[m][it]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                }
+                bf16x8 o8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o8[e] = (__bf16)v[e];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o8), yr, ooff[m][it], 0, 0);
+            }
+        }
+        __syncthreads();                                          // the transposes are done before the next halo lands
     }
 }
 
@@ -343,8 +334,8 @@ extern "C" int sp_conv3x3_direct(const sp_conv_desc* d, const void* x, const voi
     a.relu = (d->flags & SP_CONV_RELU) ? 1 : 0;
     a.x_bytes = (int)(elems * 2); a.w_bytes = d->n_pad * d->k_pad * 2;
     if (d->c_in == 64) {
-        if (sp_name_query_active()) { sp_name_query_set("conv3x3_c64_direct_kernel"); return SP_OK; }
-        a.tiles_x = (d->in_w + T6W - 1) / T6W; a.tiles_y = (d->in_h + T6H - 1) / T6H;
+        if (sp_name_query_active()) { sp_name_query_set("conv3x3_c64_tile_kernel"); return SP_OK; }
+        a.tiles_x = (d->in_w + T7C - 1) / T7C; a.tiles_y = (d->in_h + T7R - 1) / T7R;
         const long long tiles = (long long)d->batch * a.tiles_x * a.tiles_y;
         SP_REQUIRE(tiles < (1ll << 31), "sp_conv3x3_direct: too many tiles");
         int dev = 0, cus = 256;
@@ -352,12 +343,11 @@ extern "C" int sp_conv3x3_direct(const sp_conv_desc* d, const void* x, const voi
             int v = 0;
             if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
         }
-        // one persistent workgroup per CU (the filter takes 72 KiB of its LDS), walking its tiles with the next halo in flight
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_direct_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS6);
-        if (e != hipSuccess) { sp_set_error("sp_conv3x3_direct: hipFuncSetAttribute(max dynamic LDS = %d) failed: %s", LDS6, hipGetErrorString(e)); return SP_ELAUNCH; }
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS7);
+        if (e != hipSuccess) { sp_set_error("sp_conv3x3_direct: hipFuncSetAttribute(max dynamic LDS = %d) failed: %s", LDS7, hipGetErrorString(e)); return SP_ELAUNCH; }
         const long long grid = tiles < cus ? tiles : cus;
-        hipLaunchKernelGGL(conv3x3_c64_direct_kernel, dim3((unsigned)grid), dim3(256), LDS6, (hipStream_t)stream, a);
-        return sp_check_launch("conv3x3_c64_direct_kernel");
+        hipLaunchKernelGGL(conv3x3_c64_tile_kernel, dim3((unsigned)grid), dim3(512), LDS7, (hipStream_t)stream, a);
+        return sp_check_launch("conv3x3_c64_tile_kernel");
     }
     a.tiles_x = (d->in_w + TW - 1) / TW; a.tiles_y = (d->in_h + TH - 1) / TH;
     const long long blocks = (long long)d->batch * a.tiles_x * a.tiles_y;
