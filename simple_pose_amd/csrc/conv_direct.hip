@@ -1,10 +1,10 @@
-// conv_direct.hip - 3x3 stride-1 convolution for SMALL channel counts (bf16, 32 -> 32 channels: HRNet's high-resolution branch).
-// The implicit GEMM of conv_igemm.hip gathers every input pixel once per tap, i.e. it moves 9x the input through L2 -> CU; with
-// only 32 output channels there is too little MFMA work per byte to hide that (measured: 43 us per layer at bs=128 against a 15 us
-// HBM bound).  Here a workgroup loads the (8+2) x (16+2) pixel halo tile of its 8x16 output tile ONCE into LDS and forms the nine
-// taps from there; the 3x3x32x32 weights live in registers (18 MFMA B fragments per lane).  Same reduction order as the implicit
-// GEMM (tap-major, channel-minor, one v_mfma_f32_32x32x16_bf16 chain per output tile) -> bit-identical results, which is how it
-// is tested.  Replaces nets/pose_hrnet.py BasicBlock convs (conv3x3 + BN [+ residual] + ReLU) on 32-channel branches.
+// conv_direct.hip - 3x3 stride-1 convolutions for SMALL channel counts (bf16; 32 -> 32 and 64 -> 64 channels: HRNet's two high-resolution
+// branches, ResNet's layer1 conv2).  The implicit GEMM of conv_igemm.hip gathers every input pixel once per tap, i.e. it moves 9x the input
+// through L2 -> CU; with 32 / 64 output channels there is too little MFMA work per byte to hide that (measured: 43 us per 32-channel layer at
+// bs=128 against a 15 us HBM bound).  Here a workgroup stages the halo of its 16 x 24-pixel output tile ONCE in LDS (linear, padded pixel rows:
+// a tap is a compile-time offset) and forms the nine taps from there, with the filter staged once per persistent workgroup.  Same reduction
+// order as the implicit GEMM (tap-major, channel-minor, one v_mfma_f32_32x32x16_bf16 chain per output) -> bit-identical results, which is how
+// they are tested.  Replaces the conv3x3 + BN [+ residual] + ReLU of nets/pose_hrnet.py BasicBlocks and nets/pose_resnet_dconv.py:112-120.
 #include "sp_common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -13,10 +13,7 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int TH = 8, TW = 16;                 // output tile (pixels); one wave = two tile rows = 32 pixels
-constexpr int HW_ = TW + 2, HH_ = TH + 2;      // halo tile
 constexpr int CI = 32, CO = 32;
-constexpr int PIX_BYTES = CI * 2;              // 64 B per pixel = 4 chunks of 16 B
 constexpr unsigned OOB = 0x80000000u;
 
 struct DirectArgs {
@@ -31,125 +28,6 @@ struct DirectArgs {
     int relu;
     int x_bytes, w_bytes;
 };
-
-// 16-byte chunk c (0..3) of halo pixel P sits at P*64 + ((c ^ ((P >> 1) & 3)) * 16): eight consecutive pixels reading the same chunk
-// (one ds_read_b128 beat) then cover all eight 16-byte slots of a 128-byte bank row
-__device__ __forceinline__ int xoff(int P, int c) { return P * PIX_BYTES + ((c ^ ((P >> 1) & 3)) << 4); }
-
-__global__ __launch_bounds__(256, 2) void conv3x3_c32_direct_kernel(const DirectArgs p) {
-    __shared__ __attribute__((aligned(16))) unsigned char Xs[2][HH_ * HW_ * PIX_BYTES];   // 2 x 11,520 B: halo tile, double-buffered
-    __shared__ __attribute__((aligned(16))) float Tr[4][32 * 32];                         // epilogue transpose, 4 KB per wave (private)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fr = lane & 31, fh = lane >> 5;
-    const int ntiles = p.tiles_x * p.tiles_y * p.batch;
-
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), (short)0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), (short)0, p.w_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, (short)0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res ? p.res : p.y), (short)0, p.x_bytes, 0x00020000);
-
-    // this thread's three halo chunks: pixel P (of 180), 16-byte chunk c - fixed for the whole launch
-    int hP[3], hc[3], hy[3], hx[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int q = tid + 256 * i;
-        hP[i] = q >> 2; hc[i] = q & 3;
-        hy[i] = hP[i] / HW_; hx[i] = hP[i] - hy[i] * HW_;
-    }
-    u32x4 hv[3], rvn[2];
-    unsigned noff[2];
-    // everything tile `tile` needs from memory -> registers: its halo pixels and the residual behind this lane's two output chunks
-    // (out-of-image / past-the-end: zeros through an out-of-range offset)
-    auto request = [&](int tile) {
-        int t = tile;
-        const int tx = t % p.tiles_x; t /= p.tiles_x;
-        const int ty = t % p.tiles_y;
-        const int b = t / p.tiles_y;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int iy = ty * TH - 1 + hy[i], ix = tx * TW - 1 + hx[i];
-            const bool ok = tile < ntiles && tid + 256 * i < HH_ * HW_ * 4 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            hv[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? (unsigned)((((b * p.H + iy) * p.W + ix) * CI + hc[i] * 8) * 2) : OOB, 0, 0);
-        }
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int row = it * 16 + (lane >> 2), chunk = lane & 3;      // 16 pixels x 4 chunks of 8 channels per pass
-            const int oy = ty * TH + 2 * wave + (row >> 4), ox = tx * TW + (row & 15);
-            noff[it] = (tile < ntiles && oy < p.H && ox < p.W) ? (unsigned)((((b * p.H + oy) * p.W + ox) * CO + chunk * 8) * 2) : OOB;
-            rvn[it] = u32x4{0u, 0u, 0u, 0u};
-            if (p.res) rvn[it] = __builtin_amdgcn_raw_buffer_load_b128(rr, noff[it], 0, 0);
-        }
-    };
-    request(blockIdx.x);
-    // ---- weights -> registers, once per (persistent) workgroup: fragment f = tap*2 + ks: W[n = lane % 32][f*16 + (lane / 32) * 8 .. + 8]
-    u32x4 wf[18];
-#pragma unroll
-    for (int f = 0; f < 18; ++f)
-        wf[f] = __builtin_amdgcn_raw_buffer_load_b128(wr, (unsigned)((fr * p.k_pad + f * 16 + fh * 8) * 2), 0, 0);
-    float sc[8], sh[8];                                       // this lane's 8 output channels in the epilogue
-    {
-        const int chunk = lane & 3;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { sc[e] = p.scale ? p.scale[chunk * 8 + e] : 1.f; sh[e] = p.shift ? p.shift[chunk * 8 + e] : 0.f; }
-    }
-
-    const int py = 2 * wave + (fr >> 4), px = fr & 15;       // output pixel of this lane's A row inside the tile
-    float* tr = Tr[wave];
-    int cur = 0;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, cur ^= 1) {
-        unsigned char* X = Xs[cur];
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-            if (tid + 256 * i < HH_ * HW_ * 4) *reinterpret_cast<u32x4*>(X + xoff(hP[i], hc[i])) = hv[i];
-        const unsigned ooff[2] = {noff[0], noff[1]};          // this tile's output offsets and residual (arrived with its halo)
-        const u32x4 rv[2] = {rvn[0], rvn[1]};
-        __syncthreads();                                      // tile `tile` is in LDS; buffer cur^1 is no longer being read
-        request(tile + gridDim.x);                            // the next tile's operands fly during this tile's MFMAs and stores
-
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int P = (py + tap / 3) * HW_ + px + tap % 3;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const u32x4 a = *reinterpret_cast<const u32x4*>(X + xoff(P, ks * 2 + fh));
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, wf[tap * 2 + ks]), acc, 0, 0, 0);
-            }
-        }
-        // ---- epilogue: C/D map col = lane & 31 (channel), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (pixel of the wave's 32);
-        //      through the wave's private LDS slice so that a lane owns 8 consecutive channels of one pixel (16-byte stores)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + 4 * fh) * 32 + fr] = acc[r];
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int row = it * 16 + (lane >> 2), chunk = lane & 3;
-            float v[8];
-#pragma unroll
-            for (int e4 = 0; e4 < 2; ++e4) {
-                const f32x4 tt = *reinterpret_cast<const f32x4*>(tr + row * 32 + chunk * 8 + 4 * e4);
-                v[4 * e4] = tt[0]; v[4 * e4 + 1] = tt[1]; v[4 * e4 + 2] = tt[2]; v[4 * e4 + 3] = tt[3];
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
-            if (p.res) {
-                const bf16x8 r8 = __builtin_bit_cast(bf16x8, rv[it]);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
-            }
-            if (p.relu) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-            }
-            bf16x8 o8;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o8[e] = (__bf16)v[e];
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o8), yr, ooff[it], 0, 0);
-        }
-    }
-}
 
 // ---- 64 -> 64 channels (HRNet's second branch: 64 of its 293 convs at 32x24; ResNet-50 layer1.*.conv2 at 64x48) -------------------------------
 // Round 4 structure: 8 waves, 16 x 24 pixel tiles.  (The round-2 kernel - 16 x 8 tiles, ONE wave per SIMD: 72 KB filter + two halo buffers = one
@@ -306,6 +184,152 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_tile_kernel(const DirectAr
     }
 }
 
+// ---- 32 -> 32 channels (HRNet's high-resolution branch: 64 of its 293 convs) in the tile structure of the 64-channel kernel above (round 4) ------
+// (The round-1 kernel - 8 x 16 tiles, the filter in 72 registers of every lane, an XOR-swizzled 64-byte pixel image - ran at 20.1-20.5 us per
+// layer at bs=128 against a 15 us HBM floor, bound by its own instruction stream; this one measures 18.2 us, same bits.)
+// 4 waves, 16 x 24 pixel tiles, wave g = rows 4g..4g+3 as three 4 x 8-pixel row tiles (one B fragment, read from LDS, feeds three MFMAs); halo as
+// linear 80-byte pixel rows (64 B + 16 B padding), row stride 128 mod 256 bytes; filter [tap][n][80 B] in LDS; two workgroups per CU.
+constexpr int PX8 = 80;
+constexpr int RS8 = H7C * PX8 + 96;                       // 2,176 = 128 (mod 256)
+constexpr int X8_BYTES = H7R * RS8;                       // 39,168
+constexpr int W8_BYTES = 9 * 32 * 80;                     // 23,040
+constexpr int LDS8 = X8_BYTES + W8_BYTES;                 // 62,208
+constexpr int NH8 = (H7R * H7C * 4 + 255) / 256;          // 16-byte halo pieces per thread (8)
+
+__global__ __launch_bounds__(256, 2) void conv3x3_c32_tile_kernel(const DirectArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
+    unsigned char* const Xs = smem8;
+    unsigned char* const Ws = smem8 + X8_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
+    const int per_img = p.tiles_x * p.tiles_y;
+    const int ntiles = per_img * p.batch;
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), (short)0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), (short)0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, (short)0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res ? p.res : p.y), (short)0, p.x_bytes, 0x00020000);
+
+    const int h_pc = tid & 3;
+    u32x4 hv[NH8];
+    auto req_halo = [&](int tile) {
+        const int b = tile / per_img, rem = tile - b * per_img;
+        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+#pragma unroll
+        for (int i = 0; i < NH8; ++i) {
+            const int q = tid + 256 * i, P = q >> 2;
+            const int hy = (P * 2521) >> 16, hx = P - hy * H7C;          // P / 26 for P < 512
+            const int iy = ty * T7R - 1 + hy, ix = tx * T7C - 1 + hx;
+            const bool ok = tile < ntiles && q < H7R * H7C * 4 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            hv[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? (unsigned)((((b * p.H + iy) * p.W + ix) * CI + h_pc * 8) * 2) : OOB, 0, 0);
+        }
+    };
+    auto put_halo = [&]() {
+#pragma unroll
+        for (int i = 0; i < NH8; ++i) {
+            const int q = tid + 256 * i, P = q >> 2;
+            const int hy = (P * 2521) >> 16, hx = P - hy * H7C;
+            if (q < H7R * H7C * 4) *reinterpret_cast<u32x4*>(Xs + hy * RS8 + hx * PX8 + (h_pc << 4)) = hv[i];
+        }
+    };
+    int tile = blockIdx.x;
+    req_halo(tile);
+    {   // filter -> LDS: 9 taps x 32 rows x 4 pieces = 1,152 pieces; thread t: piece (t & 3) of row (t >> 2) & 31 of taps (t >> 7) + 2 i
+        const int pc = tid & 3, n = (tid >> 2) & 31, t0 = tid >> 7;
+        u32x4 wv[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int tap = t0 + 2 * i;
+            wv[i] = __builtin_amdgcn_raw_buffer_load_b128(wr, tap < 9 ? (unsigned)((n * p.k_pad + tap * 32 + pc * 8) * 2) : OOB, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int tap = t0 + 2 * i;
+            if (tap < 9) *reinterpret_cast<u32x4*>(Ws + (tap * 32 + n) * 80 + (pc << 4)) = wv[i];
+        }
+    }
+    const int g = wave;
+    const int a_r = 4 * g + (fr >> 3), a_c = fr & 7;
+    const int x_a = a_r * RS8 + a_c * PX8 + (fh << 4);             // + tap offset + 8 m pixels + 32 j
+    const int w_b = fr * 80 + (fh << 4);                           // + tap * 2560 + 32 j
+    float sc[8], sh[8];
+    const int chunk = lane & 3;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = p.scale ? p.scale[chunk * 8 + e] : 1.f; sh[e] = p.shift ? p.shift[chunk * 8 + e] : 0.f; }
+    float* const tr = reinterpret_cast<float*>(smem8) + wave * 1024;
+
+    for (; tile < ntiles; tile += gridDim.x) {
+        put_halo();
+        __syncthreads();
+        req_halo(tile + gridDim.x);
+        const int b = tile / per_img, rem = tile - b * per_img;
+        const int tyy = rem / p.tiles_x, txx = rem - tyy * p.tiles_x;
+        unsigned ooff[3][2];
+        u32x4 rv[3][2];
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int row = it * 16 + (lane >> 2);
+                const int oy = tyy * T7R + 4 * g + (row >> 3), ox = txx * T7C + 8 * m + (row & 7);
+                ooff[m][it] = (oy < p.H && ox < p.W) ? (unsigned)((((b * p.H + oy) * p.W + ox) * CO + chunk * 8) * 2) : OOB;
+                rv[m][it] = u32x4{0u, 0u, 0u, 0u};
+                if (p.res) rv[m][it] = __builtin_amdgcn_raw_buffer_load_b128(rr, ooff[m][it], 0, 0);
+            }
+        f32x16 acc[3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int toff = (tap / 3) * RS8 + (tap % 3) * PX8;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const u32x4 wb = *reinterpret_cast<const u32x4*>(Ws + tap * 2560 + w_b + j * 32);
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    const u32x4 xa = *reinterpret_cast<const u32x4*>(Xs + x_a + toff + m * 8 * PX8 + j * 32);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xa), __builtin_bit_cast(bf16x8, wb), acc[m], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + 4 * fh) * 32 + fr] = acc[m][r];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int row = it * 16 + (lane >> 2);
+                float v[8];
+#pragma unroll
+                for (int e4 = 0; e4 < 2; ++e4) {
+                    const f32x4 tt = *reinterpret_cast<const f32x4*>(tr + row * 32 + chunk * 8 + 4 * e4);
+                    v[4 * e4] = tt[0]; v[4 * e4 + 1] = tt[1]; v[4 * e4 + 2] = tt[2]; v[4 * e4 + 3] = tt[3];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+                if (p.res) {
+                    const bf16x8 r8 = __builtin_bit_cast(bf16x8, rv[m][it]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                }
+                bf16x8 o8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o8[e] = (__bf16)v[e];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o8), yr, ooff[m][it], 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 // Eligibility: what the engine checks before it offers this kernel to the tuner (sp_conv3x3_direct_ok) and what the launch re-checks.
@@ -349,12 +373,12 @@ extern "C" int sp_conv3x3_direct(const sp_conv_desc* d, const void* x, const voi
         hipLaunchKernelGGL(conv3x3_c64_tile_kernel, dim3((unsigned)grid), dim3(512), LDS7, (hipStream_t)stream, a);
         return sp_check_launch("conv3x3_c64_tile_kernel");
     }
-    a.tiles_x = (d->in_w + TW - 1) / TW; a.tiles_y = (d->in_h + TH - 1) / TH;
-    const long long blocks = (long long)d->batch * a.tiles_x * a.tiles_y;
-    SP_REQUIRE(blocks < (1ll << 31), "sp_conv3x3_direct: too many tiles");
-    // persistent workgroups: the weights (18 KB per wave) are fetched once per workgroup, the next tile's operands are requested
-    // before the current tile's MFMAs; 2 workgroups per CU are resident (~180 VGPRs: 72 of them hold the weights)
-    const long long grid = blocks < 256 * 2 ? blocks : 256 * 2;
-    hipLaunchKernelGGL(conv3x3_c32_direct_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
-    return sp_check_launch("conv3x3_c32_direct_kernel");
+    if (sp_name_query_active()) { sp_name_query_set("conv3x3_c32_tile_kernel"); return SP_OK; }
+    a.tiles_x = (d->in_w + T7C - 1) / T7C; a.tiles_y = (d->in_h + T7R - 1) / T7R;
+    const long long tiles = (long long)d->batch * a.tiles_x * a.tiles_y;
+    SP_REQUIRE(tiles < (1ll << 31), "sp_conv3x3_direct: too many tiles");
+    // persistent workgroups, two per CU (62 KB of LDS, 190 VGPRs): the filter is staged once per workgroup, the next tile's halo waits in registers
+    const long long grid = tiles < 512 ? tiles : 512;
+    hipLaunchKernelGGL(conv3x3_c32_tile_kernel, dim3((unsigned)grid), dim3(256), LDS8, (hipStream_t)stream, a);
+    return sp_check_launch("conv3x3_c32_tile_kernel");
 }
