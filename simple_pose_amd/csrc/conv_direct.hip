@@ -333,7 +333,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_tile_kernel(const DirectAr
 }  // namespace
 
 // Eligibility: what the engine checks before it offers this kernel to the tuner (sp_conv3x3_direct_ok) and what the launch re-checks.
+bool sp_tile128_ok(const sp_conv_desc* d);               // conv_tile128.hip: the 128-channel tile kernel behind the same entry point
+int sp_tile128_launch(const sp_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift, const void* residual,
+                      void* y, void* stream);
+
 static bool direct_ok(const sp_conv_desc* d) {
+    if (d && d->c_in == 128) return sp_tile128_ok(d);
     if (!d || (d->c_in != 32 && d->c_in != 64)) return false;
     const int c = d->c_in, kp = c == 32 ? 320 : 576;          // k_pad: 9 taps x c, rounded to whole 64-element K tiles
     return (d->flags & SP_CONV_BF16) && !(d->flags & (SP_CONV_OUT_NCHW | SP_CONV_PIXEL_SHUFFLE | SP_CONV_OUT_F32)) &&
@@ -348,8 +353,9 @@ extern "C" int sp_conv3x3_direct_ok(const sp_conv_desc* d) { return direct_ok(d)
 extern "C" int sp_conv3x3_direct(const sp_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift,
                                  const void* residual, void* y, void* stream) {
     SP_REQUIRE(d && x && w_packed && y, "sp_conv3x3_direct: null pointer");
-    SP_REQUIRE(direct_ok(d), "sp_conv3x3_direct: needs a bf16 3x3 stride-1 pad-1 convolution with 32 -> 32 or 64 -> 64 channels (NHWC bf16 out)");
+    SP_REQUIRE(direct_ok(d), "sp_conv3x3_direct: needs a bf16 3x3 stride-1 pad-1 convolution with 32 -> 32, 64 -> 64 or 128 -> 128 channels (NHWC bf16 out)");
     SP_REQUIRE(d->batch > 0, "sp_conv3x3_direct: bad batch");
+    if (d->c_in == 128) return sp_tile128_launch(d, x, w_packed, scale, shift, residual, y, stream);
     const long long elems = (long long)d->batch * d->in_h * d->in_w * d->c_in;
     SP_REQUIRE(elems < (1ll << 29), "sp_conv3x3_direct: tensor too large");
     DirectArgs a;

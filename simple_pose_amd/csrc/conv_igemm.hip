@@ -957,7 +957,7 @@ extern "C" int sp_conv2d_kernel_name(const sp_conv_desc* d, int has_residual, in
     SP_REQUIRE(d && buf && cap > 0, "sp_conv2d_kernel_name: null pointer");
     SP_REQUIRE(variant >= 0 && variant <= 3, "sp_conv2d_kernel_name: variant %d", variant);
     if (variant == 3) {
-        snprintf(buf, (size_t)cap, d->c_in == 64 ? "conv3x3_c64_tile_kernel" : "conv3x3_c32_tile_kernel");
+        snprintf(buf, (size_t)cap, "conv3x3_c%d_tile_kernel", d->c_in);
         return SP_OK;
     }
     void* const dummy = reinterpret_cast<void*>(16);        // never dereferenced: the launch functions return before launching

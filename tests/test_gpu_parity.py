@@ -1722,14 +1722,14 @@ def test_bf16_stem_on_pixel_pairs_vs_fp64(k, pad, H, W):
     assert err < 6e-3, err
 
 
-@pytest.mark.parametrize("C", [32, 64])
+@pytest.mark.parametrize("C", [32, 64, 128])
 @pytest.mark.parametrize("B,H,W,res_on,relu,affine", [(2, 20, 17, True, True, True), (3, 8, 16, False, False, False), (1, 7, 5, True, False, True),
                                                       (5, 33, 47, False, True, True), (128, 64, 48, True, True, True), (128, 32, 24, True, True, True),
-                                                      (300, 16, 8, False, True, True)])
+                                                      (300, 16, 8, False, True, True), (128, 16, 12, True, True, True)])
 def test_direct_3x3_kernels_are_bit_identical_to_the_implicit_gemm(B, H, W, res_on, relu, affine, C):
-    """sp_conv3x3_direct (halo tile through LDS once; 32 channels: filter in registers, 64 channels: filter resident in LDS in fragment
-    order; persistent workgroups) keeps the implicit GEMM's reduction order, so it must reproduce sp_conv2d_fwd bit for bit - ragged
-    tiles, image borders, several tiles per workgroup, with / without scale-shift, residual, ReLU."""
+    """sp_conv3x3_direct (halo tile through LDS once as linear padded pixel rows; 32 / 64 channels: the whole filter resident in LDS,
+    128 channels: streamed per tap; persistent workgroups) keeps the implicit GEMM's reduction order, so it must reproduce sp_conv2d_fwd
+    bit for bit - ragged tiles, image borders, several tiles per workgroup, with / without scale-shift, residual, ReLU."""
     lib, P = _lib.lib(), _lib.ptr
     w = torch.from_numpy(synth.tensor_normal(1, f"d/w{C}", (C, C, 3, 3), std=(2.0 / (9 * C)) ** 0.5))
     scale = torch.from_numpy(synth.tensor_uniform(1, f"d/s{C}", (C,), 0.5, 1.5)).to(DEV) if affine else None
