@@ -27,7 +27,7 @@ extern "C" {
 #define SP_EINVAL (-1)   /* bad argument / unsupported shape (message in sp_last_error) */
 #define SP_ELAUNCH (-2)  /* HIP launch or runtime failure */
 
-#define SP_ABI_VERSION 31
+#define SP_ABI_VERSION 32
 
 /* epilogue / layout flags of sp_conv_desc.flags */
 #define SP_CONV_RELU 0x1u          /* y = max(y, 0) after scale/shift (+ residual) */
@@ -321,6 +321,16 @@ int sp_conv2d_dgrad_bn_bwd_stats2(const sp_conv_desc* desc, const void* dz, cons
                                   const void* bn_y, const void* bn_z, const float* bn_mean, const float* bn_invstd, float* sum_g,
                                   float* sum_g_xhat, const void* bn2_z, const float* bn2_mean, const float* bn2_invstd,
                                   float* sum_g_xhat2, int stats_rows_capacity, void* stream);
+/* The dgrad of a STRIDE-2 conv is a family of launches, one descriptor per output phase (their tap counts differ: 3x3 -> 2x2, 2x1, 1x2, 1x1).
+ * This entry runs the family as ONE launch (blockIdx.y = phase, per-phase geometry / packed weights in the kernel arguments): descs[i] and
+ * w_packed[i] are exactly what sp_conv2d_fwd / sp_conv2d_dgrad_bn_bwd_stats(2) would take phase by phase (same batch, tensors, flags and
+ * tile; 2-4 phases), the partial rows land phase-major as that sequence leaves them, the bits of dx and of the sums are the same.
+ * bn_z NULL: plain dgrad (bn_* / sum_* unused).  Replaces the input-gradient half of `loss.backward()` for nn.Conv2d(stride=2)
+ * (nets/pose_resnet_dconv.py:100-101: conv2 of a stage's first Bottleneck). */
+int sp_conv2d_dgrad_phases(const sp_conv_desc* descs, int n_phases, const void* dz, const void* const* w_packed, const void* accumulate,
+                           void* dx, const void* bn_y, const void* bn_z, const float* bn_mean, const float* bn_invstd, float* sum_g,
+                           float* sum_g_xhat, const void* bn2_z, const float* bn2_mean, const float* bn2_invstd, float* sum_g_xhat2,
+                           int stats_rows_capacity, void* stream);
 /* The fold as the prologue of the pass that consumes it (round 4): sp_bn_fold_apply_nhwc = sp_bn_train_stats_from_conv + sp_bn_apply_nhwc
  * in ONE launch - every workgroup folds the partial rows of its 64-channel slab itself (same order as the stand-alone fold: same bits),
  * the first row stripe publishes mean / invstd / running statistics; sp_bn_fold_bwd_apply_nhwc = sp_bn_bwd_sums_from_conv (+ the same for

@@ -20,7 +20,7 @@ SP_CONV_PIXEL_SHUFFLE = 0x4
 SP_CONV_BF16 = 0x8
 SP_CONV_OUT_F32 = 0x10
 CONV_TILES = ((128, 128), (64, 128), (128, 64), (64, 64), (256, 64), (128, 32))
-ABI_VERSION = 31
+ABI_VERSION = 32
 SP_CONV_KERNEL_IGEMM, SP_CONV_KERNEL_RING, SP_CONV_KERNEL_PW = 0, 1, 2
 RING_TILES = ((256, 256), (256, 128), (128, 256), (256, 64), (128, 128), (192, 128), (192, 256))   # kernel = SP_CONV_KERNEL_RING (bf16)
 
@@ -118,6 +118,7 @@ SYMBOLS = {
     "sp_bn_train_stats_from_conv": (c_int, [_P, _P, c_int, c_int, c_int64, c_int, c_float, c_float, _P, _P, _P, _P, _P]),
     "sp_conv2d_dgrad_bn_bwd_stats": (c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "sp_conv2d_dgrad_bn_bwd_stats2": (c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
+    "sp_conv2d_dgrad_phases": (c_int, [ctypes.POINTER(ConvDesc), c_int, _P, ctypes.POINTER(_P), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "sp_bn_sums_from_conv": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
     "sp_bn_fold_apply_nhwc": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int64, c_float, c_float, _P, _P, _P, _P, c_int64, c_int, c_int, _P, _P, _P, _P, _P]),
     "sp_bn_fold_bwd_apply_nhwc": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, c_int64, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_int, _P]),

@@ -94,6 +94,10 @@ struct ConvArgs {
     const float* bmean2;
     const float* binvstd2;
     float* stats_q2;
+    // ph_n > 0: blockIdx.y walks ph_n phases with their OWN tap geometry / weights (the output phases of a stride-2 conv's dgrad, which differ
+    // in tap counts: one launch instead of one per phase); the fields above with the same names are then unused
+    struct PhaseGeo { const void* w; int taps_h, taps_w, k_pad, dy0, dx0, oy_add, ox_add, pad_; } ph[4];
+    int ph_n;
 };
 
 constexpr int BK = 32;  // floats per K tile (8 chunks of 16 B)
@@ -146,9 +150,17 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
     // ---- phase (transposed conv) ----
     const int phase = blockIdx.y;
     const int py = phase / p.phases_x, px = phase % p.phases_x;
-    const int dy0 = p.dy0 + py, dx0 = p.dx0 + px;
-    const int oy_add = p.oy_add + py, ox_add = p.ox_add + px;
+    int dy0 = p.dy0 + py, dx0 = p.dx0 + px;
+    int oy_add = p.oy_add + py, ox_add = p.ox_add + px;
+    int taps_h = p.taps_h, taps_w = p.taps_w, k_pad = p.k_pad, w_bytes = p.w_bytes;
     const char* __restrict__ wp = reinterpret_cast<const char*>(p.w) + (size_t)phase * p.n_pad * p.k_pad * ES;
+    if (p.ph_n) {                         // (wave-uniform: scalar loads from the kernel arguments)
+        const ConvArgs::PhaseGeo& g = p.ph[phase];
+        dy0 = g.dy0; dx0 = g.dx0; oy_add = g.oy_add; ox_add = g.ox_add;
+        taps_h = g.taps_h; taps_w = g.taps_w; k_pad = g.k_pad;
+        w_bytes = p.n_pad * k_pad * ES;
+        wp = reinterpret_cast<const char*>(g.w);
+    }
 
     // ---- per-row table: one decode per row per workgroup ----
     //   x: byte offset of tap (0,0), channel 0 of this output pixel's receptive field (only used through valid taps)
@@ -165,10 +177,10 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
             e.x = ((b * p.in_h + iy0) * p.in_w + ix0) * p.c_in * ES;
             unsigned msk = 0;
             if (UNIFORM_TAP) {
-                for (int ty = 0; ty < p.taps_h; ++ty)
-                    for (int tx = 0; tx < p.taps_w; ++tx) {
+                for (int ty = 0; ty < taps_h; ++ty)
+                    for (int tx = 0; tx < taps_w; ++tx) {
                         const int iy = iy0 + ty * p.dy_step, ix = ix0 + tx * p.dx_step;
-                        if ((unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w) msk |= 1u << (ty * p.taps_w + tx);
+                        if ((unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w) msk |= 1u << (ty * taps_w + tx);
                     }
             }
             e.y = (int)msk;
@@ -189,7 +201,7 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
     // compiler keeps every load of a tile in flight behind the MFMAs instead of waiting at each exec-mask join.
     constexpr unsigned OOB = 0x80000000u;  // every tensor is < 2 GiB (checked on the host)
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), (short)0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wr_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wp), (short)0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wp), (short)0, w_bytes, 0x00020000);
     const int kc = tid & 7;
     const int srow = tid >> 3;
     // Per staged row: tap-(0,0) byte offset (+ this lane's 16-byte chunk) and the tap validity mask.  Per K tile a load
@@ -206,8 +218,8 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
         a_iy[i] = e.z >> 16;
         a_ix[i] = (int)(short)(e.z & 0xffff);
     }
-    const unsigned b_voff = (unsigned)((srow * p.k_pad + kc * EPC) * ES);
-    const unsigned b_soff0 = (unsigned)n0 * p.k_pad * ES;
+    const unsigned b_voff = (unsigned)((srow * k_pad + kc * EPC) * ES);
+    const unsigned b_soff0 = (unsigned)n0 * k_pad * ES;
 
     // Staging registers.  fp32: one set (a K tile is ~3,000 cycles of MFMA, enough to cover a load).  bf16: a K tile is only
     // 130-500 cycles; the DEEP instantiation of the 64x64 tile (chosen by the launcher for K >= 12 tiles: the long-K,
@@ -228,15 +240,15 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
         t_k0 = k0;
         if (UNIFORM_TAP) {  // c_in % 32 == 0: the whole K tile sits inside one tap (all scalar)
             const int tap = k0 / p.c_in;
-            const int ty = tap / p.taps_w, tx = tap - ty * p.taps_w;
+            const int ty = tap / taps_w, tx = tap - ty * taps_w;
             t_bit = 1u << tap;
             t_shift = ((ty * p.dy_step * p.in_w + tx * p.dx_step) * p.c_in + (k0 - tap * p.c_in)) * ES;
         } else {            // small c_in (stem: NHWC4): every 16-B chunk may be a different tap
             const int q = k0 / EPC + kc;
             const int tap = q / cin_chunks;
             t_coff = (q - tap * cin_chunks) * EPC;
-            const int ty = tap / p.taps_w, tx = tap - ty * p.taps_w;
-            t_ok = ty < p.taps_h;
+            const int ty = tap / taps_w, tx = tap - ty * taps_w;
+            t_ok = ty < taps_h;
             t_ddy = ty * p.dy_step; t_ddx = tx * p.dx_step;
         }
     };
@@ -255,7 +267,7 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
     };
     auto load_b = [&](int i, auto s_tag) {
         constexpr int S = decltype(s_tag)::value;
-        sb[S][i] = __builtin_amdgcn_raw_buffer_load_b128(wr_, b_voff + (unsigned)(32 * i * p.k_pad * ES), b_soff0 + (unsigned)(t_k0 * ES), 0);
+        sb[S][i] = __builtin_amdgcn_raw_buffer_load_b128(wr_, b_voff + (unsigned)(32 * i * k_pad * ES), b_soff0 + (unsigned)(t_k0 * ES), 0);
     };
     auto store_piece = [&](int buf, int o, auto s_tag) {  // o in [0, A_CH + B_CH)
         constexpr int S = decltype(s_tag)::value;
@@ -272,7 +284,7 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
             for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.f;
 
     const int fr = lane & 31, fh = lane >> 5;
-    const int nk = p.k_pad / BKE;
+    const int nk = k_pad / BKE;
 
     // Fragment registers are double-buffered by hand (slot = k-step parity): the ds_reads of k-step j+1 are issued
     // before the MFMAs of k-step j, so LDS latency hides behind ~1000 cycles of matrix work.
@@ -551,7 +563,7 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
             const int ro = rowtab[(wr * WM + it * RPI + rsub) * 4 + 3];
             off[it] = (col_ok && ro >= 0) ? (unsigned)((ro + col_off) * ESO) : OOB;
         }
-        static_assert(!(STATS && BSTATS) && (!BSTATS || !OUT16), "BSTATS: an fp32 gradient store");
+        static_assert(!(STATS && BSTATS) && (!BSTATS || !OUT16 || BF16), "BSTATS: fp32 gradients, or bf16 gradients beside bf16 activations");
         float st_s[(STATS || BSTATS) ? CPL : 1], st_q[(STATS || BSTATS) ? CPL : 1];   // column sums over this lane's rows
         float b_mu[BSTATS ? CPL : 1], b_is[BSTATS ? CPL : 1];
         float st_q2[BSTATS ? CPL : 1], b_mu2[BSTATS ? CPL : 1], b_is2[BSTATS ? CPL : 1];
@@ -563,13 +575,16 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
 #pragma unroll
             for (int e = 0; e < CPL; ++e) { b_mu[e] = 0.f; b_is[e] = 0.f; st_q2[e] = 0.f; b_mu2[e] = 0.f; b_is2[e] = 0.f; }
             if (col_ok) {
-                const f32x4 m4 = *reinterpret_cast<const f32x4*>(p.bmean + col), i4 = *reinterpret_cast<const f32x4*>(p.binvstd + col);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { b_mu[e] = m4[e]; b_is[e] = i4[e]; }
-                if (p.bz2) {
-                    const f32x4 m2 = *reinterpret_cast<const f32x4*>(p.bmean2 + col), i2 = *reinterpret_cast<const f32x4*>(p.binvstd2 + col);
+                for (int e4 = 0; e4 < CPL / 4; ++e4) {
+                    const f32x4 m4 = *reinterpret_cast<const f32x4*>(p.bmean + col + 4 * e4), i4 = *reinterpret_cast<const f32x4*>(p.binvstd + col + 4 * e4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { b_mu2[e] = m2[e]; b_is2[e] = i2[e]; }
+                    for (int e = 0; e < 4; ++e) { b_mu[4 * e4 + e] = m4[e]; b_is[4 * e4 + e] = i4[e]; }
+                    if (p.bz2) {
+                        const f32x4 m2 = *reinterpret_cast<const f32x4*>(p.bmean2 + col + 4 * e4), i2 = *reinterpret_cast<const f32x4*>(p.binvstd2 + col + 4 * e4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { b_mu2[4 * e4 + e] = m2[e]; b_is2[4 * e4 + e] = i2[e]; }
+                    }
                 }
             }
         }
@@ -618,6 +633,10 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
                         for (int e = 0; e < 8; ++e) { const float z = (float)o8[e]; st_s[e] += z; st_q[e] += z * z; }
                     }
                 }
+                if constexpr (BSTATS) {                   // bf16 gradients: the sums are those of the ROUNDED dy (what the BatchNorm backward pass reads)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (float)o8[e];
+                }
             } else {
                 const f32x4 o4 = {v[0], v[1], v[2], v[3]};
                 o = __builtin_bit_cast(u32x4, o4);
@@ -627,35 +646,52 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
                         for (int e = 0; e < 4; ++e) { st_s[e] += v[e]; st_q[e] += v[e] * v[e]; }
                     }
                 }
-                if constexpr (BSTATS) {       // v = dy (complete: the residual input carried the other contributions)
-                    f32x4 yy, zz;
-                    f32x4 z2 = {0.f, 0.f, 0.f, 0.f};
-                    if constexpr (BF16) {     // activations are bf16: 8 bytes per 4 channels at half the fp32 byte offset
-                        const unsigned ho = off[it] == OOB ? OOB : off[it] >> 1;
-                        typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
-                        typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
-                        const bf16x4_ y4 = __builtin_bit_cast(bf16x4_, __builtin_amdgcn_raw_buffer_load_b64(byr, ho, 0, 0));
-                        const bf16x4_ z4 = __builtin_bit_cast(bf16x4_, __builtin_amdgcn_raw_buffer_load_b64(bzr, ho, 0, 0));
+            }
+            if constexpr (BSTATS) {           // v = dy (complete: the residual input carried the other contributions)
+                float yy[CPL], zz[CPL], z2[CPL];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { yy[e] = (float)y4[e]; zz[e] = (float)z4[e]; }
-                        if (p.bz2) {
-                            const bf16x4_ q4 = __builtin_bit_cast(bf16x4_, __builtin_amdgcn_raw_buffer_load_b64(bz2r, ho, 0, 0));
+                for (int e = 0; e < CPL; ++e) z2[e] = 0.f;
+                if constexpr (OUT16) {        // bf16 activations and gradients: same byte offsets, 16 bytes = 8 channels each
+                    const bf16x8 y8 = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(byr, off[it], 0, 0));
+                    const bf16x8 z8 = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(bzr, off[it], 0, 0));
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) z2[e] = (float)q4[e];
-                        }
-                    } else {
-                        yy = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(byr, off[it], 0, 0));
-                        zz = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bzr, off[it], 0, 0));
-                        if (p.bz2) z2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bz2r, off[it], 0, 0));
+                    for (int e = 0; e < 8; ++e) { yy[e] = (float)y8[e]; zz[e] = (float)z8[e]; }
+                    if (p.bz2) {
+                        const bf16x8 q8 = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(bz2r, off[it], 0, 0));
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) z2[e] = (float)q8[e];
                     }
-                    if (off[it] != OOB) {
+                } else if constexpr (BF16) {  // bf16 activations, fp32 gradients: 8 bytes per 4 channels at half the fp32 byte offset
+                    const unsigned ho = off[it] == OOB ? OOB : off[it] >> 1;
+                    typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+                    typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
+                    const bf16x4_ y4 = __builtin_bit_cast(bf16x4_, __builtin_amdgcn_raw_buffer_load_b64(byr, ho, 0, 0));
+                    const bf16x4_ z4 = __builtin_bit_cast(bf16x4_, __builtin_amdgcn_raw_buffer_load_b64(bzr, ho, 0, 0));
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float g = yy[e] > 0.f ? v[e] : 0.f;
-                            st_s[e] += g;
-                            st_q[e] += g * ((zz[e] - b_mu[e]) * b_is[e]);
-                            st_q2[e] += g * ((z2[e] - b_mu2[e]) * b_is2[e]);
-                        }
+                    for (int e = 0; e < 4; ++e) { yy[e] = (float)y4[e]; zz[e] = (float)z4[e]; }
+                    if (p.bz2) {
+                        const bf16x4_ q4 = __builtin_bit_cast(bf16x4_, __builtin_amdgcn_raw_buffer_load_b64(bz2r, ho, 0, 0));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) z2[e] = (float)q4[e];
+                    }
+                } else {
+                    const f32x4 y4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(byr, off[it], 0, 0));
+                    const f32x4 z4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bzr, off[it], 0, 0));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { yy[e] = y4[e]; zz[e] = z4[e]; }
+                    if (p.bz2) {
+                        const f32x4 q4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bz2r, off[it], 0, 0));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) z2[e] = q4[e];
+                    }
+                }
+                if (off[it] != OOB) {
+#pragma unroll
+                    for (int e = 0; e < CPL; ++e) {
+                        const float g = yy[e] > 0.f ? v[e] : 0.f;
+                        st_s[e] += g;
+                        st_q[e] += g * ((zz[e] - b_mu[e]) * b_is[e]);
+                        st_q2[e] += g * ((z2[e] - b_mu2[e]) * b_is2[e]);
                     }
                 }
             }
@@ -771,8 +807,18 @@ int launch_t(const ConvArgs& a, int phases, bool uniform, hipStream_t stream) {
         // at 4; thresholds 12 / 32 K tiles measured on HRNet-W32 and the ResNets); whole trips only: the K-tile count must be a
         // multiple of the ring depth
         constexpr int pf = BM * BN <= 64 * 64 ? 4 : 2;
-        const int nk = a.k_pad / 64;
-        if (nk % pf == 0 && nk >= (BM * BN <= 64 * 64 ? 12 : 32))
+        int nk = a.k_pad / 64;
+        bool whole = nk % pf == 0;
+        if (a.ph_n) {                                  // per-phase K: every phase in whole trips, the longest one long enough
+            nk = 0;
+            whole = true;
+            for (int i = 0; i < a.ph_n; ++i) {
+                const int n = a.ph[i].k_pad / 64;
+                whole = whole && n % pf == 0;
+                nk = n > nk ? n : nk;
+            }
+        }
+        if (whole && nk >= (BM * BN <= 64 * 64 ? 12 : 32))
             return launch_t<BM, BN, WR, WC, BF16, OUT16, STATS, true, BSTATS>(a, phases, uniform, stream);
     }
     if (sp_name_query_active()) {
@@ -812,6 +858,7 @@ int launch_t(const ConvArgs& a, int phases, bool uniform, hipStream_t stream) {
 template <int BM, int BN, int WR, int WC>
 int launch(const ConvArgs& a, int phases, bool uniform, hipStream_t stream) {
     if (a.bz) {                                        // dgrad launch that also reduces the BN backward sums of the tensor it writes
+        if ((a.flags & SP_CONV_BF16) && !(a.flags & SP_CONV_OUT_F32)) return launch_t<BM, BN, WR, WC, true, true, false, false, true>(a, phases, uniform, stream);
         if (a.flags & SP_CONV_BF16) return launch_t<BM, BN, WR, WC, true, false, false, false, true>(a, phases, uniform, stream);
         return launch_t<BM, BN, WR, WC, false, false, false, false, true>(a, phases, uniform, stream);
     }
@@ -838,9 +885,11 @@ static int tile_rows_per_block(int, int) { return 1; }   // partial rows per (ph
 
 struct BnBwdSrc { const void* y; const void* z; const float* mean; const float* invstd; const void* z2; const float* mean2; const float* invstd2; float* q2; };
 
+struct PhaseSet { const sp_conv_desc* descs; const void* const* w; int n; };
+
 static int conv_fwd_impl(const sp_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift,
                          const void* residual, void* y, float* stats_s, float* stats_q, int stats_rows_capacity, void* stream,
-                         const BnBwdSrc* bsrc = nullptr) {
+                         const BnBwdSrc* bsrc = nullptr, const PhaseSet* phs = nullptr) {
     SP_REQUIRE(d && x && w_packed && y, "sp_conv2d_fwd: null pointer");
     SP_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->grid_h > 0 && d->grid_w > 0 && d->c_out > 0,
                "sp_conv2d_fwd: non-positive dimension");
@@ -900,7 +949,27 @@ static int conv_fwd_impl(const sp_conv_desc* d, const void* x, const void* w_pac
     a.by = bsrc ? bsrc->y : nullptr; a.bz = bsrc ? bsrc->z : nullptr; a.bmean = bsrc ? bsrc->mean : nullptr; a.binvstd = bsrc ? bsrc->invstd : nullptr;
     a.bz2 = bsrc ? bsrc->z2 : nullptr; a.bmean2 = bsrc ? bsrc->mean2 : nullptr; a.binvstd2 = bsrc ? bsrc->invstd2 : nullptr; a.stats_q2 = bsrc ? bsrc->q2 : nullptr;
     a.bz_bytes = (int)(out_elems * es);
-    const int phases = d->phases_y * d->phases_x;
+    a.ph_n = 0;
+    int phases = d->phases_y * d->phases_x;
+    if (phs) {                                         // every descriptor was validated on its own by the caller; here: what they must share
+        SP_REQUIRE(phs->n >= 2 && phs->n <= 4 && phases == 1, "sp_conv2d_dgrad_phases: 2-4 single-phase descriptors");
+        for (int i = 0; i < phs->n; ++i) {
+            const sp_conv_desc& q = phs->descs[i];
+            SP_REQUIRE(q.batch == d->batch && q.in_h == d->in_h && q.in_w == d->in_w && q.c_in == d->c_in && q.grid_h == d->grid_h &&
+                           q.grid_w == d->grid_w && q.c_out == d->c_out && q.n_pad == d->n_pad && q.stride == d->stride && q.stride_x == d->stride_x &&
+                           q.dy_step == d->dy_step && q.dx_step == d->dx_step && q.out_h == d->out_h && q.out_w == d->out_w && q.out_c == d->out_c &&
+                           q.oy_mul == d->oy_mul && q.ox_mul == d->ox_mul && q.flags == d->flags && q.phases_y == 1 && q.phases_x == 1 &&
+                           q.kernel == SP_CONV_KERNEL_IGEMM && phs->w[i],
+                       "sp_conv2d_dgrad_phases: descriptor %d differs from descriptor 0 in more than its taps / offsets", i);
+            const bool uq = (q.c_in % bke == 0) && q.taps_h * q.taps_w <= 32;
+            SP_REQUIRE(uq == uniform, "sp_conv2d_dgrad_phases: descriptor %d: tap layout differs", i);
+            a.ph[i].w = phs->w[i];
+            a.ph[i].taps_h = q.taps_h; a.ph[i].taps_w = q.taps_w; a.ph[i].k_pad = q.k_pad;
+            a.ph[i].dy0 = q.dy0; a.ph[i].dx0 = q.dx0; a.ph[i].oy_add = q.oy_add; a.ph[i].ox_add = q.ox_add; a.ph[i].pad_ = 0;
+        }
+        a.ph_n = phs->n;
+        phases = phs->n;
+    }
     hipStream_t s = (hipStream_t)stream;
 
     SP_REQUIRE(d->kernel == SP_CONV_KERNEL_IGEMM || d->kernel == SP_CONV_KERNEL_RING || d->kernel == SP_CONV_KERNEL_PW,
@@ -920,9 +989,8 @@ static int conv_fwd_impl(const sp_conv_desc* d, const void* x, const void* w_pac
     SP_REQUIRE(bn > 0 && np % bn == 0, "sp_conv2d_fwd: tile_n=%d must divide n_pad=%d", bn, np);
     if (bsrc) {
         SP_REQUIRE(stats_s && stats_q && bsrc->y && bsrc->z && bsrc->mean && bsrc->invstd, "sp_conv2d_dgrad_bn_bwd_stats: null pointer");
-        SP_REQUIRE(!(d->flags & (SP_CONV_OUT_NCHW | SP_CONV_PIXEL_SHUFFLE | SP_CONV_RELU)) && (!bf16 || (d->flags & SP_CONV_OUT_F32)) &&
-                       d->c_out % 4 == 0 && !scale && !shift,
-                   "sp_conv2d_dgrad_bn_bwd_stats: needs a plain fp32 NHWC gradient store (SP_CONV_OUT_F32 with bf16 operands)");
+        SP_REQUIRE(!(d->flags & (SP_CONV_OUT_NCHW | SP_CONV_PIXEL_SHUFFLE | SP_CONV_RELU)) && d->c_out % (out16 ? 8 : 4) == 0 && !scale && !shift,
+                   "sp_conv2d_dgrad_bn_bwd_stats: needs a plain NHWC gradient store (fp32: SP_CONV_OUT_F32 with bf16 operands; or bf16, c_out %% 8 == 0)");
         const long long rows = (long long)phases * ((M + bm - 1) / bm) * tile_rows_per_block(bm, bn);
         SP_REQUIRE(rows <= stats_rows_capacity, "sp_conv2d_dgrad_bn_bwd_stats: %lld partial rows needed, capacity %d", rows, stats_rows_capacity);
     } else if (stats_s) {
@@ -1022,4 +1090,31 @@ extern "C" int sp_conv2d_default_tile(const sp_conv_desc* d, int* tile_m, int* t
         if (b >= 1024) { *tile_m = 128; *tile_n = 64; } else { *tile_m = 64; *tile_n = 64; }
     } else { *tile_m = 128; *tile_n = 32; }
     return SP_OK;
+}
+
+// The dgrad of a stride-2 conv is one launch FAMILY: one descriptor per output phase (tap counts differ: 3x3 -> 2x2, 2x1, 1x2, 1x1).  This
+// entry runs the whole family as ONE launch (blockIdx.y = phase, per-phase geometry in the kernel arguments): at 32 images each phase alone
+// fills a fraction of the chip and costs a launch boundary on the step's dependent chain.  Partial rows of the BSTATS epilogue: phase-major,
+// exactly where the one-launch-per-phase sequence puts them.  bn_* all NULL: plain dgrad (accumulate as sp_conv2d_fwd's residual).
+extern "C" int sp_conv2d_dgrad_phases(const sp_conv_desc* descs, int n_phases, const void* dz, const void* const* w_packed, const void* accumulate,
+                                      void* dx, const void* bn_y, const void* bn_z, const float* bn_mean, const float* bn_invstd, float* sum_g,
+                                      float* sum_g_xhat, const void* bn2_z, const float* bn2_mean, const float* bn2_invstd, float* sum_g_xhat2,
+                                      int stats_rows_capacity, void* stream) {
+    SP_REQUIRE(descs && w_packed && n_phases >= 2 && n_phases <= 4, "sp_conv2d_dgrad_phases: 2-4 phase descriptors");
+    SP_REQUIRE(!bn2_z || (bn_z && bn2_mean && bn2_invstd && sum_g_xhat2), "sp_conv2d_dgrad_phases: second BatchNorm needs the first and its own statistics");
+    void* const dummy = reinterpret_cast<void*>(16);
+    for (int i = 0; i < n_phases; ++i) {               // each descriptor through the full argument check of a launch of its own (nothing is launched)
+        const bool outer = sp_name_query_active();
+        if (!outer) sp_name_query_begin();
+        const int rc = conv_fwd_impl(&descs[i], dummy, dummy, nullptr, nullptr, accumulate ? dummy : nullptr, dummy, nullptr, nullptr, 0, nullptr);
+        if (!outer) sp_name_query_end();
+        if (rc != SP_OK) return rc;
+        SP_REQUIRE(descs[i].tile_m == descs[0].tile_m && descs[i].tile_n == descs[0].tile_n, "sp_conv2d_dgrad_phases: the phases share one tile");
+    }
+    const PhaseSet phs = {descs, w_packed, n_phases};
+    if (bn_z) {
+        const BnBwdSrc src = {bn_y, bn_z, bn_mean, bn_invstd, bn2_z, bn2_mean, bn2_invstd, sum_g_xhat2};
+        return conv_fwd_impl(&descs[0], dz, w_packed[0], nullptr, nullptr, accumulate, dx, sum_g, sum_g_xhat, stats_rows_capacity, stream, &src, &phs);
+    }
+    return conv_fwd_impl(&descs[0], dz, w_packed[0], nullptr, nullptr, accumulate, dx, nullptr, nullptr, 0, stream, nullptr, &phs);
 }

@@ -282,6 +282,41 @@ __global__ __launch_bounds__(FOLD_THREADS) void bn_bwd_sums_from_conv_kernel(con
 // so all workgroups of a slab hold the same bits) and then streams its stripe of rows.  Grid = (slabs of 64 channels) x (row stripes);
 // thread = (channel quad, row lane).  The workgroups of stripe 0 publish mean / invstd (saved for backward) and the running statistics.
 // Host side: used while nrows stays small (PoseTrainer.fold_in_consumer_rows); layer1 / the stem keep the stand-alone fold.
+// VW consecutive channels of an NHWC tensor as floats (iv = index in units of VW channels): 16-bit elements come in one 8- or 16-byte
+// load, fp32 in VW / 4 16-byte loads.  The fused passes below walk bf16 tensors 8 channels (16 bytes) per thread: the same pass with
+// 8-byte accesses reaches 3.7 TB/s on layer1's block outputs, with 16-byte accesses 4.5 (tools/bench_bn_passes.py).
+template <bool B16, int VW>
+__device__ __forceinline__ void ldn(const void* p, long long iv, float (&o)[VW]) {
+    if constexpr (B16 && VW == 8) {
+        typedef __bf16 bf16x8_ __attribute__((ext_vector_type(8)));
+        const bf16x8_ v = __builtin_bit_cast(bf16x8_, reinterpret_cast<const u32x4*>(p)[iv]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
+    } else {
+#pragma unroll
+        for (int h = 0; h < VW / 4; ++h) {
+            const f32x4 v = ld4<B16>(p, iv * (VW / 4) + h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[4 * h + e] = v[e];
+        }
+    }
+}
+template <bool B16, int VW>
+__device__ __forceinline__ void stn(void* p, long long iv, const float (&o)[VW]) {
+    if constexpr (B16 && VW == 8) {
+        typedef __bf16 bf16x8_ __attribute__((ext_vector_type(8)));
+        bf16x8_ v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (__bf16)o[e];
+        reinterpret_cast<u32x4*>(p)[iv] = __builtin_bit_cast(u32x4, v);
+    } else {
+#pragma unroll
+        for (int h = 0; h < VW / 4; ++h) st4<B16>(p, iv * (VW / 4) + h, f32x4{o[4 * h], o[4 * h + 1], o[4 * h + 2], o[4 * h + 3]});
+    }
+}
+
+// After the fold (1,024 threads = 16 channel quads x 64 row lanes) the threads regroup as (64 / VW channel groups) x (row lanes) with
+// VW = 4 channels (fp32) or 8 (bf16): 16 bytes per access either way.
 template <bool BF16>
 __global__ __launch_bounds__(FOLD_THREADS) void bn_fold_apply_kernel(const void* __restrict__ z, const float* __restrict__ ps, const float* __restrict__ pq,
                                                                      int nrows, int stride, double M, float eps, float momentum,
@@ -289,24 +324,28 @@ __global__ __launch_bounds__(FOLD_THREADS) void bn_fold_apply_kernel(const void*
                                                                      const void* __restrict__ res, void* __restrict__ y, int C, int relu, long long rows,
                                                                      float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ run_mean,
                                                                      float* __restrict__ run_var) {
+    constexpr int VW = BF16 ? 8 : 4, LPS = SLAB / VW, RLN = FOLD_THREADS / LPS, U = BF16 ? 2 : 4;
     __shared__ float st[2][SLAB];
     const int slab = blockIdx.x, stripe = blockIdx.y, stripes = gridDim.y;
-    const int c0 = slab * SLAB, tid = threadIdx.x, q = tid & 15, rl = tid >> 4;
-    const int c = c0 + 4 * q, C4 = C >> 2, c4 = c >> 2;
+    const int c0 = slab * SLAB, tid = threadIdx.x, qa = tid % LPS, rl = tid / LPS;
+    const int c = c0 + VW * qa, CV = C / VW, cv = c / VW;
     const bool live = c < C;
-    const long long step = (long long)stripes * 64;
-    long long r = (long long)stripe * 64 + rl;
-    // the first four rows of this thread (and gamma / beta) are requested BEFORE the fold: their latency and the prologue's overlap
-    f32x4 v[4], rr[4];
-    f32x4 g = {0.f, 0.f, 0.f, 0.f}, b = g;
+    const long long step = (long long)stripes * RLN;
+    long long r = (long long)stripe * RLN + rl;
+    // the first U rows of this thread (and gamma / beta) are requested BEFORE the fold: their latency and the prologue's overlap
+    float v[U][VW], rr[U][VW], g[VW], b[VW];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
         const long long row = r + u * step;
         const bool ok = live && row < rows;
-        v[u] = ok ? ld4<BF16>(z, row * C4 + c4) : g;
-        rr[u] = (ok && res) ? ld4<BF16>(res, row * C4 + c4) : g;
+#pragma unroll
+        for (int e = 0; e < VW; ++e) { v[u][e] = 0.f; rr[u][e] = 0.f; }
+        if (ok) ldn<BF16, VW>(z, row * CV + cv, v[u]);
+        if (ok && res) ldn<BF16, VW>(res, row * CV + cv, rr[u]);
     }
-    if (live) { g = *reinterpret_cast<const f32x4*>(gamma + c); b = *reinterpret_cast<const f32x4*>(beta + c); }
+#pragma unroll
+    for (int e = 0; e < VW; ++e) { g[e] = 0.f; b[e] = 0.f; }
+    if (live) { ldn<false, VW>(gamma, cv, g); ldn<false, VW>(beta, cv, b); }
     double s0, s1;
     if (fold_slab64(ps, pq, nrows, stride, C, c0, s0, s1)) {
         float mu, is;
@@ -315,35 +354,47 @@ __global__ __launch_bounds__(FOLD_THREADS) void bn_fold_apply_kernel(const void*
     }
     __syncthreads();
     if (!live) return;
-    const f32x4 mu = *reinterpret_cast<const f32x4*>(&st[0][4 * q]), is = *reinterpret_cast<const f32x4*>(&st[1][4 * q]);
-    auto one = [&](f32x4 x, f32x4 rx, long long row) {
-        x = bn_fwd_elem(x, mu, is, g, b);
-        if (res) x += rx;
-        if (relu) {
+    float mu[VW], is[VW];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) x[e] = x[e] > 0.f ? x[e] : 0.f;
+    for (int e = 0; e < VW; ++e) { mu[e] = st[0][VW * qa + e]; is[e] = st[1][VW * qa + e]; }
+    auto one = [&](float (&x)[VW], const float (&rx)[VW], long long row) {
+#pragma unroll
+        for (int h = 0; h < VW / 4; ++h) {
+            const int o = 4 * h;
+            const f32x4 t = bn_fwd_elem(f32x4{x[o], x[o + 1], x[o + 2], x[o + 3]}, f32x4{mu[o], mu[o + 1], mu[o + 2], mu[o + 3]},
+                                        f32x4{is[o], is[o + 1], is[o + 2], is[o + 3]}, f32x4{g[o], g[o + 1], g[o + 2], g[o + 3]},
+                                        f32x4{b[o], b[o + 1], b[o + 2], b[o + 3]});
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[o + e] = t[e];
         }
-        st4<BF16>(y, row * C4 + c4, x);
-    };
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-        if (r + u * step < rows) one(v[u], rr[u], r + u * step);
-    r += 4 * step;
-    for (; r + 3 * step < rows; r += 4 * step) {          // four rows in flight per thread
-#pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = ld4<BF16>(z, (r + u * step) * C4 + c4);
         if (res) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) rr[u] = ld4<BF16>(res, (r + u * step) * C4 + c4);
+            for (int e = 0; e < VW; ++e) x[e] += rx[e];
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < VW; ++e) x[e] = x[e] > 0.f ? x[e] : 0.f;
+        }
+        stn<BF16, VW>(y, row * CV + cv, x);
+    };
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (r + u * step < rows) one(v[u], rr[u], r + u * step);
+    r += U * step;
+    for (; r + (U - 1) * step < rows; r += U * step) {          // U rows in flight per thread
+#pragma unroll
+        for (int u = 0; u < U; ++u) ldn<BF16, VW>(z, (r + u * step) * CV + cv, v[u]);
+        if (res) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) ldn<BF16, VW>(res, (r + u * step) * CV + cv, rr[u]);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) one(v[u], rr[u], r + u * step);
+        for (int u = 0; u < U; ++u) one(v[u], rr[u], r + u * step);
     }
     for (; r < rows; r += step) {
-        const f32x4 x = ld4<BF16>(z, r * C4 + c4);
-        f32x4 rx = {0.f, 0.f, 0.f, 0.f};
-        if (res) rx = ld4<BF16>(res, r * C4 + c4);
-        one(x, rx, r);
+        ldn<BF16, VW>(z, r * CV + cv, v[0]);
+        if (res) ldn<BF16, VW>(res, r * CV + cv, rr[0]);
+        one(v[0], rr[0], r);
     }
 }
 
@@ -358,29 +409,30 @@ __global__ __launch_bounds__(FOLD_THREADS) void bn_fold_bwd_apply_kernel(const v
                                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dgamma2,
                                                                          float* __restrict__ dbeta2, void* __restrict__ dz, void* dres, int dres_accumulate,
                                                                          int C, long long rows) {
+    constexpr int VW = BF16 ? 8 : 4, LPS = SLAB / VW, RLN = FOLD_THREADS / LPS, U = BF16 ? 2 : 4;
     __shared__ float st[2][SLAB];
     const int slab = blockIdx.x, stripe = blockIdx.y, stripes = gridDim.y;
-    const int c0 = slab * SLAB, tid = threadIdx.x, q = tid & 15, rl = tid >> 4;
-    const int c = c0 + 4 * q, C4 = C >> 2, c4 = c >> 2;
+    const int c0 = slab * SLAB, tid = threadIdx.x, qa = tid % LPS, rl = tid / LPS;
+    const int c = c0 + VW * qa, CV = C / VW, cv = c / VW;
     const bool live = c < C;
-    const long long step = (long long)stripes * 64;
-    long long r = (long long)stripe * 64 + rl;
-    // first four rows (dy, z, ReLU source) and the per-channel constants requested before the fold
-    f32x4 g4[4], yy[4], zz[4];
-    f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = mu, ga = mu;
+    const long long step = (long long)stripes * RLN;
+    long long r = (long long)stripe * RLN + rl;
+    // first U rows (dy, z, ReLU source) and the per-channel constants requested before the fold
+    float g4[U][VW], yy[U][VW], zz[U][VW];
+    float mu[VW], is[VW], ga[VW];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
         const long long row = r + u * step;
         const bool ok = live && row < rows;
-        const long long i = row * C4 + c4;
-        g4[u] = ok ? ld4<G16>(dy, i) : mu;
-        zz[u] = ok ? ld4<BF16>(z, i) : mu;
-        yy[u] = (ok && relu_src) ? ld4<BF16>(relu_src, i) : zz[u];
+        const long long i = row * CV + cv;
+#pragma unroll
+        for (int e = 0; e < VW; ++e) { g4[u][e] = 0.f; zz[u][e] = 0.f; yy[u][e] = 0.f; }
+        if (ok) { ldn<G16, VW>(dy, i, g4[u]); ldn<BF16, VW>(z, i, zz[u]); }
+        if (ok && relu_src) ldn<BF16, VW>(relu_src, i, yy[u]);
     }
-    if (live) {
-        mu = *reinterpret_cast<const f32x4*>(mean + c); is = *reinterpret_cast<const f32x4*>(invstd + c);
-        ga = *reinterpret_cast<const f32x4*>(gamma + c);
-    }
+#pragma unroll
+    for (int e = 0; e < VW; ++e) { mu[e] = 0.f; is[e] = 0.f; ga[e] = 0.f; }
+    if (live) { ldn<false, VW>(mean, cv, mu); ldn<false, VW>(invstd, cv, is); ldn<false, VW>(gamma, cv, ga); }
     double s0, s1;
     if (fold_slab64(ps, pq, nrows, stride, C, c0, s0, s1)) {
         const float db = (float)s0, dg = (float)s1;
@@ -393,37 +445,57 @@ __global__ __launch_bounds__(FOLD_THREADS) void bn_fold_bwd_apply_kernel(const v
     }
     __syncthreads();
     if (!live) return;
-    const f32x4 db = *reinterpret_cast<const f32x4*>(&st[0][4 * q]), dg = *reinterpret_cast<const f32x4*>(&st[1][4 * q]);
-    auto one = [&](f32x4 g, f32x4 ys, f32x4 zs, long long row) {
+    float db[VW], dg[VW];
+#pragma unroll
+    for (int e = 0; e < VW; ++e) { db[e] = st[0][VW * qa + e]; dg[e] = st[1][VW * qa + e]; }
+    auto one = [&](float (&g)[VW], const float (&ys)[VW], const float (&zs)[VW], long long row) {
         if (relu_src) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] = ys[e] > 0.f ? g[e] : 0.f;
+            for (int e = 0; e < VW; ++e) g[e] = ys[e] > 0.f ? g[e] : 0.f;
         }
-        const f32x4 o = bn_bwd_elem(g, zs, mu, is, ga, dg, db, inv_m);
-        st4<BF16>(dz, row * C4 + c4, o);
+        float o[VW];
+#pragma unroll
+        for (int h = 0; h < VW / 4; ++h) {
+            const int k = 4 * h;
+            const f32x4 t = bn_bwd_elem(f32x4{g[k], g[k + 1], g[k + 2], g[k + 3]}, f32x4{zs[k], zs[k + 1], zs[k + 2], zs[k + 3]},
+                                        f32x4{mu[k], mu[k + 1], mu[k + 2], mu[k + 3]}, f32x4{is[k], is[k + 1], is[k + 2], is[k + 3]},
+                                        f32x4{ga[k], ga[k + 1], ga[k + 2], ga[k + 3]}, f32x4{dg[k], dg[k + 1], dg[k + 2], dg[k + 3]},
+                                        f32x4{db[k], db[k + 1], db[k + 2], db[k + 3]}, inv_m);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[k + e] = t[e];
+        }
+        stn<BF16, VW>(dz, row * CV + cv, o);
         if (dres) {
-            if (dres_accumulate) { f32x4 t = ld4<G16>(dres, row * C4 + c4); t += g; st4<G16>(dres, row * C4 + c4, t); } else st4<G16>(dres, row * C4 + c4, g);
+            if (dres_accumulate) {
+                float t[VW];
+                ldn<G16, VW>(dres, row * CV + cv, t);
+#pragma unroll
+                for (int e = 0; e < VW; ++e) t[e] += g[e];
+                stn<G16, VW>(dres, row * CV + cv, t);
+            } else stn<G16, VW>(dres, row * CV + cv, g);
         }
     };
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < U; ++u)
         if (r + u * step < rows) one(g4[u], yy[u], zz[u], r + u * step);
-    r += 4 * step;
-    for (; r + 3 * step < rows; r += 4 * step) {
+    r += U * step;
+    for (; r + (U - 1) * step < rows; r += U * step) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const long long i = (r + u * step) * C4 + c4;
-            g4[u] = ld4<G16>(dy, i);
-            zz[u] = ld4<BF16>(z, i);
-            yy[u] = relu_src ? ld4<BF16>(relu_src, i) : zz[u];
+        for (int u = 0; u < U; ++u) {
+            const long long i = (r + u * step) * CV + cv;
+            ldn<G16, VW>(dy, i, g4[u]);
+            ldn<BF16, VW>(z, i, zz[u]);
+            if (relu_src) ldn<BF16, VW>(relu_src, i, yy[u]);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) one(g4[u], yy[u], zz[u], r + u * step);
+        for (int u = 0; u < U; ++u) one(g4[u], yy[u], zz[u], r + u * step);
     }
     for (; r < rows; r += step) {
-        const long long i = r * C4 + c4;
-        const f32x4 g = ld4<G16>(dy, i), zs = ld4<BF16>(z, i);
-        one(g, relu_src ? ld4<BF16>(relu_src, i) : zs, zs, r);
+        const long long i = r * CV + cv;
+        ldn<G16, VW>(dy, i, g4[0]);
+        ldn<BF16, VW>(z, i, zz[0]);
+        if (relu_src) ldn<BF16, VW>(relu_src, i, yy[0]);
+        one(g4[0], yy[0], zz[0], r);
     }
 }
 
@@ -438,22 +510,35 @@ __global__ void pair_sum_final_f64_kernel(const double* __restrict__ part, int n
     sums[2 * c + 1] = s1;
 }
 
-// y = [relu]( (z - mean) * invstd * gamma + beta [+ res] )
-template <bool BF16>
+// y = [relu]( (z - mean) * invstd * gamma + beta [+ res] ); a thread owns VW channels of a row (bf16: 8 = 16 bytes when c % 8 == 0)
+template <bool BF16, int VW>
 __global__ void bn_apply_kernel(const void* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ invstd,
                                 const float* __restrict__ gamma, const float* __restrict__ beta, const void* __restrict__ res,
-                                void* __restrict__ y, int C4, int relu, long long total) {
+                                void* __restrict__ y, int CV, int relu, long long total) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % C4);
-        const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c4], is = reinterpret_cast<const f32x4*>(invstd)[c4];
-        const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[c4], b = reinterpret_cast<const f32x4*>(beta)[c4];
-        f32x4 v = bn_fwd_elem(ld4<BF16>(z, i), mu, is, g, b);
-        if (res) { const f32x4 r = ld4<BF16>(res, i); v += r; }
+        const int cv = (int)(i % CV);
+        float mu[VW], is[VW], g[VW], b[VW], x[VW], r[VW];
+        ldn<false, VW>(mean, cv, mu); ldn<false, VW>(invstd, cv, is); ldn<false, VW>(gamma, cv, g); ldn<false, VW>(beta, cv, b);
+        ldn<BF16, VW>(z, i, x);
+        if (res) ldn<BF16, VW>(res, i, r);
+#pragma unroll
+        for (int h = 0; h < VW / 4; ++h) {
+            const int o = 4 * h;
+            const f32x4 t = bn_fwd_elem(f32x4{x[o], x[o + 1], x[o + 2], x[o + 3]}, f32x4{mu[o], mu[o + 1], mu[o + 2], mu[o + 3]},
+                                        f32x4{is[o], is[o + 1], is[o + 2], is[o + 3]}, f32x4{g[o], g[o + 1], g[o + 2], g[o + 3]},
+                                        f32x4{b[o], b[o + 1], b[o + 2], b[o + 3]});
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[o + e] = t[e];
+        }
+        if (res) {
+#pragma unroll
+            for (int e = 0; e < VW; ++e) x[e] += r[e];
+        }
         if (relu) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            for (int e = 0; e < VW; ++e) x[e] = x[e] > 0.f ? x[e] : 0.f;
         }
-        st4<BF16>(y, i, v);
+        stn<BF16, VW>(y, i, x);
     }
 }
 
@@ -504,27 +589,43 @@ __global__ void bn_apply_sums_kernel(const void* __restrict__ z, const double* _
 }
 
 // g = dy * (y > 0);  dz = gamma*invstd * (g - dbeta/M - xhat * dgamma/M);  dres (+)= g
-template <bool BF16, bool G16>   // BF16: z, relu_src, dz;  G16: dy, dres
+template <bool BF16, bool G16, int VW>   // BF16: z, relu_src, dz;  G16: dy, dres;  VW channels per thread
 __global__ void bn_bwd_apply_kernel(const void* __restrict__ dy, const void* __restrict__ relu_src, const void* __restrict__ z,
                                     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const float* __restrict__ dgamma, const float* __restrict__ dbeta, float inv_m, void* __restrict__ dz,
-                                    void* dres, int dres_accumulate, int C4, long long total) {
+                                    void* dres, int dres_accumulate, int CV, long long total) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % C4);
-        const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c4], is = reinterpret_cast<const f32x4*>(invstd)[c4];
-        const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[c4];
-        const f32x4 dg = reinterpret_cast<const f32x4*>(dgamma)[c4], db = reinterpret_cast<const f32x4*>(dbeta)[c4];
-        f32x4 g = ld4<G16>(dy, i);
+        const int cv = (int)(i % CV);
+        float mu[VW], is[VW], ga[VW], dg[VW], db[VW], g[VW], zz[VW], o[VW];
+        ldn<false, VW>(mean, cv, mu); ldn<false, VW>(invstd, cv, is); ldn<false, VW>(gamma, cv, ga);
+        ldn<false, VW>(dgamma, cv, dg); ldn<false, VW>(dbeta, cv, db);
+        ldn<G16, VW>(dy, i, g);
         if (relu_src) {
-            const f32x4 y = ld4<BF16>(relu_src, i);
+            float yv[VW];
+            ldn<BF16, VW>(relu_src, i, yv);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] = y[e] > 0.f ? g[e] : 0.f;
+            for (int e = 0; e < VW; ++e) g[e] = yv[e] > 0.f ? g[e] : 0.f;
         }
-        const f32x4 zz = ld4<BF16>(z, i);
-        const f32x4 o = bn_bwd_elem(g, zz, mu, is, ga, dg, db, inv_m);
-        st4<BF16>(dz, i, o);
+        ldn<BF16, VW>(z, i, zz);
+#pragma unroll
+        for (int h = 0; h < VW / 4; ++h) {
+            const int k = 4 * h;
+            const f32x4 t = bn_bwd_elem(f32x4{g[k], g[k + 1], g[k + 2], g[k + 3]}, f32x4{zz[k], zz[k + 1], zz[k + 2], zz[k + 3]},
+                                        f32x4{mu[k], mu[k + 1], mu[k + 2], mu[k + 3]}, f32x4{is[k], is[k + 1], is[k + 2], is[k + 3]},
+                                        f32x4{ga[k], ga[k + 1], ga[k + 2], ga[k + 3]}, f32x4{dg[k], dg[k + 1], dg[k + 2], dg[k + 3]},
+                                        f32x4{db[k], db[k + 1], db[k + 2], db[k + 3]}, inv_m);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[k + e] = t[e];
+        }
+        stn<BF16, VW>(dz, i, o);
         if (dres) {
-            if (dres_accumulate) { f32x4 r = ld4<G16>(dres, i); r += g; st4<G16>(dres, i, r); } else st4<G16>(dres, i, g);
+            if (dres_accumulate) {
+                float t[VW];
+                ldn<G16, VW>(dres, i, t);
+#pragma unroll
+                for (int e = 0; e < VW; ++e) t[e] += g[e];
+                stn<G16, VW>(dres, i, t);
+            } else stn<G16, VW>(dres, i, g);
         }
     }
 }
@@ -881,6 +982,7 @@ extern "C" int sp_bn_fold_apply_nhwc(const void* z, int bf16, const float* stats
     SP_REQUIRE(rows > 0 && total_rows >= rows && c > 0 && c % 4 == 0 && partial_rows > 0 && stride >= c && stride % 4 == 0 && rows < (1ll << 31),
                "sp_bn_fold_apply_nhwc: bad shape");
     SP_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "sp_bn_fold_apply_nhwc: running stats come in pairs");
+    SP_REQUIRE(!(bf16 & 1) || c % 8 == 0, "sp_bn_fold_apply_nhwc: bf16 tensors are walked 8 channels at a time (c %% 8 == 0)");
     const int slabs = (c + SLAB - 1) / SLAB;
     const dim3 grid(slabs, fold_stripes(rows, slabs, partial_rows));
     if (bf16 & 1) hipLaunchKernelGGL(bn_fold_apply_kernel<true>, grid, dim3(FOLD_THREADS), 0, (hipStream_t)stream, z, stats_sum, stats_sumsq, partial_rows, stride,
@@ -900,6 +1002,7 @@ extern "C" int sp_bn_fold_bwd_apply_nhwc(const void* dy, int bf16, const void* r
                "sp_bn_fold_bwd_apply_nhwc: bad shape");
     const bool a16 = bf16 & 1, g16 = bf16 & 2;
     SP_REQUIRE(a16 || !g16, "sp_bn_fold_bwd_apply_nhwc: bf16 gradients with fp32 activations is not a supported mix");
+    SP_REQUIRE(!a16 || c % 8 == 0, "sp_bn_fold_bwd_apply_nhwc: bf16 tensors are walked 8 channels at a time (c %% 8 == 0)");
     const int slabs = (c + SLAB - 1) / SLAB;
     const dim3 grid(slabs, fold_stripes(rows, slabs, partial_rows));
     hipStream_t s = (hipStream_t)stream;
@@ -918,10 +1021,16 @@ extern "C" int sp_bn_apply_nhwc(const void* z, int bf16, const float* mean, cons
                                 const void* residual, void* y, int64_t rows, int c, int relu, void* stream) {
     SP_REQUIRE(z && mean && invstd && gamma && beta && y, "sp_bn_apply_nhwc: null pointer");
     SP_REQUIRE(rows > 0 && c > 0 && c % 4 == 0, "sp_bn_apply_nhwc: bad shape");
+    if ((bf16 & 1) && c % 8 == 0) {
+        const long long total = rows * (c / 8);
+        hipLaunchKernelGGL((bn_apply_kernel<true, 8>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, z, mean, invstd, gamma, beta, residual, y,
+                           c / 8, relu, total);
+        return sp_check_launch("bn_apply_kernel");
+    }
     const long long total = rows * (c / 4);
-    if (bf16 & 1) hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, z, mean, invstd, gamma, beta,
-                                 residual, y, c / 4, relu, total);
-    else hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, z, mean, invstd, gamma, beta,
+    if (bf16 & 1) hipLaunchKernelGGL((bn_apply_kernel<true, 4>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, z, mean, invstd, gamma, beta,
+                                     residual, y, c / 4, relu, total);
+    else hipLaunchKernelGGL((bn_apply_kernel<false, 4>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, z, mean, invstd, gamma, beta,
                             residual, y, c / 4, relu, total);
     return sp_check_launch("bn_apply_kernel");
 }
@@ -963,13 +1072,16 @@ extern "C" int sp_bn_train_bwd_apply_nhwc(const void* dy, int bf16, const void* 
     hipStream_t s = (hipStream_t)stream;
     const bool a16 = bf16 & 1, g16 = bf16 & 2;
     SP_REQUIRE(a16 || !g16, "sp_bn_train_bwd_apply_nhwc: bf16 gradients with fp32 activations is not a supported mix");
-    const long long total = rows * (c / 4);
-#define SP_BWD_APPLY(A, G)                                                                                                             \
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<A, G>), dim3(grid_for(total, 256)), dim3(256), 0, s, dy, relu_src, z, mean, invstd, gamma, sum_dgamma, \
-                       sum_dbeta, (float)(1.0 / (double)total_rows), dz, dres, dres_accumulate, c / 4, total)
-    if (a16 && g16) SP_BWD_APPLY(true, true);
-    else if (a16) SP_BWD_APPLY(true, false);
-    else SP_BWD_APPLY(false, false);
+    const int vw = (a16 && c % 8 == 0) ? 8 : 4;
+    const long long total = rows * (c / vw);
+#define SP_BWD_APPLY(A, G, V)                                                                                                                \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<A, G, V>), dim3(grid_for(total, 256)), dim3(256), 0, s, dy, relu_src, z, mean, invstd, gamma, sum_dgamma, \
+                       sum_dbeta, (float)(1.0 / (double)total_rows), dz, dres, dres_accumulate, c / V, total)
+    if (a16 && g16 && vw == 8) SP_BWD_APPLY(true, true, 8);
+    else if (a16 && g16) SP_BWD_APPLY(true, true, 4);
+    else if (a16 && vw == 8) SP_BWD_APPLY(true, false, 8);
+    else if (a16) SP_BWD_APPLY(true, false, 4);
+    else SP_BWD_APPLY(false, false, 4);
 #undef SP_BWD_APPLY
     return sp_check_launch("bn_train_bwd_apply");
 }

@@ -16,6 +16,7 @@ the kernels read are regenerated on the device after every update (sp_permute4_f
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional, Tuple
 
@@ -126,6 +127,8 @@ class Act:
     bstats: Optional[tuple] = None     # backward: (partial sums [2, rows, stride], rows) left by the dgrad launch that wrote .grad
     bn2: Optional[tuple] = None        # block output with a projection shortcut: (z, mean, invstd, bn name) of the shortcut's BatchNorm, whose
                                        # dy is this output's g: its sum g * xhat rides on the same dgrad epilogue (part[2])
+    grad_event: Optional[object] = None    # backward: .grad's first share was written on the branch stream; whoever touches .grad next waits
+    deferred: list = field(default_factory=list)   # ... and then runs these (the branch's weight-gradient jobs, queued on the main stream)
 
 
 @dataclass
@@ -225,7 +228,7 @@ class ConvT:
             g.oy_mul = g.ox_mul = 1
             g.oy_add = g.ox_add = 0
             g.phases_y = g.phases_x = 1
-            g.flags = fbf | (SP_CONV_OUT_F32 if self.bf16 else 0)   # activation gradients stay fp32
+            g.flags = fbf | (SP_CONV_OUT_F32 if (self.bf16 and not tr.g16) else 0)   # activation gradients: fp32 unless grad_dtype is bf16
             self.d_dgrad = [g]
             self.dgrad_full_cover = True
             # wgrad: dW[ci][co][ky][kx] = sum_m x[m][ci] * dy[(2iy-1+ky, 2ix-1+kx)][co]: g = x, a = dy gathered like the dgrad conv
@@ -269,7 +272,7 @@ class ConvT:
             g.oy_mul = g.ox_mul = 1
             g.oy_add = g.ox_add = 0
             g.phases_y = g.phases_x = 1
-            g.flags = fbf | (SP_CONV_OUT_F32 if self.bf16 else 0)
+            g.flags = fbf | (SP_CONV_OUT_F32 if (self.bf16 and not self.tr.g16) else 0)
             self.w_dgrad.append(wd); self.d_dgrad.append(g)
             self.dgrad_full_cover = True
         else:
@@ -296,7 +299,7 @@ class ConvT:
                     g.out_h, g.out_w, g.out_c = self.h, self.w, I
                     g.oy_mul, g.oy_add, g.ox_mul, g.ox_add = 2, py, 2, px
                     g.phases_y = g.phases_x = 1
-                    g.flags = fbf | (SP_CONV_OUT_F32 if self.bf16 else 0)
+                    g.flags = fbf | (SP_CONV_OUT_F32 if (self.bf16 and not self.tr.g16) else 0)
                     self.w_dgrad.append(wd); self.d_dgrad.append(g)
 
     # ---- launches ----
@@ -364,10 +367,18 @@ class ConvT:
                 assert self.dgrad_full_cover
                 dx = acc
             else:
-                dx = self._new((B, d0.out_h, d0.out_w, d0.out_c), torch.float32, dz.device, zero=not self.dgrad_full_cover)
+                dx = self._new((B, d0.out_h, d0.out_w, d0.out_c), self.tr.grad_dtype, dz.device, zero=not self.dgrad_full_cover)
+            one = len(self.d_dgrad) > 1 and self.dgrad_full_cover and self.one_launch_phases
+            if one and d0.tile_m == 0:
+                d0.batch = B
+                tm, tn = ctypes.c_int(0), ctypes.c_int(0)
+                _lib.check(lib.sp_conv2d_default_tile(d0, ctypes.byref(tm), ctypes.byref(tn)), self.name + ".dgrad")
+                d0.tile_m, d0.tile_n = tm.value, tn.value
             need = []
             for d in self.d_dgrad:
                 d.batch = B
+                if one:
+                    d.tile_m, d.tile_n = d0.tile_m, d0.tile_n      # one launch: one tile shape (and its partial-row count) for every phase
                 r = ctypes.c_int(0)
                 _lib.check(lib.sp_conv2d_bn_stats_rows(d, ctypes.byref(r)), self.name + ".dgrad")
                 need.append(r.value)
@@ -377,6 +388,16 @@ class ConvT:
             z, mean, invstd = bn_src.bn
             row0 = 0
             done = self._timed("dgrad")
+            if one:
+                # a stride-2 conv's output phases (different tap counts) as ONE launch: same rows, same bits, three launch boundaries less
+                descs, ws_ = self._phase_arrays()
+                z2, mean2, invstd2 = (bn_src.bn2[:3] if two else (None, None, None))
+                _lib.check(lib.sp_conv2d_dgrad_phases(descs, len(self.d_dgrad), P(dz), ws_, P(acc), P(dx), P(bn_src.data), P(z), P(mean), P(invstd),
+                                                      P(part[0]), P(part[1]), P(z2), P(mean2), P(invstd2), P(part[2]) if two else None, total,
+                                                      _lib.current_stream()), self.name + ".dgrad")
+                done()
+                bn_src.bstats = (part, total)
+                return dx
             for d, w, n in zip(self.d_dgrad, self.w_dgrad, need):
                 if two:
                     z2, mean2, invstd2, _ = bn_src.bn2
@@ -394,16 +415,37 @@ class ConvT:
         if acc is None:
             d0 = self.d_dgrad[0]
             shape = (B, d0.out_h, d0.out_w, d0.out_c)
-            acc_t = self._new(shape, torch.float32, dz.device, zero=not self.dgrad_full_cover)
+            acc_t = self._new(shape, self.tr.grad_dtype, dz.device, zero=not self.dgrad_full_cover)
             res = None
         else:
             acc_t, res = acc, acc
         done = self._timed("dgrad")
+        if len(self.d_dgrad) > 1 and self.dgrad_full_cover and self.one_launch_phases:
+            for d in self.d_dgrad:
+                d.batch = B
+            descs, ws_ = self._phase_arrays()
+            _lib.check(lib.sp_conv2d_dgrad_phases(descs, len(self.d_dgrad), P(dz), ws_, P(res), P(acc_t), None, None, None, None, None, None, None,
+                                                  None, None, None, 0, _lib.current_stream()), self.name + ".dgrad")
+            done()
+            return acc_t
         for d, w in zip(self.d_dgrad, self.w_dgrad):
             d.batch = B
             _lib.check(lib.sp_conv2d_fwd(d, P(dz), P(w), None, None, P(res), P(acc_t), _lib.current_stream()), self.name + ".dgrad")
         done()
         return acc_t
+
+    one_launch_phases = os.environ.get("SP_PHASES_ONE_LAUNCH", "1") != "0"        # (env: development knob)
+
+    def _phase_arrays(self):
+        """The phase descriptors as one contiguous C array (+ their packed-weight pointers) for sp_conv2d_dgrad_phases; all phases run the
+        tile of phase 0 (the 2x2-tap phase, three quarters of the work)."""
+        n = len(self.d_dgrad)
+        arr = (ConvDesc * n)()
+        for i, d in enumerate(self.d_dgrad):
+            ctypes.memmove(ctypes.byref(arr[i]), ctypes.byref(d), ctypes.sizeof(ConvDesc))
+            arr[i].tile_m, arr[i].tile_n = self.d_dgrad[0].tile_m, self.d_dgrad[0].tile_n
+        ws_ = (_lib.c_void_p * n)(*[w.data_ptr() for w in self.w_dgrad])
+        return arr, ws_
 
     def wgrad_job(self, x: torch.Tensor, dz: torch.Tensor, B: int, job: Optional["_lib.WgradJob"] = None) -> "_lib.WgradJob":
         """This layer's record of a sp_conv2d_wgrad_batched call (conv: g = dz, a = x; transposed conv: g = x, a = dz)."""
@@ -436,7 +478,7 @@ class PoseTrainer:
     def __init__(self, model, in_h: int = 256, in_w: int = 192, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  process_group=None, dtype: str = "fp32", sync_bn: Optional[bool] = None, bucket_mb: float = 32.0,
                  broadcast_init: bool = True, overlap_wgrad: bool = True, collectives: bool = True, sync_bn_latency_us: float = 0.0,
-                 native_comm: Optional[bool] = None, sync_bn_inline: bool = True):
+                 native_comm: Optional[bool] = None, sync_bn_inline: bool = True, grad_dtype: Optional[str] = None):
         """dtype "bf16": bf16 activations and packed weights (v_mfma_f32_32x32x16_bf16 for forward, dgrad and wgrad); the
         gradient w.r.t. a block output stays fp32 until the BatchNorm backward has subtracted its per-channel mean (rounding
         it to bf16 first costs 10-50 % gradient error in this net: the useful part is a small difference of large terms), the
@@ -462,16 +504,34 @@ class PoseTrainer:
         if getattr(model, "HEAD", None) not in ("dconv", "duc", "hrnet"):
             raise NotImplementedError("PoseTrainer lowers the ResNet DConv / DUC nets (the DDP solver's models, ddp...:65-68) and HRNet")
         self.head = model.HEAD
+        # dtype of the activation gradients (dy of every conv output / block output).  "fp32": the round 1-3 behaviour.  "bf16" (with
+        # dtype "bf16" only; the default there for the nets whose backward kernels all read it): what torch's autocast keeps - the
+        # dgrad launches store bf16 and accumulate the residual share in bf16, the BatchNorm backward reads it rounded.
+        has_se = any(".se." in k for k in model.state_dict())
+        can16 = self.bf16 and self.head == "dconv" and not has_se
+        import os
+        if grad_dtype is None:
+            grad_dtype = os.environ.get("SP_GRAD_DTYPE") or ("bf16" if can16 else "fp32")
+            if grad_dtype == "bf16" and not can16:
+                grad_dtype = "fp32"
+        if grad_dtype not in ("fp32", "bf16"):
+            raise ValueError(grad_dtype)
+        if grad_dtype == "bf16" and not can16:
+            raise NotImplementedError("grad_dtype='bf16' needs dtype='bf16' and the plain ResNet DConv net (the DUC / SELayer / HRNet backward "
+                                      "kernels read fp32 gradients)")
+        self.g16 = grad_dtype == "bf16"
+        self.grad_dtype = torch.bfloat16 if self.g16 else torch.float32
         if getattr(model, "BLOCK", "bottleneck") != "bottleneck":
             raise NotImplementedError("PoseTrainer lowers the Bottleneck ResNets (resnet50 / 101 / 152, wide_resnet*_2) and HRNet; the BasicBlock "
                                       "nets (resnet18 / resnet34) run the eval-mode forward only")
         self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
         self.pg = process_group
         self.overlap_wgrad = overlap_wgrad
-        import os
         if os.environ.get("SP_FOLD_ROWS"):                              # (development knob)
             self.fold_in_consumer_rows = int(os.environ["SP_FOLD_ROWS"])
         self._wgrad_stream = None
+        self._branch_stream = None
+        self.overlap_shortcut = os.environ.get("SP_BRANCH", "1") != "0"        # (env: development knob)
         self._opt_stream = None
         self._opt_in_backward = False
         import torch.distributed as dist
@@ -1039,6 +1099,7 @@ class PoseTrainer:
         ws = self.red_ws
 
         bf = int(self.bf16)
+        gf = bf | (2 if self.g16 else 0)          # flag word of the backward passes: bit 0 = bf16 activations, bit 1 = bf16 activation gradients
         self._wgrad_tail = None
         self._wg_flushes = 0
         side = side_h = None
@@ -1055,7 +1116,60 @@ class PoseTrainer:
         self._wg_queue = []
         self._wg_queued_flops = 0.0
         self._wg_batch, self._wg_side, self._wg_dev = B, side, dev
-        import os
+        # A stage's projection shortcut (conv + BatchNorm) depends on the block input alone: forward and backward it runs on a branch
+        # stream beside conv1 -> bn1 -> conv2 -> bn2 -> conv3 (a chain of launches that each leave most of the chip idle).  Same
+        # kernels, same accumulation order (the shortcut's share of the block input's gradient lands first, conv1's dgrad adds last
+        # and after the join), so the bits do not change.  Off with SyncBatchNorm (the pair shares one message) and for the nets whose
+        # shortcut passes use the shared reduction workspace.
+        branch = None
+        self._in_branch = False
+        self._branch_open: List[Act] = []
+        if (self.overlap_shortcut and not self.sync_bn and self.fuse_bn_stats and self.fuse_bn_bwd and self.head != "hrnet"
+                and not any(".se." in k for k in self.layers)):
+            if self._branch_stream is None:
+                self._branch_stream = torch.cuda.Stream(device=dev)
+                self._branch_events = []
+            branch = self._branch_stream
+        self._branch_n = 0
+
+        def branch_event():
+            n = self._branch_n
+            self._branch_n = n + 1
+            if n == len(self._branch_events):
+                self._branch_events.append(torch.cuda.Event())
+            return self._branch_events[n]
+
+        def run_on_branch(fn):
+            """fn() with every launch on the branch stream, behind everything the current stream holds now; returns (result, event that
+            marks the end of fn's launches on the branch stream)."""
+            nonlocal stream
+            here = torch.cuda.current_stream(dev)
+            e0, e1 = branch_event(), branch_event()
+            e0.record(here)
+            branch.wait_event(e0)
+            keep = stream
+            self._in_branch = True
+            try:
+                with torch.cuda.stream(branch):
+                    stream = _lib.current_stream()
+                    out = fn()
+                    e1.record(branch)
+            finally:
+                stream = keep
+                self._in_branch = False
+            return out, e1
+
+        def join_grad(xa: Act) -> None:
+            """Before .grad of `xa` is read or added to: wait for a branch that wrote it, then queue what the branch left for this stream."""
+            if xa.grad_event is not None:
+                torch.cuda.current_stream(dev).wait_event(xa.grad_event)
+                xa.grad_event = None
+                todo, xa.deferred = xa.deferred, []
+                for f in todo:
+                    f()
+                if xa in self._branch_open:
+                    self._branch_open.remove(xa)
+        self._join_grad = join_grad
         self._group_gflop = float(os.environ.get("SP_WGRAD_GROUP_GFLOP", self.wgrad_group_gflop))     # (env: development knob)
 
         def wgrad_async(layer, xin: torch.Tensor, dzt: torch.Tensor):
@@ -1078,6 +1192,9 @@ class PoseTrainer:
 
         def newf(shape):
             return self._take((shape,) if isinstance(shape, int) else tuple(shape), torch.float32, dev)
+
+        def newg(shape):
+            return self._take(tuple(shape), self.grad_dtype, dev)
 
         def conv_stats(xa: Act, cname: str) -> dict:
             """The conv launch of a conv + BatchNorm pair; with `fuse_bn_stats` its epilogue also leaves the per-channel partial sums."""
@@ -1130,10 +1247,12 @@ class PoseTrainer:
                                                         rm, rv, stream), bn)
 
         def conv_bn(xa: Act, cname: str, bname: str, relu: bool, res: Optional[Act] = None, pend: Optional[dict] = None,
-                    shortcut: bool = True) -> Act:
+                    shortcut: bool = True, before_apply: Optional[Callable[[], None]] = None) -> Act:
             if pend is None:
                 pend = conv_stats(xa, cname)
                 batch_stats([pend], [bname])
+            if before_apply is not None:
+                before_apply()                   # (the residual comes from the branch stream: join before the pass that reads it)
             layer, z, mean, invstd = pend["layer"], pend["z"], pend["mean"], pend["invstd"]
             rows, C = pend["rows"], pend["C"]
             gamma, beta = self.sd[bname + ".weight"], self.sd[bname + ".bias"]
@@ -1167,7 +1286,7 @@ class PoseTrainer:
                 acc = 0
                 if res is not None:
                     if res.grad is None:
-                        res.grad = newf(res.data.shape)   # activation gradients are fp32 in both modes
+                        res.grad = newg(res.data.shape)   # activation gradients: fp32, or bf16 with grad_dtype "bf16"
                     else:
                         acc = 1
                     dres = res.grad
@@ -1177,7 +1296,7 @@ class PoseTrainer:
                     # the consumer of this (projection-shortcut) BatchNorm already reduced (SyncBatchNorm: and exchanged) its two sums
                     sg, sb = ya.presums
                     ya.presums = None
-                    _lib.check(lib.sp_bn_train_bwd_apply_nhwc(P(ya.grad), bf, rs, P(z), P(mean), P(invstd), P(gamma), P(sg), P(sb),
+                    _lib.check(lib.sp_bn_train_bwd_apply_nhwc(P(ya.grad), gf, rs, P(z), P(mean), P(invstd), P(gamma), P(sg), P(sb),
                                                               rows * W, rows, C, P(dz), P(dres), acc, stream), bname + ".bwd")
                 elif ya.bstats is not None and not sync and ya.bstats[1] <= self.fold_in_consumer_rows:
                     # few partial rows: ONE launch folds them (d beta, d gamma - and the projection shortcut's pair when its sum rode on the
@@ -1190,7 +1309,7 @@ class PoseTrainer:
                         sname = ya.bn2[3]
                         dgs, dbs = self.flat.view(sname + ".weight", True), self.flat.view(sname + ".bias", True)
                         res.presums = (dgs, dbs)
-                    _lib.check(lib.sp_bn_fold_bwd_apply_nhwc(P(ya.grad), bf, rs, P(z), P(part[0]), P(part[1]), P(part[2]) if three else None, prow,
+                    _lib.check(lib.sp_bn_fold_bwd_apply_nhwc(P(ya.grad), gf, rs, P(z), P(part[0]), P(part[1]), P(part[2]) if three else None, prow,
                                                              part.shape[2], P(mean), P(invstd), P(gamma), rows, rows, C, P(dgamma), P(dbeta), P(dgs),
                                                              P(dbs), P(dz), P(dres), acc, stream), bname + ".bwd")
                 elif ya.bstats is not None or sync:
@@ -1224,7 +1343,7 @@ class PoseTrainer:
                             res.presums = (dgs, dbs)
                     else:
                         msg = None
-                        _lib.check(lib.sp_bn_train_bwd_reduce_nhwc(P(ya.grad), bf, rs, P(z), P(mean), P(invstd), rows, C, P(dgamma), P(dbeta),
+                        _lib.check(lib.sp_bn_train_bwd_reduce_nhwc(P(ya.grad), gf, rs, P(z), P(mean), P(invstd), rows, C, P(dgamma), P(dbeta),
                                                                    P(ws), stream), bname + ".bwd")
                     sg, sb, tot = dgamma, dbeta, rows
                     if sync and msg is not None:
@@ -1241,7 +1360,7 @@ class PoseTrainer:
                             # layer's g = dy * (y > 0), so its two sums are reduced here and travel in the same message
                             zs, ms, ivs, sname = sib
                             dgs, dbs = self.flat.view(sname + ".weight", True), self.flat.view(sname + ".bias", True)
-                            _lib.check(lib.sp_bn_train_bwd_reduce_nhwc(P(ya.grad), bf, rs, P(zs), P(ms), P(ivs), rows, C, P(dgs), P(dbs), P(ws),
+                            _lib.check(lib.sp_bn_train_bwd_reduce_nhwc(P(ya.grad), gf, rs, P(zs), P(ms), P(ivs), rows, C, P(dgs), P(dbs), P(ws),
                                                                        stream), sname + ".bwd")
                             parts += [dgs, dbs]
                         both = torch.cat(parts)
@@ -1251,23 +1370,33 @@ class PoseTrainer:
                         if sib is not None:
                             res.presums = (both[2 * C:3 * C], both[3 * C:])
                         sg, sb, tot = both[:C], both[C:2 * C], rows * W
-                    _lib.check(lib.sp_bn_train_bwd_apply_nhwc(P(ya.grad), bf, rs, P(z), P(mean), P(invstd), P(gamma), P(sg), P(sb), tot, rows, C,
+                    _lib.check(lib.sp_bn_train_bwd_apply_nhwc(P(ya.grad), gf, rs, P(z), P(mean), P(invstd), P(gamma), P(sg), P(sb), tot, rows, C,
                                                               P(dz), P(dres), acc, stream), bname + ".bwd")
                 else:
-                    _lib.check(lib.sp_bn_train_bwd_nhwc(P(ya.grad), bf, rs, P(z), P(mean), P(invstd), P(gamma), rows, C, P(dz), P(dgamma), P(dbeta),
+                    _lib.check(lib.sp_bn_train_bwd_nhwc(P(ya.grad), gf, rs, P(z), P(mean), P(invstd), P(gamma), rows, C, P(dz), P(dgamma), P(dbeta),
                                                         P(dres), acc, P(ws), stream), bname + ".bwd")
                 ya.grad = None
                 if res is not None:
                     res.contrib += 1
-                wgrad_async(layer, xa.data, dz)
+                in_branch = self._in_branch
+                if in_branch:
+                    # on the branch stream: the weight-gradient job (queued with an event of the MAIN stream) and the bucket bookkeeping
+                    # wait for the join
+                    xa.deferred.append(lambda: wgrad_async(layer, xa.data, dz))
+                    xa.deferred.append(lambda: self._grads_ready(bname + ".weight", bname + ".bias", cname + ".weight"))
+                else:
+                    wgrad_async(layer, xa.data, dz)
                 if xa.needs_grad and layer.need_dgrad:
+                    if not in_branch:
+                        join_grad(xa)
                     # the last consumer to contribute sees the complete dy of xa in its epilogue: BN backward sums for free.  (Block outputs:
                     # the residual share lands first, conv1 of the next block - a full-cover 1x1 - accumulates last.)
                     last = xa.contrib == xa.consumers - 1
                     fuse = self.fuse_bn_bwd and xa.bn is not None and last and (xa.grad is None or layer.dgrad_full_cover)
                     xa.grad = layer.dgrad(dz, B, xa.grad, bn_src=xa if fuse else None)
                     xa.contrib += 1
-                self._grads_ready(bname + ".weight", bname + ".bias", cname + ".weight")
+                if not in_branch:
+                    self._grads_ready(bname + ".weight", bname + ".bias", cname + ".weight")
             tape.append(bwd)
             return ya
 
@@ -1405,8 +1534,8 @@ class PoseTrainer:
         stem_out = a
 
         def pool_bwd():
-            stem_out.grad = newf(stem_out.data.shape)
-            _lib.check(lib.sp_maxpool3x3s2_bwd_idx_nhwc(P(pool_idx), P(pa.grad), 0, P(stem_out.grad), B, stem_out.h, stem_out.w, stem_out.c,
+            stem_out.grad = newg(stem_out.data.shape)
+            _lib.check(lib.sp_maxpool3x3s2_bwd_idx_nhwc(P(pool_idx), P(pa.grad), gf, P(stem_out.grad), B, stem_out.h, stem_out.w, stem_out.c,
                                                         stream), "maxpool.bwd")
             pa.grad = None
         tape.append(pool_bwd)
@@ -1419,15 +1548,30 @@ class PoseTrainer:
                     # conv1 and the projection shortcut read the same input: both convs first, ONE statistics all-reduce for the pair
                     p1, pdn = conv_stats(a, p + ".conv1"), conv_stats(a, p + ".downsample.0")
                     batch_stats([p1, pdn], [p + ".bn1", p + ".downsample.1"])
+                join_fwd = None
+                if bi == 0 and branch is not None:
+                    # projection shortcut on the branch stream; its tape entry keeps its old place (after conv2's, before conv3's)
+                    blk_in, i_ds = a, len(tape)
+                    idn, ev_ds = run_on_branch(lambda: conv_bn(blk_in, p + ".downsample.0", p + ".downsample.1", False))
+                    ds_bwd = tape.pop(i_ds)
+
+                    def ds_bwd_on_branch(ds_bwd=ds_bwd, blk_in=blk_in):
+                        _, ev = run_on_branch(ds_bwd)
+                        blk_in.grad_event = ev
+                        self._branch_open.append(blk_in)
+                    join_fwd = lambda ev_ds=ev_ds: torch.cuda.current_stream(dev).wait_event(ev_ds)
                 t = conv_bn(a, p + ".conv1", p + ".bn1", True, pend=p1)
                 t = conv_bn(t, p + ".conv2", p + ".bn2", True)
-                idn = conv_bn(a, p + ".downsample.0", p + ".downsample.1", False, pend=pdn) if bi == 0 else a
+                if join_fwd is not None:
+                    tape.append(ds_bwd_on_branch)
+                else:
+                    idn = conv_bn(a, p + ".downsample.0", p + ".downsample.1", False, pend=pdn) if bi == 0 else a
                 if (p + ".se.fc.0") in L:
                     if idn.sibling is not None:
                         idn.sibling = None                 # the shortcut's consumer is the gate, not a BatchNorm epilogue: it reduces its own sums
                     a = se_gate(conv_bn(t, p + ".conv3", p + ".bn3", False, shortcut=False), idn, p + ".se")
                 else:
-                    a = conv_bn(t, p + ".conv3", p + ".bn3", True, res=idn)
+                    a = conv_bn(t, p + ".conv3", p + ".bn3", True, res=idn, before_apply=join_fwd)
         def shuffle(xa: Act) -> Act:
             """nn.PixelShuffle(2) and, on the tape, its inverse permutation for the gradient."""
             xa.consumers += 1
@@ -1486,6 +1630,8 @@ class PoseTrainer:
             self._grads_ready("final_layer.bias", "final_layer.weight")
             for fn in reversed(tape):
                 fn()
+            for xa in list(getattr(self, "_branch_open", [])):       # (a branch nobody downstream joined: its jobs still have to be queued)
+                self._join_grad(xa)
             self._wgrad_flush()
             if self._wgrad_tail is not None:
                 torch.cuda.current_stream(dev).wait_event(self._wgrad_tail)      # join: the optimizer reads every weight gradient
@@ -1588,7 +1734,10 @@ class PoseTrainer:
     _opt_stream = None
     _wgrad_stream = None
     _wgrad_tail = None
-    fold_in_consumer_rows = 1536  # partial rows (one per phase and M tile) up to which the BatchNorm pass folds them itself (sp_bn_fold_*): above, a stand-alone fold
+    _branch_stream = None
+    overlap_shortcut = True
+    fold_in_consumer_rows = 50    # partial rows (one per phase and M tile) up to which the BatchNorm pass folds them itself (sp_bn_fold_*): above, a stand-alone
+                                  # fold + the plain pass (measured with the 16-byte bf16 passes: 1536 -> 6.06 ms, 100 -> 5.98, 50 -> 5.95, 0 -> 5.97)
     fuse_sync_finalize = True  # SyncBatchNorm: finalise inside the consuming bn_apply, message assembled by the backward fold (one launch less each way)
     fuse_bn_bwd = True         # BN backward sums from the epilogue of the dgrad launch that produces dy (single-consumer BN+ReLU outputs)
     fuse_bn_stats = True       # BN batch statistics from the conv epilogue (sp_conv2d_fwd_bn_stats), SyncBN included (sp_bn_sums_from_conv)

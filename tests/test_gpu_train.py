@@ -246,8 +246,9 @@ def test_training_is_deterministic_and_decreases_loss():
     assert losses[-1] < losses[0]
 
 
-def test_bf16_train_step_behaves_like_the_amp_oracle():
-    """dtype="bf16" (BASELINE config 4's compute type).  bf16 perturbs the forward by ~0.4 %, and in this BN-heavy net with
+@pytest.mark.parametrize("grad_dtype", ["bf16", "fp32"])
+def test_bf16_train_step_behaves_like_the_amp_oracle(grad_dtype):
+    """dtype="bf16" (BASELINE config 4's compute type), with the activation gradients kept in bf16 (the default: what autocast does) and in fp32.  bf16 perturbs the forward by ~0.4 %, and in this BN-heavy net with
     synthetic weights the gradient is extremely sensitive to that (torch's own CPU autocast-bf16 step differs from its fp32
     step by 0.5 % at the head up to ~60 % at the stem in relative L2).  So the checks are: loss within 2 % of fp32; the head
     gradients (not yet amplified) close to fp32; and layer by layer a deviation from fp32 no worse than 1.5x the deviation of
@@ -255,7 +256,8 @@ def test_bf16_train_step_behaves_like_the_amp_oracle():
     B, H, W = 4, 128, 96
     model, sd = _model(9)
     x, t, w = _batch(B, H, W, 9)
-    tr = PoseTrainer(model, in_h=H, in_w=W, lr=1e-3, dtype="bf16")
+    tr = PoseTrainer(model, in_h=H, in_w=W, lr=1e-3, dtype="bf16", grad_dtype=grad_dtype)
+    assert tr.g16 == (grad_dtype == "bf16")
     loss = tr.forward_backward(torch.from_numpy(x).to(DEV), torch.from_numpy(t).to(DEV), torch.from_numpy(w).to(DEV))
     torch.cuda.synchronize()
     xs, ts, ws = torch.from_numpy(x), torch.from_numpy(t), torch.from_numpy(w)
