@@ -35,6 +35,8 @@ extern "C" {
 #define SP_CONV_PIXEL_SHUFFLE 0x4u /* fused nn.PixelShuffle(2): weights packed with sp_pack order, see below */
 #define SP_CONV_OUT_F32 0x10u      /* with SP_CONV_BF16: NHWC y and residual are fp32 (activation gradients in the bf16
                                       train step keep fp32 until the BatchNorm backward has removed their mean) */
+#define SP_CONV_BN_Y_MASK 0x20u    /* sp_conv2d_dgrad_bn_bwd_stats* / sp_conv2d_dgrad_phases with bf16 activations AND gradients: `bn_y` is the
+                                    * ReLU bit mask sp_bn_fold_apply_nhwc / sp_bn_apply_nhwc left (one byte per 8 channels), not the tensor y */
 #define SP_CONV_BF16 0x8u          /* x, w_packed, residual and NHWC y are bf16 (fp32 accumulate; scale/shift and the NCHW
                                       output stay fp32); c_in % 8 == 0, k_pad % 64 == 0 */
 
@@ -339,14 +341,18 @@ int sp_conv2d_dgrad_phases(const sp_conv_desc* descs, int n_phases, const void* 
  * `nn.BatchNorm2d` forward / backward of processors/ddp_pose_resnet_solver.py:115,118 together with the conv launch that left the rows. */
 int sp_bn_fold_apply_nhwc(const void* z, int bf16, const float* stats_sum, const float* stats_sumsq, int partial_rows, int stride,
                           int64_t total_rows, float eps, float momentum, const float* gamma, const float* beta, const void* residual, void* y,
-                          int64_t rows, int c, int relu, float* mean, float* invstd, float* running_mean, float* running_var, void* stream);
+                          int64_t rows, int c, int relu, float* mean, float* invstd, float* running_mean, float* running_var, void* relu_mask,
+                          void* stream);
+/* `bf16` of the backward passes is a bit word: 1 = activations (z, relu_src, dz) are bf16; 2 = the activation gradients (dy, dres) are bf16 too
+ * (PoseTrainer grad_dtype "bf16"); 4 = relu_src is the ReLU BIT MASK the forward pass left in `relu_mask` (uint8 [rows * c / 8], bit e of
+ * byte i = channel 8 i + e passed the ReLU; bf16 activations, c % 8 == 0) instead of the tensor y: 1/16 of the bytes. */
 int sp_bn_fold_bwd_apply_nhwc(const void* dy, int bf16, const void* relu_src, const void* z, const float* sum_g, const float* sum_g_xhat,
                               const float* sum_g_xhat2, int partial_rows, int stride, const float* mean, const float* invstd,
                               const float* gamma, int64_t total_rows, int64_t rows, int c, float* dgamma, float* dbeta, float* dgamma2,
                               float* dbeta2, void* dz, void* dres, int dres_accumulate, void* stream);
 /* y = [relu]((z - mean) * invstd * gamma + beta [+ residual])   (Bottleneck.forward tail, pose_resnet_dconv.py:124-131) */
 int sp_bn_apply_nhwc(const void* z, int bf16, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                     const void* residual, void* y, int64_t rows, int c, int relu, void* stream);
+                     const void* residual, void* y, int64_t rows, int c, int relu, void* relu_mask /* NULL, or see above */, void* stream);
 /* backward of [relu](bn(z) [+ residual]): g = dy * (relu_src > 0) (relu_src NULL: g = dy); dgamma = sum g*xhat,
  * dbeta = sum g, dz = gamma*invstd*(g - dbeta/rows - xhat*dgamma/rows); dres (NULL or tensor) = g or += g */
 int sp_bn_train_bwd_nhwc(const void* dy, int bf16, const void* relu_src, const void* z, const float* mean, const float* invstd,

@@ -19,6 +19,7 @@ SP_CONV_OUT_NCHW = 0x2
 SP_CONV_PIXEL_SHUFFLE = 0x4
 SP_CONV_BF16 = 0x8
 SP_CONV_OUT_F32 = 0x10
+SP_CONV_BN_Y_MASK = 0x20
 CONV_TILES = ((128, 128), (64, 128), (128, 64), (64, 64), (256, 64), (128, 32))
 ABI_VERSION = 32
 SP_CONV_KERNEL_IGEMM, SP_CONV_KERNEL_RING, SP_CONV_KERNEL_PW = 0, 1, 2
@@ -72,7 +73,7 @@ SYMBOLS = {
     "sp_encode_gauss_refine": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P]),
     "sp_encode_gauss_basic": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, c_int, _P, _P, _P]),
     "sp_bn_train_stats_nhwc": (c_int, [_P, c_int, c_int64, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P]),
-    "sp_bn_apply_nhwc": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, _P]),
+    "sp_bn_apply_nhwc": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, _P, _P]),
     "sp_bn_train_partial_nhwc": (c_int, [_P, c_int, c_int64, c_int, _P, _P, _P]),
     "sp_bn_train_finalize": (c_int, [_P, c_int64, c_int, c_float, c_float, _P, _P, _P, _P, _P]),
     "sp_bn_apply_sums_nhwc": (c_int, [_P, c_int, _P, c_int64, c_float, c_float, _P, _P, _P, _P, c_int64, c_int, c_int, _P, _P, _P, _P, _P]),
@@ -120,7 +121,7 @@ SYMBOLS = {
     "sp_conv2d_dgrad_bn_bwd_stats2": (c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "sp_conv2d_dgrad_phases": (c_int, [ctypes.POINTER(ConvDesc), c_int, _P, ctypes.POINTER(_P), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "sp_bn_sums_from_conv": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
-    "sp_bn_fold_apply_nhwc": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int64, c_float, c_float, _P, _P, _P, _P, c_int64, c_int, c_int, _P, _P, _P, _P, _P]),
+    "sp_bn_fold_apply_nhwc": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int64, c_float, c_float, _P, _P, _P, _P, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "sp_bn_fold_bwd_apply_nhwc": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, c_int64, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "sp_bn_bwd_sums_from_conv": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "sp_u8hwc_bgr_to_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),

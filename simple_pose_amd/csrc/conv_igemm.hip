@@ -588,7 +588,9 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
                 }
             }
         }
-        const __amdgpu_buffer_rsrc_t byr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(BSTATS ? p.by : p.y), (short)0, BSTATS ? p.bz_bytes : 0, 0x00020000);
+        const bool by_mask = BSTATS && OUT16 && (p.flags & SP_CONV_BN_Y_MASK);     // the ReLU source is a bit mask: one byte per 8 channels
+        const __amdgpu_buffer_rsrc_t byr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(BSTATS ? p.by : p.y), (short)0,
+                                                                             BSTATS ? (by_mask ? p.bz_bytes >> 4 : p.bz_bytes) : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t bzr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(BSTATS ? p.bz : p.y), (short)0, BSTATS ? p.bz_bytes : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t bz2r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>((BSTATS && p.bz2) ? p.bz2 : p.y), (short)0, (BSTATS && p.bz2) ? p.bz_bytes : 0, 0x00020000);
         u32x4 rv[NIT];
@@ -652,10 +654,18 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
 #pragma unroll
                 for (int e = 0; e < CPL; ++e) z2[e] = 0.f;
                 if constexpr (OUT16) {        // bf16 activations and gradients: same byte offsets, 16 bytes = 8 channels each
-                    const bf16x8 y8 = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(byr, off[it], 0, 0));
                     const bf16x8 z8 = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(bzr, off[it], 0, 0));
+                    if (by_mask) {
+                        const unsigned m = __builtin_amdgcn_raw_buffer_load_b8(byr, off[it] == OOB ? OOB : off[it] >> 4, 0, 0);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { yy[e] = (float)y8[e]; zz[e] = (float)z8[e]; }
+                        for (int e = 0; e < 8; ++e) yy[e] = ((m >> e) & 1u) ? 1.f : 0.f;
+                    } else {
+                        const bf16x8 y8 = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(byr, off[it], 0, 0));
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) yy[e] = (float)y8[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) zz[e] = (float)z8[e];
                     if (p.bz2) {
                         const bf16x8 q8 = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(bz2r, off[it], 0, 0));
 #pragma unroll
@@ -905,8 +915,10 @@ static int conv_fwd_impl(const sp_conv_desc* d, const void* x, const void* w_pac
     const bool uniform = (d->c_in % bke == 0) && d->taps_h * d->taps_w <= 32;  // tap-validity bit mask is 32 bits wide
     if (uniform) SP_REQUIRE(d->k_pad == d->taps_h * d->taps_w * d->c_in, "sp_conv2d_fwd: k_pad must equal taps*c_in when c_in fills whole K tiles");
     SP_REQUIRE((d->phases_y == 1 || d->phases_y == 2) && (d->phases_x == 1 || d->phases_x == 2), "sp_conv2d_fwd: phases must be 1 or 2");
-    const unsigned known = SP_CONV_RELU | SP_CONV_OUT_NCHW | SP_CONV_PIXEL_SHUFFLE | SP_CONV_BF16 | SP_CONV_OUT_F32;
+    const unsigned known = SP_CONV_RELU | SP_CONV_OUT_NCHW | SP_CONV_PIXEL_SHUFFLE | SP_CONV_BF16 | SP_CONV_OUT_F32 | SP_CONV_BN_Y_MASK;
     const bool out16 = bf16 && !(d->flags & SP_CONV_OUT_F32);
+    SP_REQUIRE(!(d->flags & SP_CONV_BN_Y_MASK) || (bsrc && out16) || sp_name_query_active(),
+               "sp_conv2d_fwd: SP_CONV_BN_Y_MASK belongs to a BSTATS dgrad launch with bf16 activations and gradients");
     if (out16 && !(d->flags & SP_CONV_OUT_NCHW)) SP_REQUIRE(d->c_out % 8 == 0, "sp_conv2d_fwd: bf16 NHWC output needs c_out %% 8 == 0 (got %d)", d->c_out);
     SP_REQUIRE((d->flags & ~known) == 0, "sp_conv2d_fwd: unknown flag bits 0x%x", d->flags);
     SP_REQUIRE(!((d->flags & SP_CONV_OUT_NCHW) && (d->flags & SP_CONV_PIXEL_SHUFFLE)), "sp_conv2d_fwd: NCHW output and pixel shuffle are exclusive");

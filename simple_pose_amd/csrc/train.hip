@@ -315,6 +315,16 @@ __device__ __forceinline__ void stn(void* p, long long iv, const float (&o)[VW])
     }
 }
 
+// ReLU mask of 8 consecutive channels as one byte (bit e = channel e passed): bf16 training keeps it beside y, and the backward passes (and
+// the BSTATS dgrad epilogue) read this byte instead of 16 bytes of y.  y > 0 after the bf16 rounding <=> the fp32 value > 0 (a positive
+// float never rounds to zero in bf16: same exponent range).
+__device__ __forceinline__ unsigned char relu_bits8(const float (&x)[8]) {
+    unsigned m = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m |= (x[e] > 0.f ? 1u : 0u) << e;
+    return (unsigned char)m;
+}
+
 // After the fold (1,024 threads = 16 channel quads x 64 row lanes) the threads regroup as (64 / VW channel groups) x (row lanes) with
 // VW = 4 channels (fp32) or 8 (bf16): 16 bytes per access either way.
 template <bool BF16>
@@ -323,7 +333,7 @@ __global__ __launch_bounds__(FOLD_THREADS) void bn_fold_apply_kernel(const void*
                                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                      const void* __restrict__ res, void* __restrict__ y, int C, int relu, long long rows,
                                                                      float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ run_mean,
-                                                                     float* __restrict__ run_var) {
+                                                                     float* __restrict__ run_var, unsigned char* __restrict__ mask) {
     constexpr int VW = BF16 ? 8 : 4, LPS = SLAB / VW, RLN = FOLD_THREADS / LPS, U = BF16 ? 2 : 4;
     __shared__ float st[2][SLAB];
     const int slab = blockIdx.x, stripe = blockIdx.y, stripes = gridDim.y;
@@ -372,6 +382,9 @@ __global__ __launch_bounds__(FOLD_THREADS) void bn_fold_apply_kernel(const void*
             for (int e = 0; e < VW; ++e) x[e] += rx[e];
         }
         if (relu) {
+            if constexpr (VW == 8) {
+                if (mask) mask[row * CV + cv] = relu_bits8(x);
+            }
 #pragma unroll
             for (int e = 0; e < VW; ++e) x[e] = x[e] > 0.f ? x[e] : 0.f;
         }
@@ -408,8 +421,9 @@ __global__ __launch_bounds__(FOLD_THREADS) void bn_fold_bwd_apply_kernel(const v
                                                                          const float* __restrict__ invstd, const float* __restrict__ gamma, float inv_m,
                                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dgamma2,
                                                                          float* __restrict__ dbeta2, void* __restrict__ dz, void* dres, int dres_accumulate,
-                                                                         int C, long long rows) {
+                                                                         int C, long long rows, int src_is_mask) {
     constexpr int VW = BF16 ? 8 : 4, LPS = SLAB / VW, RLN = FOLD_THREADS / LPS, U = BF16 ? 2 : 4;
+    const unsigned char* mk = reinterpret_cast<const unsigned char*>(relu_src);      // src_is_mask (VW = 8 only): one byte per 8 channels
     __shared__ float st[2][SLAB];
     const int slab = blockIdx.x, stripe = blockIdx.y, stripes = gridDim.y;
     const int c0 = slab * SLAB, tid = threadIdx.x, qa = tid % LPS, rl = tid / LPS;
@@ -428,7 +442,9 @@ __global__ __launch_bounds__(FOLD_THREADS) void bn_fold_bwd_apply_kernel(const v
 #pragma unroll
         for (int e = 0; e < VW; ++e) { g4[u][e] = 0.f; zz[u][e] = 0.f; yy[u][e] = 0.f; }
         if (ok) { ldn<G16, VW>(dy, i, g4[u]); ldn<BF16, VW>(z, i, zz[u]); }
-        if (ok && relu_src) ldn<BF16, VW>(relu_src, i, yy[u]);
+        if (ok && relu_src) {
+            if (src_is_mask) yy[u][0] = __uint_as_float((unsigned)mk[i]); else ldn<BF16, VW>(relu_src, i, yy[u]);
+        }
     }
 #pragma unroll
     for (int e = 0; e < VW; ++e) { mu[e] = 0.f; is[e] = 0.f; ga[e] = 0.f; }
@@ -450,8 +466,14 @@ __global__ __launch_bounds__(FOLD_THREADS) void bn_fold_bwd_apply_kernel(const v
     for (int e = 0; e < VW; ++e) { db[e] = st[0][VW * qa + e]; dg[e] = st[1][VW * qa + e]; }
     auto one = [&](float (&g)[VW], const float (&ys)[VW], const float (&zs)[VW], long long row) {
         if (relu_src) {
+            if (src_is_mask) {
+                const unsigned m = __float_as_uint(ys[0]);
 #pragma unroll
-            for (int e = 0; e < VW; ++e) g[e] = ys[e] > 0.f ? g[e] : 0.f;
+                for (int e = 0; e < VW; ++e) g[e] = ((m >> e) & 1u) ? g[e] : 0.f;
+            } else {
+#pragma unroll
+                for (int e = 0; e < VW; ++e) g[e] = ys[e] > 0.f ? g[e] : 0.f;
+            }
         }
         float o[VW];
 #pragma unroll
@@ -485,7 +507,9 @@ __global__ __launch_bounds__(FOLD_THREADS) void bn_fold_bwd_apply_kernel(const v
             const long long i = (r + u * step) * CV + cv;
             ldn<G16, VW>(dy, i, g4[u]);
             ldn<BF16, VW>(z, i, zz[u]);
-            if (relu_src) ldn<BF16, VW>(relu_src, i, yy[u]);
+            if (relu_src) {
+                if (src_is_mask) yy[u][0] = __uint_as_float((unsigned)mk[i]); else ldn<BF16, VW>(relu_src, i, yy[u]);
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) one(g4[u], yy[u], zz[u], r + u * step);
@@ -494,7 +518,9 @@ __global__ __launch_bounds__(FOLD_THREADS) void bn_fold_bwd_apply_kernel(const v
         const long long i = r * CV + cv;
         ldn<G16, VW>(dy, i, g4[0]);
         ldn<BF16, VW>(z, i, zz[0]);
-        if (relu_src) ldn<BF16, VW>(relu_src, i, yy[0]);
+        if (relu_src) {
+            if (src_is_mask) yy[0][0] = __uint_as_float((unsigned)mk[i]); else ldn<BF16, VW>(relu_src, i, yy[0]);
+        }
         one(g4[0], yy[0], zz[0], r);
     }
 }
@@ -514,7 +540,7 @@ __global__ void pair_sum_final_f64_kernel(const double* __restrict__ part, int n
 template <bool BF16, int VW>
 __global__ void bn_apply_kernel(const void* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ invstd,
                                 const float* __restrict__ gamma, const float* __restrict__ beta, const void* __restrict__ res,
-                                void* __restrict__ y, int CV, int relu, long long total) {
+                                void* __restrict__ y, int CV, int relu, long long total, unsigned char* __restrict__ mask) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int cv = (int)(i % CV);
         float mu[VW], is[VW], g[VW], b[VW], x[VW], r[VW];
@@ -535,6 +561,9 @@ __global__ void bn_apply_kernel(const void* __restrict__ z, const float* __restr
             for (int e = 0; e < VW; ++e) x[e] += r[e];
         }
         if (relu) {
+            if constexpr (VW == 8) {
+                if (mask) mask[i] = relu_bits8(x);
+            }
 #pragma unroll
             for (int e = 0; e < VW; ++e) x[e] = x[e] > 0.f ? x[e] : 0.f;
         }
@@ -593,14 +622,18 @@ template <bool BF16, bool G16, int VW>   // BF16: z, relu_src, dz;  G16: dy, dre
 __global__ void bn_bwd_apply_kernel(const void* __restrict__ dy, const void* __restrict__ relu_src, const void* __restrict__ z,
                                     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const float* __restrict__ dgamma, const float* __restrict__ dbeta, float inv_m, void* __restrict__ dz,
-                                    void* dres, int dres_accumulate, int CV, long long total) {
+                                    void* dres, int dres_accumulate, int CV, long long total, int src_is_mask) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int cv = (int)(i % CV);
         float mu[VW], is[VW], ga[VW], dg[VW], db[VW], g[VW], zz[VW], o[VW];
         ldn<false, VW>(mean, cv, mu); ldn<false, VW>(invstd, cv, is); ldn<false, VW>(gamma, cv, ga);
         ldn<false, VW>(dgamma, cv, dg); ldn<false, VW>(dbeta, cv, db);
         ldn<G16, VW>(dy, i, g);
-        if (relu_src) {
+        if (relu_src && src_is_mask) {
+            const unsigned m = reinterpret_cast<const unsigned char*>(relu_src)[i];
+#pragma unroll
+            for (int e = 0; e < VW; ++e) g[e] = ((m >> e) & 1u) ? g[e] : 0.f;
+        } else if (relu_src) {
             float yv[VW];
             ldn<BF16, VW>(relu_src, i, yv);
 #pragma unroll
@@ -977,8 +1010,9 @@ static int fold_stripes(long long rows, int slabs, int partial_rows) {
 extern "C" int sp_bn_fold_apply_nhwc(const void* z, int bf16, const float* stats_sum, const float* stats_sumsq, int partial_rows, int stride,
                                      int64_t total_rows, float eps, float momentum, const float* gamma, const float* beta, const void* residual,
                                      void* y, int64_t rows, int c, int relu, float* mean, float* invstd, float* running_mean, float* running_var,
-                                     void* stream) {
+                                     void* relu_mask, void* stream) {
     SP_REQUIRE(z && stats_sum && stats_sumsq && gamma && beta && y && mean && invstd, "sp_bn_fold_apply_nhwc: null pointer");
+    SP_REQUIRE(!relu_mask || ((bf16 & 1) && relu), "sp_bn_fold_apply_nhwc: the ReLU bit mask exists for bf16 tensors behind a ReLU");
     SP_REQUIRE(rows > 0 && total_rows >= rows && c > 0 && c % 4 == 0 && partial_rows > 0 && stride >= c && stride % 4 == 0 && rows < (1ll << 31),
                "sp_bn_fold_apply_nhwc: bad shape");
     SP_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "sp_bn_fold_apply_nhwc: running stats come in pairs");
@@ -986,9 +1020,11 @@ extern "C" int sp_bn_fold_apply_nhwc(const void* z, int bf16, const float* stats
     const int slabs = (c + SLAB - 1) / SLAB;
     const dim3 grid(slabs, fold_stripes(rows, slabs, partial_rows));
     if (bf16 & 1) hipLaunchKernelGGL(bn_fold_apply_kernel<true>, grid, dim3(FOLD_THREADS), 0, (hipStream_t)stream, z, stats_sum, stats_sumsq, partial_rows, stride,
-                                     (double)total_rows, eps, momentum, gamma, beta, residual, y, c, relu, (long long)rows, mean, invstd, running_mean, running_var);
+                                     (double)total_rows, eps, momentum, gamma, beta, residual, y, c, relu, (long long)rows, mean, invstd, running_mean, running_var,
+                                     reinterpret_cast<unsigned char*>(relu_mask));
     else hipLaunchKernelGGL(bn_fold_apply_kernel<false>, grid, dim3(FOLD_THREADS), 0, (hipStream_t)stream, z, stats_sum, stats_sumsq, partial_rows, stride,
-                            (double)total_rows, eps, momentum, gamma, beta, residual, y, c, relu, (long long)rows, mean, invstd, running_mean, running_var);
+                            (double)total_rows, eps, momentum, gamma, beta, residual, y, c, relu, (long long)rows, mean, invstd, running_mean, running_var,
+                            (unsigned char*)nullptr);
     return sp_check_launch("bn_fold_apply_kernel");
 }
 
@@ -1003,13 +1039,15 @@ extern "C" int sp_bn_fold_bwd_apply_nhwc(const void* dy, int bf16, const void* r
     const bool a16 = bf16 & 1, g16 = bf16 & 2;
     SP_REQUIRE(a16 || !g16, "sp_bn_fold_bwd_apply_nhwc: bf16 gradients with fp32 activations is not a supported mix");
     SP_REQUIRE(!a16 || c % 8 == 0, "sp_bn_fold_bwd_apply_nhwc: bf16 tensors are walked 8 channels at a time (c %% 8 == 0)");
+    const int src_is_mask = (bf16 & 4) ? 1 : 0;
+    SP_REQUIRE(!src_is_mask || (a16 && relu_src), "sp_bn_fold_bwd_apply_nhwc: a ReLU bit mask goes with bf16 activations");
     const int slabs = (c + SLAB - 1) / SLAB;
     const dim3 grid(slabs, fold_stripes(rows, slabs, partial_rows));
     hipStream_t s = (hipStream_t)stream;
 #define SP_FBA(A, G)                                                                                                                         \
     hipLaunchKernelGGL((bn_fold_bwd_apply_kernel<A, G>), grid, dim3(FOLD_THREADS), 0, s, dy, relu_src, z, sum_g, sum_g_xhat, sum_g_xhat2, partial_rows, \
                        stride, mean, invstd, gamma, (float)(1.0 / (double)total_rows), dgamma, dbeta, dgamma2, dbeta2, dz, dres, dres_accumulate, c,  \
-                       (long long)rows)
+                       (long long)rows, src_is_mask)
     if (a16 && g16) SP_FBA(true, true);
     else if (a16) SP_FBA(true, false);
     else SP_FBA(false, false);
@@ -1018,20 +1056,21 @@ extern "C" int sp_bn_fold_bwd_apply_nhwc(const void* dy, int bf16, const void* r
 }
 
 extern "C" int sp_bn_apply_nhwc(const void* z, int bf16, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                                const void* residual, void* y, int64_t rows, int c, int relu, void* stream) {
+                                const void* residual, void* y, int64_t rows, int c, int relu, void* relu_mask, void* stream) {
+    SP_REQUIRE(!relu_mask || ((bf16 & 1) && relu && c % 8 == 0), "sp_bn_apply_nhwc: the ReLU bit mask exists for bf16 tensors (c %% 8 == 0) behind a ReLU");
     SP_REQUIRE(z && mean && invstd && gamma && beta && y, "sp_bn_apply_nhwc: null pointer");
     SP_REQUIRE(rows > 0 && c > 0 && c % 4 == 0, "sp_bn_apply_nhwc: bad shape");
     if ((bf16 & 1) && c % 8 == 0) {
         const long long total = rows * (c / 8);
         hipLaunchKernelGGL((bn_apply_kernel<true, 8>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, z, mean, invstd, gamma, beta, residual, y,
-                           c / 8, relu, total);
+                           c / 8, relu, total, reinterpret_cast<unsigned char*>(relu_mask));
         return sp_check_launch("bn_apply_kernel");
     }
     const long long total = rows * (c / 4);
     if (bf16 & 1) hipLaunchKernelGGL((bn_apply_kernel<true, 4>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, z, mean, invstd, gamma, beta,
-                                     residual, y, c / 4, relu, total);
+                                     residual, y, c / 4, relu, total, (unsigned char*)nullptr);
     else hipLaunchKernelGGL((bn_apply_kernel<false, 4>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, z, mean, invstd, gamma, beta,
-                            residual, y, c / 4, relu, total);
+                            residual, y, c / 4, relu, total, (unsigned char*)nullptr);
     return sp_check_launch("bn_apply_kernel");
 }
 
@@ -1073,10 +1112,12 @@ extern "C" int sp_bn_train_bwd_apply_nhwc(const void* dy, int bf16, const void* 
     const bool a16 = bf16 & 1, g16 = bf16 & 2;
     SP_REQUIRE(a16 || !g16, "sp_bn_train_bwd_apply_nhwc: bf16 gradients with fp32 activations is not a supported mix");
     const int vw = (a16 && c % 8 == 0) ? 8 : 4;
+    const int src_is_mask = (bf16 & 4) ? 1 : 0;
+    SP_REQUIRE(!src_is_mask || (vw == 8 && relu_src), "sp_bn_train_bwd_apply_nhwc: a ReLU bit mask goes with bf16 activations (c %% 8 == 0)");
     const long long total = rows * (c / vw);
 #define SP_BWD_APPLY(A, G, V)                                                                                                                \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<A, G, V>), dim3(grid_for(total, 256)), dim3(256), 0, s, dy, relu_src, z, mean, invstd, gamma, sum_dgamma, \
-                       sum_dbeta, (float)(1.0 / (double)total_rows), dz, dres, dres_accumulate, c / V, total)
+                       sum_dbeta, (float)(1.0 / (double)total_rows), dz, dres, dres_accumulate, c / V, total, src_is_mask)
     if (a16 && g16 && vw == 8) SP_BWD_APPLY(true, true, 8);
     else if (a16 && g16) SP_BWD_APPLY(true, true, 4);
     else if (a16 && vw == 8) SP_BWD_APPLY(true, false, 8);

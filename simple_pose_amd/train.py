@@ -23,7 +23,7 @@ from typing import Callable, Dict, List, Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, SP_CONV_BF16, SP_CONV_OUT_F32, SP_CONV_OUT_NCHW, SP_CONV_RELU
+from ._lib import ConvDesc, SP_CONV_BF16, SP_CONV_BN_Y_MASK, SP_CONV_OUT_F32, SP_CONV_OUT_NCHW, SP_CONV_RELU
 from .engine import _round_up, n_pad_for
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
@@ -127,6 +127,7 @@ class Act:
     bstats: Optional[tuple] = None     # backward: (partial sums [2, rows, stride], rows) left by the dgrad launch that wrote .grad
     bn2: Optional[tuple] = None        # block output with a projection shortcut: (z, mean, invstd, bn name) of the shortcut's BatchNorm, whose
                                        # dy is this output's g: its sum g * xhat rides on the same dgrad epilogue (part[2])
+    mask: Optional[torch.Tensor] = None    # bf16 training: the ReLU bit mask of this BatchNorm+ReLU output (uint8, one byte per 8 channels)
     grad_event: Optional[object] = None    # backward: .grad's first share was written on the branch stream; whoever touches .grad next waits
     deferred: list = field(default_factory=list)   # ... and then runs these (the branch's weight-gradient jobs, queued on the main stream)
 
@@ -387,12 +388,28 @@ class ConvT:
             part = self._new((3 if two else 2, total, stride), torch.float32, dz.device)
             z, mean, invstd = bn_src.bn
             row0 = 0
+            ysrc, mflag = bn_src.data, 0
+            if bn_src.mask is not None and self.tr.g16:
+                ysrc, mflag = bn_src.mask, SP_CONV_BN_Y_MASK        # the ReLU bit mask instead of y: 1/16 of the bytes
+            keep_flags = [d.flags for d in self.d_dgrad]
+            for d in self.d_dgrad:
+                d.flags |= mflag
+            try:
+                return self._dgrad_bstats(lib, dz, B, acc, dx, bn_src, ysrc, z, mean, invstd, part, total, need, one, two)
+            finally:
+                for d, f in zip(self.d_dgrad, keep_flags):
+                    d.flags = f
+        return self._dgrad_plain(lib, dz, B, acc)
+
+    def _dgrad_bstats(self, lib, dz, B, acc, dx, bn_src, ysrc, z, mean, invstd, part, total, need, one, two):
+        if True:
+            row0 = 0
             done = self._timed("dgrad")
             if one:
                 # a stride-2 conv's output phases (different tap counts) as ONE launch: same rows, same bits, three launch boundaries less
                 descs, ws_ = self._phase_arrays()
                 z2, mean2, invstd2 = (bn_src.bn2[:3] if two else (None, None, None))
-                _lib.check(lib.sp_conv2d_dgrad_phases(descs, len(self.d_dgrad), P(dz), ws_, P(acc), P(dx), P(bn_src.data), P(z), P(mean), P(invstd),
+                _lib.check(lib.sp_conv2d_dgrad_phases(descs, len(self.d_dgrad), P(dz), ws_, P(acc), P(dx), P(ysrc), P(z), P(mean), P(invstd),
                                                       P(part[0]), P(part[1]), P(z2), P(mean2), P(invstd2), P(part[2]) if two else None, total,
                                                       _lib.current_stream()), self.name + ".dgrad")
                 done()
@@ -401,17 +418,19 @@ class ConvT:
             for d, w, n in zip(self.d_dgrad, self.w_dgrad, need):
                 if two:
                     z2, mean2, invstd2, _ = bn_src.bn2
-                    _lib.check(lib.sp_conv2d_dgrad_bn_bwd_stats2(d, P(dz), P(w), P(acc), P(dx), P(bn_src.data), P(z), P(mean), P(invstd),
+                    _lib.check(lib.sp_conv2d_dgrad_bn_bwd_stats2(d, P(dz), P(w), P(acc), P(dx), P(ysrc), P(z), P(mean), P(invstd),
                                                                  P(part[0, row0:]), P(part[1, row0:]), P(z2), P(mean2), P(invstd2),
                                                                  P(part[2, row0:]), n, _lib.current_stream()), self.name + ".dgrad")
                 else:
-                    _lib.check(lib.sp_conv2d_dgrad_bn_bwd_stats(d, P(dz), P(w), P(acc), P(dx), P(bn_src.data), P(z), P(mean), P(invstd),
+                    _lib.check(lib.sp_conv2d_dgrad_bn_bwd_stats(d, P(dz), P(w), P(acc), P(dx), P(ysrc), P(z), P(mean), P(invstd),
                                                                 P(part[0, row0:]), P(part[1, row0:]), n, _lib.current_stream()),
                                self.name + ".dgrad")
                 row0 += n
             done()
             bn_src.bstats = (part, total)
             return dx
+
+    def _dgrad_plain(self, lib, dz, B, acc):
         if acc is None:
             d0 = self.d_dgrad[0]
             shape = (B, d0.out_h, d0.out_w, d0.out_c)
@@ -692,6 +711,9 @@ class PoseTrainer:
 
     def _take(self, shape, dtype, device, zero: bool = False) -> torch.Tensor:
         if not self._arena_on:
+            # (inside a branch-stream section the block comes from the BRANCH stream's pool of the caching allocator: right for the section's
+            # temporaries; what it hands to the main stream lives until the tape is dropped, after the join; the main-pool tensor it reads
+            # and drops is record_stream'ed there)
             return (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=device)
         a, i = self._arena, self._arena_i
         self._arena_i = i + 1
@@ -1100,6 +1122,7 @@ class PoseTrainer:
 
         bf = int(self.bf16)
         gf = bf | (2 if self.g16 else 0)          # flag word of the backward passes: bit 0 = bf16 activations, bit 1 = bf16 activation gradients
+        use_mask = self.g16 and self.relu_bit_masks    # (bit 2 of that word, per call: the ReLU source is the bit mask of Act.mask)
         self._wgrad_tail = None
         self._wg_flushes = 0
         side = side_h = None
@@ -1148,7 +1171,7 @@ class PoseTrainer:
             e0.record(here)
             branch.wait_event(e0)
             keep = stream
-            self._in_branch = True
+            self._in_branch, self._branch_main = True, here
             try:
                 with torch.cuda.stream(branch):
                     stream = _lib.current_stream()
@@ -1258,19 +1281,24 @@ class PoseTrainer:
             gamma, beta = self.sd[bname + ".weight"], self.sd[bname + ".bias"]
             nbt.append(self.buffers[bname + ".num_batches_tracked"])
             y = new(z.shape)
+            # bf16 gradients: the pass also leaves the ReLU mask as one bit per element; the BatchNorm backward pass and the dgrad epilogue
+            # that reduces its sums then read that byte instead of 16 bytes of y
+            mask = self._take((rows * C // 8,), torch.uint8, dev) if (relu and use_mask and not pend.get("from_sums") and C % 8 == 0) else None
             if pend.get("fold_in_apply"):
                 part = pend["part"]
                 _lib.check(lib.sp_bn_fold_apply_nhwc(P(z), bf, P(part[0]), P(part[1]), pend["prow"], part.shape[2], rows, BN_EPS, BN_MOMENTUM, P(gamma),
                                                      P(beta), P(res.data) if res else None, P(y), rows, C, int(relu), P(mean), P(invstd),
-                                                     P(self.buffers[bname + ".running_mean"]), P(self.buffers[bname + ".running_var"]), stream), bname)
+                                                     P(self.buffers[bname + ".running_mean"]), P(self.buffers[bname + ".running_var"]), P(mask),
+                                                     stream), bname)
             elif pend.get("from_sums"):
                 _lib.check(lib.sp_bn_apply_sums_nhwc(P(z), bf, P(pend["sums"]), rows * W, BN_EPS, BN_MOMENTUM, P(gamma), P(beta),
                                                      P(res.data) if res else None, P(y), rows, C, int(relu), P(mean), P(invstd),
                                                      P(self.buffers[bname + ".running_mean"]), P(self.buffers[bname + ".running_var"]), stream), bname)
             else:
                 _lib.check(lib.sp_bn_apply_nhwc(P(z), bf, P(mean), P(invstd), P(gamma), P(beta), P(res.data) if res else None, P(y), rows, C,
-                                                int(relu), stream), bname)
+                                                int(relu), P(mask), stream), bname)
             ya = Act(y, z.shape[1], z.shape[2], C)
+            ya.mask = mask
             if res is not None:
                 res.consumers += 1
             if relu:
@@ -1292,6 +1320,10 @@ class PoseTrainer:
                     dres = res.grad
                 dgamma, dbeta = self.flat.view(bname + ".weight", True), self.flat.view(bname + ".bias", True)
                 rs = P(y) if relu else None
+                gm = gf                                # paths that take the bit mask: the two apply kernels (not the reduction passes)
+                rsm = rs
+                if relu and ya.mask is not None:
+                    rsm, gm = P(ya.mask), gf | 4
                 if ya.presums is not None:
                     # the consumer of this (projection-shortcut) BatchNorm already reduced (SyncBatchNorm: and exchanged) its two sums
                     sg, sb = ya.presums
@@ -1309,7 +1341,7 @@ class PoseTrainer:
                         sname = ya.bn2[3]
                         dgs, dbs = self.flat.view(sname + ".weight", True), self.flat.view(sname + ".bias", True)
                         res.presums = (dgs, dbs)
-                    _lib.check(lib.sp_bn_fold_bwd_apply_nhwc(P(ya.grad), gf, rs, P(z), P(part[0]), P(part[1]), P(part[2]) if three else None, prow,
+                    _lib.check(lib.sp_bn_fold_bwd_apply_nhwc(P(ya.grad), gm, rsm, P(z), P(part[0]), P(part[1]), P(part[2]) if three else None, prow,
                                                              part.shape[2], P(mean), P(invstd), P(gamma), rows, rows, C, P(dgamma), P(dbeta), P(dgs),
                                                              P(dbs), P(dz), P(dres), acc, stream), bname + ".bwd")
                 elif ya.bstats is not None or sync:
@@ -1370,15 +1402,17 @@ class PoseTrainer:
                         if sib is not None:
                             res.presums = (both[2 * C:3 * C], both[3 * C:])
                         sg, sb, tot = both[:C], both[C:2 * C], rows * W
-                    _lib.check(lib.sp_bn_train_bwd_apply_nhwc(P(ya.grad), gf, rs, P(z), P(mean), P(invstd), P(gamma), P(sg), P(sb), tot, rows, C,
+                    _lib.check(lib.sp_bn_train_bwd_apply_nhwc(P(ya.grad), gm, rsm, P(z), P(mean), P(invstd), P(gamma), P(sg), P(sb), tot, rows, C,
                                                               P(dz), P(dres), acc, stream), bname + ".bwd")
                 else:
                     _lib.check(lib.sp_bn_train_bwd_nhwc(P(ya.grad), gf, rs, P(z), P(mean), P(invstd), P(gamma), rows, C, P(dz), P(dgamma), P(dbeta),
                                                         P(dres), acc, P(ws), stream), bname + ".bwd")
+                in_branch = self._in_branch
+                if in_branch and not self._arena_on:
+                    ya.grad.record_stream(self._branch_stream)     # (allocator-owned, from the main stream's pool, read by the branch stream)
                 ya.grad = None
                 if res is not None:
                     res.contrib += 1
-                in_branch = self._in_branch
                 if in_branch:
                     # on the branch stream: the weight-gradient job (queued with an event of the MAIN stream) and the bucket bookkeeping
                     # wait for the join
@@ -1552,14 +1586,21 @@ class PoseTrainer:
                 if bi == 0 and branch is not None:
                     # projection shortcut on the branch stream; its tape entry keeps its old place (after conv2's, before conv3's)
                     blk_in, i_ds = a, len(tape)
-                    idn, ev_ds = run_on_branch(lambda: conv_bn(blk_in, p + ".downsample.0", p + ".downsample.1", False))
+                    mode = os.environ.get("SP_BRANCH", "1")
+                    if mode == "bwd":
+                        idn, ev_ds = conv_bn(blk_in, p + ".downsample.0", p + ".downsample.1", False), None
+                    else:
+                        idn, ev_ds = run_on_branch(lambda: conv_bn(blk_in, p + ".downsample.0", p + ".downsample.1", False))
                     ds_bwd = tape.pop(i_ds)
 
-                    def ds_bwd_on_branch(ds_bwd=ds_bwd, blk_in=blk_in):
+                    def ds_bwd_on_branch(ds_bwd=ds_bwd, blk_in=blk_in, mode=mode):
+                        if mode == "fwd":
+                            ds_bwd()
+                            return
                         _, ev = run_on_branch(ds_bwd)
                         blk_in.grad_event = ev
                         self._branch_open.append(blk_in)
-                    join_fwd = lambda ev_ds=ev_ds: torch.cuda.current_stream(dev).wait_event(ev_ds)
+                    join_fwd = (lambda ev_ds=ev_ds: torch.cuda.current_stream(dev).wait_event(ev_ds)) if ev_ds is not None else (lambda: None)
                 t = conv_bn(a, p + ".conv1", p + ".bn1", True, pend=p1)
                 t = conv_bn(t, p + ".conv2", p + ".bn2", True)
                 if join_fwd is not None:
@@ -1735,7 +1776,10 @@ class PoseTrainer:
     _wgrad_stream = None
     _wgrad_tail = None
     _branch_stream = None
+    _branch_main = None
+    _in_branch = False
     overlap_shortcut = True
+    relu_bit_masks = os.environ.get("SP_RELU_MASK", "1") != "0"        # (env: development knob)
     fold_in_consumer_rows = 50    # partial rows (one per phase and M tile) up to which the BatchNorm pass folds them itself (sp_bn_fold_*): above, a stand-alone
                                   # fold + the plain pass (measured with the 16-byte bf16 passes: 1536 -> 6.06 ms, 100 -> 5.98, 50 -> 5.95, 0 -> 5.97)
     fuse_sync_finalize = True  # SyncBatchNorm: finalise inside the consuming bn_apply, message assembled by the backward fold (one launch less each way)

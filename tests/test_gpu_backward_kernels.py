@@ -255,7 +255,7 @@ def test_batchnorm_train_backward_vs_float64(rows_hw, C, relu, res_on, bf16, mea
     rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
     _lib.check(lib.sp_bn_train_stats_nhwc(P(zd), int(bf16), rows, C, 1e-5, 0.1, P(mean), P(invstd), P(rm), P(rv), P(ws), st), "stats")
     yd = torch.empty((rows, C), dtype=adt, device=DEV)
-    _lib.check(lib.sp_bn_apply_nhwc(P(zd), int(bf16), P(mean), P(invstd), P(gd), P(bd), P(resd), P(yd), rows, C, int(relu), st), "apply")
+    _lib.check(lib.sp_bn_apply_nhwc(P(zd), int(bf16), P(mean), P(invstd), P(gd), P(bd), P(resd), P(yd), rows, C, int(relu), None, st), "apply")
     torch.cuda.synchronize()
     # float64 reference; the ReLU mask is taken from the kernel's own y (a pre-activation within rounding of 0 has no defined sign)
     zr = z.clone().requires_grad_(True)
@@ -517,16 +517,23 @@ def test_conv_epilogue_statistics_and_fused_fold_forward(case, bf16, measured):
         m_a, i_a = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
         rm_a, rv_a = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
         y_a = torch.empty((rows, C), dtype=adt, device=DEV)
+        want_mask = bool(bf16) and bool(relu) and C % 8 == 0          # bf16 + ReLU: both passes also leave the ReLU bit mask (one byte per 8 channels)
+        mk_a = torch.zeros(rows * C // 8, dtype=torch.uint8, device=DEV) if want_mask else None
+        mk_b = torch.zeros(rows * C // 8, dtype=torch.uint8, device=DEV) if want_mask else None
         _lib.check(lib.sp_bn_train_stats_from_conv(P(part[0]), P(part[1]), prow, part.shape[2], rows, C, 1e-5, 0.1, P(m_a), P(i_a), P(rm_a), P(rv_a), st), "fold")
-        _lib.check(lib.sp_bn_apply_nhwc(P(z), int(bf16), P(m_a), P(i_a), P(gamma), P(beta), P(rd), P(y_a), rows, C, relu, st), "apply")
+        _lib.check(lib.sp_bn_apply_nhwc(P(z), int(bf16), P(m_a), P(i_a), P(gamma), P(beta), P(rd), P(y_a), rows, C, relu, P(mk_a), st), "apply")
         m_b, i_b = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
         rm_b, rv_b = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
         y_b = torch.empty((rows, C), dtype=adt, device=DEV)
         _lib.check(lib.sp_bn_fold_apply_nhwc(P(z), int(bf16), P(part[0]), P(part[1]), prow, part.shape[2], rows, 1e-5, 0.1, P(gamma), P(beta), P(rd),
-                                             P(y_b), rows, C, relu, P(m_b), P(i_b), P(rm_b), P(rv_b), st), "fold+apply")
+                                             P(y_b), rows, C, relu, P(m_b), P(i_b), P(rm_b), P(rv_b), P(mk_b), st), "fold+apply")
         torch.cuda.synchronize()
         assert torch.equal(m_a, m_b) and torch.equal(i_a, i_b) and torch.equal(rm_a, rm_b) and torch.equal(rv_a, rv_b)
         assert torch.equal(y_a, y_b)
+        if want_mask:
+            bits = (y_b.float().reshape(-1, 8) > 0).to(torch.uint8)
+            ref_mask = (bits << torch.arange(8, device=DEV, dtype=torch.uint8)).sum(1).to(torch.uint8)
+            assert torch.equal(mk_a, ref_mask) and torch.equal(mk_b, ref_mask)
         m64, v64 = z64.mean(0), z64.var(0, unbiased=False)
         em, ei = _rel(m_b, m64), _rel(i_b, 1 / torch.sqrt(v64 + 1e-5))
         measured("mean_rel", em, 1e-6)
@@ -542,7 +549,7 @@ def test_conv_epilogue_statistics_and_fused_fold_forward(case, bf16, measured):
         assert e <= (4e-3 if bf16 else 3e-6)
 
 
-@pytest.mark.parametrize("bf16", [0, 1, 3], ids=["fp32", "bf16", "bf16_grads"])
+@pytest.mark.parametrize("bf16", [0, 1, 3, 7], ids=["fp32", "bf16", "bf16_grads", "bf16_grads_relu_mask"])
 @pytest.mark.parametrize("two", [False, True], ids=["one_bn", "with_shortcut_bn"])
 @pytest.mark.parametrize("case", STATS_CASES, ids=[c[0] for c in STATS_CASES])
 def test_dgrad_epilogue_sums_and_fused_fold_backward(case, two, bf16, measured):
@@ -551,7 +558,7 @@ def test_dgrad_epilogue_sums_and_fused_fold_backward(case, two, bf16, measured):
     "bf16_grads" (PoseTrainer grad_dtype "bf16"): the dgrad launch stores dy in bf16, its sums are those of the ROUNDED dy, dres is bf16."""
     from simple_pose_amd.train import Act
     name, I, O, k, s, p, H, W, B = case
-    flag, g16 = bf16, bool(bf16 & 2)
+    flag, g16, masked = bf16, bool(bf16 & 2), bool(bf16 & 4)     # masked: the ReLU source is the bit mask the forward pass leaves, not y
     bf16 = bool(bf16 & 1)
     if g16 and I % 8:
         pytest.skip("a bf16 NHWC gradient store needs c % 8 == 0")
@@ -576,6 +583,10 @@ def test_dgrad_epilogue_sums_and_fused_fold_backward(case, two, bf16, measured):
     dzn = torch.randn(B, oh, ow, L.c_out_buf, generator=g).to(adt).to(DEV)
     src = Act(yd, H, W, C)
     src.bn = (zd, mean, invstd)
+    rsrc = yd
+    if masked:
+        bits = (yd.float().reshape(-1, 8) > 0).to(torch.uint8)
+        src.mask = rsrc = (bits << torch.arange(8, device=DEV, dtype=torch.uint8)).sum(1).to(torch.uint8).contiguous()
     if two:
         src.bn2 = (z2d, mean2, invstd2, "shortcut")
     dy = L.dgrad(dzn, B, None, bn_src=src)
@@ -596,14 +607,14 @@ def test_dgrad_epilogue_sums_and_fused_fold_backward(case, two, bf16, measured):
         _lib.check(lib.sp_bn_bwd_sums_from_conv(P(part[0]), P(part[2]), prow, part.shape[2], C, P(dg2a), P(db2a), st), "fold2")
     base = torch.randn(rows, C, generator=torch.Generator().manual_seed(3)).to(DEV).to(dy.dtype)
     dz_a, dres_a = torch.empty((rows, C), dtype=adt, device=DEV), base.clone()
-    _lib.check(lib.sp_bn_train_bwd_apply_nhwc(P(dy), flag, P(yd), P(zd), P(mean), P(invstd), P(gamma), P(dga), P(dba), rows, rows, C, P(dz_a),
+    _lib.check(lib.sp_bn_train_bwd_apply_nhwc(P(dy), flag, P(rsrc), P(zd), P(mean), P(invstd), P(gamma), P(dga), P(dba), rows, rows, C, P(dz_a),
                                               P(dres_a), 1, st), "apply")
     # fused
     dgb, dbb = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
     dg2b = torch.empty(C, device=DEV) if two else None
     db2b = torch.empty(C, device=DEV) if two else None
     dz_b, dres_b = torch.empty((rows, C), dtype=adt, device=DEV), base.clone()
-    _lib.check(lib.sp_bn_fold_bwd_apply_nhwc(P(dy), flag, P(yd), P(zd), P(part[0]), P(part[1]), P(part[2]) if two else None, prow, part.shape[2],
+    _lib.check(lib.sp_bn_fold_bwd_apply_nhwc(P(dy), flag, P(rsrc), P(zd), P(part[0]), P(part[1]), P(part[2]) if two else None, prow, part.shape[2],
                                              P(mean), P(invstd), P(gamma), rows, rows, C, P(dgb), P(dbb), P(dg2b), P(db2b), P(dz_b), P(dres_b), 1, st),
                "fold+bwd apply")
     torch.cuda.synchronize()

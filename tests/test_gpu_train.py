@@ -669,6 +669,43 @@ def test_full_size_step_properties(dtype, tol):
     assert np.isfinite(runs["a"][0]) and runs["a"][0] > 0
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_shortcut_branch_stream_changes_no_bits(dtype, monkeypatch):
+    """The projection shortcuts run on a branch stream beside the main chain (forward and backward).  Same kernels, same accumulation
+    order: three steps give the same parameters bit for bit as the serial schedule - through PoseTrainer.step (step arena) and through
+    the autograd surface (caching allocator: the tensors that cross streams must be kept alive / recorded on the right stream)."""
+    x, t, w = _batch(4, 64, 64, 11)
+    xd, td, wd = (torch.from_numpy(a).to(DEV) for a in (x, t, w))
+
+    def steps(branch):
+        monkeypatch.setenv("SP_BRANCH", "1" if branch else "0")
+        m, _ = _model(11)
+        tr = PoseTrainer(m, in_h=64, in_w=64, lr=1e-3, dtype=dtype)
+        assert tr.overlap_shortcut == branch
+        for _ in range(3):
+            tr.step(xd, td, wd)
+        torch.cuda.synchronize()
+        return tr.flat.data.clone()
+
+    def autograd(branch):
+        monkeypatch.setenv("SP_BRANCH", "1" if branch else "0")
+        m, _ = _model(11)
+        m.compute_dtype = dtype
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        for _ in range(3):
+            opt.zero_grad()
+            p = m(xd)
+            (0.5 * torch.nn.functional.mse_loss(p * wd[..., None, None], td * wd[..., None, None])).backward()
+            opt.step()
+        torch.cuda.synchronize()
+        return torch.cat([q.detach().reshape(-1) for q in m.parameters()]).clone()
+
+    for fn in (steps, autograd):
+        ref = fn(False)
+        for _ in range(2):
+            assert torch.equal(fn(True), ref), fn.__name__
+
+
 # ---------------------------------------------------------------------------------------------- the reference's own loop, through autograd
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_reference_training_loop_through_autograd(dtype):

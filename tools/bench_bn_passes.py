@@ -42,7 +42,7 @@ def main():
         def fwd(i):
             z, y, dy, r, dres, out = sets[i % nset]
             _lib.check(lib.sp_bn_fold_apply_nhwc(P(z), 1, P(part[0]), P(part[1]), prow, C, rows, 1e-5, 0.1, P(gamma), P(beta), P(r), P(out), rows, C, 1,
-                                                 P(mean), P(invstd), P(rm), P(rv), st), name)
+                                                 P(mean), P(invstd), P(rm), P(rv), None, st), name)
 
         def bwd(i):
             z, y, dy, r, dres, out = sets[i % nset]
@@ -50,7 +50,7 @@ def main():
                                                      rows, C, P(dg), P(db), None, None, P(out), P(dres), 0, st), name)
         def fwd_plain(i):
             z, y, dy, r, dres, out = sets[i % nset]
-            _lib.check(lib.sp_bn_apply_nhwc(P(z), 1, P(mean), P(invstd), P(gamma), P(beta), P(r), P(out), rows, C, 1, st), name)
+            _lib.check(lib.sp_bn_apply_nhwc(P(z), 1, P(mean), P(invstd), P(gamma), P(beta), P(r), P(out), rows, C, 1, None, st), name)
 
         def bwd_plain(i):
             z, y, dy, r, dres, out = sets[i % nset]

@@ -95,7 +95,7 @@ def main(argv=None):
             mean, invstd = torch.zeros(C, device=dev), torch.ones(C, device=dev)
             gamma, beta = torch.ones(C, device=dev), torch.zeros(C, device=dev)
             timed(f"sp_bn_apply_nhwc (+res, relu) {'bf16' if bf16 else 'fp32'} C={C} {tag}", "pose_resnet_dconv.py:124-131", rows_n * C * es * 3,
-                  lambda: _lib.check(lib.sp_bn_apply_nhwc(P(z), bf16, P(mean), P(invstd), P(gamma), P(beta), P(res), P(y), rows_n, C, 1, st)))
+                  lambda: _lib.check(lib.sp_bn_apply_nhwc(P(z), bf16, P(mean), P(invstd), P(gamma), P(beta), P(res), P(y), rows_n, C, 1, None, st)))
             dy = torch.randn((rows_n, C), device=dev)
             dz = torch.empty_like(z)
             dres = torch.empty((rows_n, C), device=dev)
