@@ -358,6 +358,18 @@ int sp_bn_apply_nhwc(const void* z, int bf16, const float* mean, const float* in
 int sp_bn_train_bwd_nhwc(const void* dy, int bf16, const void* relu_src, const void* z, const float* mean, const float* invstd,
                          const float* gamma, int64_t rows, int c, void* dz, float* dgamma, float* dbeta, void* dres,
                          int dres_accumulate, void* workspace, void* stream);
+/* The ResNet stem in training (pose_resnet_dconv.py:251-256: bn1 -> relu -> maxpool): relu(bn1(z)) feeds the pooling only, so
+ * sp_bn_apply_maxpool_nhwc applies the BatchNorm + ReLU map to the taps of each window and writes the POOLED map + the winning tap per element
+ * (same values and indices as sp_bn_apply_nhwc + sp_maxpool3x3s2_idx_nhwc, without the full-resolution tensor in between), and
+ * sp_bn_maxpool_bwd_nhwc is the backward of that pair from the pooled gradient: d gamma / d beta summed over the pooled grid (a pooled
+ * gradient reaches exactly one stem pixel; xhat and the ReLU mask re-formed from z at the winner; fp64 partials, fixed order), then dz of
+ * the stem conv by gathering each pixel's <= 4 windows.  `bf16`: bit 0 activations, bit 1 gradients (as the other backward passes);
+ * workspace: SP_REDUCE_WORKSPACE_BYTES. */
+int sp_bn_apply_maxpool_nhwc(const void* z, int bf16, const float* mean, const float* invstd, const float* gamma, const float* beta, void* y,
+                             void* idx, int batch, int h, int w, int c, void* stream);
+int sp_bn_maxpool_bwd_nhwc(const void* dy_pooled, int bf16, const void* idx, const void* z, const float* mean, const float* invstd,
+                           const float* gamma, const float* beta, int batch, int h, int w, int c, float* dgamma, float* dbeta, void* dz,
+                           void* workspace, void* stream);
 /* nn.SyncBatchNorm (ddp...:89-90) = the same three steps with a cross-rank SUM between the halves:
  *   forward : sp_bn_train_partial_nhwc -> all-reduce(sums [c][2] fp64: sum, sum of squares) -> sp_bn_train_finalize(total_rows)
  *   backward: sp_bn_train_bwd_reduce_nhwc (LOCAL dgamma, dbeta = this rank's parameter gradients) -> all-reduce(copy of them)

@@ -73,6 +73,8 @@ SYMBOLS = {
     "sp_encode_gauss_refine": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P]),
     "sp_encode_gauss_basic": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, c_int, _P, _P, _P]),
     "sp_bn_train_stats_nhwc": (c_int, [_P, c_int, c_int64, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P]),
+    "sp_bn_apply_maxpool_nhwc": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "sp_bn_maxpool_bwd_nhwc": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "sp_bn_apply_nhwc": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, _P, _P]),
     "sp_bn_train_partial_nhwc": (c_int, [_P, c_int, c_int64, c_int, _P, _P, _P]),
     "sp_bn_train_finalize": (c_int, [_P, c_int64, c_int, c_float, c_float, _P, _P, _P, _P, _P]),

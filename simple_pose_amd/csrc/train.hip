@@ -765,6 +765,140 @@ __global__ void maxpool3x3s2_bwd_idx_kernel(const unsigned int* __restrict__ idx
     }
 }
 
+// ---- the ResNet stem in training: bn1 + ReLU + MaxPool2d(3,2,1) as ONE forward pass and TWO backward passes (round 4) ----------------------
+// relu(bn1(z)) feeds the pooling only (pose_resnet_dconv.py:251-256): nothing reads it as a tensor, so the forward pass applies the BatchNorm
+// map to the nine taps of a window, pools, and writes the pooled map + the winning tap per element (as sp_maxpool3x3s2_idx_nhwc) - the 128 x 96
+// map is neither written nor read back.  Backward: a pooled gradient reaches exactly one stem pixel, so d beta = sum g and d gamma = sum g * xhat
+// run over the POOLED grid (4x fewer elements; xhat and the ReLU mask are re-formed from z at the winner), and dz gathers its <= 4 windows as
+// sp_maxpool3x3s2_bwd_idx_nhwc does - the pooling's input gradient is never materialised either.
+template <bool BF16>
+__global__ void bn_apply_maxpool_kernel(const void* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                        const float* __restrict__ gamma, const float* __restrict__ beta, void* __restrict__ y,
+                                        unsigned int* __restrict__ idx, int H, int W, int C4, int Ho, int Wo, long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long long r = i / C4;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho);
+        const long long b = r / Ho;
+        const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c], is = reinterpret_cast<const f32x4*>(invstd)[c];
+        const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[c], be = reinterpret_cast<const f32x4*>(beta)[c];
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        unsigned int tap[4] = {4u, 4u, 4u, 4u};                 // the centre tap is always inside the image
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yy = oy * 2 - 1 + ky;
+            if ((unsigned)yy >= (unsigned)H) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int xx = ox * 2 - 1 + kx;
+                if ((unsigned)xx >= (unsigned)W) continue;
+                f32x4 v = bn_fwd_elem(ld4<BF16>(z, ((b * H + yy) * W + xx) * C4 + c), mu, is, ga, be);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = v[e] > 0.f ? v[e] : 0.f;
+                    if (BF16) v[e] = (float)(__bf16)v[e];       // the value nn.MaxPool2d would see: the stored bf16 activation
+                    if (v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; tap[e] = (unsigned)(ky * 3 + kx); }   // torch: (val > max) || isnan(val)
+                }
+            }
+        }
+        st4<BF16>(y, i, best);
+        idx[i] = tap[0] | (tap[1] << 8) | (tap[2] << 16) | (tap[3] << 24);
+    }
+}
+
+// sums over the pooled grid: s0 = sum g, s1 = sum g * xhat with g = dyp * (bn(z) > 0) at the window's winner.  Same block structure and
+// fixed-order folds as channel_reduce_kernel (part: [gridDim.x][C][2] doubles -> pair_sum_final_kernel).
+template <bool BF16, bool G16>
+__global__ __launch_bounds__(256) void stem_pool_bwd_reduce_kernel(const void* __restrict__ dyp, const unsigned int* __restrict__ idx, const void* __restrict__ z,
+                                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta, int H, int W, int Ho,
+                                                                   int Wo, int M, int C, double* __restrict__ part) {
+    const int C4 = C >> 2;
+    const int lanes_c = C4 < 256 ? C4 : 256;
+    const int rows_par = 256 / lanes_c;
+    const int tc = threadIdx.x % lanes_c, tr = threadIdx.x / lanes_c;
+    __shared__ double sm[256 * 8];
+    for (int c4 = tc; c4 < C4; c4 += lanes_c) {
+        double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+        const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c4], is = reinterpret_cast<const f32x4*>(invstd)[c4];
+        const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[c4], be = reinterpret_cast<const f32x4*>(beta)[c4];
+        if (tr < rows_par) {
+            for (long long r = (long long)blockIdx.x * rows_par + tr; r < M; r += (long long)gridDim.x * rows_par) {
+                const int ox = (int)(r % Wo);
+                const long long q = r / Wo;
+                const int oy = (int)(q % Ho);
+                const long long b = q / Ho;
+                const f32x4 g = ld4<G16>(dyp, r * C4 + c4);
+                const unsigned t = idx[r * C4 + c4];
+                const float* zf = reinterpret_cast<const float*>(z);
+                const __bf16* zh = reinterpret_cast<const __bf16*>(z);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int tap = (int)((t >> (8 * e)) & 0xffu), ky = tap / 3, kx = tap - 3 * ky;
+                    const long long zi = (((b * H + (oy * 2 - 1 + ky)) * W + (ox * 2 - 1 + kx)) * C4 + c4) * 4 + e;
+                    const float zz = BF16 ? (float)zh[zi] : zf[zi];
+                    f32x4 v4 = {zz, zz, zz, zz};
+                    v4 = bn_fwd_elem(v4, f32x4{mu[e], mu[e], mu[e], mu[e]}, f32x4{is[e], is[e], is[e], is[e]}, f32x4{ga[e], ga[e], ga[e], ga[e]},
+                                     f32x4{be[e], be[e], be[e], be[e]});
+                    const float ge = v4[0] > 0.f ? g[e] : 0.f;
+                    s0[e] += (double)ge;
+                    s1[e] += (double)ge * (double)((zz - mu[e]) * is[e]);
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sm[threadIdx.x * 8 + e] = s0[e]; sm[threadIdx.x * 8 + 4 + e] = s1[e]; }
+        __syncthreads();
+        if (tr == 0) {
+            for (int k = 1; k < rows_par; ++k)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sm[tc * 8 + e] += sm[(k * lanes_c + tc) * 8 + e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                part[((size_t)blockIdx.x * C + c4 * 4 + e) * 2 + 0] = sm[tc * 8 + e];
+                part[((size_t)blockIdx.x * C + c4 * 4 + e) * 2 + 1] = sm[tc * 8 + 4 + e];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// dz of the stem conv: g at a stem pixel = the pooled gradients of the (<= 4) windows it won, through the ReLU mask re-formed from z
+template <bool BF16, bool G16>
+__global__ void stem_pool_bwd_apply_kernel(const void* __restrict__ dyp, const unsigned int* __restrict__ idx, const void* __restrict__ z,
+                                           const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                           const float* __restrict__ beta, const float* __restrict__ dgamma, const float* __restrict__ dbeta, float inv_m,
+                                           void* __restrict__ dz, int H, int W, int C4, int Ho, int Wo, long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long long r = i / C4;
+        const int ix = (int)(r % W); r /= W;
+        const int iy = (int)(r % H);
+        const long long b = r / H;
+        const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c], is = reinterpret_cast<const f32x4*>(invstd)[c];
+        const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[c], be = reinterpret_cast<const f32x4*>(beta)[c];
+        const f32x4 dg = reinterpret_cast<const f32x4*>(dgamma)[c], db = reinterpret_cast<const f32x4*>(dbeta)[c];
+        const f32x4 zz = ld4<BF16>(z, i);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {        // windows oy with iy in [2oy-1, 2oy+1]
+            if (oy >= Ho) continue;
+            const unsigned ky = (unsigned)(iy - (2 * oy - 1));
+            for (int ox = ix / 2; ox <= (ix + 1) / 2; ++ox) {
+                if (ox >= Wo) continue;
+                const unsigned mine = ky * 3u + (unsigned)(ix - (2 * ox - 1));
+                const long long o = ((b * Ho + oy) * Wo + ox) * C4 + c;
+                const unsigned int t = idx[o];
+                const f32x4 g = ld4<G16>(dyp, o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (((t >> (8 * e)) & 0xffu) == mine) acc[e] += g[e];
+            }
+        }
+        const f32x4 v = bn_fwd_elem(zz, mu, is, ga, be);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = v[e] > 0.f ? acc[e] : 0.f;
+        st4<BF16>(dz, i, bn_bwd_elem(acc, zz, mu, is, ga, dg, db, inv_m));
+    }
+}
+
 // [B,C,H,W] fp32 -> [B,H,W,Cpad] (fp32 or bf16), channels >= C zero: the loss gradient d loss / d heat-map in the layout (and
 // K-tile padding) the final layer's dgrad / wgrad launches read.  One thread per (pixel, 4 output channels).
 template <bool BF16OUT>
@@ -1237,6 +1371,45 @@ extern "C" int sp_maxpool3x3s2_bwd_idx_nhwc(const void* idx, const void* dy, int
     else hipLaunchKernelGGL(maxpool3x3s2_bwd_idx_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
                             reinterpret_cast<const unsigned int*>(idx), dy, dx, h, w, c / 4, ho, wo, total);
     return sp_check_launch("maxpool3x3s2_bwd_idx_kernel");
+}
+
+extern "C" int sp_bn_apply_maxpool_nhwc(const void* z, int bf16, const float* mean, const float* invstd, const float* gamma, const float* beta, void* y,
+                                       void* idx, int batch, int h, int w, int c, void* stream) {
+    SP_REQUIRE(z && mean && invstd && gamma && beta && y && idx, "sp_bn_apply_maxpool_nhwc: null pointer");
+    SP_REQUIRE(batch > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "sp_bn_apply_maxpool_nhwc: bad shape");
+    const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+    const long long total = (long long)batch * ho * wo * (c / 4);
+    SP_REQUIRE((long long)batch * h * w * c < (1ll << 31), "sp_bn_apply_maxpool_nhwc: tensor too large");
+    if (bf16 & 1) hipLaunchKernelGGL(bn_apply_maxpool_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, z, mean, invstd, gamma, beta, y,
+                                     reinterpret_cast<unsigned int*>(idx), h, w, c / 4, ho, wo, total);
+    else hipLaunchKernelGGL(bn_apply_maxpool_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, z, mean, invstd, gamma, beta, y,
+                            reinterpret_cast<unsigned int*>(idx), h, w, c / 4, ho, wo, total);
+    return sp_check_launch("bn_apply_maxpool_kernel");
+}
+
+extern "C" int sp_bn_maxpool_bwd_nhwc(const void* dy_pooled, int bf16, const void* idx, const void* z, const float* mean, const float* invstd,
+                                      const float* gamma, const float* beta, int batch, int h, int w, int c, float* dgamma, float* dbeta, void* dz,
+                                      void* workspace, void* stream) {
+    SP_REQUIRE(dy_pooled && idx && z && mean && invstd && gamma && beta && dgamma && dbeta && dz && workspace, "sp_bn_maxpool_bwd_nhwc: null pointer");
+    SP_REQUIRE(batch > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "sp_bn_maxpool_bwd_nhwc: bad shape");
+    const bool a16 = bf16 & 1, g16 = bf16 & 2;
+    SP_REQUIRE(a16 || !g16, "sp_bn_maxpool_bwd_nhwc: bf16 gradients with fp32 activations is not a supported mix");
+    const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+    const long long rows = (long long)batch * h * w, prows = (long long)batch * ho * wo, total = rows * (c / 4);
+    SP_REQUIRE(total * 4 < (1ll << 31), "sp_bn_maxpool_bwd_nhwc: tensor too large");
+    hipStream_t s = (hipStream_t)stream;
+    double* part = reinterpret_cast<double*>(workspace);
+    const int nblk = red_blocks(prows, c);
+    const unsigned int* ix = reinterpret_cast<const unsigned int*>(idx);
+#define SP_SPR(A, G) hipLaunchKernelGGL((stem_pool_bwd_reduce_kernel<A, G>), dim3(nblk), dim3(256), 0, s, dy_pooled, ix, z, mean, invstd, gamma, beta, h, w, ho, wo, (int)prows, c, part)
+    if (a16 && g16) SP_SPR(true, true); else if (a16) SP_SPR(true, false); else SP_SPR(false, false);
+#undef SP_SPR
+    hipLaunchKernelGGL(pair_sum_final_kernel, dim3((c + 3) / 4), dim3(256), 0, s, part, nblk, c, dbeta, dgamma);
+    const float inv_m = (float)(1.0 / (double)rows);
+#define SP_SPA(A, G) hipLaunchKernelGGL((stem_pool_bwd_apply_kernel<A, G>), dim3(grid_for(total, 256)), dim3(256), 0, s, dy_pooled, ix, z, mean, invstd, gamma, beta, dgamma, dbeta, inv_m, dz, h, w, c / 4, ho, wo, total)
+    if (a16 && g16) SP_SPA(true, true); else if (a16) SP_SPA(true, false); else SP_SPA(false, false);
+#undef SP_SPA
+    return sp_check_launch("sp_bn_maxpool_bwd_nhwc");
 }
 
 extern "C" int sp_nchw_to_nhwc_pad(const float* x, void* y, int y_bf16, int batch, int channels, int h, int w, int c_pad, void* stream) {

@@ -1557,23 +1557,56 @@ class PoseTrainer:
         cp = 8 if self.bf16 else 4
         x4 = new((B, self.in_h, self.in_w, cp))
         _lib.check((lib.sp_nchw_to_nhwc8_bf16 if self.bf16 else lib.sp_nchw_to_nhwc4)(P(x), P(x4), B, 3, self.in_h, self.in_w, stream), "to_nhwc")
-        a = conv_bn(Act(x4, self.in_h, self.in_w, cp, needs_grad=False), "conv1", "bn1", True)
+        xin = Act(x4, self.in_h, self.in_w, cp, needs_grad=False)
         if self.head == "hrnet":
-            a = hrnet_forward(a)
+            a = hrnet_forward(conv_bn(xin, "conv1", "bn1", True))
             return self._finish_forward(a, tape, nbt, B, wgrad_async, new, newf)
-        pooled = new((B, a.h // 2, a.w // 2, a.c))
-        pool_idx = self._take(tuple(pooled.shape), torch.uint8, dev)               # winning tap per output element
-        _lib.check(lib.sp_maxpool3x3s2_idx_nhwc(P(a.data), bf, P(pooled), P(pool_idx), B, a.h, a.w, a.c, stream), "maxpool")
-        pa = Act(pooled, a.h // 2, a.w // 2, a.c)
-        stem_out = a
 
-        def pool_bwd():
-            stem_out.grad = newg(stem_out.data.shape)
-            _lib.check(lib.sp_maxpool3x3s2_bwd_idx_nhwc(P(pool_idx), P(pa.grad), gf, P(stem_out.grad), B, stem_out.h, stem_out.w, stem_out.c,
-                                                        stream), "maxpool.bwd")
-            pa.grad = None
-        tape.append(pool_bwd)
-        a = pa
+        def stem_fused() -> Act:
+            """conv1 -> bn1 -> relu -> maxpool with the BatchNorm map applied inside the pooling pass (sp_bn_apply_maxpool_nhwc): relu(bn1(z)) feeds the
+            pooling only, so the 128 x 96 map is never written; backward sums d gamma / d beta over the POOLED grid and gathers dz
+            (sp_bn_maxpool_bwd_nhwc) - no pooling input gradient either.  Same values as conv_bn + sp_maxpool3x3s2_idx_nhwc."""
+            layer = L["conv1"]
+            xin.consumers += 1
+            z, part, prow = layer.forward_bn_stats(xin.data, B)
+            hs, wsz, C = z.shape[1], z.shape[2], z.shape[3]
+            mean, invstd = newf(C), newf(C)
+            gamma, beta = self.sd["bn1.weight"], self.sd["bn1.bias"]
+            _lib.check(lib.sp_bn_train_stats_from_conv(P(part[0]), P(part[1]), prow, part.shape[2], B * hs * wsz, C, BN_EPS, BN_MOMENTUM, P(mean), P(invstd),
+                                                       P(self.buffers["bn1.running_mean"]), P(self.buffers["bn1.running_var"]), stream), "bn1")
+            nbt.append(self.buffers["bn1.num_batches_tracked"])
+            pooled = new((B, hs // 2, wsz // 2, C))
+            pidx = self._take(tuple(pooled.shape), torch.uint8, dev)
+            _lib.check(lib.sp_bn_apply_maxpool_nhwc(P(z), bf, P(mean), P(invstd), P(gamma), P(beta), P(pooled), P(pidx), B, hs, wsz, C, stream), "bn1+maxpool")
+            out = Act(pooled, hs // 2, wsz // 2, C)
+
+            def bwd():
+                dz = new(z.shape)
+                _lib.check(lib.sp_bn_maxpool_bwd_nhwc(P(out.grad), gf, P(pidx), P(z), P(mean), P(invstd), P(gamma), P(beta), B, hs, wsz, C,
+                                                      P(self.flat.view("bn1.weight", True)), P(self.flat.view("bn1.bias", True)), P(dz), P(ws), stream),
+                           "bn1+maxpool.bwd")
+                out.grad = None
+                wgrad_async(layer, xin.data, dz)
+                self._grads_ready("bn1.weight", "bn1.bias", "conv1.weight")
+            tape.append(bwd)
+            return out
+
+        if self.fuse_stem_pool and not sync and self.fuse_bn_stats and self.in_h % 4 == 0 and self.in_w % 4 == 0:
+            a = stem_fused()
+        else:
+            stem_out = conv_bn(xin, "conv1", "bn1", True)
+            pooled = new((B, stem_out.h // 2, stem_out.w // 2, stem_out.c))
+            pool_idx = self._take(tuple(pooled.shape), torch.uint8, dev)               # winning tap per output element
+            _lib.check(lib.sp_maxpool3x3s2_idx_nhwc(P(stem_out.data), bf, P(pooled), P(pool_idx), B, stem_out.h, stem_out.w, stem_out.c, stream), "maxpool")
+            pa = Act(pooled, stem_out.h // 2, stem_out.w // 2, stem_out.c)
+
+            def pool_bwd():
+                stem_out.grad = newg(stem_out.data.shape)
+                _lib.check(lib.sp_maxpool3x3s2_bwd_idx_nhwc(P(pool_idx), P(pa.grad), gf, P(stem_out.grad), B, stem_out.h, stem_out.w, stem_out.c,
+                                                            stream), "maxpool.bwd")
+                pa.grad = None
+            tape.append(pool_bwd)
+            a = pa
         for li, n in enumerate(self.model.BLOCKS, start=1):
             for bi in range(n):
                 p = f"layer{li}.{bi}"
@@ -1775,6 +1808,7 @@ class PoseTrainer:
     _opt_stream = None
     _wgrad_stream = None
     _wgrad_tail = None
+    fuse_stem_pool = os.environ.get("SP_STEM_POOL", "1") != "0"        # (env: development knob)
     _branch_stream = None
     _branch_main = None
     _in_branch = False

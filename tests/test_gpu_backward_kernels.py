@@ -637,3 +637,68 @@ def test_dgrad_epilogue_sums_and_fused_fold_backward(case, two, bf16, measured):
         assert _rel_bf16(dres_b.float(), base.double().cpu() + g64) <= 4e-3
     else:
         assert _rel(dres_b - base, g64) <= 2e-6
+
+
+# ---- the stem in training: bn1 + ReLU + maxpool as one forward pass / one backward entry ---------------------------------------------------
+@pytest.mark.parametrize("mode", [0, 1, 3], ids=["fp32", "bf16", "bf16_grads"])
+def test_stem_bn_relu_maxpool_fused_matches_the_separate_passes(mode, measured):
+    """sp_bn_apply_maxpool_nhwc == sp_bn_apply_nhwc + sp_maxpool3x3s2_idx_nhwc bit for bit (pooled map and winning taps), without the
+    full-resolution activation; sp_bn_maxpool_bwd_nhwc == sp_maxpool3x3s2_bwd_idx_nhwc + sp_bn_train_bwd_nhwc (sums over the pooled grid
+    instead of the full one: fp64 partials, so d gamma / d beta agree to fp32 rounding and dz with them)."""
+    bf16, g16 = bool(mode & 1), bool(mode & 2)
+    B, H, W, C = 3, 24, 20, 64
+    g = torch.Generator().manual_seed(77)
+    adt, gdt = (torch.bfloat16 if bf16 else torch.float32), (torch.bfloat16 if g16 else torch.float32)
+    z = (torch.randn(B, H, W, C, generator=g) * 1.3 + 0.2).to(adt).to(DEV)
+    rows = B * H * W
+    z64 = z.double().reshape(rows, C)
+    mean, invstd = z64.mean(0).float().contiguous(), (1 / torch.sqrt(z64.var(0, unbiased=False) + 1e-5)).float().contiguous()
+    gamma, beta = (0.75 + 0.5 * torch.rand(C, generator=g)).to(DEV), (0.2 * torch.randn(C, generator=g)).to(DEV)
+    lib, st = _lib.lib(), _lib.current_stream()
+    Ho, Wo = H // 2, W // 2
+    # separate passes
+    y = torch.empty_like(z)
+    _lib.check(lib.sp_bn_apply_nhwc(P(z), mode & 1, P(mean), P(invstd), P(gamma), P(beta), None, P(y), rows, C, 1, None, st), "apply")
+    pa, ia = torch.empty(B, Ho, Wo, C, dtype=adt, device=DEV), torch.empty(B, Ho, Wo, C, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.sp_maxpool3x3s2_idx_nhwc(P(y), mode & 1, P(pa), P(ia), B, H, W, C, st), "pool")
+    # fused
+    pb, ib = torch.empty_like(pa), torch.empty_like(ia)
+    _lib.check(lib.sp_bn_apply_maxpool_nhwc(P(z), mode & 1, P(mean), P(invstd), P(gamma), P(beta), P(pb), P(ib), B, H, W, C, st), "apply+pool")
+    torch.cuda.synchronize()
+    assert torch.equal(pa, pb) and torch.equal(ia, ib)
+    # backward
+    dyp = torch.randn(B, Ho, Wo, C, generator=g).to(gdt).to(DEV)
+    ws = torch.empty(4 << 20, dtype=torch.uint8, device=DEV)
+    dy = torch.empty(B, H, W, C, dtype=gdt, device=DEV)
+    _lib.check(lib.sp_maxpool3x3s2_bwd_idx_nhwc(P(ia), P(dyp), mode, P(dy), B, H, W, C, st), "pool bwd")
+    dz_a, dg_a, db_a = torch.empty_like(z), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    _lib.check(lib.sp_bn_train_bwd_nhwc(P(dy), mode, P(y), P(z), P(mean), P(invstd), P(gamma), rows, C, P(dz_a), P(dg_a), P(db_a), None, 0, P(ws), st), "bn bwd")
+    dz_b, dg_b, db_b = torch.empty_like(z), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    _lib.check(lib.sp_bn_maxpool_bwd_nhwc(P(dyp), mode, P(ib), P(z), P(mean), P(invstd), P(gamma), P(beta), B, H, W, C, P(dg_b), P(db_b), P(dz_b), P(ws), st),
+               "fused bwd")
+    torch.cuda.synchronize()
+    # (bf16 gradients: the separate path rounds the pooling's input gradient - a sum of up to four windows - to bf16 before the BatchNorm
+    # reduction reads it; the fused path never forms that tensor, so the two differ by that rounding: the bar is bf16's, and the fused sums
+    # are the more exact ones - checked against float64 below)
+    sbar = 1e-2 if g16 else 2e-6
+    eg, eb = _rel(dg_b, dg_a.double()), _rel(db_b, db_a.double())
+    measured("stem_dgamma_rel", eg, sbar)
+    assert eg <= sbar and eb <= sbar, (eg, eb)
+    e = (_rel_bf16 if bf16 else _rel)(dz_b.float(), dz_a.double())
+    zbar = 1.2e-2 if g16 else (4e-3 if bf16 else 4e-6)
+    measured("stem_dz_rel", e, zbar)
+    assert e <= zbar
+    # float64 reference of the sums from the pooled gradient itself
+    yy = y.double().cpu().reshape(B, H, W, C)
+    gfull = torch.zeros(B, H, W, C, dtype=torch.float64)
+    iac, dypc = ia.cpu().long(), dyp.double().cpu()
+    for oy in range(Ho):
+        for ox in range(Wo):
+            t = iac[:, oy, ox, :]
+            iy, ix = 2 * oy - 1 + t // 3, 2 * ox - 1 + t % 3
+            bi = torch.arange(B)[:, None].expand(B, C)
+            ci = torch.arange(C)[None, :].expand(B, C)
+            gfull.index_put_((bi, iy, ix, ci), dypc[:, oy, ox, :], accumulate=True)
+    gm = (gfull * (yy > 0)).reshape(rows, C)
+    xh = (z64.cpu() - mean.double().cpu()) * invstd.double().cpu()
+    assert _rel(db_b, gm.sum(0)) <= 3e-6 and _rel(dg_b, (gm * xh).sum(0)) <= 3e-6

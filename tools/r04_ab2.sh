@@ -6,7 +6,7 @@ OUT=$ROOT/gpurun_out/r04_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 T=${TILES:-$ROOT/profiles/r03_train_bf16_tiles.json}
-for rep in 1 2; do
+for rep in $(seq 1 ${REPS:-2}); do
   i=0
   for v in "$@"; do
     i=$((i+1))
