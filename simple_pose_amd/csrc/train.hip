@@ -186,6 +186,18 @@ __device__ __forceinline__ bool fold_slab64(const float* __restrict__ ps, const 
     double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0}, b0[4] = {0, 0, 0, 0}, b1[4] = {0, 0, 0, 0};
     if (c < C) {
         int r = rl;
+        // (two trips per iteration: eight 16-byte loads in flight per thread, added in the order of the one-trip loop below - same bits; a
+        // 3,072-row fold is 24 dependent trips otherwise)
+        for (; r + 192 < nrows; r += 256) {
+            const f32x4 u0 = *reinterpret_cast<const f32x4*>(ps + (size_t)r * stride + c), u1 = *reinterpret_cast<const f32x4*>(pq + (size_t)r * stride + c);
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(ps + (size_t)(r + 64) * stride + c), v1 = *reinterpret_cast<const f32x4*>(pq + (size_t)(r + 64) * stride + c);
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(ps + (size_t)(r + 128) * stride + c), w1 = *reinterpret_cast<const f32x4*>(pq + (size_t)(r + 128) * stride + c);
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(ps + (size_t)(r + 192) * stride + c), x1 = *reinterpret_cast<const f32x4*>(pq + (size_t)(r + 192) * stride + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a0[e] += (double)u0[e]; a1[e] += (double)u1[e]; b0[e] += (double)v0[e]; b1[e] += (double)v1[e]; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a0[e] += (double)w0[e]; a1[e] += (double)w1[e]; b0[e] += (double)x0[e]; b1[e] += (double)x1[e]; }
+        }
         for (; r + 64 < nrows; r += 128) {
             const f32x4 u0 = *reinterpret_cast<const f32x4*>(ps + (size_t)r * stride + c), u1 = *reinterpret_cast<const f32x4*>(pq + (size_t)r * stride + c);
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(ps + (size_t)(r + 64) * stride + c), v1 = *reinterpret_cast<const f32x4*>(pq + (size_t)(r + 64) * stride + c);
