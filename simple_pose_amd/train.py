@@ -498,11 +498,14 @@ class PoseTrainer:
                  process_group=None, dtype: str = "fp32", sync_bn: Optional[bool] = None, bucket_mb: float = 32.0,
                  broadcast_init: bool = True, overlap_wgrad: bool = True, collectives: bool = True, sync_bn_latency_us: float = 0.0,
                  native_comm: Optional[bool] = None, sync_bn_inline: bool = True, grad_dtype: Optional[str] = None):
-        """dtype "bf16": bf16 activations and packed weights (v_mfma_f32_32x32x16_bf16 for forward, dgrad and wgrad); the
-        gradient w.r.t. a block output stays fp32 until the BatchNorm backward has subtracted its per-channel mean (rounding
-        it to bf16 first costs 10-50 % gradient error in this net: the useful part is a small difference of large terms), the
+        """dtype "bf16": bf16 activations and packed weights (v_mfma_f32_32x32x16_bf16 for forward, dgrad and wgrad), the
         BN-input gradient dz that feeds the MFMAs is bf16; fp32 master weights / weight gradients / BN statistics / Adam.
         The reference's `optim.amp` mode (ddp...:121-127) without a GradScaler (bf16 keeps fp32's exponent range).
+        `grad_dtype` - the activation gradients (dy of every conv / block output): "bf16" = what autocast keeps (the default with
+        dtype "bf16" on the plain DConv net: the dgrad launches store bf16, the residual share accumulates in bf16, the BatchNorm
+        backward reads it rounded; 2.2 GB less traffic per 32-image step), "fp32" = rounds 1-3 (dy stays fp32 until the BatchNorm
+        backward has subtracted its per-channel means; the only setting for DUC / SELayer / HRNet, whose backward kernels read fp32).
+        Both sit inside the same bar against the reference-style AMP oracle (tests/test_gpu_train.py).
 
         With a process group of W > 1 ranks (one process per GPU):
           * parameters and BN buffers are broadcast from rank 0 at construction (DistributedDataParallel's init, ddp...:91-93);
