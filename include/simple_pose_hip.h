@@ -398,6 +398,8 @@ int sp_bn_train_bwd_apply_nhwc(const void* dy, int bf16, const void* relu_src, c
                                int c, void* dz, void* dres, int dres_accumulate, void* stream);
 /* backward of nn.PixelShuffle(2) (DUC head, nets/commons.py:36-41): dy [B,2h,2w,c/4] fp32 -> dx [B,h,w,c] fp32 */
 int sp_pixel_unshuffle2_nhwc(const float* dy, float* dx, int batch, int h, int w, int c, void* stream);
+/* the same permutation on a bf16 gradient (activation gradients kept in bf16: PoseTrainer grad_dtype "bf16" on the DUC head); c % 32 == 0 */
+int sp_pixel_unshuffle2_nhwc_bf16(const void* dy, void* dx, int batch, int h, int w, int c, void* stream);
 /* x [B,channels,h,w] fp32 -> y [B,h,w,c_pad] (fp32, or bf16 when y_bf16), channels >= `channels` zero-filled: puts
  * d loss / d heat-map (sp_masked_mse's grad) into the layout and K-tile padding the final layer's backward launches read */
 int sp_nchw_to_nhwc_pad(const float* x, void* y, int y_bf16, int batch, int channels, int h, int w, int c_pad, void* stream);

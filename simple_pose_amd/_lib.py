@@ -112,6 +112,7 @@ SYMBOLS = {
     "sp_pose_rescore": (c_int, [_P, _P, c_int, c_int, c_double, _P, _P, _P]),
     "sp_oks_nms": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_double, c_double, _P, _P, _P]),
     "sp_pixel_unshuffle2_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "sp_pixel_unshuffle2_nhwc_bf16": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "sp_maxpool3x3s2_idx_nhwc": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "sp_maxpool3x3s2_bwd_idx_nhwc": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
     "sp_nchw_to_nhwc_pad": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),

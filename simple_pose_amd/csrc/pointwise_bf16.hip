@@ -88,6 +88,33 @@ __global__ void pixel_shuffle2_bf16_kernel(const __bf16* __restrict__ x, u32x4* 
     }
 }
 
+// backward of nn.PixelShuffle(2) on a bf16 gradient (PoseTrainer grad_dtype "bf16", DUC head): gather form - one lane owns 8 consecutive
+// channels of a source pixel = output channels k0, k0 + 1 of its four sub-pixels (source channel 4 k + sub), reads four 4-byte pairs and
+// stores 16 bytes
+__global__ void pixel_unshuffle2_bf16_kernel(const unsigned int* __restrict__ dy, u32x4* __restrict__ dx, int h, int w, int C, long long total) {
+    const int C8 = C >> 3, Co = C >> 2, W2 = 2 * w;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % C8);
+        long long r = i / C8;
+        const int x = (int)(r % w); r /= w;
+        const int y = (int)(r % h);
+        const long long b = r / h;
+        const int k0 = c8 << 1;                       // output channels k0, k0 + 1
+        unsigned int pr[4];
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            const long long o = ((b * 2 * h + (2 * y + (sub >> 1))) * W2 + (2 * x + (sub & 1))) * Co + k0;
+            pr[sub] = dy[o >> 1];                     // (k0 is even: the pair is 4-byte aligned)
+        }
+        u32x4 v;                                      // source order: (k0,0) (k0,1) (k0,2) (k0,3) (k0+1,0) ... (k0+1,3)
+        v[0] = (pr[0] & 0xffffu) | (pr[1] << 16);
+        v[1] = (pr[2] & 0xffffu) | (pr[3] << 16);
+        v[2] = (pr[0] >> 16) | (pr[1] & 0xffff0000u);
+        v[3] = (pr[2] >> 16) | (pr[3] & 0xffff0000u);
+        dx[i] = v;
+    }
+}
+
 __global__ void upsample_add_bf16_kernel(const u32x4* __restrict__ x, const u32x4* base, u32x4* y, int h, int w, int C8, int f, int relu,
                                          long long total) {
     const int W = w * f, H = h * f;
@@ -281,6 +308,16 @@ extern "C" int sp_pixel_shuffle2_nhwc_bf16(const void* x, void* y, int batch, in
     hipLaunchKernelGGL(pixel_shuffle2_bf16_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const __bf16*>(x), reinterpret_cast<u32x4*>(y), h, w, c, total);
     return sp_check_launch("pixel_shuffle2_bf16_kernel");
+}
+
+extern "C" int sp_pixel_unshuffle2_nhwc_bf16(const void* dy, void* dx, int batch, int h, int w, int c, void* stream) {
+    SP_REQUIRE(dy && dx, "sp_pixel_unshuffle2_nhwc_bf16: null pointer");
+    SP_REQUIRE(batch > 0 && h > 0 && w > 0 && c > 0 && c % 32 == 0, "sp_pixel_unshuffle2_nhwc_bf16: c=%d must be a multiple of 32", c);
+    const long long total = (long long)batch * h * w * c / 8;
+    SP_REQUIRE(total * 8 < (1ll << 31), "sp_pixel_unshuffle2_nhwc_bf16: tensor too large");
+    hipLaunchKernelGGL(pixel_unshuffle2_bf16_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const unsigned int*>(dy), reinterpret_cast<u32x4*>(dx), h, w, c, total);
+    return sp_check_launch("pixel_unshuffle2_bf16_kernel");
 }
 
 extern "C" int sp_upsample_add_nhwc_bf16(const void* x, const void* base, void* y, int batch, int h, int w, int c, int factor, int relu,

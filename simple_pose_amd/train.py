@@ -502,9 +502,9 @@ class PoseTrainer:
         BN-input gradient dz that feeds the MFMAs is bf16; fp32 master weights / weight gradients / BN statistics / Adam.
         The reference's `optim.amp` mode (ddp...:121-127) without a GradScaler (bf16 keeps fp32's exponent range).
         `grad_dtype` - the activation gradients (dy of every conv / block output): "bf16" = what autocast keeps (the default with
-        dtype "bf16" on the plain DConv net: the dgrad launches store bf16, the residual share accumulates in bf16, the BatchNorm
+        dtype "bf16" on the plain DConv / DUC nets: the dgrad launches store bf16, the residual share accumulates in bf16, the BatchNorm
         backward reads it rounded; 2.2 GB less traffic per 32-image step), "fp32" = rounds 1-3 (dy stays fp32 until the BatchNorm
-        backward has subtracted its per-channel means; the only setting for DUC / SELayer / HRNet, whose backward kernels read fp32).
+        backward has subtracted its per-channel means; the only setting for the SELayer nets and HRNet, whose backward kernels read fp32).
         Both sit inside the same bar against the reference-style AMP oracle (tests/test_gpu_train.py).
 
         With a process group of W > 1 ranks (one process per GPU):
@@ -530,7 +530,7 @@ class PoseTrainer:
         # dtype "bf16" only; the default there for the nets whose backward kernels all read it): what torch's autocast keeps - the
         # dgrad launches store bf16 and accumulate the residual share in bf16, the BatchNorm backward reads it rounded.
         has_se = any(".se." in k for k in model.state_dict())
-        can16 = self.bf16 and self.head == "dconv" and not has_se
+        can16 = self.bf16 and self.head in ("dconv", "duc") and not has_se
         import os
         if grad_dtype is None:
             grad_dtype = os.environ.get("SP_GRAD_DTYPE") or ("bf16" if can16 else "fp32")
@@ -539,8 +539,8 @@ class PoseTrainer:
         if grad_dtype not in ("fp32", "bf16"):
             raise ValueError(grad_dtype)
         if grad_dtype == "bf16" and not can16:
-            raise NotImplementedError("grad_dtype='bf16' needs dtype='bf16' and the plain ResNet DConv net (the DUC / SELayer / HRNet backward "
-                                      "kernels read fp32 gradients)")
+            raise NotImplementedError("grad_dtype='bf16' needs dtype='bf16' and a plain ResNet DConv / DUC net (the SELayer / HRNet backward kernels "
+                                      "read fp32 gradients)")
         self.g16 = grad_dtype == "bf16"
         self.grad_dtype = torch.bfloat16 if self.g16 else torch.float32
         if getattr(model, "BLOCK", "bottleneck") != "bottleneck":
@@ -1659,8 +1659,9 @@ class PoseTrainer:
 
             def bwd():
                 assert xa.grad is None
-                xa.grad = newf(xa.data.shape)
-                _lib.check(lib.sp_pixel_unshuffle2_nhwc(P(ya.grad), P(xa.grad), B, xa.h, xa.w, xa.c, stream), "pixel_shuffle.bwd")
+                xa.grad = newg(xa.data.shape)
+                _lib.check((lib.sp_pixel_unshuffle2_nhwc_bf16 if self.g16 else lib.sp_pixel_unshuffle2_nhwc)(P(ya.grad), P(xa.grad), B, xa.h, xa.w, xa.c,
+                                                                                                               stream), "pixel_shuffle.bwd")
                 xa.contrib += 1
                 ya.grad = None
             tape.append(bwd)

@@ -702,3 +702,19 @@ def test_stem_bn_relu_maxpool_fused_matches_the_separate_passes(mode, measured):
     gm = (gfull * (yy > 0)).reshape(rows, C)
     xh = (z64.cpu() - mean.double().cpu()) * invstd.double().cpu()
     assert _rel(db_b, gm.sum(0)) <= 3e-6 and _rel(dg_b, (gm * xh).sum(0)) <= 3e-6
+
+
+def test_pixel_unshuffle_bf16_is_the_fp32_permutation():
+    """sp_pixel_unshuffle2_nhwc_bf16 (bf16 activation gradients through the DUC head's PixelShuffle) moves the same elements as the fp32 kernel."""
+    B, h, w, C = 3, 6, 5, 64
+    g = torch.Generator().manual_seed(5)
+    dy = torch.randn(B, 2 * h, 2 * w, C // 4, generator=g).to(torch.bfloat16).to(DEV)
+    lib, st = _lib.lib(), _lib.current_stream()
+    a = torch.empty(B, h, w, C, device=DEV)
+    _lib.check(lib.sp_pixel_unshuffle2_nhwc(P(dy.float().contiguous()), P(a), B, h, w, C, st), "fp32")
+    b = torch.empty(B, h, w, C, dtype=torch.bfloat16, device=DEV)
+    _lib.check(lib.sp_pixel_unshuffle2_nhwc_bf16(P(dy), P(b), B, h, w, C, st), "bf16")
+    torch.cuda.synchronize()
+    assert torch.equal(a, b.float())
+    ref = torch.nn.functional.pixel_unshuffle(dy.float().permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+    assert torch.equal(a, ref.contiguous())
