@@ -191,12 +191,27 @@ def check(rc: int, what: str = ""):
 
 
 def ptr(t):
-    """Device pointer of a torch tensor (or None)."""
-    return None if t is None else c_void_p(t.data_ptr())
+    """Device pointer of a torch tensor (or None) - a plain int: every pointer parameter is declared c_void_p, ctypes converts."""
+    return None if t is None else t.data_ptr()
+
+
+# The train step issues ~350 launches per step from Python; `torch.cuda.current_stream()` costs ~5 us a call (device index lookups,
+# `is_available`, an os.environ read) and was a sixth of the step's host time.  While a PoseTrainer tape runs it pins the handle of the
+# stream it is issuing to here (`pin_stream`); everything else asks torch as before.
+_pinned_stream = None
+
+
+def pin_stream(handle):
+    """Make `current_stream()` return `handle` (a hipStream_t as c_void_p / int; None: ask torch again).  Returns the previous pin."""
+    global _pinned_stream
+    prev, _pinned_stream = _pinned_stream, handle
+    return prev
 
 
 def current_stream(device=None):
     """torch's current stream of `device` (a tensor's .device; default: the current device) as a hipStream_t."""
+    if _pinned_stream is not None:
+        return _pinned_stream
     import torch
 
     return c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1108,6 +1108,23 @@ class PoseTrainer:
         return self.loss_buf
 
     def forward_tape(self, x: torch.Tensor):
+        """See `_forward_tape`.  While the tape is being issued the handle of the stream it goes to is pinned (`_lib.pin_stream`): the ~170
+        `torch.cuda.current_stream()` lookups of a step were a sixth of its host time."""
+        prev = _lib.pin_stream(_lib.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+        try:
+            heat, backward = self._forward_tape(x)
+        finally:
+            _lib.pin_stream(prev)
+
+        def pinned_backward(dheat: torch.Tensor) -> None:
+            prev = _lib.pin_stream(_lib.c_void_p(torch.cuda.current_stream(dheat.device).cuda_stream))
+            try:
+                backward(dheat)
+            finally:
+                _lib.pin_stream(prev)
+        return heat, pinned_backward
+
+    def _forward_tape(self, x: torch.Tensor):
         """Train-mode forward (batch-statistics BatchNorm, running statistics updated): x [B,3,H,W] -> (heat maps [B,J,H/4,W/4],
         backward) where `backward(dheat)` runs the recorded tape - dgrad / wgrad / BN backward - and leaves every parameter gradient
         in the flat gradient buffer `self.flat.grad` (overwritten, not accumulated).  `forward_backward` = this + the masked-MSE
@@ -1175,12 +1192,14 @@ class PoseTrainer:
             branch.wait_event(e0)
             keep = stream
             self._in_branch, self._branch_main = True, here
+            pinned = _lib.pin_stream(_lib.c_void_p(branch.cuda_stream))
             try:
                 with torch.cuda.stream(branch):
                     stream = _lib.current_stream()
                     out = fn()
                     e1.record(branch)
             finally:
+                _lib.pin_stream(pinned)
                 stream = keep
                 self._in_branch = False
             return out, e1
