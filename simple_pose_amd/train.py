@@ -1641,21 +1641,14 @@ class PoseTrainer:
                 if bi == 0 and branch is not None:
                     # projection shortcut on the branch stream; its tape entry keeps its old place (after conv2's, before conv3's)
                     blk_in, i_ds = a, len(tape)
-                    mode = os.environ.get("SP_BRANCH", "1")
-                    if mode == "bwd":
-                        idn, ev_ds = conv_bn(blk_in, p + ".downsample.0", p + ".downsample.1", False), None
-                    else:
-                        idn, ev_ds = run_on_branch(lambda: conv_bn(blk_in, p + ".downsample.0", p + ".downsample.1", False))
+                    idn, ev_ds = run_on_branch(lambda: conv_bn(blk_in, p + ".downsample.0", p + ".downsample.1", False))
                     ds_bwd = tape.pop(i_ds)
 
-                    def ds_bwd_on_branch(ds_bwd=ds_bwd, blk_in=blk_in, mode=mode):
-                        if mode == "fwd":
-                            ds_bwd()
-                            return
+                    def ds_bwd_on_branch(ds_bwd=ds_bwd, blk_in=blk_in):
                         _, ev = run_on_branch(ds_bwd)
                         blk_in.grad_event = ev
                         self._branch_open.append(blk_in)
-                    join_fwd = (lambda ev_ds=ev_ds: torch.cuda.current_stream(dev).wait_event(ev_ds)) if ev_ds is not None else (lambda: None)
+                    join_fwd = lambda ev_ds=ev_ds: torch.cuda.current_stream(dev).wait_event(ev_ds)
                 t = conv_bn(a, p + ".conv1", p + ".bn1", True, pend=p1)
                 t = conv_bn(t, p + ".conv2", p + ".bn2", True)
                 if join_fwd is not None:
