@@ -323,6 +323,14 @@ int sp_conv2d_dgrad_bn_bwd_stats2(const sp_conv_desc* desc, const void* dz, cons
                                   const void* bn_y, const void* bn_z, const float* bn_mean, const float* bn_invstd, float* sum_g,
                                   float* sum_g_xhat, const void* bn2_z, const float* bn2_mean, const float* bn2_invstd,
                                   float* sum_g_xhat2, int stats_rows_capacity, void* stream);
+/* sp_conv2d_dgrad_bn_bwd_stats(2) for conv1 of an identity Bottleneck with bf16 gradients: the block input's gradient also receives the
+ * residual share g = dy_out * (ReLU mask of the block output, pose_resnet_dconv.py:124-131).  Instead of `accumulate` = g written by bn3's
+ * backward pass, this launch takes (acc_dy = dy_out, acc_mask = the block output's ReLU bit mask) and adds dy_out where the bit is set: the
+ * pass writes 2 bytes per element less, the bits are the same.  bn2_* all NULL: one BatchNorm. */
+int sp_conv2d_dgrad_bn_bwd_stats_macc(const sp_conv_desc* desc, const void* dz, const void* w_packed, const void* acc_dy, const void* acc_mask,
+                                      void* dx, const void* bn_y, const void* bn_z, const float* bn_mean, const float* bn_invstd, float* sum_g,
+                                      float* sum_g_xhat, const void* bn2_z, const float* bn2_mean, const float* bn2_invstd, float* sum_g_xhat2,
+                                      int stats_rows_capacity, void* stream);
 /* The dgrad of a STRIDE-2 conv is a family of launches, one descriptor per output phase (their tap counts differ: 3x3 -> 2x2, 2x1, 1x2, 1x1).
  * This entry runs the family as ONE launch (blockIdx.y = phase, per-phase geometry / packed weights in the kernel arguments): descs[i] and
  * w_packed[i] are exactly what sp_conv2d_fwd / sp_conv2d_dgrad_bn_bwd_stats(2) would take phase by phase (same batch, tensors, flags and

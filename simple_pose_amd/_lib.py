@@ -122,6 +122,7 @@ SYMBOLS = {
     "sp_bn_train_stats_from_conv": (c_int, [_P, _P, c_int, c_int, c_int64, c_int, c_float, c_float, _P, _P, _P, _P, _P]),
     "sp_conv2d_dgrad_bn_bwd_stats": (c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "sp_conv2d_dgrad_bn_bwd_stats2": (c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
+    "sp_conv2d_dgrad_bn_bwd_stats_macc": (c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "sp_conv2d_dgrad_phases": (c_int, [ctypes.POINTER(ConvDesc), c_int, _P, ctypes.POINTER(_P), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "sp_bn_sums_from_conv": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
     "sp_bn_fold_apply_nhwc": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int64, c_float, c_float, _P, _P, _P, _P, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P]),

@@ -63,6 +63,8 @@ struct ConvArgs {
     const float* scale;
     const float* shift;
     const void* res;     // same dtype/layout as y
+    const unsigned char* res_mask;   // bf16 y only: add res where its bit is set (one byte per 8 channels) - a dgrad launch that takes the
+                                     // residual share of a block input's gradient as (dy of the block output, its ReLU bit mask)
     void* y;             // NHWC (dtype of x) or NCHW fp32
     int M;  // batch * grid_h * grid_w
     int in_h, in_w, c_in;
@@ -611,8 +613,15 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
             if (p.res) {
                 if constexpr (OUT16) {
                     const bf16x8 r8 = __builtin_bit_cast(bf16x8, rv[it]);
+                    if (p.res_mask) {
+                        const __amdgpu_buffer_rsrc_t rmr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.res_mask), (short)0, p.y_bytes >> 4, 0x00020000);
+                        const unsigned m = __builtin_amdgcn_raw_buffer_load_b8(rmr, off[it] == OOB ? OOB : off[it] >> 4, 0, 0);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
+                        for (int e = 0; e < 8; ++e) v[e] += ((m >> e) & 1u) ? (float)r8[e] : 0.f;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
+                    }
                 } else {
                     const f32x4 r4 = __builtin_bit_cast(f32x4, rv[it]);
 #pragma unroll
@@ -893,7 +902,8 @@ int sp_conv_pw_launch(const sp_conv_desc* d, const void* x, const void* w_packed
 
 static int tile_rows_per_block(int, int) { return 1; }   // partial rows per (phase, M tile): the wave rows are added inside the launch
 
-struct BnBwdSrc { const void* y; const void* z; const float* mean; const float* invstd; const void* z2; const float* mean2; const float* invstd2; float* q2; };
+struct BnBwdSrc { const void* y; const void* z; const float* mean; const float* invstd; const void* z2; const float* mean2; const float* invstd2; float* q2;
+                  const void* res_mask = nullptr; };
 
 struct PhaseSet { const sp_conv_desc* descs; const void* const* w; int n; };
 
@@ -946,6 +956,8 @@ static int conv_fwd_impl(const sp_conv_desc* d, const void* x, const void* w_pac
 
     ConvArgs a;
     a.x = x; a.w = w_packed; a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
+    a.res_mask = bsrc ? reinterpret_cast<const unsigned char*>(bsrc->res_mask) : nullptr;
+    SP_REQUIRE(!a.res_mask || (residual && out16 && !(d->flags & SP_CONV_OUT_NCHW)), "sp_conv2d_dgrad: a masked accumulate operand needs bf16 NHWC gradients");
     a.M = (int)M;
     a.in_h = d->in_h; a.in_w = d->in_w; a.c_in = d->c_in;
     a.grid_h = d->grid_h; a.grid_w = d->grid_w;
@@ -1129,4 +1141,19 @@ extern "C" int sp_conv2d_dgrad_phases(const sp_conv_desc* descs, int n_phases, c
         return conv_fwd_impl(&descs[0], dz, w_packed[0], nullptr, nullptr, accumulate, dx, sum_g, sum_g_xhat, stats_rows_capacity, stream, &src, &phs);
     }
     return conv_fwd_impl(&descs[0], dz, w_packed[0], nullptr, nullptr, accumulate, dx, nullptr, nullptr, 0, stream, nullptr, &phs);
+}
+
+// The BSTATS dgrad launch of a 1x1 conv1 whose block input also feeds the block's residual add (an identity Bottleneck): the residual share
+// of that input's gradient is g = dy_out * (ReLU mask of the block output).  Instead of bn3's backward pass writing g and this launch
+// reading it back as `accumulate`, the launch takes (dy_out, mask_out) and forms g in its epilogue: 2 bytes per element less written and the
+// same bits (g is dy_out or zero).  bf16 gradients only; bn2_* NULL: no second BatchNorm.
+extern "C" int sp_conv2d_dgrad_bn_bwd_stats_macc(const sp_conv_desc* d, const void* dz, const void* w_packed, const void* acc_dy, const void* acc_mask,
+                                                void* dx, const void* bn_y, const void* bn_z, const float* bn_mean, const float* bn_invstd, float* sum_g,
+                                                float* sum_g_xhat, const void* bn2_z, const float* bn2_mean, const float* bn2_invstd, float* sum_g_xhat2,
+                                                int stats_rows_capacity, void* stream) {
+    SP_REQUIRE(acc_dy && acc_mask, "sp_conv2d_dgrad_bn_bwd_stats_macc: null accumulate operand");
+    SP_REQUIRE(!bn2_z || (bn2_mean && bn2_invstd && sum_g_xhat2), "sp_conv2d_dgrad_bn_bwd_stats_macc: null pointer");
+    BnBwdSrc src = {bn_y, bn_z, bn_mean, bn_invstd, bn2_z, bn2_mean, bn2_invstd, sum_g_xhat2};
+    src.res_mask = acc_mask;
+    return conv_fwd_impl(d, dz, w_packed, nullptr, nullptr, acc_dy, dx, sum_g, sum_g_xhat, stats_rows_capacity, stream, &src);
 }

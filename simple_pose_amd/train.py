@@ -127,6 +127,9 @@ class Act:
     bstats: Optional[tuple] = None     # backward: (partial sums [2, rows, stride], rows) left by the dgrad launch that wrote .grad
     bn2: Optional[tuple] = None        # block output with a projection shortcut: (z, mean, invstd, bn name) of the shortcut's BatchNorm, whose
                                        # dy is this output's g: its sum g * xhat rides on the same dgrad epilogue (part[2])
+    lazy_ok: bool = False              # an identity Bottleneck's input: its other consumer is conv1 (1x1, stride 1), whose dgrad can take the
+                                       # residual share of .grad as (dy of the block output, its ReLU bit mask) instead of a written tensor
+    lazy_g: Optional[tuple] = None     # backward: that pair, left by bn3's pass for conv1's dgrad (sp_conv2d_dgrad_bn_bwd_stats_macc)
     mask: Optional[torch.Tensor] = None    # bf16 training: the ReLU bit mask of this BatchNorm+ReLU output (uint8, one byte per 8 channels)
     grad_event: Optional[object] = None    # backward: .grad's first share was written on the branch stream; whoever touches .grad next waits
     deferred: list = field(default_factory=list)   # ... and then runs these (the branch's weight-gradient jobs, queued on the main stream)
@@ -355,7 +358,8 @@ class ConvT:
         done()
         return out, part, rows.value
 
-    def dgrad(self, dz: torch.Tensor, B: int, acc: Optional[torch.Tensor], bn_src: Optional["Act"] = None) -> torch.Tensor:
+    def dgrad(self, dz: torch.Tensor, B: int, acc: Optional[torch.Tensor], bn_src: Optional["Act"] = None,
+              acc_masked: Optional[tuple] = None) -> torch.Tensor:
         """dx (+= into `acc` when given).  `bn_src`: the activation dx is the gradient of, when it came out of a BatchNorm(+residual)+ReLU
         and this launch family is the LAST of its consumers to contribute: the epilogue then holds the complete dy and also reduces
         that layer's backward sums (bn_src.bstats)."""
@@ -395,6 +399,17 @@ class ConvT:
             for d in self.d_dgrad:
                 d.flags |= mflag
             try:
+                if acc_masked is not None:
+                    assert len(self.d_dgrad) == 1 and acc is None and self.tr.g16
+                    d = self.d_dgrad[0]
+                    z2, mean2, invstd2 = (bn_src.bn2[:3] if two else (None, None, None))
+                    done = self._timed("dgrad")
+                    _lib.check(lib.sp_conv2d_dgrad_bn_bwd_stats_macc(d, P(dz), P(self.w_dgrad[0]), P(acc_masked[0]), P(acc_masked[1]), P(dx), P(ysrc),
+                                                                     P(z), P(mean), P(invstd), P(part[0]), P(part[1]), P(z2), P(mean2), P(invstd2),
+                                                                     P(part[2]) if two else None, total, _lib.current_stream()), self.name + ".dgrad")
+                    done()
+                    bn_src.bstats = (part, total)
+                    return dx
                 return self._dgrad_bstats(lib, dz, B, acc, dx, bn_src, ysrc, z, mean, invstd, part, total, need, one, two)
             finally:
                 for d, f in zip(self.d_dgrad, keep_flags):
@@ -1334,7 +1349,13 @@ class PoseTrainer:
                 dz = new(z.shape)                      # MFMA operand of dgrad / wgrad: activation dtype
                 dres = None
                 acc = 0
-                if res is not None:
+                lazy = (res is not None and res.lazy_ok and res.grad is None and relu and ya.mask is not None and self.g16
+                        and self.lazy_residual_grad and self.fuse_bn_bwd and not sync)
+                if lazy:
+                    # the residual share g = dy * mask is not written: conv1's dgrad (the block input's other consumer, still to come on
+                    # the tape) adds it from (dy, mask) in its epilogue
+                    res.lazy_g = (ya.grad, ya.mask)
+                elif res is not None:
                     if res.grad is None:
                         res.grad = newg(res.data.shape)   # activation gradients: fp32, or bf16 with grad_dtype "bf16"
                     else:
@@ -1449,7 +1470,12 @@ class PoseTrainer:
                     # the residual share lands first, conv1 of the next block - a full-cover 1x1 - accumulates last.)
                     last = xa.contrib == xa.consumers - 1
                     fuse = self.fuse_bn_bwd and xa.bn is not None and last and (xa.grad is None or layer.dgrad_full_cover)
-                    xa.grad = layer.dgrad(dz, B, xa.grad, bn_src=xa if fuse else None)
+                    if xa.lazy_g is not None:
+                        assert fuse and xa.grad is None, "a lazy residual share needs the BSTATS dgrad of conv1 as the last contributor"
+                        xa.grad = layer.dgrad(dz, B, None, bn_src=xa, acc_masked=xa.lazy_g)
+                        xa.lazy_g = None
+                    else:
+                        xa.grad = layer.dgrad(dz, B, xa.grad, bn_src=xa if fuse else None)
                     xa.contrib += 1
                 if not in_branch:
                     self._grads_ready(bname + ".weight", bname + ".bias", cname + ".weight")
@@ -1649,6 +1675,8 @@ class PoseTrainer:
                         blk_in.grad_event = ev
                         self._branch_open.append(blk_in)
                     join_fwd = lambda ev_ds=ev_ds: torch.cuda.current_stream(dev).wait_event(ev_ds)
+                if bi > 0 and len(L[p + ".conv1"].d_dgrad) == 1 and L[p + ".conv1"].dgrad_full_cover and (p + ".se.fc.0") not in L:
+                    a.lazy_ok = True                   # identity block: consumers = conv1 and the residual add
                 t = conv_bn(a, p + ".conv1", p + ".bn1", True, pend=p1)
                 t = conv_bn(t, p + ".conv2", p + ".bn2", True)
                 if join_fwd is not None:
@@ -1830,6 +1858,7 @@ class PoseTrainer:
     _in_branch = False
     overlap_shortcut = True
     relu_bit_masks = os.environ.get("SP_RELU_MASK", "1") != "0"        # (env: development knob)
+    lazy_residual_grad = os.environ.get("SP_LAZY_RES", "1") != "0"      # (env: development knob)
     fold_in_consumer_rows = 50    # partial rows (one per phase and M tile) up to which the BatchNorm pass folds them itself (sp_bn_fold_*): above, a stand-alone
                                   # fold + the plain pass (measured with the 16-byte bf16 passes: 1536 -> 6.06 ms, 100 -> 5.98, 50 -> 5.95, 0 -> 5.97)
     fuse_sync_finalize = True  # SyncBatchNorm: finalise inside the consuming bn_apply, message assembled by the backward fold (one launch less each way)

@@ -708,6 +708,24 @@ def test_shortcut_branch_stream_changes_no_bits(dtype, monkeypatch):
             assert torch.equal(fn(True), ref), fn.__name__
 
 
+def test_lazy_residual_gradient_changes_no_bits():
+    """bf16 gradients: bn3's backward pass of an identity Bottleneck does not write the residual share g = dy * mask; conv1's dgrad forms it
+    from (dy, ReLU bit mask) in its epilogue (sp_conv2d_dgrad_bn_bwd_stats_macc).  g is dy or zero, so three steps end on the same bits."""
+    x, t, w = _batch(4, 64, 64, 13)
+    xd, td, wd = (torch.from_numpy(a).to(DEV) for a in (x, t, w))
+    outs = []
+    for lazy in (False, True, True):
+        m, _ = _model(13)
+        tr = PoseTrainer(m, in_h=64, in_w=64, lr=1e-3, dtype="bf16")
+        assert tr.g16
+        tr.lazy_residual_grad = lazy
+        losses = [float(tr.step(xd, td, wd)) for _ in range(3)]
+        torch.cuda.synchronize()
+        outs.append((losses, tr.flat.data.clone()))
+    assert outs[0][0] == outs[1][0] == outs[2][0]
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[1][1], outs[2][1])
+
+
 # ---------------------------------------------------------------------------------------------- the reference's own loop, through autograd
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_reference_training_loop_through_autograd(dtype):
