@@ -99,6 +99,7 @@ class FlatParams:
         self.numel = _round_up(off, 4)
         self.data = torch.zeros(self.numel, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self._views: Dict[tuple, tuple] = {}
         for n, p in params:
             o, k = self.offsets[n]
             self.data[o:o + k].copy_(p.detach().reshape(-1))
@@ -107,8 +108,15 @@ class FlatParams:
                 p.grad = self.grad[o:o + k].view(p.shape)
 
     def view(self, name: str, grad: bool = False) -> torch.Tensor:
+        base = self.grad if grad else self.data
+        key = (name, grad)
+        hit = self._views.get(key)
+        if hit is not None and hit[0] is base:           # (the gradient buffer can be swapped: PoseTrainer.autograd_backward)
+            return hit[1]
         o, k = self.offsets[name]
-        return (self.grad if grad else self.data)[o:o + k]
+        v = base[o:o + k]
+        self._views[key] = (base, v)
+        return v
 
 
 @dataclass
@@ -153,6 +161,7 @@ class ConvT:
                  c_in_buf: Optional[int] = None, bias_name: Optional[str] = None, out_nchw: bool = False, need_dgrad: bool = True,
                  taps_w: Optional[int] = None):
         self.tr, self.name, self.kind, self.wname = tr, name, kind, name + ".weight"
+        self._rows_cache: Dict[tuple, int] = {}
         self.stride, self.pad, self.h, self.w = stride, pad, h, w
         self.bias_name, self.out_nchw, self.need_dgrad = bias_name, out_nchw, need_dgrad
         dev = weight.device
@@ -307,6 +316,17 @@ class ConvT:
                     self.w_dgrad.append(wd); self.d_dgrad.append(g)
 
     # ---- launches ----
+    def _stats_rows(self, d, B: int, what: str) -> int:
+        """Partial rows the STATS / BSTATS epilogue of a launch of `d` writes (a pure function of the grid and the tile: asked once)."""
+        key = (id(d), B, d.tile_m, d.tile_n)
+        r = self._rows_cache.get(key)
+        if r is None:
+            d.batch = B
+            c = ctypes.c_int(0)
+            _lib.check(_lib.lib().sp_conv2d_bn_stats_rows(d, ctypes.byref(c)), what)
+            r = self._rows_cache[key] = c.value
+        return r
+
     def _new(self, shape, dtype, device, zero: bool = False) -> torch.Tensor:
         """A result / scratch tensor: from the trainer's step arena when it has one (PoseTrainer._take), else a fresh allocation."""
         take = getattr(self.tr, "_take", None)
@@ -348,15 +368,14 @@ class ConvT:
         Returns (z, partial sums [rows, n_pad], partial sums of squares, rows)."""
         lib, d = _lib.lib(), self.d_fwd
         d.batch = B
-        rows = ctypes.c_int(0)
-        _lib.check(lib.sp_conv2d_bn_stats_rows(d, ctypes.byref(rows)), self.name)
-        part = self._new((2, rows.value, d.n_pad), torch.float32, x.device)
+        rows = self._stats_rows(d, B, self.name)
+        part = self._new((2, rows, d.n_pad), torch.float32, x.device)
         out = self._new((B, d.out_h, d.out_w, d.out_c), self._wdt, x.device)
         done = self._timed("forward")
-        _lib.check(lib.sp_conv2d_fwd_bn_stats(d, P(x), P(self.w_fwd), P(out), P(part[0]), P(part[1]), rows.value, _lib.current_stream()),
+        _lib.check(lib.sp_conv2d_fwd_bn_stats(d, P(x), P(self.w_fwd), P(out), P(part[0]), P(part[1]), rows, _lib.current_stream()),
                    self.name)
         done()
-        return out, part, rows.value
+        return out, part, rows
 
     def dgrad(self, dz: torch.Tensor, B: int, acc: Optional[torch.Tensor], bn_src: Optional["Act"] = None,
               acc_masked: Optional[tuple] = None) -> torch.Tensor:
@@ -384,9 +403,7 @@ class ConvT:
                 d.batch = B
                 if one:
                     d.tile_m, d.tile_n = d0.tile_m, d0.tile_n      # one launch: one tile shape (and its partial-row count) for every phase
-                r = ctypes.c_int(0)
-                _lib.check(lib.sp_conv2d_bn_stats_rows(d, ctypes.byref(r)), self.name + ".dgrad")
-                need.append(r.value)
+                need.append(self._stats_rows(d, B, self.name + ".dgrad"))
             total, stride = sum(need), self.d_dgrad[0].n_pad
             two = bn_src.bn2 is not None
             part = self._new((3 if two else 2, total, stride), torch.float32, dz.device)
@@ -736,14 +753,14 @@ class PoseTrainer:
         a, i = self._arena, self._arena_i
         self._arena_i = i + 1
         if i < len(a):
-            t = a[i]
-            if tuple(t.shape) == tuple(shape) and t.dtype == dtype and t.device == device:
+            t, key = a[i]
+            if key == (shape, dtype, device):
                 if zero:
                     t.zero_()
                 return t
             del a[i:]                      # the request sequence changed (another batch size): rebuild from here on
         t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=device)
-        a.append(t)
+        a.append((t, (tuple(shape), dtype, device)))
         return t
 
     # ---- SyncBatchNorm messages: issued where the sums exist, waited for where the statistics are consumed -----------------------
