@@ -397,6 +397,10 @@ int sp_bn_train_finalize(const double* sums, int64_t total_rows, int c, float ep
 int sp_bn_apply_sums_nhwc(const void* z, int bf16, const double* sums, int64_t total_rows, float eps, float momentum, const float* gamma,
                           const float* beta, const void* residual, void* y, int64_t rows, int c, int relu, float* mean, float* invstd,
                           float* running_mean, float* running_var, void* stream);
+/* sp_bn_bwd_sums_from_conv for a BatchNorm AND the projection shortcut's BatchNorm that shares its g (sum_g_xhat2: the third array of
+ * sp_conv2d_dgrad_bn_bwd_stats2; d beta2 = the same sum g) in one launch; the bits of two separate calls. */
+int sp_bn_bwd_sums_from_conv_pair(const float* sum_g, const float* sum_g_xhat, const float* sum_g_xhat2, int partial_rows, int stride, int c,
+                                  float* dgamma, float* dbeta, float* dgamma2, float* dbeta2, void* stream);
 int sp_bn_bwd_sums_from_conv2(const float* sum_g, const float* sum_g_xhat, int partial_rows, int stride, int c, float* dgamma, float* dbeta,
                               float* dgamma_copy, float* dbeta_copy, void* stream);
 int sp_bn_train_bwd_reduce_nhwc(const void* dy, int bf16, const void* relu_src, const void* z, const float* mean, const float* invstd,

@@ -128,6 +128,7 @@ SYMBOLS = {
     "sp_bn_fold_apply_nhwc": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int64, c_float, c_float, _P, _P, _P, _P, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "sp_bn_fold_bwd_apply_nhwc": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, c_int64, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "sp_bn_bwd_sums_from_conv": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
+    "sp_bn_bwd_sums_from_conv_pair": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "sp_u8hwc_bgr_to_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "sp_nchw_to_nhwc4_bf16": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "sp_conv3x3_direct_ok": (c_int, [ctypes.POINTER(ConvDesc)]),

@@ -272,9 +272,13 @@ __global__ __launch_bounds__(FOLD_THREADS) void bn_sums_from_conv_kernel(const f
 }
 
 // dbeta = sum g, dgamma = sum g*xhat from the partial rows a BSTATS dgrad launch (or several: one per output phase) left
+// (gridDim.y = 2: the second row of workgroups folds (ps, pq2) into (dbeta2, dgamma2) - the projection shortcut's BatchNorm, whose d beta is
+// the same sum g and whose d gamma comes from the third array of the BSTATS2 epilogue: one launch for the pair)
 __global__ __launch_bounds__(FOLD_THREADS) void bn_bwd_sums_from_conv_kernel(const float* __restrict__ ps, const float* __restrict__ pq, int nrows, int stride, int C,
                                              float* __restrict__ dbeta, float* __restrict__ dgamma, float* __restrict__ dbeta_copy,
-                                             float* __restrict__ dgamma_copy) {
+                                             float* __restrict__ dgamma_copy, const float* __restrict__ pq2 = nullptr,
+                                             float* __restrict__ dbeta2 = nullptr, float* __restrict__ dgamma2 = nullptr) {
+    if (blockIdx.y == 1) { pq = pq2; dbeta = dbeta2; dgamma = dgamma2; dbeta_copy = nullptr; dgamma_copy = nullptr; }
     double s0, s1;
     const int c0 = blockIdx.x * SLAB;
     if (!fold_slab64(ps, pq, nrows, stride, C, c0, s0, s1)) return;
@@ -1126,6 +1130,15 @@ extern "C" int sp_bn_bwd_sums_from_conv(const float* sum_g, const float* sum_g_x
     SP_REQUIRE(sum_g && sum_g_xhat && dgamma && dbeta && partial_rows > 0 && stride >= c && c > 0, "sp_bn_bwd_sums_from_conv: bad argument");
     hipLaunchKernelGGL(bn_bwd_sums_from_conv_kernel, dim3((c + SLAB - 1) / SLAB), dim3(FOLD_THREADS), 0, (hipStream_t)stream, sum_g, sum_g_xhat, partial_rows, stride,
                        c, dbeta, dgamma, nullptr, nullptr);
+    return sp_check_launch("bn_bwd_sums_from_conv_kernel");
+}
+
+extern "C" int sp_bn_bwd_sums_from_conv_pair(const float* sum_g, const float* sum_g_xhat, const float* sum_g_xhat2, int partial_rows, int stride, int c,
+                                             float* dgamma, float* dbeta, float* dgamma2, float* dbeta2, void* stream) {
+    SP_REQUIRE(sum_g && sum_g_xhat && sum_g_xhat2 && dgamma && dbeta && dgamma2 && dbeta2 && partial_rows > 0 && stride >= c && c > 0,
+               "sp_bn_bwd_sums_from_conv_pair: bad argument");
+    hipLaunchKernelGGL(bn_bwd_sums_from_conv_kernel, dim3((c + SLAB - 1) / SLAB, 2), dim3(FOLD_THREADS), 0, (hipStream_t)stream, sum_g, sum_g_xhat, partial_rows,
+                       stride, c, dbeta, dgamma, nullptr, nullptr, sum_g_xhat2, dbeta2, dgamma2);
     return sp_check_launch("bn_bwd_sums_from_conv_kernel");
 }
 

@@ -1423,16 +1423,17 @@ class PoseTrainer:
                                 _lib.check(lib.sp_bn_bwd_sums_from_conv2(P(part[0]), P(part[2]), prow, part.shape[2], C, P(dgs), P(dbs),
                                                                          P(msg[2 * C:3 * C]), P(msg[3 * C:]), stream), sname + ".bwd")
                                 res.presums = (msg[2 * C:3 * C], msg[3 * C:])       # (global after the exchange below)
+                        elif part.shape[0] == 3 and res is not None and acc == 0:
+                            # the projection shortcut's sums came out of the same epilogue: d beta = sum g (shared), d gamma = sum g * xhat2;
+                            # both BatchNorms' folds in one launch
+                            sname = ya.bn2[3]
+                            dgs, dbs = self.flat.view(sname + ".weight", True), self.flat.view(sname + ".bias", True)
+                            _lib.check(lib.sp_bn_bwd_sums_from_conv_pair(P(part[0]), P(part[1]), P(part[2]), prow, part.shape[2], C, P(dgamma), P(dbeta),
+                                                                         P(dgs), P(dbs), stream), bname + ".bwd")
+                            res.presums = (dgs, dbs)
                         else:
                             _lib.check(lib.sp_bn_bwd_sums_from_conv(P(part[0]), P(part[1]), prow, part.shape[2], C, P(dgamma), P(dbeta), stream),
                                        bname + ".bwd")
-                        if msg is None and part.shape[0] == 3 and res is not None and acc == 0:
-                            # the projection shortcut's sums came out of the same epilogue: d beta = sum g (shared), d gamma = sum g * xhat2
-                            sname = ya.bn2[3]
-                            dgs, dbs = self.flat.view(sname + ".weight", True), self.flat.view(sname + ".bias", True)
-                            _lib.check(lib.sp_bn_bwd_sums_from_conv(P(part[0]), P(part[2]), prow, part.shape[2], C, P(dgs), P(dbs), stream),
-                                       sname + ".bwd")
-                            res.presums = (dgs, dbs)
                     else:
                         msg = None
                         _lib.check(lib.sp_bn_train_bwd_reduce_nhwc(P(ya.grad), gf, rs, P(z), P(mean), P(invstd), rows, C, P(dgamma), P(dbeta),

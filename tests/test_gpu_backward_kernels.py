@@ -605,6 +605,11 @@ def test_dgrad_epilogue_sums_and_fused_fold_backward(case, two, bf16, measured):
     if two:
         dg2a, db2a = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
         _lib.check(lib.sp_bn_bwd_sums_from_conv(P(part[0]), P(part[2]), prow, part.shape[2], C, P(dg2a), P(db2a), st), "fold2")
+    if two:                                # both folds in one launch (sp_bn_bwd_sums_from_conv_pair): the bits of the two calls
+        pg, pb, pg2, pb2 = (torch.empty(C, device=DEV) for _ in range(4))
+        _lib.check(lib.sp_bn_bwd_sums_from_conv_pair(P(part[0]), P(part[1]), P(part[2]), prow, part.shape[2], C, P(pg), P(pb), P(pg2), P(pb2), st), "pair")
+        torch.cuda.synchronize()
+        assert torch.equal(pg, dga) and torch.equal(pb, dba) and torch.equal(pg2, dg2a) and torch.equal(pb2, db2a)
     base = torch.randn(rows, C, generator=torch.Generator().manual_seed(3)).to(DEV).to(dy.dtype)
     dz_a, dres_a = torch.empty((rows, C), dtype=adt, device=DEV), base.clone()
     _lib.check(lib.sp_bn_train_bwd_apply_nhwc(P(dy), flag, P(rsrc), P(zd), P(mean), P(invstd), P(gamma), P(dga), P(dba), rows, rows, C, P(dz_a),
