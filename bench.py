@@ -263,6 +263,12 @@ def launch_ranks(args) -> int:
             if all(c == 0 for c in codes):
                 break
     finally:
+        if rc != 0:
+            # a rank died: the others usually follow within moments for the same reason (no GPU, a failed rendezvous) - let them say
+            # so themselves before anything is terminated, so that every rank's message reaches stderr
+            t_end = time.time() + 5.0
+            while time.time() < t_end and any(p.poll() is None for p in procs):
+                time.sleep(0.1)
         for p in procs:                              # exact PIDs of the children this launcher started
             if p.poll() is None:
                 p.terminate()
@@ -317,7 +323,7 @@ def main():
     if args.mode == "micro":                           # the HBM-bound kernels of the path one by one (tools/bench_micro.py)
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_micro
-        raise SystemExit(bench_micro.main([]))
+        raise SystemExit(bench_micro.main([], emit=emit))
     import torch
     import torch.distributed as dist
 
@@ -376,11 +382,18 @@ def main():
             line["config"] = cfg
             if "other_configs" in line:                  # keep it the last key
                 line["other_configs"] = line.pop("other_configs")
+    if abandoned and line is not None:
+        line["rccl_census"] = "abandoned"                 # top-level, so that a reader of the line cannot take the run for a checked one
+        if "other_configs" in line:
+            line["other_configs"] = line.pop("other_configs")
     if rank == 0 and line is not None:
         emit(line)
     if abandoned:
+        # the measurement is complete and printed; the diagnostic that hung is named in the line (`rccl_census`, `config.rccl.error`) and on
+        # stderr.  SP_CENSUS_STRICT=1 turns it into a failing exit code (4) for callers that want the census to gate the run.
+        print(f"bench.py rank {rank}: RCCL communicator census abandoned after 120 s (line printed; see config.rccl.error)", file=sys.stderr)
         sys.stderr.flush()
-        os._exit(0)
+        os._exit(4 if os.environ.get("SP_CENSUS_STRICT", "0") == "1" else 0)
     if world > 1:
         dist.destroy_process_group()
 

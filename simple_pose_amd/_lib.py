@@ -200,20 +200,40 @@ def ptr(t):
 # The train step issues ~350 launches per step from Python; `torch.cuda.current_stream()` costs ~5 us a call (device index lookups,
 # `is_available`, an os.environ read) and was a sixth of the step's host time.  While a PoseTrainer tape runs it pins the handle of the
 # stream it is issuing to here (`pin_stream`); everything else asks torch as before.
-_pinned_stream = None
+# The pin is per THREAD and per DEVICE: a data-loader thread that encodes targets, a decode on another GPU or a second trainer never see the
+# trainer's handle (round-4 advisor finding: a process-global pin handed it to every caller).
+import threading
+
+_pin = threading.local()
 
 
-def pin_stream(handle):
-    """Make `current_stream()` return `handle` (a hipStream_t as c_void_p / int; None: ask torch again).  Returns the previous pin."""
-    global _pinned_stream
-    prev, _pinned_stream = _pinned_stream, handle
+def _device_index(device) -> int:
+    """Index of a torch.device / int / None (None: the current device)."""
+    if device is None:
+        import torch
+        return torch.cuda.current_device()
+    if isinstance(device, int):
+        return device
+    idx = getattr(device, "index", None)
+    if idx is None:
+        import torch
+        return torch.cuda.current_device()
+    return idx
+
+
+def pin_stream(pin):
+    """Make `current_stream(device)` on THIS thread return a pinned handle for that device.  `pin`: (hipStream_t as c_void_p / int, device
+    index) or None (ask torch again).  Returns the previous pin (hand it back to restore)."""
+    prev = getattr(_pin, "value", None)
+    _pin.value = pin
     return prev
 
 
 def current_stream(device=None):
     """torch's current stream of `device` (a tensor's .device; default: the current device) as a hipStream_t."""
-    if _pinned_stream is not None:
-        return _pinned_stream
+    pin = getattr(_pin, "value", None)
+    if pin is not None and (device is None or _device_index(device) == pin[1]):
+        return pin[0]
     import torch
 
     return c_void_p(torch.cuda.current_stream(device).cuda_stream)

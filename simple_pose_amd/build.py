@@ -1,6 +1,6 @@
 """Build recipe of libsimple_pose_hip.so (gfx950 only; hipcc cross-compiles without a GPU).
 
-    python -m simple_pose_amd.build [--force]
+    python -m simple_pose_amd.build [--force]          (SP_FORCE_BUILD=1 in the environment = --force)
 
 The library is built IN-TREE (simple_pose_amd/lib/) so that it travels with the repo snapshot to the GPU box.
 """
@@ -32,11 +32,19 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+last_build = {"compiled": 0, "reused": 0, "linked": False}      # what the last build() call did (evidence for the "does it build" check)
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every csrc/*.hip for gfx950 and link the library.  `force` (or SP_FORCE_BUILD=1 in the environment) recompiles every
+    object; otherwise objects and the library are reused when newer than every source / header."""
+    force = force or os.environ.get("SP_FORCE_BUILD", "0") == "1"
+    last_build.update(compiled=0, reused=len(sources()), linked=False)
     if not force and not _stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     objs = []
+    last_build.update(reused=0)
     for src in sources():
         obj = os.path.join(LIB_DIR, os.path.basename(src)[:-4] + ".o")
         if force or not os.path.isfile(obj) or os.path.getmtime(obj) < max(
@@ -47,11 +55,15 @@ def build(force: bool = False, verbose: bool = False) -> str:
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.run(cmd, check=True)
+            last_build["compiled"] += 1
+        else:
+            last_build["reused"] += 1
         objs.append(obj)
     cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
+    last_build["linked"] = True
     return LIB_PATH
 
 

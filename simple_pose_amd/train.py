@@ -1142,14 +1142,14 @@ class PoseTrainer:
     def forward_tape(self, x: torch.Tensor):
         """See `_forward_tape`.  While the tape is being issued the handle of the stream it goes to is pinned (`_lib.pin_stream`): the ~170
         `torch.cuda.current_stream()` lookups of a step were a sixth of its host time."""
-        prev = _lib.pin_stream(_lib.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+        prev = _lib.pin_stream((_lib.c_void_p(torch.cuda.current_stream(x.device).cuda_stream), _lib._device_index(x.device)))
         try:
             heat, backward = self._forward_tape(x)
         finally:
             _lib.pin_stream(prev)
 
         def pinned_backward(dheat: torch.Tensor) -> None:
-            prev = _lib.pin_stream(_lib.c_void_p(torch.cuda.current_stream(dheat.device).cuda_stream))
+            prev = _lib.pin_stream((_lib.c_void_p(torch.cuda.current_stream(dheat.device).cuda_stream), _lib._device_index(dheat.device)))
             try:
                 backward(dheat)
             finally:
@@ -1224,7 +1224,7 @@ class PoseTrainer:
             branch.wait_event(e0)
             keep = stream
             self._in_branch, self._branch_main = True, here
-            pinned = _lib.pin_stream(_lib.c_void_p(branch.cuda_stream))
+            pinned = _lib.pin_stream((_lib.c_void_p(branch.cuda_stream), _lib._device_index(dev)))
             try:
                 with torch.cuda.stream(branch):
                     stream = _lib.current_stream()
@@ -1436,6 +1436,7 @@ class PoseTrainer:
                                        bname + ".bwd")
                     else:
                         msg = None
+                        assert not self._in_branch, "the shared reduction workspace is the main chain's"
                         _lib.check(lib.sp_bn_train_bwd_reduce_nhwc(P(ya.grad), gf, rs, P(z), P(mean), P(invstd), rows, C, P(dgamma), P(dbeta),
                                                                    P(ws), stream), bname + ".bwd")
                     sg, sb, tot = dgamma, dbeta, rows
@@ -1466,6 +1467,8 @@ class PoseTrainer:
                     _lib.check(lib.sp_bn_train_bwd_apply_nhwc(P(ya.grad), gm, rsm, P(z), P(mean), P(invstd), P(gamma), P(sg), P(sb), tot, rows, C,
                                                               P(dz), P(dres), acc, stream), bname + ".bwd")
                 else:
+                    # (uses the shared reduction workspace `ws`: never from the branch stream, the main chain may be inside it)
+                    assert not self._in_branch, "a branch-stream BatchNorm backward must come with its sums (Act.presums): it has no workspace of its own"
                     _lib.check(lib.sp_bn_train_bwd_nhwc(P(ya.grad), gf, rs, P(z), P(mean), P(invstd), P(gamma), rows, C, P(dz), P(dgamma), P(dbeta),
                                                         P(dres), acc, P(ws), stream), bname + ".bwd")
                 in_branch = self._in_branch

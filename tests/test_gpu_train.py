@@ -194,7 +194,10 @@ def test_selayer_train_step_is_bit_reproducible_and_bf16_tracks_fp32(dtype):
 # conv1.weight moved to 2.7e-2.  tests/measure_reference_spread.py: the reference's own fp32 step moves by 1.8e-2 ... 2.1e-2 on this metric
 # when only its thread count changes (and sits 1.2e-2 ... 2.0e-2 from fp64) - this B = 2 BatchNorm net is chaotic at that level, so the bar
 # is 2x the reference's own spread; the per-kernel tests (test_gpu_backward_kernels.py: every sum against float64 at 1e-6) are the sharp ones
-GRAD_SLICE_BAR = 4e-2
+# Round 5 (advisor): the wider bar is kept ONLY for the slice that moved (conv1.weight 1.5e-2 -> 2.7e-2); every other slice is back at 2e-2, so a
+# regression of that size elsewhere fails again.
+GRAD_SLICE_BAR = 2e-2
+GRAD_SLICE_BAR_OF = {"conv1.weight": 4e-2}
 ADAM_CLOSE_BAR = 0.995
 
 
@@ -215,8 +218,9 @@ def test_train_step_vs_reference_golden(golden, measured):
         ref = g[key]
         got = named[k].grad.cpu().numpy()[tuple(slice(0, s) for s in ref.shape)]
         scale = float(g["gradnorm/" + k]) / np.sqrt(named[k].numel())
-        measured(f"grad_slice_err_over_scale/{k}", np.abs(got - ref).max() / scale, GRAD_SLICE_BAR)
-        assert np.abs(got - ref).max() <= GRAD_SLICE_BAR * scale + 1e-12, (k, np.abs(got - ref).max(), scale)
+        bar = GRAD_SLICE_BAR_OF.get(k, GRAD_SLICE_BAR)
+        measured(f"grad_slice_err_over_scale/{k}", np.abs(got - ref).max() / scale, bar)
+        assert np.abs(got - ref).max() <= bar * scale + 1e-12, (k, np.abs(got - ref).max(), scale)
     bufs = dict(model.named_buffers())
     for k in ("bn1.running_mean", "bn1.running_var", "layer3.5.bn3.running_var", "deconv_layers.7.running_mean"):
         assert np.abs(bufs[k].cpu().numpy() - g["buf/" + k]).max() <= 1e-4 * max(1.0, np.abs(g["buf/" + k]).max()), k
