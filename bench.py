@@ -489,9 +489,15 @@ def run_once(args, ctx):
         from simple_pose_amd.commons.transforms import RefineSimpleTransform
         from simple_pose_amd.train import PoseTrainer
         model.train()
+        # N > 1: which path the step's collectives take is decided here, before the timed region (untimed setup): over an nccl group the
+        # native RCCL path is taken when a start-up self-check reproduces torch.distributed bit for bit on every rank (comm_select), else
+        # torch.distributed with the reason in the line; --torch-collectives / --native-comm force either
+        from simple_pose_amd import comm_select
+        coll = comm_select.select(model, None, 256, 192, "bf16" if args.dtype == "bf16" else "fp32", not args.no_sync_bn,
+                                  requested=False if args.torch_collectives else (True if (args.native_comm and world > 1) else None))
         trainer = PoseTrainer(model, lr=1e-3, dtype="bf16" if args.dtype == "bf16" else "fp32", sync_bn=not args.no_sync_bn,
                               bucket_mb=args.bucket_mb, sync_bn_latency_us=args.sync_bn_latency_us,
-                              native_comm=False if args.torch_collectives else (True if (args.native_comm and world > 1) else None),
+                              native_comm=coll["native"] if world > 1 else None,
                               sync_bn_inline=not args.torch_collectives)
         # untimed setup: the tile of every forward / dgrad launch.  Default: the tracked table of this dtype under profiles/ (the one the
         # committed rocprofv3 summaries were taken with: no tuner launches in a profiled run, same launches on every rank and box);
@@ -674,6 +680,7 @@ def run_once(args, ctx):
                 "host_enqueue_ms_per_step": round(host_enqueue_ms, 3), "sync_bn_latency_us_emulated": args.sync_bn_latency_us,
                 "step_as_hip_graph": bool(args.graph), "rccl_preflight_one_rank": bool(args.preflight_rccl and world == 1),
                 "collective_path": "torch.distributed" if (args.torch_collectives or trainer._comm is None and world > 1) else ("sp_comm (RCCL on the step's streams)" if trainer._comm is not None else "none"),
+                "collective_self_check": {k: coll[k] for k in ("path", "reason", "self_check")},
                 "collectives_per_step": {"gradient_buckets": len(trainer.buckets) if world > 1 else 0, "sync_bn": trainer.collective_count}}
         else:
             peak = FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else BF16_MATRIX_PEAK_TFLOPS

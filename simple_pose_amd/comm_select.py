@@ -1,0 +1,144 @@
+"""Which path the train step's collectives take when there is more than one rank - decided at start-up, proven before it is used.
+
+The step has two ways to exchange (SyncBatchNorm messages and gradient buckets; the reference: SyncBatchNorm + DistributedDataParallel,
+processors/ddp_pose_resnet_solver.py:36,89-93):
+
+  * "sp_comm"            RCCL called directly on the step's own streams (csrc/comm.hip, two private communicators): one host call per
+                         message, nothing between the message and its consumer but the stream's order;
+  * "torch.distributed"  the process group's collectives (one communicator on RCCL's own stream, five stream / event calls per message
+                         from Python: with SyncBatchNorm on the step is host-bound).
+
+The native path is the design, but it has never met a second rank on this pool's 1-GPU boxes.  So nobody has to trust it: when a peer
+exists (world >= 2 over an nccl group) `select()` runs the comparison that `tests/test_gpu_train.py::test_two_rank_rccl_*` runs - a few
+small steps through BOTH paths from identical state, parameters / BatchNorm buffers compared bit for bit on every rank, the verdict agreed
+over the group - and takes the native path only if it reproduced torch.distributed exactly.  Anything else falls back, with the reason
+logged and carried in bench.py's line (`collective_self_check`).  The decision logic is pure (no GPU): `decide()`; covered over gloo with
+two ranks in tests/test_multi_rank_cpu.py.
+"""
+from __future__ import annotations
+
+import copy
+import os
+import sys
+from typing import Callable, Optional, Tuple
+
+
+def _agree_min(ok: bool, group) -> bool:
+    """True only if EVERY rank of `group` says ok (all-reduce MIN over the process group, on the device its backend wants)."""
+    import torch
+    import torch.distributed as dist
+
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.item()))
+
+
+def decide(requested: Optional[bool], backend: str, rccl_available: bool, world: int,
+           self_check: Optional[Callable[[], Tuple[bool, str]]] = None, agree: Optional[Callable[[bool], bool]] = None) -> dict:
+    """The decision, as data: {"path": "none" | "sp_comm" | "torch.distributed", "native": bool, "reason": str, "self_check": str}.
+
+    requested   True: the caller insists on the native path (raises when it cannot exist); False: torch.distributed; None: automatic.
+    backend     the process group's backend name ("nccl" is RCCL on ROCm); rccl_available: `sp_comm_available()`.
+    self_check  () -> (this rank's verdict, detail): runs the two-path comparison; only called on the automatic route when a peer exists.
+    agree       (local verdict) -> global verdict (every rank must pass; default: all-reduce MIN over the default group).
+    Every rank must call this with the same arguments at the same point (the self-check and the agreement are collectives)."""
+    if world <= 1:
+        return {"path": "none", "native": False, "reason": "one rank: nothing to exchange", "self_check": "not run"}
+    usable = backend == "nccl" and bool(rccl_available)
+    why_not = (f"process group backend is {backend!r}, not nccl" if backend != "nccl" else "librccl could not be loaded (sp_comm_available() == 0)")
+    if requested is False:
+        return {"path": "torch.distributed", "native": False, "reason": "requested (native_comm=False / --torch-collectives)", "self_check": "not run"}
+    if requested is True:
+        if not usable:
+            raise RuntimeError(f"native collectives requested but unavailable: {why_not}")
+        return {"path": "sp_comm", "native": True, "reason": "requested (native_comm=True / --native-comm / SP_NATIVE_COMM=1)", "self_check": "not run"}
+    if not usable:
+        return {"path": "torch.distributed", "native": False, "reason": why_not, "self_check": "not run"}
+    if self_check is None:
+        return {"path": "torch.distributed", "native": False, "reason": "no self-check available: the native path is taken only when proven", "self_check": "not run"}
+    try:
+        ok, detail = self_check()
+    except Exception as e:                                   # a rank that cannot even run the comparison votes no; the others follow
+        ok, detail = False, f"{type(e).__name__}: {e}"[:300]
+    all_ok = (agree or (lambda v: _agree_min(v, None)))(bool(ok))
+    if all_ok:
+        return {"path": "sp_comm", "native": True, "reason": "start-up self-check passed on every rank", "self_check": f"passed: {detail}"}
+    verdict = f"failed on this rank: {detail}" if not ok else f"passed here ({detail}) but failed on another rank"
+    return {"path": "torch.distributed", "native": False, "reason": "start-up self-check did not reproduce torch.distributed bit for bit", "self_check": verdict}
+
+
+def two_path_self_check(model, group, in_h: int, in_w: int, dtype: str, sync_bn: bool, images: int = 4, steps: int = 2,
+                        trainer_kwargs: Optional[dict] = None) -> Tuple[bool, str]:
+    """`steps` train steps of `images` images per rank through the native path and through torch.distributed, from identical copies of
+    `model` (which is left untouched): parameters, Adam moments and BatchNorm buffers must be equal bit for bit between the two paths on
+    this rank, and equal to rank 0's (the ranks hold replicas).  Needs the GPU and an nccl group; returns (verdict of this rank, detail)."""
+    import torch
+    import torch.distributed as dist
+
+    from . import synth
+    from .commons.transforms import RefineSimpleTransform
+    from .train import PoseTrainer
+
+    dev = next(model.parameters()).device
+    rank = dist.get_rank(group)
+    x = torch.from_numpy(synth.input_images(images, seed=4100 + rank)).to(dev)
+    if (in_h, in_w) != (256, 192):
+        if in_h > 256 or in_w > 192:
+            raise ValueError("self-check inputs are crops of the 256x192 synthetic images")
+        x = x[:, :, :in_h, :in_w].contiguous()
+    joints = torch.from_numpy(synth.joints_batch(images, 17, seed=4200 + rank)).to(dev)
+    targets, mask = RefineSimpleTransform.get_heat_map(joints, 2.0, (in_w // 4, in_h // 4))
+    kw = dict(trainer_kwargs or {})
+    results = []
+    for native in (True, False):
+        m = copy.deepcopy(model).train()
+        tr = PoseTrainer(m, in_h=in_h, in_w=in_w, lr=1e-3, dtype=dtype, sync_bn=sync_bn, process_group=group, native_comm=native, **kw)
+        try:
+            assert (tr._comm is not None) == native          # (sp_comm_create is itself a collective: every rank has it or none does)
+            losses = [float(tr.step(x, targets, mask).item()) for _ in range(steps)]
+            torch.cuda.synchronize(dev)
+            bufs = torch.cat([b.detach().reshape(-1).to(torch.float64) for b in m.buffers()])
+            results.append((losses, tr.flat.data.clone(), tr.exp_avg.clone(), tr.exp_avg_sq.clone(), bufs, tr.collective_count))
+        finally:
+            tr.close()
+            del tr, m
+    a, b = results
+    ok, detail = True, ""
+    names = ("losses", "parameters", "exp_avg", "exp_avg_sq", "BatchNorm buffers")
+    for name, u, v in zip(names, a[:5], b[:5]):
+        same = (u == v) if isinstance(u, list) else torch.equal(u, v)
+        if not same and ok:
+            ok, detail = False, f"{name} differ between the native and the torch.distributed path after {steps} steps"
+    # replicas: every rank must hold rank 0's parameters (checksum in fp64, MAX - MIN over the group == 0).  Every rank gets here whatever
+    # its local verdict: the two all-reduces are collectives.
+    s = a[1].to(torch.float64).sum().reshape(1)
+    hi, lo = s.clone(), s.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    if ok and float((hi - lo).item()) != 0.0:
+        ok, detail = False, "ranks disagree on the updated parameters (replicas diverged)"
+    if ok:
+        detail = f"{steps} steps x {images} images per rank, {a[5]} SyncBatchNorm messages per step: both paths bitwise equal, replicas equal"
+    return ok, detail
+
+
+def select(model, group=None, in_h: int = 256, in_w: int = 192, dtype: str = "fp32", sync_bn: bool = True, requested: Optional[bool] = None,
+           log=None) -> dict:
+    """Decide for this job (collective call: every rank).  `requested` None also honours SP_NATIVE_COMM=1 / =0 in the environment."""
+    import torch.distributed as dist
+
+    from . import _lib
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return decide(requested, "none", False, 1)
+    world = dist.get_world_size(group)
+    if requested is None and os.environ.get("SP_NATIVE_COMM") in ("0", "1"):
+        requested = os.environ["SP_NATIVE_COMM"] == "1"
+    backend = dist.get_backend(group)
+    out = decide(requested, backend, bool(_lib.lib().sp_comm_available()) if backend == "nccl" else False, world,
+                 self_check=lambda: two_path_self_check(model, group, in_h, in_w, dtype, sync_bn),
+                 agree=lambda v: _agree_min(v, group))
+    if dist.get_rank(group) == 0:
+        print(f"[simple_pose_amd] collectives: {out['path']} ({out['reason']}; self-check {out['self_check']})", file=log or sys.stderr, flush=True)
+    return out

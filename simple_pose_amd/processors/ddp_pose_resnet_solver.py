@@ -92,8 +92,13 @@ class DDPProcessor(object):
             pretrained=self.model_cfg["pretrained"], num_classes=self.model_cfg["num_joints"])
         self.model = model.to(self.device).train()
         self.base_lr = float(self.optim_cfg["lr"])
-        self.trainer = PoseTrainer(self.model, lr=self.base_lr, dtype="bf16" if self.optim_cfg["amp"] else "fp32",
-                                   sync_bn=bool(self.optim_cfg["sync_bn"]))
+        # N > 1 over RCCL: the step's collectives go to RCCL directly when a start-up self-check (a few 4-image steps through both paths,
+        # compared bit for bit on every rank) says the native path reproduces torch.distributed; else torch.distributed, reason logged
+        from .. import comm_select
+        dtype = "bf16" if self.optim_cfg["amp"] else "fp32"
+        self.collectives = comm_select.select(self.model, None, 256, 192, dtype, bool(self.optim_cfg["sync_bn"]))
+        self.trainer = PoseTrainer(self.model, lr=self.base_lr, dtype=dtype, sync_bn=bool(self.optim_cfg["sync_bn"]),
+                                   native_comm=self.collectives["native"] if self.world > 1 else None)
         bs, J = int(self.data_cfg["batch_size"]), int(self.model_cfg["num_joints"])
         n_syn = self.data_cfg.get("synthetic")
         if train_loader is None:

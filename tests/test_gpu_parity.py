@@ -1878,6 +1878,16 @@ def test_bench_self_launches_two_ranks(mode):
     assert line["value"] > 0 and line["scaling"] == "weak" and line["cpu_baseline"] is None
     # whole-job throughput = units of all ranks / MAX time: consistent with ms_per_step
     assert abs(line["value"] - 16 / (line["ms_per_step"] * 1e-3)) / line["value"] < 0.02
+    if mode == "train":
+        # an N > 1 train line says which path its collectives took and why (comm_select), and splits the step (round-4 verdict, next 4b)
+        chk = line["collective_self_check"]
+        if backend == "gloo":
+            assert line["collective_path"] == "torch.distributed" and chk["path"] == "torch.distributed" and "gloo" in chk["reason"]
+        else:
+            assert chk["path"] in ("sp_comm", "torch.distributed") and chk["self_check"] != "not run"      # a peer exists: the check ran
+            assert ("sp_comm" in line["collective_path"]) == (chk["path"] == "sp_comm")
+            assert "rccl" in line["config"]
+        assert "allreduce_wait" in line["step_split_ms"] and line["collectives_per_step"]["gradient_buckets"] >= 1
 
 
 def test_bench_micro_mode_prints_one_json_line_on_stdout():

@@ -84,3 +84,67 @@ def test_gradient_all_reduce_is_sum_with_scale_one_over_world():
         scale, g0, pad = res[rank]
         assert scale == 0.5 and pad == 0
         assert g0 == [3.0 * (i + 1) for i in range(len(g0))]     # (1 + 2) * (index + 1): SUM over the two ranks
+
+
+# ---------------------------------------------------------------------------------------------- which path the step's collectives take
+def test_collective_path_decision_table():
+    """simple_pose_amd.comm_select.decide without a process group: the static rows of the decision (round-4 verdict, next 4a)."""
+    from simple_pose_amd.comm_select import decide
+
+    assert decide(None, "nccl", True, 1)["path"] == "none"
+    d = decide(None, "gloo", False, 2, self_check=lambda: (_ for _ in ()).throw(AssertionError("must not run over gloo")))
+    assert d["path"] == "torch.distributed" and "gloo" in d["reason"] and d["self_check"] == "not run"
+    assert decide(None, "nccl", False, 8)["path"] == "torch.distributed"                       # librccl missing
+    assert decide(False, "nccl", True, 8)["path"] == "torch.distributed"                       # --torch-collectives
+    d = decide(True, "nccl", True, 8)
+    assert d["native"] and d["self_check"] == "not run"                                        # explicit request: taken as asked
+    with pytest.raises(RuntimeError):
+        decide(True, "gloo", False, 2)
+    assert decide(None, "nccl", True, 2)["path"] == "torch.distributed"                        # automatic, but nothing to prove it with
+    ok = decide(None, "nccl", True, 2, self_check=lambda: (True, "2 steps"), agree=lambda v: v)
+    assert ok["path"] == "sp_comm" and ok["native"] and ok["self_check"].startswith("passed: 2 steps")
+    bad = decide(None, "nccl", True, 2, self_check=lambda: (False, "parameters differ"), agree=lambda v: v)
+    assert bad["path"] == "torch.distributed" and "parameters differ" in bad["self_check"]
+    boom = decide(None, "nccl", True, 2, self_check=lambda: 1 / 0, agree=lambda v: v)
+    assert boom["path"] == "torch.distributed" and "ZeroDivisionError" in boom["self_check"]
+
+
+def _decide_worker(rank, world, port, out):
+    """Two ranks over gloo standing in for an nccl job: the agreement is the real all-reduce(MIN) over the group; the self-check's local
+    verdict is injected (the comparison itself needs two GPUs: tests/test_gpu_train.py::test_two_rank_rccl_*)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from simple_pose_amd.comm_select import _agree_min, decide
+        agree = lambda v: _agree_min(v, None)
+        # (a) every rank passes -> native on every rank
+        a = decide(None, "nccl", True, world, self_check=lambda: (True, f"rank {rank} ok"), agree=agree)
+        # (b) rank 1 alone sees a mismatch -> BOTH ranks fall back, each saying why
+        b = decide(None, "nccl", True, world, self_check=lambda: (rank != 1, "exp_avg differ" if rank == 1 else "ok"), agree=agree)
+        # (c) rank 0's comparison raises -> both fall back (the raising rank still takes part in the agreement)
+        def chk():
+            if rank == 0:
+                raise RuntimeError("sp_comm_create failed")
+            return True, "ok"
+        c = decide(None, "nccl", True, world, self_check=chk, agree=agree)
+        # (d) the real group's backend: gloo -> torch.distributed without running anything
+        d = decide(None, dist.get_backend(), False, world, self_check=lambda: (True, "never"), agree=agree)
+        out[rank] = (a, b, c, d)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_collective_path_self_check_is_agreed_over_the_group():
+    world, port = 2, _free_port()
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_decide_worker, args=(world, port, out), nprocs=world, join=True)
+        res = dict(out)
+    for rank in range(world):
+        a, b, c, d = res[rank]
+        assert a["path"] == "sp_comm" and a["native"]
+        assert b["path"] == "torch.distributed" and not b["native"]
+        assert c["path"] == "torch.distributed"
+        assert d["path"] == "torch.distributed" and d["self_check"] == "not run"
+    assert "exp_avg differ" in res[1][1]["self_check"] and "another rank" in res[0][1]["self_check"]
+    assert "sp_comm_create failed" in res[0][2]["self_check"] and "another rank" in res[1][2]["self_check"]
