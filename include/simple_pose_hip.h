@@ -27,7 +27,7 @@ extern "C" {
 #define SP_EINVAL (-1)   /* bad argument / unsupported shape (message in sp_last_error) */
 #define SP_ELAUNCH (-2)  /* HIP launch or runtime failure */
 
-#define SP_ABI_VERSION 32
+#define SP_ABI_VERSION 33
 
 /* epilogue / layout flags of sp_conv_desc.flags */
 #define SP_CONV_RELU 0x1u          /* y = max(y, 0) after scale/shift (+ residual) */
@@ -70,7 +70,7 @@ typedef struct sp_conv_desc {
     int32_t stride_x;                /* 0: same as `stride`.  Otherwise the x stride where it differs from the y stride (`stride`):
                                         the bf16 stem reads the 4-channel image as x-PAIRS of 8 values, where a stride of two
                                         pixels is a stride of one pair */
-    int32_t kernel;                  /* SP_CONV_KERNEL_IGEMM (0, default) or SP_CONV_KERNEL_RING: which kernel structure runs the
+    int32_t kernel;                  /* SP_CONV_KERNEL_IGEMM (0, default), SP_CONV_KERNEL_RING / _RING_LW or SP_CONV_KERNEL_PW: which kernel structure runs the
                                         launch; same results bit for bit (same K order, same MFMA chain per output) */
 } sp_conv_desc;
 
@@ -78,6 +78,9 @@ typedef struct sp_conv_desc {
 #define SP_CONV_KERNEL_IGEMM 0 /* 4-wave workgroups, register-staged double buffer: every dtype / flag / tile listed at sp_conv2d_default_tile */
 #define SP_CONV_KERNEL_RING 1  /* bf16 only: persistent 8-wave workgroups fed by an LDS-DMA ring (buffer_load ... lds, counted vmcnt);
                                   tiles 256x256 256x128 128x256 256x64 128x128 192x128 192x256; needs sp_conv2d_ring_ok(desc) == 1 */
+#define SP_CONV_KERNEL_RING_LW 3 /* the same ring with four extra "loader" waves per workgroup (one per SIMD) that issue every LDS-DMA piece; the eight
+                                  MFMA waves only read fragments and multiply (round 5; same bits as 0 / 1); tiles 256x128 128x256 256x64 128x128
+                                  192x128; needs sp_conv2d_ring_ok(desc) == 1 with desc.kernel set to this id */
 #define SP_CONV_KERNEL_PW 2    /* fp32 1x1 stride-1 NHWC layers with c_in 64 / 128 and c_out % 256 == 0 (bottleneck conv3, projection shortcut):
                                   one persistent workgroup per CU streams 64-row tiles, weights in registers (sp_conv2d_pw_ok); tile_m / tile_n unused */
 

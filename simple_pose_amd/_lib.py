@@ -21,8 +21,9 @@ SP_CONV_BF16 = 0x8
 SP_CONV_OUT_F32 = 0x10
 SP_CONV_BN_Y_MASK = 0x20
 CONV_TILES = ((128, 128), (64, 128), (128, 64), (64, 64), (256, 64), (128, 32))
-ABI_VERSION = 32
-SP_CONV_KERNEL_IGEMM, SP_CONV_KERNEL_RING, SP_CONV_KERNEL_PW = 0, 1, 2
+ABI_VERSION = 33
+SP_CONV_KERNEL_IGEMM, SP_CONV_KERNEL_RING, SP_CONV_KERNEL_PW, SP_CONV_KERNEL_RING_LW = 0, 1, 2, 3
+RING_LW_TILES = ((256, 128), (128, 256), (256, 64), (128, 128), (192, 128))   # kernel = SP_CONV_KERNEL_RING_LW (bf16; the ring with loader waves)
 RING_TILES = ((256, 256), (256, 128), (128, 256), (256, 64), (128, 128), (192, 128), (192, 256))   # kernel = SP_CONV_KERNEL_RING (bf16)
 
 

@@ -253,11 +253,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_tile_kernel(const DirectAr
     const int a_r = 4 * g + (fr >> 3), a_c = fr & 7;
     const int x_a = a_r * RS8 + a_c * PX8 + (fh << 4);             // + tap offset + 8 m pixels + 32 j
     const int w_b = fr * 80 + (fh << 4);                           // + tap * 2560 + 32 j
-    float sc[8], sh[8];
-    const int chunk = lane & 3;
+    // Epilogue in registers (round 5).  The MFMA runs with the FILTER as its first operand, so an accumulator holds 16 output channels of ONE
+    // pixel (column fr = pixel, rows (r & 3) + 8 (r >> 2) + 4 fh = channels); lanes l and l + 32 hold complementary channel quads of the same
+    // pixel, and eight v_permlane32_swap turn them into two runs of 8 consecutive channels per lane (fh = 0: channels 0-7 and 16-23, fh = 1:
+    // 8-15 and 24-31): 16-byte residual loads and stores straight from registers.  The round-4 epilogue went through LDS (16 ds_write_b32 +
+    // 4 ds_read_b128 per 32 x 32 tile and a workgroup barrier per pixel tile); operand order does not change an MFMA's sum (same products,
+    // same k order), so the bits are the implicit GEMM's as before (`test_direct_3x3_kernels_are_bit_identical_to_the_implicit_gemm`).
+    float sc[2][8], sh[2][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { sc[e] = p.scale ? p.scale[chunk * 8 + e] : 1.f; sh[e] = p.shift ? p.shift[chunk * 8 + e] : 0.f; }
-    float* const tr = reinterpret_cast<float*>(smem8) + wave * 1024;
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ch = 16 * q + 8 * fh + e;
+            sc[q][e] = p.scale ? p.scale[ch] : 1.f;
+            sh[q][e] = p.shift ? p.shift[ch] : 0.f;
+        }
 
     for (; tile < ntiles; tile += gridDim.x) {
         put_halo();
@@ -265,18 +275,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_tile_kernel(const DirectAr
         req_halo(tile + gridDim.x);
         const int b = tile / per_img, rem = tile - b * per_img;
         const int tyy = rem / p.tiles_x, txx = rem - tyy * p.tiles_x;
-        unsigned ooff[3][2];
+        unsigned ooff[3];
         u32x4 rv[3][2];
 #pragma unroll
-        for (int m = 0; m < 3; ++m)
+        for (int m = 0; m < 3; ++m) {
+            const int oy = tyy * T7R + 4 * g + (fr >> 3), ox = txx * T7C + 8 * m + (fr & 7);
+            ooff[m] = (oy < p.H && ox < p.W) ? (unsigned)((((b * p.H + oy) * p.W + ox) * CO + 8 * fh) * 2) : OOB;
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int row = it * 16 + (lane >> 2);
-                const int oy = tyy * T7R + 4 * g + (row >> 3), ox = txx * T7C + 8 * m + (row & 7);
-                ooff[m][it] = (oy < p.H && ox < p.W) ? (unsigned)((((b * p.H + oy) * p.W + ox) * CO + chunk * 8) * 2) : OOB;
-                rv[m][it] = u32x4{0u, 0u, 0u, 0u};
-                if (p.res) rv[m][it] = __builtin_amdgcn_raw_buffer_load_b128(rr, ooff[m][it], 0, 0);
+            for (int q = 0; q < 2; ++q) {
+                rv[m][q] = u32x4{0u, 0u, 0u, 0u};
+                if (p.res) rv[m][q] = __builtin_amdgcn_raw_buffer_load_b128(rr, ooff[m] + 32u * q, 0, 0);
             }
+        }
         f32x16 acc[3];
 #pragma unroll
         for (int m = 0; m < 3; ++m)
@@ -291,28 +301,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_tile_kernel(const DirectAr
 #pragma unroll
                 for (int m = 0; m < 3; ++m) {
                     const u32x4 xa = *reinterpret_cast<const u32x4*>(Xs + x_a + toff + m * 8 * PX8 + j * 32);
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xa), __builtin_bit_cast(bf16x8, wb), acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wb), __builtin_bit_cast(bf16x8, xa), acc[m], 0, 0, 0);
                 }
             }
         }
-        __syncthreads();
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + 4 * fh) * 32 + fr] = acc[m][r];
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int row = it * 16 + (lane >> 2);
-                float v[8];
-#pragma unroll
-                for (int e4 = 0; e4 < 2; ++e4) {
-                    const f32x4 tt = *reinterpret_cast<const f32x4*>(tr + row * 32 + chunk * 8 + 4 * e4);
-                    v[4 * e4] = tt[0]; v[4 * e4 + 1] = tt[1]; v[4 * e4 + 2] = tt[2]; v[4 * e4 + 3] = tt[3];
+                for (int i = 0; i < 4; ++i) {
+                    // upper 32 lanes of the first register <-> lower 32 lanes of the second.  (The elements go through scalar temporaries:
+                    // `__builtin_bit_cast(unsigned, vec[k])` on an ext_vector ELEMENT reads element 0 with this hipcc - ROCm 7.2, found here.)
+                    const float lo = acc[m][8 * h + i], hi = acc[m][8 * h + 4 + i];
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+                    acc[m][8 * h + i] = __uint_as_float(sw[0]);
+                    acc[m][8 * h + 4 + i] = __uint_as_float(sw[1]);
                 }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+            for (int q = 0; q < 2; ++q) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = acc[m][8 * q + e] * sc[q][e] + sh[q][e];
                 if (p.res) {
-                    const bf16x8 r8 = __builtin_bit_cast(bf16x8, rv[m][it]);
+                    const bf16x8 r8 = __builtin_bit_cast(bf16x8, rv[m][q]);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
                 }
@@ -323,10 +335,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_tile_kernel(const DirectAr
                 bf16x8 o8;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o8[e] = (__bf16)v[e];
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o8), yr, ooff[m][it], 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o8), yr, ooff[m] + 32u * q, 0, 0);
             }
         }
-        __syncthreads();
+        __syncthreads();                                        // every wave is done with this tile's halo before the next one is put down
     }
 }
 

@@ -90,13 +90,23 @@ __device__ __forceinline__ void dma16(unsigned lds_addr, unsigned voff, u32x4 rs
 
 // HAS_RES: a residual tensor is added in the epilogue (compile-time, so that its loads and their use sit on one path: with a run-time
 // test on both, hipcc has to assume a load may still be pending at the next K tile and drains the ring there)
-template <int BM, int BN, int WR, int WC, int NS, bool HAS_RES>
-__global__ __launch_bounds__(512, 2) void conv_ring_kernel(const RingArgs p) {
-    static_assert(WR * WC == 8, "8 waves per workgroup");
+//
+// NLW (round 5): 0 = every one of the eight MFMA waves also issues its share of the LDS-DMA pieces (rounds 2-4); 4 = the workgroup has four
+// more waves (one per SIMD) that do nothing but issue the pieces ("loader waves"), the eight MFMA waves only read fragments and multiply.
+// Why: a piece costs the wave that issues it ~150 cycles inside a phase that also carries ds_reads (tools/diag_ring.py; 25-60 when the wave
+// does nothing else) - on the 192x128 tile 5 pieces per 12 MFMAs, i.e. more issue time than matrix time, in the very waves whose MFMA chain
+// it interrupts.  The ring, the counted vmcnt + one barrier per K tile, the fragment reads and the MFMA chain per output are unchanged, so
+// the bits are too (`test_ring_kernel_matches_igemm_on_ragged_shapes` covers both).
+template <int BM, int BN, int WR, int WC, int NS, bool HAS_RES, int NLW>
+__global__ __launch_bounds__(512 + 64 * NLW, NLW ? 3 : 2) void conv_ring_kernel(const RingArgs p) {
+    static_assert(WR * WC == 8, "8 MFMA waves per workgroup");
+    static_assert(NLW == 0 || NLW == 4, "loader waves: none or one per SIMD");
     constexpr int WM = BM / WR, WN = BN / WC;          // wave tile
     constexpr int TM = WM / 32, TN = WN / 32;          // 32x32 MFMA tiles per wave
     static_assert(TM >= 1 && TN >= 1 && BM % 64 == 0 && BN % 64 == 0, "tile shape");
-    constexpr int LA = BM / 64, LB = BN / 64, L = LA + LB;   // 1-KiB DMA pieces per wave per K tile (8 rows of 128 B each)
+    constexpr int NIW = NLW ? NLW : 8;                 // waves that issue the LDS-DMA pieces
+    static_assert((BM / 8) % NIW == 0 && (BN / 8) % NIW == 0, "whole pieces per issuing wave");
+    constexpr int LA = BM / 8 / NIW, LB = BN / 8 / NIW, L = LA + LB;   // 1-KiB DMA pieces per issuing wave per K tile (8 rows of 128 B each)
     constexpr int SB = (BM + BN) * 128;                // bytes of one ring slot: A rows, then B rows
     constexpr int D = NS - 1;                          // K tiles in flight ahead of the one being multiplied
     constexpr int NM = 4 * TM * TN;                    // MFMAs per wave per K tile
@@ -112,6 +122,8 @@ __global__ __launch_bounds__(512, 2) void conv_ring_kernel(const RingArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WC, wc = wave % WC;
     const int fr = lane & 31, fh = lane >> 5;
+    const bool loader_wave = NLW > 0 && wave >= 8;      // (wave-uniform)
+    const int iw = NLW ? (wave >= 8 ? wave - 8 : 0) : wave;   // index among the issuing waves
 #ifdef SP_RING_DIAG
     unsigned long long dg_wait = 0, dg_bar = 0, dg_mma = 0, dg_epi = 0, dg_tiles = 0;
     SP_RSTAMP(dg_entry)
@@ -181,7 +193,7 @@ __global__ __launch_bounds__(512, 2) void conv_ring_kernel(const RingArgs p) {
     unsigned b_tile_soff = 0;
 #pragma unroll
     for (int j = 0; j < LB; ++j) {
-        const int brow = 8 * (wave + 8 * j) + (lane >> 3);
+        const int brow = 8 * (iw + NIW * j) + (lane >> 3);
         b_voff[j] = (unsigned)(brow * p.k_pad * 2 + (((lane & 7) ^ ((brow >> 1) & 7)) << 4));
     }
     unsigned t_shift = 0, t_bit = 0, b_soff = 0;
@@ -195,7 +207,7 @@ __global__ __launch_bounds__(512, 2) void conv_ring_kernel(const RingArgs p) {
             const int4* tb = tab + (ld_i & 1) * BM;
 #pragma unroll
             for (int j = 0; j < LA; ++j) {
-                const int row = 8 * (wave + 8 * j) + (lane >> 3);
+                const int row = 8 * (iw + NIW * j) + (lane >> 3);
                 const int4 e = tb[row];
                 a_off0[j] = e.x + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
                 a_mask[j] = (unsigned)e.y;
@@ -210,10 +222,10 @@ __global__ __launch_bounds__(512, 2) void conv_ring_kernel(const RingArgs p) {
         const unsigned slot = ring_lds + (unsigned)(ld_slot * SB);
         if (o < LA) {
             const unsigned off = (a_mask[o] & t_bit) ? (unsigned)a_off0[o] + t_shift : OOB;
-            dma16(slot + (unsigned)((wave + 8 * o) * 1024), off, xr, 0u);
+            dma16(slot + (unsigned)((iw + NIW * o) * 1024), off, xr, 0u);
         } else {
             const int j = o - LA;
-            dma16(slot + (unsigned)(BM * 128 + (wave + 8 * j) * 1024), b_voff[j], wrs, b_soff);
+            dma16(slot + (unsigned)(BM * 128 + (iw + NIW * j) * 1024), b_voff[j], wrs, b_soff);
         }
     };
     auto loader_advance = [&]() __attribute__((always_inline)) {
@@ -230,13 +242,40 @@ __global__ __launch_bounds__(512, 2) void conv_ring_kernel(const RingArgs p) {
     // ---- prologue: table of the first tile, then D stages in flight ----
     make_table(perm, tab);
     __syncthreads();
+    if (NLW == 0 || loader_wave) {
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        if (d < S) {
-            loader_begin();
+        for (int d = 0; d < D; ++d) {
+            if (d < S) {
+                loader_begin();
 #pragma unroll
-            for (int o = 0; o < L; ++o) loader_piece(o);
-            loader_advance();
+                for (int o = 0; o < L; ++o) loader_piece(o);
+                loader_advance();
+            }
+        }
+    }
+    if constexpr (NLW > 0) {
+        if (loader_wave) {
+            // ---- a loader wave's whole life: per stage g, wait until ITS pieces of stage g have landed, meet the MFMA waves at the stage's
+            // barrier (they are then done with stage g-1, whose slot is the one stage g+D goes into), issue stage g+D; and stand at the
+            // extra barrier the MFMA waves take before an output tile's epilogue.  Same number of barriers on every wave of the workgroup.
+            static_assert((NS - 1) * L <= 56, "outstanding pieces must fit the vmcnt counter");
+            int ckt = 0;
+            for (int g = 0; g < S; ++g) {
+                if (g + D < S) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * L) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (g + D < S) {
+                    loader_begin();
+#pragma unroll
+                    for (int o = 0; o < L; ++o) loader_piece(o);
+                    loader_advance();
+                }
+                if (++ckt == nk) {
+                    ckt = 0;
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+            return;
         }
     }
 
@@ -420,6 +459,13 @@ __global__ __launch_bounds__(512, 2) void conv_ring_kernel(const RingArgs p) {
 #define SP_RD2
 #define SP_RD3
 #endif
+    if constexpr (NLW > 0) {
+        for (; g < S; ++g) {                               // MFMA waves of the loader-wave variant: nothing to wait for but the barrier
+            __builtin_amdgcn_s_barrier();
+            SP_SB();
+            stage(std::false_type{});
+        }
+    } else {
     for (; g + D < S; ++g) {
         SP_RD0
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * L) : "memory");
@@ -439,6 +485,7 @@ __global__ __launch_bounds__(512, 2) void conv_ring_kernel(const RingArgs p) {
         SP_RD2
         stage(std::false_type{});
         SP_RD3
+    }
     }
 #undef SP_SB
 #ifdef SP_RING_DIAG
@@ -466,10 +513,10 @@ int device_cus() {                       // CUs of the current device (cached pe
     return cache[dev];
 }
 
-template <int BM, int BN, int WR, int WC, int NS, bool HAS_RES>
+template <int BM, int BN, int WR, int WC, int NS, bool HAS_RES, int NLW>
 int launch_ring_t(const RingArgs& a, hipStream_t stream) {
     if (sp_name_query_active()) {
-        sp_name_query_set("conv_ring_kernel<%d, %d, %d, %d, %d, %s>", BM, BN, WR, WC, NS, HAS_RES ? "true" : "false");
+        sp_name_query_set("conv_ring_kernel<%d, %d, %d, %d, %d, %s, %d>", BM, BN, WR, WC, NS, HAS_RES ? "true" : "false", NLW);
         return SP_OK;
     }
     RingArgs p = a;
@@ -480,19 +527,19 @@ int launch_ring_t(const RingArgs& a, hipStream_t stream) {
     const int cus = device_cus();
     const int grid = p.total_tiles < cus ? p.total_tiles : cus;   // one workgroup per CU (its LDS ring takes the CU's whole LDS)
     const size_t lds = (size_t)NS * (BM + BN) * 128 + (size_t)2 * BM * sizeof(int4);
-    const void* fn = reinterpret_cast<const void*>(&conv_ring_kernel<BM, BN, WR, WC, NS, HAS_RES>);
+    const void* fn = reinterpret_cast<const void*>(&conv_ring_kernel<BM, BN, WR, WC, NS, HAS_RES, NLW>);
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // per device: set before every launch
     if (e != hipSuccess) {
         sp_set_error("conv_ring: hipFuncSetAttribute(max dynamic LDS = %zu) failed: %s", lds, hipGetErrorString(e));
         return SP_ELAUNCH;
     }
-    hipLaunchKernelGGL((conv_ring_kernel<BM, BN, WR, WC, NS, HAS_RES>), dim3(grid, 1, 1), dim3(512, 1, 1), lds, stream, p);
+    hipLaunchKernelGGL((conv_ring_kernel<BM, BN, WR, WC, NS, HAS_RES, NLW>), dim3(grid, 1, 1), dim3(512 + 64 * NLW, 1, 1), lds, stream, p);
     return sp_check_launch("conv_ring_kernel");
 }
 
-template <int BM, int BN, int WR, int WC, int NS>
+template <int BM, int BN, int WR, int WC, int NS, int NLW = 0>
 int launch_ring(const RingArgs& a, hipStream_t stream) {
-    return a.res ? launch_ring_t<BM, BN, WR, WC, NS, true>(a, stream) : launch_ring_t<BM, BN, WR, WC, NS, false>(a, stream);
+    return a.res ? launch_ring_t<BM, BN, WR, WC, NS, true, NLW>(a, stream) : launch_ring_t<BM, BN, WR, WC, NS, false, NLW>(a, stream);
 }
 
 struct RingTile { int bm, bn, ns; };
@@ -500,7 +547,16 @@ struct RingTile { int bm, bn, ns; };
 // quarters of the 256 CUs for one round; 192x128 and 192x256 give 256 tiles of three quarters the work)
 constexpr RingTile kRingTiles[] = {{256, 256, 2}, {256, 128, 3}, {128, 256, 3}, {256, 64, 3}, {128, 128, 4}, {192, 128, 3}, {192, 256, 2}};
 
-const RingTile* find_tile(int bm, int bn) {
+// the loader-wave variant (kernel = SP_CONV_KERNEL_RING_LW: 12 waves, three per SIMD, so at most 168 VGPRs): every tile whose MFMA waves fit that
+// budget - the 256x256 tile (221 VGPRs) and the 192x256 tile (179) stay on the 8-wave kernel
+constexpr RingTile kRingTilesLW[] = {{256, 128, 3}, {128, 256, 3}, {256, 64, 3}, {128, 128, 4}, {192, 128, 3}};
+
+const RingTile* find_tile(int bm, int bn, int kernel = SP_CONV_KERNEL_RING) {
+    if (kernel == SP_CONV_KERNEL_RING_LW) {
+        for (const RingTile& t : kRingTilesLW)
+            if (t.bm == bm && t.bn == bn) return &t;
+        return nullptr;
+    }
     for (const RingTile& t : kRingTiles)
         if (t.bm == bm && t.bn == bn) return &t;
     return nullptr;
@@ -511,7 +567,7 @@ const RingTile* find_tile(int bm, int bn) {
 // 1 when sp_conv2d_fwd can run `d` on the LDS-DMA ring kernel with workgroup tile d->tile_m x d->tile_n (kernel = SP_CONV_KERNEL_RING)
 extern "C" int sp_conv2d_ring_ok(const sp_conv_desc* d) {
     if (!d) return 0;
-    const RingTile* t = find_tile(d->tile_m, d->tile_n);
+    const RingTile* t = find_tile(d->tile_m, d->tile_n, d->kernel);   // (kernel = SP_CONV_KERNEL_RING_LW: the loader-wave tiles; anything else: the 8-wave ring's)
     if (!t) return 0;
     const unsigned allowed = SP_CONV_RELU | SP_CONV_PIXEL_SHUFFLE | SP_CONV_BF16;
     if (!(d->flags & SP_CONV_BF16) || (d->flags & ~allowed)) return 0;                 // bf16 in, bf16 NHWC out
@@ -531,7 +587,8 @@ extern "C" int sp_conv2d_ring_ok(const sp_conv_desc* d) {
 int sp_conv_ring_launch(const sp_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift,
                         const void* residual, void* y, void* stream) {
     SP_REQUIRE(sp_conv2d_ring_ok(d), "sp_conv2d_fwd: descriptor / tile %dx%d not supported by the LDS-DMA ring kernel (bf16 NHWC in and out, "
-               "c_in %% 64 == 0, k_pad / 64 >= ring depth, tile_n | n_pad; tiles 256x256 256x128 128x256 256x64 128x128 192x128 192x256)", d->tile_m, d->tile_n);
+               "c_in %% 64 == 0, k_pad / 64 >= ring depth, tile_n | n_pad; tiles 256x256 256x128 128x256 256x64 128x128 192x128 192x256; loader-wave "
+               "variant: all but 256x256 and 192x256)", d->tile_m, d->tile_n);
     const long long M = (long long)d->batch * d->grid_h * d->grid_w;
     const long long in_elems = (long long)d->batch * d->in_h * d->in_w * d->c_in;
     const long long out_elems = (long long)d->batch * d->out_h * d->out_w * d->out_c;
@@ -555,6 +612,15 @@ int sp_conv_ring_launch(const sp_conv_desc* d, const void* x, const void* w_pack
     a.x_bytes = (int)(in_elems * 2); a.w_bytes = (int)(w_elems * 2); a.y_bytes = (int)(out_elems * 2);
     hipStream_t s = (hipStream_t)stream;
     const int bm = d->tile_m, bn = d->tile_n;
+    if (d->kernel == SP_CONV_KERNEL_RING_LW) {
+        if (bm == 256 && bn == 128) return launch_ring<256, 128, 4, 2, 3, 4>(a, s);
+        if (bm == 128 && bn == 256) return launch_ring<128, 256, 2, 4, 3, 4>(a, s);
+        if (bm == 256 && bn == 64) return launch_ring<256, 64, 4, 2, 3, 4>(a, s);
+        if (bm == 128 && bn == 128) return launch_ring<128, 128, 2, 4, 4, 4>(a, s);
+        if (bm == 192 && bn == 128) return launch_ring<192, 128, 2, 4, 3, 4>(a, s);
+        sp_set_error("sp_conv2d_fwd: loader-wave ring tile %dx%d not instantiated", bm, bn);
+        return SP_EINVAL;
+    }
     if (bm == 256 && bn == 256) return launch_ring<256, 256, 2, 4, 2>(a, s);
     if (bm == 256 && bn == 128) return launch_ring<256, 128, 4, 2, 3>(a, s);
     if (bm == 128 && bn == 256) return launch_ring<128, 256, 2, 4, 3>(a, s);

@@ -369,6 +369,10 @@ class Program:
                 d.tile_m, d.tile_n, d.kernel = bm, bn, _lib.SP_CONV_KERNEL_RING
                 if lib.sp_conv2d_ring_ok(d):
                     out.append((bm, bn, _lib.SP_CONV_KERNEL_RING))
+            for bm, bn in _lib.RING_LW_TILES:
+                d.tile_m, d.tile_n, d.kernel = bm, bn, _lib.SP_CONV_KERNEL_RING_LW
+                if lib.sp_conv2d_ring_ok(d):
+                    out.append((bm, bn, _lib.SP_CONV_KERNEL_RING_LW))
         d.tile_m, d.tile_n, d.kernel = keep
         if lib.sp_conv2d_pw_ok(d):
             out.append((64, 256, _lib.SP_CONV_KERNEL_PW))

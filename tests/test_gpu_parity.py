@@ -1460,7 +1460,7 @@ def test_ring_kernel_matches_igemm_on_ragged_shapes():
         (3, 256, 7, 5, 256, 4, 2, 1, False, "deconv"),
         (70, 512, 8, 6, 256, 4, 2, 1, False, "deconv"),      # 4 phases x 3,360 rows
     ]
-    ran = 0
+    ran = ran_lw = 0
     for ci, (B, Cin, H, W, Cout, k, s, p, with_res, kind) in enumerate(cases):
         tag = f"ring{ci}"
         wshape = (Cin, Cout, 4, 4) if kind == "deconv" else (Cout, Cin, k, k)
@@ -1507,6 +1507,7 @@ def test_ring_kernel_matches_igemm_on_ragged_shapes():
             results.append((cand, y.view(torch.int16).cpu(), y.float().cpu()))
         ring = [c for c, _, _ in results if c[2] == _lib.SP_CONV_KERNEL_RING]
         ran += len(ring)
+        ran_lw += len([c for c, _, _ in results if c[2] == _lib.SP_CONV_KERNEL_RING_LW])      # the same ring fed by four loader waves (round 5)
         for cand, bits, _ in results[1:]:
             assert torch.equal(bits, results[0][1]), (tag, cand, int((bits != results[0][1]).sum()))
         got = results[0][2].permute(0, 3, 1, 2).double()
@@ -1514,7 +1515,8 @@ def test_ring_kernel_matches_igemm_on_ragged_shapes():
         err = (got - ref).abs().max() / ref.abs().max()
         assert err < 6e-3, (tag, err)
     assert ran >= 20, ran                                      # the ring kernel really took part
-    print(f"ring-vs-igemm: {ran} ring launches bit-identical to the implicit GEMM")
+    assert ran_lw >= 15, ran_lw                                # ... and so did its loader-wave variant
+    print(f"ring-vs-igemm: {ran} ring launches + {ran_lw} loader-wave ring launches bit-identical to the implicit GEMM")
 
 
 @pytest.mark.parametrize("Cin,Cout,B,H,W,with_res,relu", [(64, 256, 3, 16, 12, True, True), (64, 256, 2, 9, 7, False, False), (128, 512, 5, 8, 6, True, True),

@@ -194,10 +194,12 @@ def test_selayer_train_step_is_bit_reproducible_and_bf16_tracks_fp32(dtype):
 # conv1.weight moved to 2.7e-2.  tests/measure_reference_spread.py: the reference's own fp32 step moves by 1.8e-2 ... 2.1e-2 on this metric
 # when only its thread count changes (and sits 1.2e-2 ... 2.0e-2 from fp64) - this B = 2 BatchNorm net is chaotic at that level, so the bar
 # is 2x the reference's own spread; the per-kernel tests (test_gpu_backward_kernels.py: every sum against float64 at 1e-6) are the sharp ones
-# Round 5 (advisor): the wider bar is kept ONLY for the slices that moved past 2e-2 - the two at the far end of the backward chain (measured
-# round 5: conv1.weight 2.8e-2, layer1.0.conv1.weight 2.4e-2); every other slice is back at 2e-2, so a regression of that size elsewhere fails again.
+# Round 5 (advisor): the wider bar is kept ONLY for the slices that moved past 2e-2 - the three at the far end of the backward chain (measured
+# round 5: conv1.weight 2.81e-2, layer1.0.conv1.weight 2.44e-2, bn1.weight 2.02e-2; the next ones: layer2.0.conv2.weight 1.96e-2,
+# layer2.0.downsample.0.weight 1.90e-2, layer4 / deconv0 1.5e-2, the head 1e-6); every other slice is back at 2e-2, so a regression of that size
+# elsewhere fails again.  (The step is bit-reproducible for a given tile table, so these are not box-to-box noise.)
 GRAD_SLICE_BAR = 2e-2
-GRAD_SLICE_BAR_OF = {"conv1.weight": 4e-2, "layer1.0.conv1.weight": 4e-2}
+GRAD_SLICE_BAR_OF = {"conv1.weight": 4e-2, "layer1.0.conv1.weight": 4e-2, "bn1.weight": 4e-2}
 ADAM_CLOSE_BAR = 0.995
 
 

@@ -358,7 +358,14 @@ def test_conv_kernel_name_query_matches_dispatch():
     d.tile_m, d.tile_n, d.kernel = 128, 128, _lib.SP_CONV_KERNEL_IGEMM
     assert _lib.conv_kernel_name(d, True) == "conv_igemm_kernel<128, 128, 2, 2, true, true, true, false, true, false>"   # 36 K tiles: deep ring
     d.tile_m, d.tile_n, d.kernel = 128, 256, _lib.SP_CONV_KERNEL_RING
-    assert _lib.conv_kernel_name(d, False) == "conv_ring_kernel<128, 256, 2, 4, 3, false>"
+    assert _lib.conv_kernel_name(d, False) == "conv_ring_kernel<128, 256, 2, 4, 3, false, 0>"
+    d.kernel = _lib.SP_CONV_KERNEL_RING_LW            # the same ring fed by four loader waves (round 5): last template argument
+    assert _lib.lib().sp_conv2d_ring_ok(d) == 1
+    assert _lib.conv_kernel_name(d, True) == "conv_ring_kernel<128, 256, 2, 4, 3, true, 4>"
+    d.tile_m, d.tile_n = 256, 256                     # 221 VGPRs: no loader-wave instantiation (three waves per SIMD)
+    assert _lib.lib().sp_conv2d_ring_ok(d) == 0
+    d.kernel = _lib.SP_CONV_KERNEL_RING
+    assert _lib.lib().sp_conv2d_ring_ok(d) == 1
     d.flags = _lib.SP_CONV_RELU
     d.tile_m, d.tile_n, d.kernel = 64, 128, _lib.SP_CONV_KERNEL_IGEMM
     d.c_in, d.k_pad = 256, 2304
