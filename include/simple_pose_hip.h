@@ -473,11 +473,15 @@ int sp_permute4_f32(const float* src, void* dst, int dst_bf16, const int32_t* ds
                     const int32_t* valid, int64_t src_base, int64_t dst_offset, void* stream);
 
 /* every pack job of a network in one launch: `jobs_device` = device array of n_jobs records
- *   { int32 dst_dims[4]; int64 src_strides[4]; int32 valid[4]; int64 src_base; int64 dst_address; int64 total; int32 dst_bf16; int32 walk; }
+ *   { int32 dst_dims[4]; int64 src_strides[4]; int32 valid[4]; int64 src_base; int64 dst_address; int64 total; int32 dst_bf16; int32 walk;
+ *     int32 tap0; int32 tile0; }
  * (dst_address = device pointer of the destination incl. its offset), blocks_per_job workgroups grid-stride over a job.
  * walk: how the job's elements are visited (same result, other access pattern): 0 destination order (sources contiguous along the
  * last destination index), 1 multi-tap filters - a thread takes one (i0, i3) pair and loops over the (i1, i2) taps, whose sources
- * are one contiguous run, 2 a 2-D transpose (dims 1 and 2 of extent 1, source contiguous along i0) in 32x32 tiles through LDS */
+ * are one contiguous run, 2 a 2-D transpose (dims 1 and 2 of extent 1, source contiguous along i0) in 32x32 tiles through LDS,
+ * 3 multi-tap filters whose fastest destination index is the source's slowest (stride[0] = floats per (i0, i3) block < |stride[3]|): tiles of
+ * 32 i3 x tile0 i0 values through LDS, coalesced both ways; the record then ends in two more int32: tap0 (offset <= 0 from `base` to the
+ * block's first tap) and tile0 (32 * (tile0 * stride[0] | 1) <= 10240).  Record size: 104 bytes (ABI 33; 96 before). */
 int sp_permute4_batched(const float* src, const void* jobs_device, int n_jobs, int blocks_per_job, void* stream);
 
 /* measurement aid: occupies `stream` for `us` microseconds (one idle wave on the 100 MHz constant clock) - bench.py's stand-in for the

@@ -838,26 +838,51 @@ __global__ __launch_bounds__(256) void stem_pool_bwd_reduce_kernel(const void* _
         const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c4], is = reinterpret_cast<const f32x4*>(invstd)[c4];
         const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[c4], be = reinterpret_cast<const f32x4*>(beta)[c4];
         if (tr < rows_par) {
-            for (long long r = (long long)blockIdx.x * rows_par + tr; r < M; r += (long long)gridDim.x * rows_par) {
-                const int ox = (int)(r % Wo);
-                const long long q = r / Wo;
-                const int oy = (int)(q % Ho);
-                const long long b = q / Ho;
-                const f32x4 g = ld4<G16>(dyp, r * C4 + c4);
-                const unsigned t = idx[r * C4 + c4];
-                const float* zf = reinterpret_cast<const float*>(z);
-                const __bf16* zh = reinterpret_cast<const __bf16*>(z);
+            // four pooled rows per trip (round 5): their gradient / winner loads go out together, then the sixteen winner gathers of z, then the
+            // sums in row order - the per-row chain (index load -> gather -> use) was two dependent round trips per 4 channels
+            constexpr int U = 4;
+            const long long stride = (long long)gridDim.x * rows_par;
+            const float* zf = reinterpret_cast<const float*>(z);
+            const __bf16* zh = reinterpret_cast<const __bf16*>(z);
+            for (long long r0 = (long long)blockIdx.x * rows_par + tr; r0 < M; r0 += U * stride) {
+                f32x4 g[U];
+                unsigned t[U];
+                float zz[U][4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int tap = (int)((t >> (8 * e)) & 0xffu), ky = tap / 3, kx = tap - 3 * ky;
-                    const long long zi = (((b * H + (oy * 2 - 1 + ky)) * W + (ox * 2 - 1 + kx)) * C4 + c4) * 4 + e;
-                    const float zz = BF16 ? (float)zh[zi] : zf[zi];
-                    f32x4 v4 = {zz, zz, zz, zz};
-                    v4 = bn_fwd_elem(v4, f32x4{mu[e], mu[e], mu[e], mu[e]}, f32x4{is[e], is[e], is[e], is[e]}, f32x4{ga[e], ga[e], ga[e], ga[e]},
-                                     f32x4{be[e], be[e], be[e], be[e]});
-                    const float ge = v4[0] > 0.f ? g[e] : 0.f;
-                    s0[e] += (double)ge;
-                    s1[e] += (double)ge * (double)((zz - mu[e]) * is[e]);
+                for (int u = 0; u < U; ++u) {
+                    const long long r = r0 + u * stride;
+                    g[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    t[u] = 0x04040404u;
+                    if (r < M) { g[u] = ld4<G16>(dyp, r * C4 + c4); t[u] = idx[r * C4 + c4]; }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const long long r = r0 + u * stride;
+                    const int ox = (int)(r % Wo);
+                    const long long q = r / Wo;
+                    const int oy = (int)(q % Ho);
+                    const long long b = q / Ho;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int tap = (int)((t[u] >> (8 * e)) & 0xffu), ky = (tap * 11) >> 5, kx = tap - 3 * ky;   // tap / 3 for tap < 9
+                        const long long zi = (((b * H + (oy * 2 - 1 + ky)) * W + (ox * 2 - 1 + kx)) * C4 + c4) * 4 + e;
+                        zz[u][e] = 0.f;
+                        if (r < M) zz[u][e] = BF16 ? (float)zh[zi] : zf[zi];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (r0 + u * stride >= M) continue;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float z1 = zz[u][e];
+                        f32x4 v4 = {z1, z1, z1, z1};
+                        v4 = bn_fwd_elem(v4, f32x4{mu[e], mu[e], mu[e], mu[e]}, f32x4{is[e], is[e], is[e], is[e]}, f32x4{ga[e], ga[e], ga[e], ga[e]},
+                                         f32x4{be[e], be[e], be[e], be[e]});
+                        const float ge = v4[0] > 0.f ? g[u][e] : 0.f;
+                        s0[e] += (double)ge;
+                        s1[e] += (double)ge * (double)((z1 - mu[e]) * is[e]);
+                    }
                 }
             }
         }
@@ -878,40 +903,58 @@ __global__ __launch_bounds__(256) void stem_pool_bwd_reduce_kernel(const void* _
     }
 }
 
-// dz of the stem conv: g at a stem pixel = the pooled gradients of the (<= 4) windows it won, through the ReLU mask re-formed from z
-template <bool BF16, bool G16>
+// dz of the stem conv: g at a stem pixel = the pooled gradients of the (<= 4) windows it won, through the ReLU mask re-formed from z.
+// VW channels per thread: 4, or 8 where every operand is bf16 (round 5: 16-byte accesses - half the memory instructions per byte; the element
+// maps run on the same 4-channel groups, so the bits do not move).
+template <bool BF16, bool G16, int VW>
 __global__ void stem_pool_bwd_apply_kernel(const void* __restrict__ dyp, const unsigned int* __restrict__ idx, const void* __restrict__ z,
                                            const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
                                            const float* __restrict__ beta, const float* __restrict__ dgamma, const float* __restrict__ dbeta, float inv_m,
-                                           void* __restrict__ dz, int H, int W, int C4, int Ho, int Wo, long long total) {
+                                           void* __restrict__ dz, int H, int W, int CV, int Ho, int Wo, long long total) {
+    constexpr int Q = VW / 4;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C4);
-        long long r = i / C4;
+        const int c = (int)(i % CV);
+        long long r = i / CV;
         const int ix = (int)(r % W); r /= W;
         const int iy = (int)(r % H);
         const long long b = r / H;
-        const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c], is = reinterpret_cast<const f32x4*>(invstd)[c];
-        const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[c], be = reinterpret_cast<const f32x4*>(beta)[c];
-        const f32x4 dg = reinterpret_cast<const f32x4*>(dgamma)[c], db = reinterpret_cast<const f32x4*>(dbeta)[c];
-        const f32x4 zz = ld4<BF16>(z, i);
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        float zz[VW], acc[VW];
+        ldn<BF16, VW>(z, i, zz);
+#pragma unroll
+        for (int e = 0; e < VW; ++e) acc[e] = 0.f;
         for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {        // windows oy with iy in [2oy-1, 2oy+1]
             if (oy >= Ho) continue;
             const unsigned ky = (unsigned)(iy - (2 * oy - 1));
             for (int ox = ix / 2; ox <= (ix + 1) / 2; ++ox) {
                 if (ox >= Wo) continue;
                 const unsigned mine = ky * 3u + (unsigned)(ix - (2 * ox - 1));
-                const long long o = ((b * Ho + oy) * Wo + ox) * C4 + c;
-                const unsigned int t = idx[o];
-                const f32x4 g = ld4<G16>(dyp, o);
+                const long long o = ((b * Ho + oy) * Wo + ox) * CV + c;
+                unsigned int t[Q];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if (((t >> (8 * e)) & 0xffu) == mine) acc[e] += g[e];
+                for (int h = 0; h < Q; ++h) t[h] = idx[o * Q + h];
+                float g[VW];
+                ldn<G16, VW>(dyp, o, g);
+#pragma unroll
+                for (int e = 0; e < VW; ++e) if (((t[e >> 2] >> (8 * (e & 3))) & 0xffu) == mine) acc[e] += g[e];
             }
         }
-        const f32x4 v = bn_fwd_elem(zz, mu, is, ga, be);
+        float o8[VW];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = v[e] > 0.f ? acc[e] : 0.f;
-        st4<BF16>(dz, i, bn_bwd_elem(acc, zz, mu, is, ga, dg, db, inv_m));
+        for (int h = 0; h < Q; ++h) {
+            const int c4 = c * Q + h;
+            const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c4], is = reinterpret_cast<const f32x4*>(invstd)[c4];
+            const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[c4], be = reinterpret_cast<const f32x4*>(beta)[c4];
+            const f32x4 dg = reinterpret_cast<const f32x4*>(dgamma)[c4], db = reinterpret_cast<const f32x4*>(dbeta)[c4];
+            const f32x4 z4 = {zz[4 * h], zz[4 * h + 1], zz[4 * h + 2], zz[4 * h + 3]};
+            f32x4 a4 = {acc[4 * h], acc[4 * h + 1], acc[4 * h + 2], acc[4 * h + 3]};
+            const f32x4 v = bn_fwd_elem(z4, mu, is, ga, be);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a4[e] = v[e] > 0.f ? a4[e] : 0.f;
+            const f32x4 d4 = bn_bwd_elem(a4, z4, mu, is, ga, dg, db, inv_m);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o8[4 * h + e] = d4[e];
+        }
+        stn<BF16, VW>(dz, i, o8);
     }
 }
 
@@ -994,6 +1037,8 @@ struct PackJobDev {
     long long total;
     int dst_bf16;
     int pad;
+    int tap0;            // walk 3: offset (<= 0) from the job's `base` to the first tap of an (i0, i3) pair's source block
+    int tile0;           // walk 3: i0 values per LDS tile (32 i3 values x tile0 blocks of s[0] floats fit the 40 KB buffer)
 };
 // `pad` of a job selects how its elements are walked (the result is the same gather-copy; only the access pattern differs):
 //   0  destination order, one element per thread: fine when the fastest destination index is also contiguous in the source;
@@ -1002,13 +1047,60 @@ struct PackJobDev {
 //      Destination order would read 4 bytes per 36 / 64 / 2,304-byte stride: measured 567 MB of HBM traffic per repack launch for
 //      ~70 MB of compulsory bytes (2.3 GB of the bf16 train step's 20.5);
 //   2  1x1 filters packed transposed ([o][c] -> [c][o]: d1 = d2 = 1, the source contiguous along i0): 32x32 tiles through LDS, both
-//      the loads and the stores are whole 128-byte rows.
+//      the loads and the stores are whole 128-byte rows;
+//   3  (round 5) multi-tap filters whose FASTEST destination index is the source's slowest (the dgrad packs of k > 1 convs,
+//      Wd[c][taps][o] <- W[o][c][taps], and the four phase packs of a transposed conv): walk 1 gives every thread a 36 / 64-byte run in a
+//      row of its own - 2.3-3.5x the compulsory sectors (the repack moved 680 MB per step for 408 MB of compulsory bytes).  Here a tile of
+//      32 i3 values x tile0 i0 values is read as 32 contiguous runs of tile0 * s[0] floats (the (i0, taps) blocks of one i3 are adjacent
+//      in the source), parked in LDS with an odd row pitch, and written with i3 fastest: 64 / 128-byte runs both ways.
 __global__ void permute4_batched_kernel(const float* __restrict__ src, const PackJobDev* __restrict__ jobs) {
     const PackJobDev pm = jobs[blockIdx.y];
     auto put = [&](long long i, float v) __attribute__((always_inline)) {
         if (pm.dst_bf16) reinterpret_cast<__bf16*>(pm.dst_ptr)[i] = (__bf16)v;
         else reinterpret_cast<float*>(pm.dst_ptr)[i] = v;
     };
+    if (pm.pad == 3) {
+        constexpr int T3 = 32, BUF = 10240;
+        __shared__ float buf[BUF];
+        __shared__ int tap_src[32], tap_dst[32];           // per destination tap: offset inside the source block (-1: zero fill), (i1 * d2 + i2) * d3
+        const int span = (int)pm.s[0], T0 = pm.tile0, run = T0 * span, pitch = run | 1;     // (host: 32 * (T0 * span | 1) <= BUF)
+        const int taps = pm.d[1] * pm.d[2];                 // (host: <= 32)
+        if (threadIdx.x < taps) {
+            const int i1 = threadIdx.x / pm.d[2], i2 = threadIdx.x - i1 * pm.d[2];
+            tap_src[threadIdx.x] = (i1 < pm.lim[1] && i2 < pm.lim[2]) ? (int)(i1 * pm.s[1] + i2 * pm.s[2]) - pm.tap0 : -1;
+            tap_dst[threadIdx.x] = (i1 * pm.d[2] + i2) * pm.d[3];
+        }
+        const int t0n = (pm.d[0] + T0 - 1) / T0, t3n = (pm.d[3] + T3 - 1) / T3;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+        const int r3s = threadIdx.x & (T3 - 1), sub = threadIdx.x >> 5, nsub = blockDim.x >> 5;
+        for (int tl = blockIdx.x; tl < t0n * t3n; tl += gridDim.x) {
+            const int a0 = (tl % t0n) * T0, a3 = (tl / t0n) * T3;
+            // load: wave w takes rows w, w + 4, ...; a row is one contiguous run of the source (no per-element index arithmetic)
+            const int kmax = max(0, min(T0, pm.lim[0] - a0)) * span;      // floats of the run that belong to valid i0
+            for (int r3 = wave; r3 < T3; r3 += nw) {
+                const bool row_ok = a3 + r3 < pm.lim[3];
+                const float* row = src + pm.base + pm.tap0 + (long long)a0 * pm.s[0] + (long long)(a3 + r3) * pm.s[3];
+                for (int k = lane; k < run; k += 64) buf[r3 * pitch + k] = (row_ok && k < kmax) ? row[k] : 0.f;
+            }
+            __syncthreads();
+            // store: thread = (i3 lane, one of 8 (i0, tap) walkers); (cl, tp) advance without divisions
+            const int i3 = a3 + r3s;
+            int cl = 0, tp = sub;
+            while (tp >= taps) { tp -= taps; ++cl; }
+            for (; cl < T0; ) {
+                const int i0 = a0 + cl;
+                if (i0 < pm.d[0] && i3 < pm.d[3]) {
+                    const int so = tap_src[tp];
+                    const float v = (so >= 0 && i0 < pm.lim[0] && i3 < pm.lim[3]) ? buf[r3s * pitch + cl * span + so] : 0.f;
+                    put((long long)i0 * taps * pm.d[3] + tap_dst[tp] + i3, v);
+                }
+                tp += nsub;
+                while (tp >= taps) { tp -= taps; ++cl; }
+            }
+            __syncthreads();
+        }
+        return;
+    }
     if (pm.pad == 1) {
         const long long pairs = (long long)pm.d[0] * pm.d[3];
         const int taps = pm.d[1] * pm.d[2];
@@ -1424,15 +1516,19 @@ extern "C" int sp_bn_maxpool_bwd_nhwc(const void* dy_pooled, int bf16, const voi
     SP_REQUIRE(total * 4 < (1ll << 31), "sp_bn_maxpool_bwd_nhwc: tensor too large");
     hipStream_t s = (hipStream_t)stream;
     double* part = reinterpret_cast<double*>(workspace);
-    const int nblk = red_blocks(prows, c);
+    // (512 partial blocks at most: with four rows in flight per thread two workgroups per CU cover the latency, and the fixed-order fold of the
+    // partials - a launch on the chain - reads half the rows the generic reduction's 1,024 would give it)
+    static const bool wide = !(getenv("SP_STEM_BWD_NARROW") && atoi(getenv("SP_STEM_BWD_NARROW")));   // (env: development knob - the round-4 geometry for same-box A/Bs)
+    int nblk = red_blocks(prows, c);
+    if (wide && nblk > 512) nblk = 512;
     const unsigned int* ix = reinterpret_cast<const unsigned int*>(idx);
 #define SP_SPR(A, G) hipLaunchKernelGGL((stem_pool_bwd_reduce_kernel<A, G>), dim3(nblk), dim3(256), 0, s, dy_pooled, ix, z, mean, invstd, gamma, beta, h, w, ho, wo, (int)prows, c, part)
     if (a16 && g16) SP_SPR(true, true); else if (a16) SP_SPR(true, false); else SP_SPR(false, false);
 #undef SP_SPR
     hipLaunchKernelGGL(pair_sum_final_kernel, dim3((c + 3) / 4), dim3(256), 0, s, part, nblk, c, dbeta, dgamma);
     const float inv_m = (float)(1.0 / (double)rows);
-#define SP_SPA(A, G) hipLaunchKernelGGL((stem_pool_bwd_apply_kernel<A, G>), dim3(grid_for(total, 256)), dim3(256), 0, s, dy_pooled, ix, z, mean, invstd, gamma, beta, dgamma, dbeta, inv_m, dz, h, w, c / 4, ho, wo, total)
-    if (a16 && g16) SP_SPA(true, true); else if (a16) SP_SPA(true, false); else SP_SPA(false, false);
+#define SP_SPA(A, G, V) hipLaunchKernelGGL((stem_pool_bwd_apply_kernel<A, G, V>), dim3(grid_for(total * 4 / V, 256)), dim3(256), 0, s, dy_pooled, ix, z, mean, invstd, gamma, beta, dgamma, dbeta, inv_m, dz, h, w, c / V, ho, wo, total * 4 / V)
+    if (a16 && g16 && c % 8 == 0 && wide) SP_SPA(true, true, 8); else if (a16 && g16) SP_SPA(true, true, 4); else if (a16) SP_SPA(true, false, 4); else SP_SPA(false, false, 4);
 #undef SP_SPA
     return sp_check_launch("sp_bn_maxpool_bwd_nhwc");
 }

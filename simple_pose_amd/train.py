@@ -947,7 +947,7 @@ class PoseTrainer:
         if getattr(self, "_pack_table", None) is None:
             import numpy as np
             rec = np.dtype([("d", "<i4", 4), ("s", "<i8", 4), ("lim", "<i4", 4), ("base", "<i8"), ("dst", "<i8"), ("total", "<i8"),
-                            ("bf16", "<i4"), ("pad", "<i4")], align=True)
+                            ("bf16", "<i4"), ("pad", "<i4"), ("tap0", "<i4"), ("tile0", "<i4")], align=True)
             jobs = [j for layer in self.layers.values() for j in layer.pack_jobs]
             rows = []
             for j in jobs:                                     # cut every job into slabs of <= ~64 K elements along its first axis
@@ -960,14 +960,24 @@ class PoseTrainer:
                     # how the kernel walks the slab (sp_permute4_batched): filters with taps read a run of taps per (i0, i3) pair, 1x1
                     # filters packed transposed go through LDS tiles, the rest (sources contiguous along the last index) in destination order
                     walk = 1 if j.dims[1] * j.dims[2] > 1 else (2 if abs(j.strides[0]) == 1 and abs(j.strides[3]) > 1 else 0)
+                    tap0 = tile0 = 0
+                    if walk == 1 and self.repack_tiled and 0 < j.strides[0] < abs(j.strides[3]) and j.strides[0] * 32 + 1 <= 320 and j.dims[1] * j.dims[2] <= 32:
+                        # the fastest destination index is the source's slowest (dgrad packs of k > 1 convs, a transposed conv's phase packs):
+                        # tiles through LDS, coalesced both ways (sp_permute4_batched walk 3).  `j.base` is the tap offset inside an
+                        # (i0, i3) pair's block of strides[0] source floats.
+                        walk, tap0 = 3, -int(j.base)
+                        tile0 = 32
+                        while 32 * ((tile0 * j.strides[0]) | 1) > 10240:
+                            tile0 //= 2
                     rows.append(((n0,) + tuple(j.dims[1:]), j.strides, (max(0, min(n0, j.valid[0] - r0)),) + tuple(j.valid[1:]),
                                  o + j.base + r0 * j.strides[0], j.dst.data_ptr() + (j.dst_off + r0 * inner) * es, n0 * inner,
-                                 int(j.dst.dtype == torch.bfloat16), walk))
+                                 int(j.dst.dtype == torch.bfloat16), walk, tap0, tile0))
             tab = np.zeros(len(rows), dtype=rec)
-            for i, (d, st, lim, base, dst, total, b16, walk) in enumerate(rows):
+            for i, (d, st, lim, base, dst, total, b16, walk, tap0, tile0) in enumerate(rows):
                 tab[i]["d"], tab[i]["s"], tab[i]["lim"] = d, st, lim
                 tab[i]["base"], tab[i]["dst"], tab[i]["total"], tab[i]["bf16"], tab[i]["pad"] = base, dst, total, b16, walk
-            assert rec.itemsize == 96, rec.itemsize
+                tab[i]["tap0"], tab[i]["tile0"] = tap0, tile0
+            assert rec.itemsize == 104, rec.itemsize
             self._pack_table = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(self.flat.data.device)
             self._pack_n = len(rows)
             # rows are in parameter order: the rows that read from a gradient bucket's slice of the flat buffer are one range
@@ -981,7 +991,7 @@ class PoseTrainer:
         if rows_range is None:
             self._packed_version = self._param_version()
         if hi > lo:
-            tab = _lib.c_void_p(self._pack_table.data_ptr() + 96 * lo)
+            tab = _lib.c_void_p(self._pack_table.data_ptr() + 104 * lo)
             _lib.check(_lib.lib().sp_permute4_batched(P(self.flat.data), tab, hi - lo, 8, stream if stream is not None else _lib.current_stream()),
                        "repack")
 
@@ -1879,6 +1889,7 @@ class PoseTrainer:
     _in_branch = False
     overlap_shortcut = True
     relu_bit_masks = os.environ.get("SP_RELU_MASK", "1") != "0"        # (env: development knob)
+    repack_tiled = os.environ.get("SP_REPACK_TILED", "1") != "0"       # (env: development knob; walk 3 of sp_permute4_batched)
     lazy_residual_grad = os.environ.get("SP_LAZY_RES", "1") != "0"      # (env: development knob)
     fold_in_consumer_rows = 50    # partial rows (one per phase and M tile) up to which the BatchNorm pass folds them itself (sp_bn_fold_*): above, a stand-alone
                                   # fold + the plain pass (measured with the 16-byte bf16 passes: 1536 -> 6.06 ms, 100 -> 5.98, 50 -> 5.95, 0 -> 5.97)

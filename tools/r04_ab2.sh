@@ -5,7 +5,7 @@ TAG=$1; shift
 OUT=$ROOT/gpurun_out/r04_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-T=${TILES:-$ROOT/profiles/r03_train_bf16_tiles.json}
+T=${TILES:-$ROOT/profiles/r04_train_bf16_tiles.json}; case "$T" in /*) ;; *) T=$ROOT/$T;; esac
 for rep in $(seq 1 ${REPS:-2}); do
   i=0
   for v in "$@"; do
