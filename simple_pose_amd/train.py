@@ -575,9 +575,8 @@ class PoseTrainer:
                                       "read fp32 gradients)")
         self.g16 = grad_dtype == "bf16"
         self.grad_dtype = torch.bfloat16 if self.g16 else torch.float32
-        if getattr(model, "BLOCK", "bottleneck") != "bottleneck":
-            raise NotImplementedError("PoseTrainer lowers the Bottleneck ResNets (resnet50 / 101 / 152, wide_resnet*_2) and HRNet; the BasicBlock "
-                                      "nets (resnet18 / resnet34) run the eval-mode forward only")
+        if getattr(model, "BLOCK", "bottleneck") not in ("bottleneck", "basic"):
+            raise NotImplementedError(f"PoseTrainer lowers the Bottleneck / BasicBlock ResNets and HRNet, not block type {model.BLOCK!r}")
         self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
         self.pg = process_group
         self.overlap_wgrad = overlap_wgrad
@@ -914,10 +913,24 @@ class PoseTrainer:
         self._conv("conv1", H, W, stride=2, pad=3, c_in_buf=8 if self.bf16 else 4, need_dgrad=False)
         h, w = H // 4, W // 4
         inpl = 64
+        basic = getattr(self.model, "BLOCK", "bottleneck") == "basic"
         for li, (planes, n) in enumerate(zip((64, 128, 256, 512), self.model.BLOCKS), start=1):
             for bi in range(n):
                 s = 2 if (bi == 0 and li > 1) else 1
                 p = f"layer{li}.{bi}"
+                if basic:
+                    # BasicBlock (resnet18 / resnet34, pose_resnet_dconv.py:38-80): conv1 3x3 carries the stride, conv2 3x3; a projection
+                    # shortcut (and, with reduction=True, the SELayer) only where the shape changes
+                    self._conv(p + ".conv1", h, w, stride=s, pad=1)
+                    self._conv(p + ".conv2", h // s, w // s, pad=1)
+                    if (p + ".downsample.0.weight") in self.sd:
+                        self._conv(p + ".downsample.0", h, w, stride=s)
+                    if (p + ".se.fc.0.weight") in self.sd:
+                        self._conv(p + ".se.fc.0", 1, 1)
+                        self._conv(p + ".se.fc.2", 1, 1)
+                    h, w = h // s, w // s
+                    inpl = planes
+                    continue
                 self._conv(p + ".conv1", h, w)
                 self._conv(p + ".conv2", h, w, stride=s, pad=1)
                 self._conv(p + ".conv3", h // s, w // s)
@@ -1177,575 +1190,10 @@ class PoseTrainer:
         self.refresh_packed_weights()
         if getattr(self.model, "_program", None) is not None:
             self.model._program = None        # running statistics change below: the eval-mode program folds them into its weights
-        tape: List[Callable[[], None]] = []
-        nbt: List[torch.Tensor] = []
-        L = self.layers
-        ws = self.red_ws
-
-        bf = int(self.bf16)
-        gf = bf | (2 if self.g16 else 0)          # flag word of the backward passes: bit 0 = bf16 activations, bit 1 = bf16 activation gradients
-        use_mask = self.g16 and self.relu_bit_masks    # (bit 2 of that word, per call: the ReLU source is the bit mask of Act.mask)
-        self._wgrad_tail = None
-        self._wg_flushes = 0
-        side = side_h = None
-        if self.overlap_wgrad:
-            # weight gradients only feed the optimizer: they run on a second HIP stream beside the dgrad / BN-backward chain, which
-            # at 32 images per GPU is a string of small launches that leave most CUs idle
-            if self._wgrad_stream is None:
-                self._wgrad_stream = torch.cuda.Stream(device=dev)
-                self._wgrad_events = {}
-            side = self._wgrad_stream
-            side_h = _lib.c_void_p(side.cuda_stream)
-            main = torch.cuda.current_stream(dev)
-
-        self._wg_queue = []
-        self._wg_queued_flops = 0.0
-        self._wg_batch, self._wg_side, self._wg_dev = B, side, dev
-        # A stage's projection shortcut (conv + BatchNorm) depends on the block input alone: forward and backward it runs on a branch
-        # stream beside conv1 -> bn1 -> conv2 -> bn2 -> conv3 (a chain of launches that each leave most of the chip idle).  Same
-        # kernels, same accumulation order (the shortcut's share of the block input's gradient lands first, conv1's dgrad adds last
-        # and after the join), so the bits do not change.  Off with SyncBatchNorm (the pair shares one message) and for the nets whose
-        # shortcut passes use the shared reduction workspace.
-        branch = None
-        self._in_branch = False
-        self._branch_open: List[Act] = []
-        if (self.overlap_shortcut and not self.sync_bn and self.fuse_bn_stats and self.fuse_bn_bwd and self.head != "hrnet"
-                and not any(".se." in k for k in self.layers)):
-            if self._branch_stream is None:
-                self._branch_stream = torch.cuda.Stream(device=dev)
-                self._branch_events = []
-            branch = self._branch_stream
-        self._branch_n = 0
-
-        def branch_event():
-            n = self._branch_n
-            self._branch_n = n + 1
-            if n == len(self._branch_events):
-                self._branch_events.append(torch.cuda.Event())
-            return self._branch_events[n]
-
-        def run_on_branch(fn):
-            """fn() with every launch on the branch stream, behind everything the current stream holds now; returns (result, event that
-            marks the end of fn's launches on the branch stream)."""
-            nonlocal stream
-            here = torch.cuda.current_stream(dev)
-            e0, e1 = branch_event(), branch_event()
-            e0.record(here)
-            branch.wait_event(e0)
-            keep = stream
-            self._in_branch, self._branch_main = True, here
-            pinned = _lib.pin_stream((_lib.c_void_p(branch.cuda_stream), _lib._device_index(dev)))
-            try:
-                with torch.cuda.stream(branch):
-                    stream = _lib.current_stream()
-                    out = fn()
-                    e1.record(branch)
-            finally:
-                _lib.pin_stream(pinned)
-                stream = keep
-                self._in_branch = False
-            return out, e1
-
-        def join_grad(xa: Act) -> None:
-            """Before .grad of `xa` is read or added to: wait for a branch that wrote it, then queue what the branch left for this stream."""
-            if xa.grad_event is not None:
-                torch.cuda.current_stream(dev).wait_event(xa.grad_event)
-                xa.grad_event = None
-                todo, xa.deferred = xa.deferred, []
-                for f in todo:
-                    f()
-                if xa in self._branch_open:
-                    self._branch_open.remove(xa)
-        self._join_grad = join_grad
-        self._group_gflop = float(os.environ.get("SP_WGRAD_GROUP_GFLOP", self.wgrad_group_gflop))     # (env: development knob)
-
-        def wgrad_async(layer, xin: torch.Tensor, dzt: torch.Tensor):
-            # weight gradients are launched in GROUPS (sp_conv2d_wgrad_batched: every layer of a group in one launch per dW tile shape plus
-            # one fold launch): a layer alone has too few dW tiles to fill 256 CUs without cutting its pixels into hundreds of partial
-            # slabs.  The group goes out when a gradient bucket completes, when `wgrad_group_gflop` of work is queued, or at the end.
-            self._wg_queue.append((layer, xin, dzt))
-            self._wg_queued_flops += layer.flops * B
-            if self._wg_queued_flops >= self._group_gflop * 1e9 or len(self._wg_queue) >= 64:     # (64 jobs: the batched call's limit)
-                self._wgrad_flush()
-
-        self._pending = [set(b["names"]) for b in self.buckets]
-        self._works: List[Optional[object]] = [None] * len(self.buckets)
-        self.collective_count = 0          # SyncBatchNorm all-reduces of this step (gradient buckets are counted in len(self.buckets))
-        sync = self.sync_bn
-        W = self.world
-
-        def new(shape, dtype=None):
-            return self._take((shape,) if isinstance(shape, int) else tuple(shape), dtype or self.act_dtype, dev)
-
-        def newf(shape):
-            return self._take((shape,) if isinstance(shape, int) else tuple(shape), torch.float32, dev)
-
-        def newg(shape):
-            return self._take(tuple(shape), self.grad_dtype, dev)
-
-        def conv_stats(xa: Act, cname: str) -> dict:
-            """The conv launch of a conv + BatchNorm pair; with `fuse_bn_stats` its epilogue also leaves the per-channel partial sums."""
-            layer = L[cname]
-            xa.consumers += 1
-            if self.fuse_bn_stats:
-                z, part, prow = layer.forward_bn_stats(xa.data, B)
-            else:
-                z, part, prow = layer.forward(xa.data, B), None, 0
-            return dict(layer=layer, z=z, part=part, prow=prow, rows=z.shape[0] * z.shape[1] * z.shape[2], C=z.shape[3])
-
-        def batch_stats(pends: List[dict], bnames: List[str]) -> None:
-            """Batch mean / invstd (+ running statistics) of the BatchNorm layers behind the pending convs.  SyncBatchNorm: every
-            layer folds its fp64 (sum, sum of squares) into a slice of ONE buffer and the group shares ONE all-reduce (the conv1 /
-            downsample pair of a stage's first bottleneck); no second pass over z either way when the conv left partial sums."""
-            for pd in pends:
-                pd["mean"], pd["invstd"] = newf(pd["C"]), newf(pd["C"])
-            run = lambda bn: (P(self.buffers[bn + ".running_mean"]), P(self.buffers[bn + ".running_var"]))
-            if not sync:
-                for pd, bn in zip(pends, bnames):
-                    rm, rv = run(bn)
-                    if pd["part"] is not None and pd["prow"] <= self.fold_in_consumer_rows:
-                        pd["fold_in_apply"] = True      # few partial rows: the consuming sp_bn_fold_apply_nhwc folds them in its prologue
-                        continue
-                    if pd["part"] is not None:
-                        part = pd["part"]
-                        _lib.check(lib.sp_bn_train_stats_from_conv(P(part[0]), P(part[1]), pd["prow"], part.shape[2], pd["rows"], pd["C"], BN_EPS,
-                                                                   BN_MOMENTUM, P(pd["mean"]), P(pd["invstd"]), rm, rv, stream), bn)
-                    else:
-                        _lib.check(lib.sp_bn_train_stats_nhwc(P(pd["z"]), bf, pd["rows"], pd["C"], BN_EPS, BN_MOMENTUM, P(pd["mean"]),
-                                                              P(pd["invstd"]), rm, rv, P(ws), stream), bn)
-                return
-            sums = self._take((2 * sum(pd["C"] for pd in pends),), torch.float64, dev)
-            off = 0
-            for pd, bn in zip(pends, bnames):
-                pd["sums"] = sums[off:off + 2 * pd["C"]]
-                off += 2 * pd["C"]
-                if pd["part"] is not None:
-                    part = pd["part"]
-                    _lib.check(lib.sp_bn_sums_from_conv(P(part[0]), P(part[1]), pd["prow"], part.shape[2], pd["C"], P(pd["sums"]), stream), bn)
-                else:
-                    _lib.check(lib.sp_bn_train_partial_nhwc(P(pd["z"]), bf, pd["rows"], pd["C"], P(pd["sums"]), P(ws), stream), bn)
-            self._exchange_wait(self._exchange(sums))
-            for pd, bn in zip(pends, bnames):
-                if self.fuse_sync_finalize:
-                    pd["from_sums"] = True         # the consuming sp_bn_apply_sums_nhwc finalises (mean, invstd, running statistics) itself
-                else:
-                    rm, rv = run(bn)
-                    _lib.check(lib.sp_bn_train_finalize(P(pd["sums"]), pd["rows"] * W, pd["C"], BN_EPS, BN_MOMENTUM, P(pd["mean"]), P(pd["invstd"]),
-                                                        rm, rv, stream), bn)
-
-        def conv_bn(xa: Act, cname: str, bname: str, relu: bool, res: Optional[Act] = None, pend: Optional[dict] = None,
-                    shortcut: bool = True, before_apply: Optional[Callable[[], None]] = None) -> Act:
-            if pend is None:
-                pend = conv_stats(xa, cname)
-                batch_stats([pend], [bname])
-            if before_apply is not None:
-                before_apply()                   # (the residual comes from the branch stream: join before the pass that reads it)
-            layer, z, mean, invstd = pend["layer"], pend["z"], pend["mean"], pend["invstd"]
-            rows, C = pend["rows"], pend["C"]
-            gamma, beta = self.sd[bname + ".weight"], self.sd[bname + ".bias"]
-            nbt.append(self.buffers[bname + ".num_batches_tracked"])
-            y = new(z.shape)
-            # bf16 gradients: the pass also leaves the ReLU mask as one bit per element; the BatchNorm backward pass and the dgrad epilogue
-            # that reduces its sums then read that byte instead of 16 bytes of y
-            mask = self._take((rows * C // 8,), torch.uint8, dev) if (relu and use_mask and not pend.get("from_sums") and C % 8 == 0) else None
-            if pend.get("fold_in_apply"):
-                part = pend["part"]
-                _lib.check(lib.sp_bn_fold_apply_nhwc(P(z), bf, P(part[0]), P(part[1]), pend["prow"], part.shape[2], rows, BN_EPS, BN_MOMENTUM, P(gamma),
-                                                     P(beta), P(res.data) if res else None, P(y), rows, C, int(relu), P(mean), P(invstd),
-                                                     P(self.buffers[bname + ".running_mean"]), P(self.buffers[bname + ".running_var"]), P(mask),
-                                                     stream), bname)
-            elif pend.get("from_sums"):
-                _lib.check(lib.sp_bn_apply_sums_nhwc(P(z), bf, P(pend["sums"]), rows * W, BN_EPS, BN_MOMENTUM, P(gamma), P(beta),
-                                                     P(res.data) if res else None, P(y), rows, C, int(relu), P(mean), P(invstd),
-                                                     P(self.buffers[bname + ".running_mean"]), P(self.buffers[bname + ".running_var"]), stream), bname)
-            else:
-                _lib.check(lib.sp_bn_apply_nhwc(P(z), bf, P(mean), P(invstd), P(gamma), P(beta), P(res.data) if res else None, P(y), rows, C,
-                                                int(relu), P(mask), stream), bname)
-            ya = Act(y, z.shape[1], z.shape[2], C)
-            ya.mask = mask
-            if res is not None:
-                res.consumers += 1
-            if relu:
-                ya.bn = (z, mean, invstd)      # y = relu(bn(z) [+ res]): backward masks with y > 0 either way
-            if not relu and res is None and shortcut:
-                ya.sibling = (z, mean, invstd, bname)      # a projection shortcut: its backward sums ride on its consumer's (message / epilogue)
-            if relu and res is not None and res.sibling is not None and self.fuse_bn_bwd and (not sync or self.fuse_sync_finalize):
-                ya.bn2 = res.sibling                       # the shortcut's dy is this layer's g = dy * (y > 0): one more sum in the same epilogue
-
-            def bwd():
-                dz = new(z.shape)                      # MFMA operand of dgrad / wgrad: activation dtype
-                dres = None
-                acc = 0
-                lazy = (res is not None and res.lazy_ok and res.grad is None and relu and ya.mask is not None and self.g16
-                        and self.lazy_residual_grad and self.fuse_bn_bwd and not sync)
-                if lazy:
-                    # the residual share g = dy * mask is not written: conv1's dgrad (the block input's other consumer, still to come on
-                    # the tape) adds it from (dy, mask) in its epilogue
-                    res.lazy_g = (ya.grad, ya.mask)
-                elif res is not None:
-                    if res.grad is None:
-                        res.grad = newg(res.data.shape)   # activation gradients: fp32, or bf16 with grad_dtype "bf16"
-                    else:
-                        acc = 1
-                    dres = res.grad
-                dgamma, dbeta = self.flat.view(bname + ".weight", True), self.flat.view(bname + ".bias", True)
-                rs = P(y) if relu else None
-                gm = gf                                # paths that take the bit mask: the two apply kernels (not the reduction passes)
-                rsm = rs
-                if relu and ya.mask is not None:
-                    rsm, gm = P(ya.mask), gf | 4
-                if ya.presums is not None:
-                    # the consumer of this (projection-shortcut) BatchNorm already reduced (SyncBatchNorm: and exchanged) its two sums
-                    sg, sb = ya.presums
-                    ya.presums = None
-                    _lib.check(lib.sp_bn_train_bwd_apply_nhwc(P(ya.grad), gf, rs, P(z), P(mean), P(invstd), P(gamma), P(sg), P(sb),
-                                                              rows * W, rows, C, P(dz), P(dres), acc, stream), bname + ".bwd")
-                elif ya.bstats is not None and not sync and ya.bstats[1] <= self.fold_in_consumer_rows:
-                    # few partial rows: ONE launch folds them (d beta, d gamma - and the projection shortcut's pair when its sum rode on the
-                    # same dgrad epilogue) in its prologue and applies the BatchNorm backward
-                    part, prow = ya.bstats
-                    ya.bstats = None
-                    three = part.shape[0] == 3 and res is not None and acc == 0
-                    dgs = dbs = None
-                    if three:
-                        sname = ya.bn2[3]
-                        dgs, dbs = self.flat.view(sname + ".weight", True), self.flat.view(sname + ".bias", True)
-                        res.presums = (dgs, dbs)
-                    _lib.check(lib.sp_bn_fold_bwd_apply_nhwc(P(ya.grad), gm, rsm, P(z), P(part[0]), P(part[1]), P(part[2]) if three else None, prow,
-                                                             part.shape[2], P(mean), P(invstd), P(gamma), rows, rows, C, P(dgamma), P(dbeta), P(dgs),
-                                                             P(dbs), P(dz), P(dres), acc, stream), bname + ".bwd")
-                elif ya.bstats is not None or sync:
-                    if ya.bstats is not None:
-                        # the dgrad launch that completed ya.grad already reduced sum g and sum g*xhat (sp_conv2d_dgrad_bn_bwd_stats)
-                        part, prow = ya.bstats
-                        ya.bstats = None
-                        msg = None
-                        three = part.shape[0] == 3 and res is not None and acc == 0
-                        if sync and self.fuse_sync_finalize and (three or not (res is not None and acc == 0 and res.sibling is not None)):
-                            # SyncBatchNorm: the fold also writes the sums into the message (no concatenation launch); with the projection
-                            # shortcut's sum g * xhat2 out of the same dgrad epilogue its pair travels in the same message
-                            msg = newf((4 if three else 2) * C)
-                            _lib.check(lib.sp_bn_bwd_sums_from_conv2(P(part[0]), P(part[1]), prow, part.shape[2], C, P(dgamma), P(dbeta),
-                                                                     P(msg[:C]), P(msg[C:2 * C]), stream), bname + ".bwd")
-                            if three:
-                                sname = ya.bn2[3]
-                                dgs, dbs = self.flat.view(sname + ".weight", True), self.flat.view(sname + ".bias", True)
-                                _lib.check(lib.sp_bn_bwd_sums_from_conv2(P(part[0]), P(part[2]), prow, part.shape[2], C, P(dgs), P(dbs),
-                                                                         P(msg[2 * C:3 * C]), P(msg[3 * C:]), stream), sname + ".bwd")
-                                res.presums = (msg[2 * C:3 * C], msg[3 * C:])       # (global after the exchange below)
-                        elif part.shape[0] == 3 and res is not None and acc == 0:
-                            # the projection shortcut's sums came out of the same epilogue: d beta = sum g (shared), d gamma = sum g * xhat2;
-                            # both BatchNorms' folds in one launch
-                            sname = ya.bn2[3]
-                            dgs, dbs = self.flat.view(sname + ".weight", True), self.flat.view(sname + ".bias", True)
-                            _lib.check(lib.sp_bn_bwd_sums_from_conv_pair(P(part[0]), P(part[1]), P(part[2]), prow, part.shape[2], C, P(dgamma), P(dbeta),
-                                                                         P(dgs), P(dbs), stream), bname + ".bwd")
-                            res.presums = (dgs, dbs)
-                        else:
-                            _lib.check(lib.sp_bn_bwd_sums_from_conv(P(part[0]), P(part[1]), prow, part.shape[2], C, P(dgamma), P(dbeta), stream),
-                                       bname + ".bwd")
-                    else:
-                        msg = None
-                        assert not self._in_branch, "the shared reduction workspace is the main chain's"
-                        _lib.check(lib.sp_bn_train_bwd_reduce_nhwc(P(ya.grad), gf, rs, P(z), P(mean), P(invstd), rows, C, P(dgamma), P(dbeta),
-                                                                   P(ws), stream), bname + ".bwd")
-                    sg, sb, tot = dgamma, dbeta, rows
-                    if sync and msg is not None:
-                        token = self._exchange(msg)
-                        self._wgrad_flush_if(0.5)            # queued weight gradients go out under the message rather than after it
-                        self._exchange_wait(token)
-                        sg, sb, tot = msg[:C], msg[C:2 * C], rows * W
-                    elif sync:
-                        # local sums are this rank's parameter gradients (DDP averages them later); dz needs the global ones
-                        parts = [dgamma, dbeta]
-                        sib = res.sibling if (res is not None and acc == 0) else None
-                        if sib is not None:
-                            # the residual is a projection shortcut's BatchNorm output and this layer is its only consumer: its dy IS this
-                            # layer's g = dy * (y > 0), so its two sums are reduced here and travel in the same message
-                            zs, ms, ivs, sname = sib
-                            dgs, dbs = self.flat.view(sname + ".weight", True), self.flat.view(sname + ".bias", True)
-                            _lib.check(lib.sp_bn_train_bwd_reduce_nhwc(P(ya.grad), gf, rs, P(zs), P(ms), P(ivs), rows, C, P(dgs), P(dbs), P(ws),
-                                                                       stream), sname + ".bwd")
-                            parts += [dgs, dbs]
-                        both = torch.cat(parts)
-                        token = self._exchange(both)
-                        self._wgrad_flush_if(0.5)            # queued weight gradients go out under the message rather than after it
-                        self._exchange_wait(token)
-                        if sib is not None:
-                            res.presums = (both[2 * C:3 * C], both[3 * C:])
-                        sg, sb, tot = both[:C], both[C:2 * C], rows * W
-                    _lib.check(lib.sp_bn_train_bwd_apply_nhwc(P(ya.grad), gm, rsm, P(z), P(mean), P(invstd), P(gamma), P(sg), P(sb), tot, rows, C,
-                                                              P(dz), P(dres), acc, stream), bname + ".bwd")
-                else:
-                    # (uses the shared reduction workspace `ws`: never from the branch stream, the main chain may be inside it)
-                    assert not self._in_branch, "a branch-stream BatchNorm backward must come with its sums (Act.presums): it has no workspace of its own"
-                    _lib.check(lib.sp_bn_train_bwd_nhwc(P(ya.grad), gf, rs, P(z), P(mean), P(invstd), P(gamma), rows, C, P(dz), P(dgamma), P(dbeta),
-                                                        P(dres), acc, P(ws), stream), bname + ".bwd")
-                in_branch = self._in_branch
-                if in_branch and not self._arena_on:
-                    ya.grad.record_stream(self._branch_stream)     # (allocator-owned, from the main stream's pool, read by the branch stream)
-                ya.grad = None
-                if res is not None:
-                    res.contrib += 1
-                if in_branch:
-                    # on the branch stream: the weight-gradient job (queued with an event of the MAIN stream) and the bucket bookkeeping
-                    # wait for the join
-                    xa.deferred.append(lambda: wgrad_async(layer, xa.data, dz))
-                    xa.deferred.append(lambda: self._grads_ready(bname + ".weight", bname + ".bias", cname + ".weight"))
-                else:
-                    wgrad_async(layer, xa.data, dz)
-                if xa.needs_grad and layer.need_dgrad:
-                    if not in_branch:
-                        join_grad(xa)
-                    # the last consumer to contribute sees the complete dy of xa in its epilogue: BN backward sums for free.  (Block outputs:
-                    # the residual share lands first, conv1 of the next block - a full-cover 1x1 - accumulates last.)
-                    last = xa.contrib == xa.consumers - 1
-                    fuse = self.fuse_bn_bwd and xa.bn is not None and last and (xa.grad is None or layer.dgrad_full_cover)
-                    if xa.lazy_g is not None:
-                        assert fuse and xa.grad is None, "a lazy residual share needs the BSTATS dgrad of conv1 as the last contributor"
-                        xa.grad = layer.dgrad(dz, B, None, bn_src=xa, acc_masked=xa.lazy_g)
-                        xa.lazy_g = None
-                    else:
-                        xa.grad = layer.dgrad(dz, B, xa.grad, bn_src=xa if fuse else None)
-                    xa.contrib += 1
-                if not in_branch:
-                    self._grads_ready(bname + ".weight", bname + ".bias", cname + ".weight")
-            tape.append(bwd)
-            return ya
-
-        def se_gate(ua: Act, idn: Act, sname: str) -> Act:
-            """SELayer + the block tail (nets/commons.py:4-18, pose_resnet_dconv.py:124-131): y = relu(u * sigmoid(fc2(relu(fc0(mean_hw u)))) + identity).
-            The FC layers are 1x1 convs on the pooled [B,1,1,C] map (conv kernels forward, backward and for the weight gradients)."""
-            fc0, fc2 = L[sname + ".fc.0"], L[sname + ".fc.2"]
-            u, C, hw = ua.data, ua.c, ua.h * ua.w
-            ua.consumers += 1
-            idn.consumers += 1
-            sq = new((B, 1, 1, C))
-            _lib.check((lib.sp_global_avg_pool_nhwc_bf16 if self.bf16 else lib.sp_global_avg_pool_nhwc)(P(u), P(sq), B, hw, C, stream), sname + ".pool")
-            hid = fc0.forward(sq, B, shift=self.sd[sname + ".fc.0.bias"], relu=True)
-            gl = fc2.forward(hid, B, shift=self.sd[sname + ".fc.2.bias"])
-            y = new(u.shape)
-            _lib.check((lib.sp_se_gate_add_relu_nhwc_bf16 if self.bf16 else lib.sp_se_gate_add_relu_nhwc)(P(u), P(gl), P(idn.data), P(y), B, hw, C,
-                                                                                                         stream), sname + ".gate")
-            ya = Act(y, ua.h, ua.w, C)
-
-            def bwd():
-                dy = ya.grad
-                da = newf((B, C))
-                _lib.check(lib.sp_se_gate_bwd_reduce(P(dy), bf, P(y), P(u), B, hw, C, P(da), stream), sname + ".bwd")
-                dg = new((B, 1, 1, C))
-                _lib.check(lib.sp_se_sigmoid_bwd(P(da), bf, P(gl), B, C, P(dg), P(self.flat.view(sname + ".fc.2.bias", True)), stream), sname + ".bwd")
-                wgrad_async(fc2, hid, dg)
-                dh = fc2.dgrad(dg, B, None)
-                dhm = new((B, 1, 1, fc0.O))
-                _lib.check(lib.sp_relu_bwd_rows(P(dh), bf, P(hid), B, fc0.O, P(dhm), P(self.flat.view(sname + ".fc.0.bias", True)), stream), sname + ".bwd")
-                wgrad_async(fc0, sq, dhm)
-                ds = fc0.dgrad(dhm, B, None)
-                acc = 0
-                if idn.grad is None:
-                    idn.grad = newf(idn.data.shape)
-                else:
-                    acc = 1
-                ua.grad = newf(u.shape)
-                _lib.check(lib.sp_se_gate_bwd_apply(P(dy), bf, P(y), P(gl), P(ds), B, hw, C, P(ua.grad), P(idn.grad), acc, stream), sname + ".bwd")
-                ua.contrib += 1
-                idn.contrib += 1
-                ya.grad = None
-                self._grads_ready(sname + ".fc.0.weight", sname + ".fc.0.bias", sname + ".fc.2.weight", sname + ".fc.2.bias")
-            tape.append(bwd)
-            return ya
-
-        def upsample_add(xa: Act, base: Act, f: int, relu: bool) -> Act:
-            """y = [relu](base + nearest_upsample(x, f)) (HRNet fuse layers, pose_hrnet.py:192-202,250-257; f = 1: the identity term)."""
-            xa.consumers += 1
-            base.consumers += 1
-            y = new(base.data.shape)
-            _lib.check((lib.sp_upsample_add_nhwc_bf16 if self.bf16 else lib.sp_upsample_add_nhwc)(P(xa.data), P(base.data), P(y), B, xa.h, xa.w, xa.c, f,
-                                                                                                 int(relu), stream), "fuse")
-            ya = Act(y, base.h, base.w, base.c)
-
-            def bwd():
-                accs = []
-                for t in (base, xa):
-                    accs.append(0 if t.grad is None else 1)
-                    if t.grad is None:
-                        t.grad = newf(t.data.shape)
-                _lib.check(lib.sp_upsample_add_bwd_nhwc(P(ya.grad), bf, P(y) if relu else None, B, xa.h, xa.w, xa.c, f, P(base.grad), accs[0],
-                                                        P(xa.grad), accs[1], stream), "fuse.bwd")
-                base.contrib += 1
-                xa.contrib += 1
-                ya.grad = None
-            tape.append(bwd)
-            return ya
-
-        def hrnet_forward(a: Act) -> Act:
-            """PoseHighResolutionNet.forward after the first stem conv (pose_hrnet.py:419-454, :241-259, :181-236, :327-366)."""
-            extra = self.model.cfg["MODEL"]["EXTRA"]
-            a = conv_bn(a, "conv2", "bn2", True)
-            for k in range(4):
-                p = f"layer1.{k}"
-                t = conv_bn(a, p + ".conv1", p + ".bn1", True)
-                t = conv_bn(t, p + ".conv2", p + ".bn2", True)
-                idn = conv_bn(a, p + ".downsample.0", p + ".downsample.1", False) if k == 0 else a
-                a = conv_bn(t, p + ".conv3", p + ".bn3", True, res=idn)
-            ys, pre_n = [a], 1
-            for si, st in enumerate((2, 3, 4)):
-                sc = extra[f"STAGE{st}"]
-                nb = sc["NUM_BRANCHES"]
-                tn = f"transition{si + 1}"
-                xs: List[Act] = []
-                for i in range(nb):
-                    if i < pre_n:
-                        xs.append(conv_bn(ys[i], f"{tn}.{i}.0", f"{tn}.{i}.1", True) if (f"{tn}.{i}.0") in L else ys[i])
-                    else:
-                        v = ys[-1]
-                        for j in range(i + 1 - pre_n):
-                            v = conv_bn(v, f"{tn}.{i}.{j}.0", f"{tn}.{i}.{j}.1", True)
-                        xs.append(v)
-                for m in range(sc["NUM_MODULES"]):
-                    multi = not (st == 4 and m == sc["NUM_MODULES"] - 1)
-                    base = f"stage{st}.{m}"
-                    for i in range(nb):
-                        for k in range(sc["NUM_BLOCKS"][i]):
-                            p = f"{base}.branches.{i}.{k}"
-                            t = conv_bn(xs[i], p + ".conv1", p + ".bn1", True)
-                            xs[i] = conv_bn(t, p + ".conv2", p + ".bn2", True, res=xs[i])
-                    outs = []
-                    for i in range(nb if multi else 1):
-                        y: Optional[Act] = None
-                        for j in range(nb):
-                            last = j == nb - 1
-                            f = f"{base}.fuse_layers.{i}.{j}"
-                            if j == i:
-                                y = xs[i] if y is None else upsample_add(xs[i], y, 1, last)
-                            elif j > i:
-                                t = conv_bn(xs[j], f + ".0", f + ".1", False, shortcut=False)
-                                y = upsample_add(t, y, 2 ** (j - i), last)
-                            else:
-                                t = xs[j]
-                                for k in range(i - j):
-                                    fin = k == i - j - 1
-                                    t = conv_bn(t, f"{f}.{k}.0", f"{f}.{k}.1", last if fin else True, res=y if fin else None, shortcut=False)
-                                y = t
-                        outs.append(y)
-                    xs = outs
-                ys, pre_n = xs, nb
-            return ys[0]
-
-        # ---- forward ----
-        cp = 8 if self.bf16 else 4
-        x4 = new((B, self.in_h, self.in_w, cp))
-        _lib.check((lib.sp_nchw_to_nhwc8_bf16 if self.bf16 else lib.sp_nchw_to_nhwc4)(P(x), P(x4), B, 3, self.in_h, self.in_w, stream), "to_nhwc")
-        xin = Act(x4, self.in_h, self.in_w, cp, needs_grad=False)
-        if self.head == "hrnet":
-            a = hrnet_forward(conv_bn(xin, "conv1", "bn1", True))
-            return self._finish_forward(a, tape, nbt, B, wgrad_async, new, newf)
-
-        def stem_fused() -> Act:
-            """conv1 -> bn1 -> relu -> maxpool with the BatchNorm map applied inside the pooling pass (sp_bn_apply_maxpool_nhwc): relu(bn1(z)) feeds the
-            pooling only, so the 128 x 96 map is never written; backward sums d gamma / d beta over the POOLED grid and gathers dz
-            (sp_bn_maxpool_bwd_nhwc) - no pooling input gradient either.  Same values as conv_bn + sp_maxpool3x3s2_idx_nhwc."""
-            layer = L["conv1"]
-            xin.consumers += 1
-            z, part, prow = layer.forward_bn_stats(xin.data, B)
-            hs, wsz, C = z.shape[1], z.shape[2], z.shape[3]
-            mean, invstd = newf(C), newf(C)
-            gamma, beta = self.sd["bn1.weight"], self.sd["bn1.bias"]
-            _lib.check(lib.sp_bn_train_stats_from_conv(P(part[0]), P(part[1]), prow, part.shape[2], B * hs * wsz, C, BN_EPS, BN_MOMENTUM, P(mean), P(invstd),
-                                                       P(self.buffers["bn1.running_mean"]), P(self.buffers["bn1.running_var"]), stream), "bn1")
-            nbt.append(self.buffers["bn1.num_batches_tracked"])
-            pooled = new((B, hs // 2, wsz // 2, C))
-            pidx = self._take(tuple(pooled.shape), torch.uint8, dev)
-            _lib.check(lib.sp_bn_apply_maxpool_nhwc(P(z), bf, P(mean), P(invstd), P(gamma), P(beta), P(pooled), P(pidx), B, hs, wsz, C, stream), "bn1+maxpool")
-            out = Act(pooled, hs // 2, wsz // 2, C)
-
-            def bwd():
-                dz = new(z.shape)
-                _lib.check(lib.sp_bn_maxpool_bwd_nhwc(P(out.grad), gf, P(pidx), P(z), P(mean), P(invstd), P(gamma), P(beta), B, hs, wsz, C,
-                                                      P(self.flat.view("bn1.weight", True)), P(self.flat.view("bn1.bias", True)), P(dz), P(ws), stream),
-                           "bn1+maxpool.bwd")
-                out.grad = None
-                wgrad_async(layer, xin.data, dz)
-                self._grads_ready("bn1.weight", "bn1.bias", "conv1.weight")
-            tape.append(bwd)
-            return out
-
-        if self.fuse_stem_pool and not sync and self.fuse_bn_stats and self.in_h % 4 == 0 and self.in_w % 4 == 0:
-            a = stem_fused()
-        else:
-            stem_out = conv_bn(xin, "conv1", "bn1", True)
-            pooled = new((B, stem_out.h // 2, stem_out.w // 2, stem_out.c))
-            pool_idx = self._take(tuple(pooled.shape), torch.uint8, dev)               # winning tap per output element
-            _lib.check(lib.sp_maxpool3x3s2_idx_nhwc(P(stem_out.data), bf, P(pooled), P(pool_idx), B, stem_out.h, stem_out.w, stem_out.c, stream), "maxpool")
-            pa = Act(pooled, stem_out.h // 2, stem_out.w // 2, stem_out.c)
-
-            def pool_bwd():
-                stem_out.grad = newg(stem_out.data.shape)
-                _lib.check(lib.sp_maxpool3x3s2_bwd_idx_nhwc(P(pool_idx), P(pa.grad), gf, P(stem_out.grad), B, stem_out.h, stem_out.w, stem_out.c,
-                                                            stream), "maxpool.bwd")
-                pa.grad = None
-            tape.append(pool_bwd)
-            a = pa
-        for li, n in enumerate(self.model.BLOCKS, start=1):
-            for bi in range(n):
-                p = f"layer{li}.{bi}"
-                p1 = pdn = None
-                if bi == 0 and sync:
-                    # conv1 and the projection shortcut read the same input: both convs first, ONE statistics all-reduce for the pair
-                    p1, pdn = conv_stats(a, p + ".conv1"), conv_stats(a, p + ".downsample.0")
-                    batch_stats([p1, pdn], [p + ".bn1", p + ".downsample.1"])
-                join_fwd = None
-                if bi == 0 and branch is not None:
-                    # projection shortcut on the branch stream; its tape entry keeps its old place (after conv2's, before conv3's)
-                    blk_in, i_ds = a, len(tape)
-                    idn, ev_ds = run_on_branch(lambda: conv_bn(blk_in, p + ".downsample.0", p + ".downsample.1", False))
-                    ds_bwd = tape.pop(i_ds)
-
-                    def ds_bwd_on_branch(ds_bwd=ds_bwd, blk_in=blk_in):
-                        _, ev = run_on_branch(ds_bwd)
-                        blk_in.grad_event = ev
-                        self._branch_open.append(blk_in)
-                    join_fwd = lambda ev_ds=ev_ds: torch.cuda.current_stream(dev).wait_event(ev_ds)
-                if bi > 0 and len(L[p + ".conv1"].d_dgrad) == 1 and L[p + ".conv1"].dgrad_full_cover and (p + ".se.fc.0") not in L:
-                    a.lazy_ok = True                   # identity block: consumers = conv1 and the residual add
-                t = conv_bn(a, p + ".conv1", p + ".bn1", True, pend=p1)
-                t = conv_bn(t, p + ".conv2", p + ".bn2", True)
-                if join_fwd is not None:
-                    tape.append(ds_bwd_on_branch)
-                else:
-                    idn = conv_bn(a, p + ".downsample.0", p + ".downsample.1", False, pend=pdn) if bi == 0 else a
-                if (p + ".se.fc.0") in L:
-                    if idn.sibling is not None:
-                        idn.sibling = None                 # the shortcut's consumer is the gate, not a BatchNorm epilogue: it reduces its own sums
-                    a = se_gate(conv_bn(t, p + ".conv3", p + ".bn3", False, shortcut=False), idn, p + ".se")
-                else:
-                    a = conv_bn(t, p + ".conv3", p + ".bn3", True, res=idn, before_apply=join_fwd)
-        def shuffle(xa: Act) -> Act:
-            """nn.PixelShuffle(2) and, on the tape, its inverse permutation for the gradient."""
-            xa.consumers += 1
-            y = new((B, 2 * xa.h, 2 * xa.w, xa.c // 4))
-            _lib.check((lib.sp_pixel_shuffle2_nhwc_bf16 if self.bf16 else lib.sp_pixel_shuffle2_nhwc)(P(xa.data), P(y), B, xa.h, xa.w, xa.c,
-                                                                                                       stream), "pixel_shuffle")
-            ya = Act(y, 2 * xa.h, 2 * xa.w, xa.c // 4)
-
-            def bwd():
-                assert xa.grad is None
-                xa.grad = newg(xa.data.shape)
-                _lib.check((lib.sp_pixel_unshuffle2_nhwc_bf16 if self.g16 else lib.sp_pixel_unshuffle2_nhwc)(P(ya.grad), P(xa.grad), B, xa.h, xa.w, xa.c,
-                                                                                                               stream), "pixel_shuffle.bwd")
-                xa.contrib += 1
-                ya.grad = None
-            tape.append(bwd)
-            return ya
-
-        if self.head == "dconv":
-            for idx in (0, 3, 6):
-                a = conv_bn(a, f"deconv_layers.{idx}", f"deconv_layers.{idx + 1}", True)
-        else:
-            a = shuffle(a)
-            for idx in (1, 2):
-                a = shuffle(conv_bn(a, f"duc_layers.{idx}.conv", f"duc_layers.{idx}.bn", True))
-        return self._finish_forward(a, tape, nbt, B, wgrad_async, new, newf)
+        # the forward launches and their backward closures: simple_pose_amd/tape.py (primitives + one builder per net family)
+        from . import tape as tape_mod
+        a, t = tape_mod.record(self, x)
+        return self._finish_forward(a, t.tape, t.nbt, B, t.wgrad_async, t.new, t.newf)
 
     def _finish_forward(self, a: Act, tape, nbt, B, wgrad_async, new, newf):
         """final_layer (+ bias, NCHW heat maps) on the last activation; returns (heat maps, backward closure)."""
@@ -1889,7 +1337,7 @@ class PoseTrainer:
     _in_branch = False
     overlap_shortcut = True
     relu_bit_masks = os.environ.get("SP_RELU_MASK", "1") != "0"        # (env: development knob)
-    repack_tiled = os.environ.get("SP_REPACK_TILED", "1") != "0"       # (env: development knob; walk 3 of sp_permute4_batched)
+    repack_tiled = os.environ.get("SP_REPACK_TILED", "0") == "1"       # (walk 3 of sp_permute4_batched: fewer bytes, same-box A/B 5.83 vs 5.90 ms - off)
     lazy_residual_grad = os.environ.get("SP_LAZY_RES", "1") != "0"      # (env: development knob)
     fold_in_consumer_rows = 50    # partial rows (one per phase and M tile) up to which the BatchNorm pass folds them itself (sp_bn_fold_*): above, a stand-alone
                                   # fold + the plain pass (measured with the 16-byte bf16 passes: 1536 -> 6.06 ms, 100 -> 5.98, 50 -> 5.95, 0 -> 5.97)

@@ -104,6 +104,58 @@ def test_train_step_with_selayer_vs_oracle(B, H, W):
     assert losses[-1] < losses[0]
 
 
+BASIC_NETS = [("resnet18", "dconv", False), ("resnet34", "duc", False), ("resnet18", "dconv", True)]
+
+
+@pytest.mark.parametrize("arch,head,se", BASIC_NETS, ids=[f"{a}_{h}" + ("_se" if s else "") for a, h, s in BASIC_NETS])
+def test_basic_block_nets_train_step_vs_oracle(arch, head, se):
+    """The BasicBlock factories (resnet18 / resnet34, pose_resnet_dconv.py:38-80,282-304; heads from 512 channels; SELayer on the blocks with a
+    projection shortcut) in train mode through the same tape as the Bottleneck nets (round 5: `tape.build_resnet_basic`): loss, heat maps,
+    every gradient against the float64 oracle at the bars of the ResNet-50 tests, the streamed step bit-reproducible with a falling loss,
+    and the bf16 step (bf16 activation gradients) running and learning."""
+    from simple_pose_amd.nets import pose_resnet_duc
+    B, H, W = 3, 96, 64
+    mod = pose_resnet_dconv if head == "dconv" else pose_resnet_duc
+
+    def make():
+        m = getattr(mod, arch)(pretrained=False, num_classes=17, reduction=se)
+        layout = [(k, tuple(v.shape), str(v.dtype)) for k, v in m.state_dict().items()]
+        sdn = synth.conditioned_state_dict(layout, 11)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sdn.items()}, strict=True)
+        return m.to(DEV).train(), sdn
+    model, sdn = make()
+    sd = {k: torch.from_numpy(v.copy()) for k, v in sdn.items()}
+    x, t, w = _batch(B, H, W, 11)
+    xs, ts, ws = (torch.from_numpy(v).to(DEV) for v in (x, t, w))
+    tr = PoseTrainer(model, in_h=H, in_w=W, lr=1e-3)
+    assert not any(n.endswith(".conv3") for n in tr.layers)                       # BasicBlocks: two 3x3 convs per block
+    loss = tr.forward_backward(xs, ts, ws)
+    torch.cuda.synchronize()
+    okey = "resnet50_" + head                                                     # (the oracle's trunk reads the block type off the keys)
+    oloss, ograds, oheat = train_oracle.forward_backward(sd, torch.from_numpy(x), torch.from_numpy(t), torch.from_numpy(w), arch=okey)
+    assert _rel(tr.last_heat.cpu().numpy(), oheat.numpy()) < 1e-3
+    assert abs(loss.item() - float(oloss)) <= 1e-4 * abs(float(oloss))
+    named = dict(model.named_parameters())
+    sd64 = {k: (torch.from_numpy(v.copy()).double() if v.dtype.kind == "f" else torch.from_numpy(v.copy())) for k, v in sdn.items()}
+    _, g64, _ = train_oracle.forward_backward(sd64, torch.from_numpy(x).double(), torch.from_numpy(t).double(), torch.from_numpy(w).double(), arch=okey)
+    assert set(g64) == set(named)
+    l2 = sorted(((float((named[k].grad.cpu().double() - g64[k]).norm() / (g64[k].norm() + 1e-30)), k) for k in g64), reverse=True)
+    l2_torch = sorted((float((ograds[k].double() - g64[k]).norm() / (g64[k].norm() + 1e-30)) for k in g64), reverse=True)
+    assert l2[0][0] < max(3e-2, 8 * l2_torch[0]), (l2[:6], l2_torch[:3])
+    assert np.median([e for e, _ in l2]) < max(1e-2, 4 * np.median(l2_torch)), (np.median([e for e, _ in l2]), np.median(l2_torch))
+    runs = []
+    for _ in range(2):
+        m2, _ = make()
+        tr2 = PoseTrainer(m2, in_h=H, in_w=W, lr=1e-3)
+        runs.append([tr2.step(xs, ts, ws).item() for _ in range(4)])
+    assert runs[0] == runs[1] and runs[0][-1] < runs[0][0]                        # bit-reproducible, learning
+    m3, _ = make()
+    tr3 = PoseTrainer(m3, in_h=H, in_w=W, lr=1e-3, dtype="bf16")
+    assert tr3.g16 == (not se)                                                    # bf16 activation gradients on the plain nets
+    lb = [tr3.step(xs, ts, ws).item() for _ in range(4)]
+    assert abs(lb[0] - runs[0][0]) <= 2e-2 * abs(runs[0][0]) and lb[-1] < lb[0]
+
+
 def _hrnet(seed):
     import functools
     import os
