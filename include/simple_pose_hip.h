@@ -72,6 +72,10 @@ typedef struct sp_conv_desc {
                                         pixels is a stride of one pair */
     int32_t kernel;                  /* SP_CONV_KERNEL_IGEMM (0, default), SP_CONV_KERNEL_RING / _RING_LW or SP_CONV_KERNEL_PW: which kernel structure runs the
                                         launch; same results bit for bit (same K order, same MFMA chain per output) */
+    int32_t c_in_group;              /* 0: dense.  > 0 (ABI 33): grouped convolution with c_out == c_in (ResNeXt's conv2, nets/pose_resnet_dconv.py:101):
+                                        an N tile of tile_n == c_in_group output channels reads only the c_in_group input channels of its own groups;
+                                        k_pad = taps * c_in_group and the weights are packed by sp_pack_conv_weights_grouped (one block-diagonal panel
+                                        [tile_n][k_pad] per N tile).  Implicit-GEMM kernel only, c_in_group a whole number of K tiles and of groups. */
 } sp_conv_desc;
 
 /* sp_conv_desc.kernel */
@@ -540,6 +544,10 @@ int sp_pack_conv_weights(const float* w, int c_out, int c_in, int kh, int kw, in
 /* nn.ConvTranspose2d(k=4, s=2, p=1) weight [c_in, c_out, 4, 4] (nets/pose_resnet_dconv.py:236-244) -> [4 phases][n_pad][4*c_in]:
  * phase (py,px) holds the 2x2 taps W[:, :, 2ty+1-py, 2tx+1-px] that reach output pixels (2y+py, 2x+px) - no multiply is spent
  * on the zeros a transposed conv inserts */
+/* nn.Conv2d(groups = g) weight [c_out][c_in / g][kh][kw] with c_out == c_in -> block-diagonal panels [c_out][kh * kw * panel] (K = (tap, channel
+ * within the panel); row n belongs to panel n / panel and holds its group's weights at the group's channels inside the panel, zeros elsewhere).
+ * `panel` = sp_conv_desc.c_in_group = tile_n of the launch: a multiple of c_in / g and of the K tile (32 fp32 / 64 bf16 elements). */
+int sp_pack_conv_weights_grouped(const float* w, int c_out, int groups, int kh, int kw, int panel, void* dst, int dst_bf16, void* stream);
 int sp_pack_deconv_k4s2p1(const float* w, int c_in, int c_out, int n_pad, void* dst, int dst_bf16, void* stream);
 /* eval-mode nn.BatchNorm2d as the conv epilogue's (scale, shift): scale = weight / sqrt(running_var + eps),
  * shift = bias - running_mean * scale (each operation rounded on its own, as the torch expressions); weight / bias NULL = 1 / 0;

@@ -36,7 +36,7 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [(n, c_int32) for n in (
         "batch", "in_h", "in_w", "c_in", "grid_h", "grid_w", "c_out", "n_pad", "taps_h", "taps_w", "k_pad", "stride",
         "dy0", "dy_step", "dx0", "dx_step", "out_h", "out_w", "out_c", "oy_mul", "oy_add", "ox_mul", "ox_add",
-        "phases_y", "phases_x")] + [("flags", c_uint32), ("tile_m", c_int32), ("tile_n", c_int32), ("stride_x", c_int32), ("kernel", c_int32)]
+        "phases_y", "phases_x")] + [("flags", c_uint32), ("tile_m", c_int32), ("tile_n", c_int32), ("stride_x", c_int32), ("kernel", c_int32), ("c_in_group", c_int32)]
 
 
 class WgradJob(ctypes.Structure):
@@ -149,6 +149,7 @@ SYMBOLS = {
     "sp_masked_mse": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
     "sp_conv_packed_dims": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "sp_pack_conv_weights": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),
+    "sp_pack_conv_weights_grouped": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),
     "sp_pack_deconv_k4s2p1": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P]),
     "sp_fold_bn": (c_int, [_P, _P, _P, _P, c_int, c_float, c_int, _P, _P, _P]),
 }

@@ -100,6 +100,11 @@ struct ConvArgs {
     // in tap counts: one launch instead of one per phase); the fields above with the same names are then unused
     struct PhaseGeo { const void* w; int taps_h, taps_w, k_pad, dy0, dx0, oy_add, ox_add, pad_; } ph[4];
     int ph_n;
+    // grouped convolution (ResNeXt's conv2, nets/pose_resnet_dconv.py:101: groups = 32): the weight matrix is block-diagonal, so an N tile of
+    // tile_n = c_in_g output channels only reads the c_in_g input channels of its own groups - K per tap is c_in_g, not c_in, the packed
+    // panel of the tile is [tile_n][taps * c_in_g] (zeros where a panel spans several groups), and the A gather adds the tile's channel offset.
+    // 0: dense.
+    int c_in_g;
 };
 
 constexpr int BK = 32;  // floats per K tile (8 chunks of 16 B)
@@ -241,10 +246,11 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
         const int k0 = kt * BKE;
         t_k0 = k0;
         if (UNIFORM_TAP) {  // c_in % 32 == 0: the whole K tile sits inside one tap (all scalar)
-            const int tap = k0 / p.c_in;
+            const int cg = p.c_in_g ? p.c_in_g : p.c_in;       // channels of one tap in K (grouped: the tile's own channel range)
+            const int tap = k0 / cg;
             const int ty = tap / taps_w, tx = tap - ty * taps_w;
             t_bit = 1u << tap;
-            t_shift = ((ty * p.dy_step * p.in_w + tx * p.dx_step) * p.c_in + (k0 - tap * p.c_in)) * ES;
+            t_shift = ((ty * p.dy_step * p.in_w + tx * p.dx_step) * p.c_in + (k0 - tap * cg) + (p.c_in_g ? tn * p.c_in_g : 0)) * ES;
         } else {            // small c_in (stem: NHWC4): every 16-B chunk may be a different tap
             const int q = k0 / EPC + kc;
             const int tap = q / cin_chunks;
@@ -917,13 +923,21 @@ static int conv_fwd_impl(const sp_conv_desc* d, const void* x, const void* w_pac
     const int es = bf16 ? 2 : 4, epc = 16 / es, bke = 128 / es;
     SP_REQUIRE(d->c_in > 0 && d->c_in % epc == 0, "sp_conv2d_fwd: c_in=%d must be a positive multiple of %d", d->c_in, epc);
     SP_REQUIRE(d->taps_h > 0 && d->taps_w > 0 && d->stride > 0 && d->stride_x >= 0, "sp_conv2d_fwd: bad taps/stride");
-    SP_REQUIRE(d->k_pad % bke == 0 && d->k_pad >= d->taps_h * d->taps_w * d->c_in,
+    const int cg = d->c_in_group > 0 ? d->c_in_group : d->c_in;      // K channels per tap (grouped: one N tile's channel range)
+    SP_REQUIRE(d->k_pad % bke == 0 && d->k_pad >= d->taps_h * d->taps_w * cg,
                "sp_conv2d_fwd: k_pad=%d must be a multiple of %d and >= taps*c_in=%d", d->k_pad, bke,
-               d->taps_h * d->taps_w * d->c_in);
+               d->taps_h * d->taps_w * cg);
+    if (d->c_in_group > 0) {
+        SP_REQUIRE(d->c_in_group % bke == 0 && d->c_in % d->c_in_group == 0 && d->c_out == d->c_in && d->n_pad == d->c_out &&
+                       d->tile_n == d->c_in_group && d->kernel == SP_CONV_KERNEL_IGEMM && d->phases_y == 1 && d->phases_x == 1 && !bsrc && !stats_s && !phs &&
+                       !(d->flags & SP_CONV_PIXEL_SHUFFLE) && d->taps_h * d->taps_w <= 32,
+                   "sp_conv2d_fwd: grouped launch needs c_in_group = tile_n (a multiple of %d dividing c_in), c_out == c_in == n_pad, the implicit-GEMM "
+                   "kernel, one phase, no statistics epilogue (c_in_group %d, tile_n %d, c_in %d, c_out %d)", bke, d->c_in_group, d->tile_n, d->c_in, d->c_out);
+    }
     SP_REQUIRE(d->n_pad % 32 == 0 && d->n_pad >= d->c_out, "sp_conv2d_fwd: n_pad=%d must be a multiple of 32 >= c_out=%d",
                d->n_pad, d->c_out);
-    const bool uniform = (d->c_in % bke == 0) && d->taps_h * d->taps_w <= 32;  // tap-validity bit mask is 32 bits wide
-    if (uniform) SP_REQUIRE(d->k_pad == d->taps_h * d->taps_w * d->c_in, "sp_conv2d_fwd: k_pad must equal taps*c_in when c_in fills whole K tiles");
+    const bool uniform = (cg % bke == 0) && d->taps_h * d->taps_w <= 32;  // tap-validity bit mask is 32 bits wide
+    if (uniform) SP_REQUIRE(d->k_pad == d->taps_h * d->taps_w * cg, "sp_conv2d_fwd: k_pad must equal taps*c_in when c_in fills whole K tiles");
     SP_REQUIRE((d->phases_y == 1 || d->phases_y == 2) && (d->phases_x == 1 || d->phases_x == 2), "sp_conv2d_fwd: phases must be 1 or 2");
     const unsigned known = SP_CONV_RELU | SP_CONV_OUT_NCHW | SP_CONV_PIXEL_SHUFFLE | SP_CONV_BF16 | SP_CONV_OUT_F32 | SP_CONV_BN_Y_MASK;
     const bool out16 = bf16 && !(d->flags & SP_CONV_OUT_F32);
@@ -973,6 +987,7 @@ static int conv_fwd_impl(const sp_conv_desc* d, const void* x, const void* w_pac
     a.by = bsrc ? bsrc->y : nullptr; a.bz = bsrc ? bsrc->z : nullptr; a.bmean = bsrc ? bsrc->mean : nullptr; a.binvstd = bsrc ? bsrc->invstd : nullptr;
     a.bz2 = bsrc ? bsrc->z2 : nullptr; a.bmean2 = bsrc ? bsrc->mean2 : nullptr; a.binvstd2 = bsrc ? bsrc->invstd2 : nullptr; a.stats_q2 = bsrc ? bsrc->q2 : nullptr;
     a.bz_bytes = (int)(out_elems * es);
+    a.c_in_g = d->c_in_group > 0 ? d->c_in_group : 0;
     a.ph_n = 0;
     int phases = d->phases_y * d->phases_x;
     if (phs) {                                         // every descriptor was validated on its own by the caller; here: what they must share

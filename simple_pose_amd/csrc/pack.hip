@@ -42,6 +42,23 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, void* __restrict__
     }
 }
 
+// grouped conv (c_out == c_in, `groups` groups of cpg channels): dst [O][taps][panel], row n's panel covers input channels
+// [(n / panel) * panel, +panel); element (n, tap, cl) = W[n][c % cpg][tap] when channel c = (n / panel) * panel + cl lies in n's group, else 0
+template <bool BF16OUT>
+__global__ void pack_conv_grouped_kernel(const float* __restrict__ w, void* __restrict__ dst, int O, int cpg, int taps, int panel) {
+    const int K = taps * panel;
+    const long long total = (long long)O * K;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / K), k = (int)(i - (long long)n * K);
+        const int tap = k / panel, cl = k - tap * panel;
+        const int c = (n / panel) * panel + cl;
+        float v = 0.f;
+        if (c / cpg == n / cpg) v = w[((long long)n * cpg + (c % cpg)) * taps + tap];
+        if constexpr (BF16OUT) reinterpret_cast<__bf16*>(dst)[i] = (__bf16)v;
+        else reinterpret_cast<float*>(dst)[i] = v;
+    }
+}
+
 // ConvTranspose2d(k=4, s=2, p=1) weight [I][O][4][4] -> [4 phases][n_pad][4*I]: output pixel (2y+py, 2x+px) = sum over the 2x2 taps
 // (ty,tx) of x[y+py-ty, x+px-tx] * W[:, :, 2ty+1-py, 2tx+1-px]
 template <bool BF16OUT>
@@ -119,6 +136,18 @@ extern "C" int sp_pack_conv_weights(const float* w, int c_out, int c_in, int kh,
     if (dst_bf16) hipLaunchKernelGGL(pack_conv_kernel<true>, dim3(grid_of(total)), dim3(256), 0, (hipStream_t)stream, w, dst, p);
     else hipLaunchKernelGGL(pack_conv_kernel<false>, dim3(grid_of(total)), dim3(256), 0, (hipStream_t)stream, w, dst, p);
     return sp_check_launch("pack_conv_kernel");
+}
+
+extern "C" int sp_pack_conv_weights_grouped(const float* w, int c_out, int groups, int kh, int kw, int panel, void* dst, int dst_bf16, void* stream) {
+    SP_REQUIRE(w && dst, "sp_pack_conv_weights_grouped: null pointer");
+    SP_REQUIRE(c_out > 0 && groups > 0 && c_out % groups == 0 && kh > 0 && kw > 0, "sp_pack_conv_weights_grouped: bad shape");
+    const int cpg = c_out / groups;
+    SP_REQUIRE(panel > 0 && panel % cpg == 0 && c_out % panel == 0 && panel % (dst_bf16 ? 64 : 32) == 0,
+               "sp_pack_conv_weights_grouped: panel=%d must be a multiple of the group size %d and of the K tile, and divide c_out=%d", panel, cpg, c_out);
+    const long long total = (long long)c_out * kh * kw * panel;
+    if (dst_bf16) hipLaunchKernelGGL(pack_conv_grouped_kernel<true>, dim3(grid_of(total)), dim3(256), 0, (hipStream_t)stream, w, dst, c_out, cpg, kh * kw, panel);
+    else hipLaunchKernelGGL(pack_conv_grouped_kernel<false>, dim3(grid_of(total)), dim3(256), 0, (hipStream_t)stream, w, dst, c_out, cpg, kh * kw, panel);
+    return sp_check_launch("pack_conv_grouped_kernel");
 }
 
 extern "C" int sp_pack_deconv_k4s2p1(const float* w, int c_in, int c_out, int n_pad, void* dst, int dst_bf16, void* stream) {

@@ -120,7 +120,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(handle, name), name
     lib = _lib.lib()
     assert lib.sp_abi_version() == _lib.ABI_VERSION
-    assert ctypes.sizeof(_lib.ConvDesc) == 30 * 4          # 25 geometry ints, flags, tile_m, tile_n, stride_x, kernel
+    assert ctypes.sizeof(_lib.ConvDesc) == 31 * 4          # 25 geometry ints, flags, tile_m, tile_n, stride_x, kernel, c_in_group
 
 
 def test_bad_arguments_are_rejected_without_touching_the_gpu():
