@@ -14,6 +14,7 @@ is committed - never reference source.  Fixture inventory
   g3_hrnet_w32_fwd.npz  HRNet-W32 eval forward, B=1, + the reference's state_dict key/shape list
   g7_next.npz        HeatMapAcc values and collate_fn normalisation
   g11_resnet_variants.npz  resnet18-dconv, resnet34-duc, wide_resnet50_2-dconv, resnet18-dconv+SE (2 images; key lists, sub-sampled maps, key points)
+  g12_resnext.npz          resnext50_32x4d-dconv, resnext101_32x8d-duc (grouped 3x3, groups = 32; same content as g11)
   g10_fwd_wide.npz   8 / 8 / 4 / 4 distinct images through DConv / DUC / HRNet-W32 / DConv+SE (sub-sampled maps, per-joint sums, key points)
   g6_train_step.npz  one reference training step (B=2): loss, gradient slices, BN running stats, params after Adam
   g5_encode.npz      encoders (Refine + Basic) incl. out-of-range / trunc-toward-zero / vis=0 cases
@@ -419,7 +420,7 @@ def gen_forward_wide(ns):
 VARIANTS = (("resnet18", "dconv", False), ("resnet34", "duc", False), ("wide_resnet50_2", "dconv", False), ("resnet18", "dconv", True))
 
 
-def gen_variants(ns):
+def gen_variants(ns, fname="g11_resnet_variants.npz"):
     """g11_resnet_variants.npz (round 4): the reference's other ResNet factories (nets/pose_resnet_dconv.py:282-403, pose_resnet_duc.py) - the
     BasicBlock nets and a wide Bottleneck net, one with SELayers - eval forward on 2 images (weight seed 1, input seed 7): state_dict key
     lists + shapes, sub-sampled heat maps, per-joint sums / norms / arg-max, the reference's GaussTaylor key points."""
@@ -446,8 +447,21 @@ def gen_variants(ns):
         out[f"{tag}/heat_max"] = flat.max(-1)
         out[f"{tag}/heat_argmax"] = flat.argmax(-1).astype(np.int64)
         out[f"{tag}/gt_kps"] = kps.numpy()
-        print("g11", tag, h.shape, "absmax", np.abs(h).max(), "std", h.std(), "keys", len(sd))
-    np.savez_compressed(os.path.join(GOLD, "g11_resnet_variants.npz"), **out)
+        print(fname[:3], tag, h.shape, "absmax", np.abs(h).max(), "std", h.std(), "keys", len(sd))
+    np.savez_compressed(os.path.join(GOLD, fname), **out)
+
+
+RESNEXT = (("resnext50_32x4d", "dconv", False), ("resnext101_32x8d", "duc", False))
+
+
+def gen_resnext(ns):
+    """g12_resnext.npz (round 5): the reference's grouped factories (nets/pose_resnet_dconv.py:342-368, `groups = 32` at :101), same content as g11."""
+    global VARIANTS
+    keep, VARIANTS = VARIANTS, RESNEXT
+    try:
+        gen_variants(ns, fname="g12_resnext.npz")
+    finally:
+        VARIANTS = keep
 
 
 def main():
@@ -459,6 +473,9 @@ def main():
         return
     if "--only-variants" in sys.argv:
         gen_variants(ns)
+        return
+    if "--only-resnext" in sys.argv:
+        gen_resnext(ns)
         return
     hm = gen_forward(ns)  # returns the DUC maps last; reload dconv maps for the decoder set
     net_maps = np.load(os.path.join(GOLD, "g1_dconv_fwd.npz"))["heat_maps"]
@@ -472,6 +489,7 @@ def main():
     gen_crop(ns)
     gen_forward_wide(ns)
     gen_variants(ns)
+    gen_resnext(ns)
     del hm
 
 

@@ -41,7 +41,8 @@ def _se(x, sd, prefix):
 def _bottleneck(x, sd, p, stride, training=False):
     # nets/pose_resnet_dconv.py:112-133 (stride sits on conv2: "ResNet v1.5", :84-88)
     out = F.relu(_bn(F.conv2d(x, sd[p + ".conv1.weight"]), sd, p + ".bn1", training))
-    out = F.relu(_bn(F.conv2d(out, sd[p + ".conv2.weight"], stride=stride, padding=1), sd, p + ".bn2", training))
+    w2 = sd[p + ".conv2.weight"]                     # (resnext*: groups = 32, :101 - read off the weight's shape)
+    out = F.relu(_bn(F.conv2d(out, w2, stride=stride, padding=1, groups=out.shape[1] // w2.shape[1]), sd, p + ".bn2", training))
     out = _bn(F.conv2d(out, sd[p + ".conv3.weight"]), sd, p + ".bn3", training)
     if (p + ".se.fc.0.weight") in sd:
         out = _se(out, sd, p + ".se")

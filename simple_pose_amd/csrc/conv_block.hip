@@ -232,6 +232,7 @@ __global__ __launch_bounds__(256, 2) void basic_block_c32_kernel(const BlockArgs
 }
 
 bool block_ok(const sp_conv_desc* d) {
+    if (d && d->c_in_group > 0) return false;
     return d && (d->flags & SP_CONV_BF16) && !(d->flags & (SP_CONV_OUT_NCHW | SP_CONV_PIXEL_SHUFFLE | SP_CONV_OUT_F32)) && d->c_in == 32 &&
            d->c_out == 32 && d->out_c == 32 && d->taps_h == 3 && d->taps_w == 3 && d->stride == 1 && (d->stride_x == 0 || d->stride_x == 1) &&
            d->dy0 == -1 && d->dx0 == -1 && d->dy_step == 1 && d->dx_step == 1 && d->phases_y == 1 && d->phases_x == 1 && d->k_pad == 320 &&

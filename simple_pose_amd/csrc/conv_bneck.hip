@@ -369,6 +369,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_c64_kernel(const BneckArgs 
 }
 
 bool bneck_ok(const sp_conv_desc* d) {
+    if (d && d->c_in_group > 0) return false;
     // `d`: the block's 3x3 convolution (64 -> 64, stride 1, pad 1) on bf16 NHWC; conv1 / conv3 are 1x1 on the same grid
     return d && (d->flags & SP_CONV_BF16) && !(d->flags & (SP_CONV_OUT_NCHW | SP_CONV_PIXEL_SHUFFLE | SP_CONV_OUT_F32)) && d->c_in == CM &&
            d->c_out == CM && d->taps_h == 3 && d->taps_w == 3 && d->stride == 1 && (d->stride_x == 0 || d->stride_x == 1) && d->dy0 == -1 &&

@@ -350,6 +350,7 @@ int sp_tile128_launch(const sp_conv_desc* d, const void* x, const void* w_packed
                       void* y, void* stream);
 
 static bool direct_ok(const sp_conv_desc* d) {
+    if (d && d->c_in_group > 0) return false;            // grouped convolutions run on the implicit GEMM only
     if (d && d->c_in == 128) return sp_tile128_ok(d);
     if (!d || (d->c_in != 32 && d->c_in != 64)) return false;
     const int c = d->c_in, kp = c == 32 ? 320 : 576;          // k_pad: 9 taps x c, rounded to whole 64-element K tiles

@@ -185,6 +185,7 @@ int launch_pw(const PwArgs& a, hipStream_t stream) {
 }  // namespace
 
 extern "C" int sp_conv2d_pw_ok(const sp_conv_desc* d) {
+    if (d && d->c_in_group > 0) return 0;
     if (!d) return 0;
     if (d->flags & (SP_CONV_BF16 | SP_CONV_OUT_NCHW | SP_CONV_PIXEL_SHUFFLE | SP_CONV_OUT_F32)) return 0;
     if (d->taps_h != 1 || d->taps_w != 1 || d->stride != 1 || (d->stride_x != 0 && d->stride_x != 1)) return 0;

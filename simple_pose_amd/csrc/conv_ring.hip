@@ -566,7 +566,7 @@ const RingTile* find_tile(int bm, int bn, int kernel = SP_CONV_KERNEL_RING) {
 
 // 1 when sp_conv2d_fwd can run `d` on the LDS-DMA ring kernel with workgroup tile d->tile_m x d->tile_n (kernel = SP_CONV_KERNEL_RING)
 extern "C" int sp_conv2d_ring_ok(const sp_conv_desc* d) {
-    if (!d) return 0;
+    if (!d || d->c_in_group > 0) return 0;             // (grouped convolutions: implicit GEMM only)
     const RingTile* t = find_tile(d->tile_m, d->tile_n, d->kernel);   // (kernel = SP_CONV_KERNEL_RING_LW: the loader-wave tiles; anything else: the 8-wave ring's)
     if (!t) return 0;
     const unsigned allowed = SP_CONV_RELU | SP_CONV_PIXEL_SHUFFLE | SP_CONV_BF16;

@@ -192,6 +192,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c128_tile_kernel(const Tile128
 }  // namespace
 
 bool sp_tile128_ok(const sp_conv_desc* d) {
+    if (d && d->c_in_group > 0) return false;
     return d && d->c_in == C9 && (d->flags & SP_CONV_BF16) && !(d->flags & (SP_CONV_OUT_NCHW | SP_CONV_PIXEL_SHUFFLE | SP_CONV_OUT_F32)) &&
            d->c_out == C9 && d->out_c == C9 && d->taps_h == 3 && d->taps_w == 3 && d->stride == 1 && (d->stride_x == 0 || d->stride_x == 1) &&
            d->dy0 == -1 && d->dx0 == -1 && d->dy_step == 1 && d->dx_step == 1 && d->phases_y == 1 && d->phases_x == 1 && d->k_pad == 9 * C9 &&

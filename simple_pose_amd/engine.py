@@ -67,6 +67,15 @@ class HipPacker:
                                                    int(bf16), _lib.current_stream()), "sp_pack_conv_weights")
         return out, kh, tw, ci, k_pad
 
+    def grouped(self, w: torch.Tensor, groups: int, panel: int, *, bf16: bool = False) -> torch.Tensor:
+        """nn.Conv2d(groups = g) weight [O, O / g, kh, kw] -> block-diagonal panels [O, kh * kw * panel] (sp_pack_conv_weights_grouped)."""
+        w = _lib.require_cuda_f32(w.detach(), "grouped conv weight")
+        O, cpg, kh, kw = w.shape
+        out = torch.empty((O, kh * kw * panel), dtype=torch.bfloat16 if bf16 else torch.float32, device=w.device)
+        _lib.check(_lib.lib().sp_pack_conv_weights_grouped(_lib.ptr(w), O, groups, kh, kw, panel, _lib.ptr(out), int(bf16), _lib.current_stream()),
+                   "sp_pack_conv_weights_grouped")
+        return out
+
     def deconv(self, w: torch.Tensor, *, bf16: bool = False) -> Tuple[torch.Tensor, int]:
         """ConvTranspose2d(k=4, s=2, p=1) weight [I,O,4,4] -> ([4 * n_pad, 4*I], n_pad): one 2x2-tap slab per output phase."""
         w = _lib.require_cuda_f32(w.detach(), "deconv weight")
@@ -362,6 +371,8 @@ class Program:
         """Every way this conv launch can run: (tile_m, tile_n, kernel) with kernel 0 = register-staged implicit GEMM, 1 = LDS-DMA ring
         (bf16 layers it supports), (-1, -1, 0) = the direct 3x3 kernel."""
         d = op.desc
+        if d.c_in_group:                # grouped: the N tile IS the panel; implicit GEMM only
+            return [(bm, bn, _lib.SP_CONV_KERNEL_IGEMM) for bm, bn in _lib.CONV_TILES if bn == d.c_in_group]
         keep = (d.tile_m, d.tile_n, d.kernel)
         out = [(bm, bn, _lib.SP_CONV_KERNEL_IGEMM) for bm, bn in _lib.CONV_TILES if d.n_pad % bn == 0]
         if d.flags & SP_CONV_BF16:
@@ -830,12 +841,24 @@ class ProgramBuilder:
 
     def conv(self, src: str, weight: torch.Tensor, *, stride: int = 1, pad: int = 0, scale=None, shift=None,
              relu: bool = False, res: Optional[str] = None, pixel_shuffle: bool = False, out_nchw: bool = False,
-             dst: Optional[str] = None, name: str = "conv") -> str:
+             dst: Optional[str] = None, name: str = "conv", groups: int = 1) -> str:
         h, w, c_buf = self.p.shapes[src]
         O, I, kh, kw = weight.shape
         paired = False
         pk = self.packer
-        if self.bf16 and c_buf == 4 and I < 4:
+        panel = 0
+        if groups > 1:
+            # grouped convolution (ResNeXt's conv2, pose_resnet_dconv.py:101): block-diagonal panels of `panel` channels, one per N tile; K per
+            # tap is the panel, not c_in (sp_conv_desc.c_in_group).  64 = one bf16 K tile / two fp32 ones and a legal tile_n of the implicit GEMM.
+            if not (O == c_buf and c_buf % groups == 0 and I == c_buf // groups and not pixel_shuffle and not out_nchw):
+                raise NotImplementedError(f"{name}: grouped convolutions are lowered for c_out == c_in (got {tuple(weight.shape)} on {c_buf} channels)")
+            panel = 64
+            while panel % I:
+                panel *= 2
+            if O % panel or panel > 128:
+                raise NotImplementedError(f"{name}: no panel width for {groups} groups of {I} channels in {O}")
+            packed, th, tw, ci, k_pad = pk.grouped(weight, groups, panel, bf16=self.bf16), kh, kw, c_buf, kh * kw * panel
+        elif self.bf16 and c_buf == 4 and I < 4:
             # bf16 stem on the NHWC4 image read as pixel pairs [h, w/2, 8]: pixel 2*ox - pad + kx = pair (ox - ceil(pad/2)) + pt, half
             # `sub`, with kx + s0 = 2*pt + sub.  A stride of 2 pixels is a stride of ONE pair: separate x / y strides (stride_x).
             if stride != 2 or w % 2:
@@ -876,6 +899,8 @@ class ProgramBuilder:
         if self.bf16:
             flags |= SP_CONV_BF16
         d.flags = flags
+        if panel:
+            d.c_in_group, d.tile_m, d.tile_n = panel, 128, panel
         dst = dst or self._fresh(name)
         self.p.shapes[dst] = (d.out_h, d.out_w, d.out_c)
         op = Op("conv", src, dst, res=res, desc=d, w=packed, scale=scale, shift=shift, name=name, flops=2 * gh * gw * O * I * kh * kw)
@@ -1023,7 +1048,8 @@ def _bottleneck(b: ProgramBuilder, sd, x: str, p: str, stride: int) -> str:
     s1, h1 = _bn(b, sd, p + ".bn1")
     t = b.conv(x, sd[p + ".conv1.weight"], scale=s1, shift=h1, relu=True, name=p + ".conv1")
     s2, h2 = _bn(b, sd, p + ".bn2")
-    t = b.conv(t, sd[p + ".conv2.weight"], stride=stride, pad=1, scale=s2, shift=h2, relu=True, name=p + ".conv2")
+    w2 = sd[p + ".conv2.weight"]
+    t = b.conv(t, w2, stride=stride, pad=1, scale=s2, shift=h2, relu=True, name=p + ".conv2", groups=w2.shape[0] // w2.shape[1])   # (resnext*: groups = 32)
     idn = x
     if (p + ".downsample.0.weight") in sd:
         sdn, hdn = _bn(b, sd, p + ".downsample.1")

@@ -22,12 +22,12 @@ class _Bottleneck(nn.Module):
     optional `downsample` = Sequential(conv1x1, bn).  Keys as in nets/pose_resnet_dconv.py:83-110."""
     expansion = 4
 
-    def __init__(self, inplanes: int, planes: int, stride: int, with_downsample: bool, with_se: bool = False, width: int = 0):
+    def __init__(self, inplanes: int, planes: int, stride: int, with_downsample: bool, with_se: bool = False, width: int = 0, groups: int = 1):
         super().__init__()
-        width = width or planes          # wide_resnet*_2: width = 2 * planes (`int(planes * (base_width / 64.)) * groups`, pose_resnet_dconv.py:97)
+        width = width or planes          # wide_resnet*_2 / resnext*: width = `int(planes * (base_width / 64.)) * groups` (pose_resnet_dconv.py:97)
         self.conv1 = nn.Conv2d(inplanes, width, 1, bias=False)
         self.bn1 = nn.BatchNorm2d(width)
-        self.conv2 = nn.Conv2d(width, width, 3, stride=stride, padding=1, bias=False)
+        self.conv2 = nn.Conv2d(width, width, 3, stride=stride, padding=1, groups=groups, bias=False)      # (:101)
         self.bn2 = nn.BatchNorm2d(width)
         self.conv3 = nn.Conv2d(width, planes * 4, 1, bias=False)
         self.bn3 = nn.BatchNorm2d(planes * 4)
@@ -47,7 +47,7 @@ class _BasicBlock(nn.Module):
     conv2/bn2 (3x3), optional `downsample` = Sequential(conv1x1, bn), optional SELayer(planes)."""
     expansion = 1
 
-    def __init__(self, inplanes: int, planes: int, stride: int, with_downsample: bool, with_se: bool = False, width: int = 0):
+    def __init__(self, inplanes: int, planes: int, stride: int, with_downsample: bool, with_se: bool = False, width: int = 0, groups: int = 1):
         super().__init__()
         self.conv1 = nn.Conv2d(inplanes, planes, 3, stride=stride, padding=1, bias=False)
         self.bn1 = nn.BatchNorm2d(planes)
@@ -69,15 +69,17 @@ class PoseResNetBase(nn.Module):
     HEAD = ""
     BLOCKS = (3, 4, 6, 3)
     BLOCK = "bottleneck"       # or "basic"
-    WIDTH_PER_GROUP = 64       # 128: wide_resnet50_2 / wide_resnet101_2 (pose_resnet_dconv.py:370-403)
+    WIDTH_PER_GROUP = 64       # 128: wide_resnet50_2 / wide_resnet101_2 (pose_resnet_dconv.py:370-403); 4 / 8: resnext50_32x4d / resnext101_32x8d
+    GROUPS = 1                 # 32: the resnext factories (pose_resnet_dconv.py:342-368)
 
-    def __init__(self, num_classes: int = 17, reduction: bool = False, blocks=None, block: str = "bottleneck", width_per_group: int = 64):
+    def __init__(self, num_classes: int = 17, reduction: bool = False, blocks=None, block: str = "bottleneck", width_per_group: int = 64,
+                 groups: int = 1):
         super().__init__()
         if block not in ("bottleneck", "basic"):
             raise ValueError(block)
-        if block == "basic" and width_per_group != 64:
+        if block == "basic" and (width_per_group != 64 or groups != 1):
             raise ValueError("BasicBlock only supports groups=1 and base_width=64")      # (the reference's own check, :46-47)
-        self.BLOCK, self.WIDTH_PER_GROUP = block, width_per_group
+        self.BLOCK, self.WIDTH_PER_GROUP, self.GROUPS = block, width_per_group, groups
         if blocks is not None:           # resnet101 / resnet152: same bottleneck trunk, other depths (pose_resnet_dconv.py:318-339)
             self.BLOCKS = tuple(blocks)
         self.reduction = reduction     # SELayer on the first block of every layer (pose_resnet_dconv.py:215-218)
@@ -94,7 +96,7 @@ class PoseResNetBase(nn.Module):
                 # Bottleneck; NOT for layer1.0 of the BasicBlock nets), and the SELayer only on blocks that have one
                 down = bi == 0 and (stride != 1 or inplanes != planes * Block.expansion)
                 blocks.append(Block(inplanes, planes, stride, with_downsample=down, with_se=(reduction and down),
-                                    width=planes * width_per_group // 64))
+                                    width=planes * width_per_group // 64 * groups, groups=groups))
                 inplanes = planes * Block.expansion
             setattr(self, f"layer{li}", nn.Sequential(*blocks))
         self._build_head(inplanes, num_classes)

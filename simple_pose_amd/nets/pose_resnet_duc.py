@@ -22,9 +22,9 @@ class ResNet(PoseResNetBase):
         self.final_layer = nn.Conv2d(128, num_classes, kernel_size=3, padding=1)
 
 
-def _resnet(arch: str, blocks, pretrained: bool, kwargs, block: str = "bottleneck", width_per_group: int = 64) -> ResNet:
+def _resnet(arch: str, blocks, pretrained: bool, kwargs, block: str = "bottleneck", width_per_group: int = 64, groups: int = 1) -> ResNet:
     model = ResNet(num_classes=kwargs.pop("num_classes", 1000), reduction=kwargs.pop("reduction", False), blocks=blocks, block=block,
-                   width_per_group=width_per_group)
+                   width_per_group=width_per_group, groups=groups)
     if kwargs:
         raise TypeError(f"unsupported arguments for the HIP {arch}: {sorted(kwargs)}")
     if pretrained:
@@ -67,15 +67,13 @@ def wide_resnet101_2(pretrained: bool = False, progress: bool = True, **kwargs) 
     return _resnet("wide_resnet101_2", (3, 4, 23, 3), pretrained, kwargs, width_per_group=128)
 
 
-def _grouped(arch: str):
-    raise NotImplementedError(f"{arch}: grouped 3x3 convolutions (groups = 32) are not lowered to the HIP kernels - the implicit GEMM is a dense "
-                              "contraction per launch; the reference's resnext factories have no counterpart here (DESIGN.md section 7)")
+def resnext50_32x4d(pretrained: bool = False, progress: bool = True, **kwargs) -> ResNet:
+    """Bottlenecks [3, 4, 6, 3] whose 3x3 conv has 32 groups of 4 x (planes / 64) channels (reference factory of the same name, pose_resnet_duc.py;
+    `groups = 32`, `width_per_group = 4`).  Eval-mode forward on the HIP kernels (grouped implicit GEMM: sp_conv_desc.c_in_group); training is
+    refused by PoseTrainer with a message."""
+    return _resnet("resnext50_32x4d", (3, 4, 6, 3), pretrained, kwargs, width_per_group=4, groups=32)
 
 
-def resnext50_32x4d(pretrained: bool = False, progress: bool = True, **kwargs):
-    """Refused with a message (see `_grouped`): the factory name exists so that a caller of the reference's API fails loudly, not with AttributeError."""
-    _grouped("resnext50_32x4d")
-
-
-def resnext101_32x8d(pretrained: bool = False, progress: bool = True, **kwargs):
-    _grouped("resnext101_32x8d")
+def resnext101_32x8d(pretrained: bool = False, progress: bool = True, **kwargs) -> ResNet:
+    """Bottlenecks [3, 4, 23, 3], 32 groups of 8 x (planes / 64) channels (reference factory of the same name)."""
+    return _resnet("resnext101_32x8d", (3, 4, 23, 3), pretrained, kwargs, width_per_group=8, groups=32)

@@ -575,6 +575,8 @@ class PoseTrainer:
                                       "read fp32 gradients)")
         self.g16 = grad_dtype == "bf16"
         self.grad_dtype = torch.bfloat16 if self.g16 else torch.float32
+        if getattr(model, "GROUPS", 1) != 1:
+            raise NotImplementedError("PoseTrainer: the grouped resnext* nets run the eval-mode forward only (their grouped 3x3 has no dgrad / wgrad lowering)")
         if getattr(model, "BLOCK", "bottleneck") not in ("bottleneck", "basic"):
             raise NotImplementedError(f"PoseTrainer lowers the Bottleneck / BasicBlock ResNets and HRNet, not block type {model.BLOCK!r}")
         self.model, self.lr, self.betas, self.eps = model, lr, betas, eps

@@ -27,9 +27,17 @@ def conv_desc_cpu(d, x, w, scale, shift, res, y, B):
                 iyc, ixc = iy.clamp(0, d.in_h - 1).expand(d.grid_h, d.grid_w), ix.clamp(0, d.in_w - 1).expand(d.grid_h, d.grid_w)
                 g = x[:, iyc, ixc, :].float() * ok.expand(d.grid_h, d.grid_w)[None, :, :, None]
                 cols.append(g)
-        A = torch.cat(cols, dim=-1)  # [B,gh,gw,taps*c_in]
-        k = A.shape[-1]
-        acc = A.double() @ wp[ph, :, :k].double().t()  # [B,gh,gw,n_pad]
+        if getattr(d, "c_in_group", 0):
+            # grouped launch (sp_conv_desc.c_in_group): N tile t of c_in_group columns reads channels [t * g, (t + 1) * g) of every tap, K = taps * g
+            g = d.c_in_group
+            acc = torch.zeros(A0 := cols[0].shape[:-1] + (d.n_pad,), dtype=torch.float64)
+            for t in range(d.c_out // g):
+                At = torch.cat([c[..., t * g:(t + 1) * g] for c in cols], dim=-1)
+                acc[..., t * g:(t + 1) * g] = At.double() @ wp[ph, t * g:(t + 1) * g, :At.shape[-1]].double().t()
+        else:
+            A = torch.cat(cols, dim=-1)  # [B,gh,gw,taps*c_in]
+            k = A.shape[-1]
+            acc = A.double() @ wp[ph, :, :k].double().t()  # [B,gh,gw,n_pad]
         acc = acc[..., :d.c_out]
         if scale is not None:
             acc = acc * scale.double()
@@ -142,6 +150,17 @@ class TorchPacker:
         out = torch.zeros((n_pad, k_pad), dtype=torch.float32, device=w.device)
         out[:O, :k] = p
         return (out.to(torch.bfloat16) if bf16 else out).contiguous(), kh, tw, ci, k_pad
+
+    def grouped(self, w, groups, panel, *, bf16=False):
+        """sp_pack_conv_weights_grouped restated: [O, O/g, kh, kw] -> [O, kh*kw*panel], row n's panel = channels [(n // panel) * panel, +panel)."""
+        wf = w.detach().float()
+        O, cpg, kh, kw = wf.shape
+        out = torch.zeros((O, kh * kw, panel), dtype=torch.float32, device=w.device)
+        for n in range(O):
+            lo = (n // cpg) * cpg - (n // panel) * panel          # the group's first channel inside the panel
+            out[n, :, lo:lo + cpg] = wf[n].reshape(cpg, kh * kw).t()
+        out = out.reshape(O, kh * kw * panel)
+        return (out.to(torch.bfloat16) if bf16 else out).contiguous()
 
     def deconv(self, w, *, bf16=False):
         wf = w.detach().float()

@@ -344,6 +344,50 @@ def test_c_abi_packing_matches_the_layout_spec_bit_for_bit():
         assert torch.equal(got[0].cpu(), want[0]) and torch.equal(got[1].cpu(), want[1]), C
 
 
+@pytest.mark.parametrize("bf16", [False, True], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("O,groups,panel", [(128, 32, 64), (256, 32, 64), (1024, 32, 64), (2048, 32, 64), (256, 4, 64), (256, 2, 128)])
+def test_grouped_pack_and_conv_vs_torch(O, groups, panel, bf16):
+    """Grouped 3x3 convolution (ResNeXt's conv2, nets/pose_resnet_dconv.py:101): sp_pack_conv_weights_grouped equals the layout restated in
+    tests/desc_interp.TorchPacker bit for bit, and the launch (sp_conv_desc.c_in_group = tile_n = the panel) equals torch's grouped conv2d in
+    float64 on the same operands, on every tile_m the kernel offers for that panel, stride 1 and 2."""
+    lib = _lib.lib()
+    cpg = O // groups
+    g = torch.Generator().manual_seed(O + groups)
+    w = (torch.randn(O, cpg, 3, 3, generator=g) * (2.0 / (cpg * 9)) ** 0.5)
+    if bf16:
+        w = w.bfloat16().float()
+    packed = engine.HipPacker().grouped(w.to(DEV), groups, panel, bf16=bf16)
+    torch.cuda.synchronize()
+    assert torch.equal(packed.cpu(), TorchPacker().grouped(w, groups, panel, bf16=bf16))
+    for stride, (B, H, W) in ((1, (2, 9, 7)), (2, (3, 12, 10))):
+        x = torch.randn(B, O, H, W, generator=g)
+        if bf16:
+            x = x.bfloat16().float()
+        ref = torch.nn.functional.conv2d(x.double(), w.double(), stride=stride, padding=1, groups=groups)
+        b = engine.ProgramBuilder(H, W, dtype="bf16" if bf16 else "fp32")
+        b.p.shapes["input"] = (H, W, O)
+        out = b.conv("input", w.to(DEV), stride=stride, pad=1, name="c", groups=groups)
+        prog = b.p
+        op = [o for o in prog.ops if o.kind == "conv"][0]
+        assert op.desc.c_in_group == panel and not op.direct
+        xin = x.permute(0, 2, 3, 1).contiguous().to(DEV).to(torch.bfloat16 if bf16 else torch.float32)
+        op.desc.batch = B
+        res = []
+        for cand in prog._candidates(lib, op):
+            op.desc.tile_m, op.desc.tile_n, op.desc.kernel = cand
+            y = torch.full((B,) + tuple(prog.shapes[out]), float("nan"), dtype=xin.dtype, device=DEV)
+            _lib.check(lib.sp_conv2d_fwd(op.desc, _lib.ptr(xin), _lib.ptr(op.w), None, None, None, _lib.ptr(y), _lib.current_stream()), str(cand))
+            torch.cuda.synchronize()
+            res.append(y.float().cpu())
+        assert len(res) >= 2
+        for r in res[1:]:
+            assert torch.equal(r, res[0])                       # every tile the same bits
+        got = res[0].permute(0, 3, 1, 2).double()
+        assert not torch.isnan(got).any()
+        err = float((got - ref).abs().max() / ref.abs().max())
+        assert err < (6e-3 if bf16 else 3e-6), (stride, err)
+
+
 def test_ctypes_only_pack_and_run_one_conv():
     """What a maintainer binding only include/simple_pose_hip.h does: no simple_pose_amd.engine, just the
     C entry points - sp_conv_packed_dims + sp_pack_conv_weights + sp_fold_bn + a hand-filled sp_conv_desc + sp_conv2d_fwd -
@@ -484,7 +528,8 @@ def test_forward_vs_reference_on_the_wide_set(golden, measured, tag, B):
     assert same >= 0.99 and within >= 0.9, (same, within)
 
 
-RESNET_VARIANTS = [("resnet18", "dconv", False), ("resnet34", "duc", False), ("wide_resnet50_2", "dconv", False), ("resnet18", "dconv", True)]
+RESNET_VARIANTS = [("resnet18", "dconv", False), ("resnet34", "duc", False), ("wide_resnet50_2", "dconv", False), ("resnet18", "dconv", True),
+                   ("resnext50_32x4d", "dconv", False), ("resnext101_32x8d", "duc", False)]      # (round 5: the grouped resnext factories, golden g12 from the real reference)
 
 
 @pytest.mark.parametrize("arch,head,se", RESNET_VARIANTS, ids=[f"{a}_{h}" + ("_se" if s else "") for a, h, s in RESNET_VARIANTS])
@@ -493,7 +538,7 @@ def test_resnet_variants_forward_vs_reference_golden(golden, measured, arch, hea
     (BasicBlock: two 3x3 convs, projection shortcut only where the shape changes, head from 512 channels) and wide_resnet50_2 (Bottleneck with
     twice the inner width), one with SELayers - HIP forward against g11 (real reference, 2 images) within the 1e-4 contract; bf16 operands
     within the bf16 bar of the fp32 program."""
-    g = golden("g11_resnet_variants.npz")
+    g = golden("g12_resnext.npz" if arch.startswith("resnext") else "g11_resnet_variants.npz")
     tag = f"{arch}_{head}" + ("_se" if se else "")
     m = getattr(pose_resnet_dconv if head == "dconv" else pose_resnet_duc, arch)(pretrained=False, num_classes=17, reduction=se)
     layout = [(k, tuple(v.shape), str(v.dtype)) for k, v in m.state_dict().items()]

@@ -49,7 +49,8 @@ def test_packing_and_descriptors_reproduce_oracle_forward(head):
     assert abs(full.flops_per_image - expect) / expect < 1e-4, full.flops_per_image
 
 
-VARIANTS = [("resnet18", "dconv", False), ("resnet34", "duc", False), ("wide_resnet50_2", "dconv", False), ("resnet18", "dconv", True)]
+VARIANTS = [("resnet18", "dconv", False), ("resnet34", "duc", False), ("wide_resnet50_2", "dconv", False), ("resnet18", "dconv", True),
+            ("resnext50_32x4d", "dconv", False), ("resnext101_32x8d", "duc", False)]      # (round 5: the grouped resnext factories, golden g12)
 
 
 def _variant_model(arch, head, se):
@@ -61,7 +62,7 @@ def test_resnet_variant_layout_and_lowering(golden, arch, head, se):
     """The reference's other ResNet factories (nets/pose_resnet_dconv.py:282-403: BasicBlock nets resnet18 / 34, wide_resnet*_2): the module
     tree has the reference's state_dict keys and shapes in the reference's order (key lists frozen in g11 from the real reference), and the
     lowered program interpreted on the CPU equals the oracle forward."""
-    g = golden("g11_resnet_variants.npz")
+    g = golden("g12_resnext.npz" if arch.startswith("resnext") else "g11_resnet_variants.npz")
     tag = f"{arch}_{head}" + ("_se" if se else "")
     m = _variant_model(arch, head, se)
     sd0 = m.state_dict()
@@ -77,13 +78,16 @@ def test_resnet_variant_layout_and_lowering(golden, arch, head, se):
     assert got.shape == ref.shape == (2, 17, 16, 16)
     rel = (got - ref).abs().max() / ref.abs().max()
     assert rel < 1e-5, rel
+    if arch.startswith("resnext"):          # grouped 3x3 (groups = 32): block-diagonal panels, K per tap = the panel (sp_conv_desc.c_in_group)
+        grouped = [op for op in prog.ops if op.kind == "conv" and op.desc.c_in_group]
+        assert len(grouped) == sum(m.BLOCKS) and all(op.desc.tile_n == op.desc.c_in_group and op.desc.k_pad == 9 * op.desc.c_in_group for op in grouped)
 
 
-def test_grouped_factories_fail_loudly():
+def test_grouped_nets_refuse_training_loudly():
+    """resnext*: eval forward is lowered (round 5, grouped implicit GEMM); PoseTrainer says that training is not."""
+    from simple_pose_amd.train import PoseTrainer
     with pytest.raises(NotImplementedError, match="grouped"):
-        pose_resnet_dconv.resnext50_32x4d(num_classes=17)
-    with pytest.raises(NotImplementedError, match="grouped"):
-        pose_resnet_duc.resnext101_32x8d(num_classes=17)
+        PoseTrainer(pose_resnet_dconv.resnext50_32x4d(num_classes=17))
     # (round 5: the BasicBlock nets train through the same tape - tests/test_gpu_train.py::test_basic_block_nets_train_step_vs_oracle)
 
 

@@ -250,7 +250,8 @@ def test_forward_oracle_matches_reference_on_the_wide_set(golden, tag, B):
     assert (err <= 1e-3).mean() >= 0.9, (err <= 1e-3).mean()        # noise-like maps: the tail is the ill-conditioned -H^-1 g
 
 
-VARIANTS = [("resnet18", "dconv", False), ("resnet34", "duc", False), ("wide_resnet50_2", "dconv", False), ("resnet18", "dconv", True)]
+VARIANTS = [("resnet18", "dconv", False), ("resnet34", "duc", False), ("wide_resnet50_2", "dconv", False), ("resnet18", "dconv", True),
+            ("resnext50_32x4d", "dconv", False), ("resnext101_32x8d", "duc", False)]      # (round 5: grouped factories, g12_resnext.npz)
 
 
 @pytest.mark.parametrize("arch,head,se", VARIANTS, ids=[f"{a}_{h}" + ("_se" if s else "") for a, h, s in VARIANTS])
@@ -258,7 +259,7 @@ def test_forward_oracle_matches_reference_on_the_resnet_variants(golden, arch, h
     """g11_resnet_variants.npz: the BasicBlock nets, a wide Bottleneck net and an SELayer variant through the real reference - the forward oracle
     (driven by the state_dict alone) reproduces the sub-sampled maps, norms and arg-max cells."""
     from simple_pose_amd.nets import pose_resnet_dconv, pose_resnet_duc
-    g = golden("g11_resnet_variants.npz")
+    g = golden("g12_resnext.npz" if arch.startswith("resnext") else "g11_resnet_variants.npz")
     tag = f"{arch}_{head}" + ("_se" if se else "")
     m = getattr(pose_resnet_dconv if head == "dconv" else pose_resnet_duc, arch)(pretrained=False, num_classes=17, reduction=se)
     layout = [(k, tuple(v.shape), str(v.dtype)) for k, v in m.state_dict().items()]
