@@ -495,6 +495,17 @@ int plan_job(const sp_wgrad_job& j, Plan* pl) {
     const double unit_px = unit_ns(bf16) / (bf16 ? t.ns_per_px_bf16 : t.ns_per_px_f32);
     long long splits = (long long)((double)M / unit_px + 0.5);
     if (splits < 1) splits = 1;
+    // A layer with more units than CUs (the stem: 393,216 pixels -> 384 units of 50 us) is the step's TAIL when its gradient is the last to
+    // exist - 1.5 rounds of workgroups take the time of 2.  Its splits are rounded so that the units fill whole rounds of 256 (round 5: the
+    // stem's 512 units of 37 us finish in 2 x 37 instead of 2 x 50 us).  Still a function of the layer alone: bits do not depend on the group.
+    {
+        const long long tiles = (long long)pl->tiles_g * pl->tiles_a, units = tiles * splits;
+        if (units > 256) {
+            const long long rounds = (units + 128) / 256;
+            splits = rounds * 256 / tiles;
+            if (splits < 1) splits = 1;
+        }
+    }
     long long pps = ((M + splits - 1) / splits + pix - 1) / pix * pix;
     splits = (M + pps - 1) / pps;
     pl->splits = (int)splits;

@@ -52,17 +52,27 @@ def flat_layout(named_shapes) -> Tuple[Dict[str, Tuple[int, int]], int]:
     return offsets, _round_up(off, 4)
 
 
-def plan_gradient_buckets(offsets: Dict[str, Tuple[int, int]], numel: int, bucket_mb: float) -> List[dict]:
+def plan_gradient_buckets(offsets: Dict[str, Tuple[int, int]], numel: int, bucket_mb: float, stem_params: int = 3) -> List[dict]:
     """Contiguous slices of the flat gradient buffer, cut at parameter boundaries walking from the END of the buffer (backward produces
     final_layer first); each bucket knows which parameter gradients it waits for.  Pure host arithmetic (no device): PoseTrainer uses it
-    at construction, `bench.py --dry-launch` to print the plan of a world-8 job on the CPU."""
+    at construction, `bench.py --dry-launch` to print the plan of a world-8 job on the CPU.
+
+    `stem_params` (round 5): the first parameters of the net (conv1.weight, bn1.weight, bn1.bias - the stem, whose gradients are the LAST to
+    exist) get a bucket of their own.  With the optimizer inside backward a bucket's all-reduce -> Adam -> repack starts when its last
+    gradient lands; in one bucket with layer1 those ~24 MB of optimizer work sat exposed behind the stem's backward and its weight gradient
+    (the one-step timeline of round 4: 220 us from the chain's last kernel to the end of the step).  Now layer1's bucket goes out when
+    layer1.0 is done, under the stem's backward, and what follows the chain is the stem's own 9,536 parameters."""
     names = list(offsets.keys())
     cap = max(1, int(bucket_mb * (1 << 20) / 4))
+    stem = set(names[:stem_params]) if 0 < stem_params < len(names) else set()
     buckets: List[dict] = []
     hi = numel
     cur: List[str] = []
     lo = hi
     for n in reversed(names):
+        if stem and n in stem and cur and not (set(cur) & stem):
+            buckets.append({"lo": lo, "hi": hi, "names": set(cur)})       # everything behind the stem closes here, whatever its size
+            hi, cur = lo, []
         o, _ = offsets[n]
         cur.append(n)
         lo = o
@@ -690,7 +700,7 @@ class PoseTrainer:
     def _plan_buckets(self, bucket_mb: float):
         """Contiguous slices of the flat gradient buffer, cut at parameter boundaries walking from the END of the buffer (backward
         produces final_layer first).  Each bucket knows which parameter gradients it waits for."""
-        self.buckets: List[dict] = plan_gradient_buckets(self.flat.offsets, self.flat.numel, bucket_mb)
+        self.buckets: List[dict] = plan_gradient_buckets(self.flat.offsets, self.flat.numel, bucket_mb, self.stem_bucket_params)
         self._bucket_of = {n: i for i, b in enumerate(self.buckets) for n in b["names"]}
 
     def _grads_ready(self, *names: str):
@@ -1339,6 +1349,7 @@ class PoseTrainer:
     _in_branch = False
     overlap_shortcut = True
     relu_bit_masks = os.environ.get("SP_RELU_MASK", "1") != "0"        # (env: development knob)
+    stem_bucket_params = int(os.environ.get("SP_STEM_BUCKET", "3"))      # (env: development knob; 0 = the stem shares layer1's bucket, rounds 1-4)
     repack_tiled = os.environ.get("SP_REPACK_TILED", "0") == "1"       # (walk 3 of sp_permute4_batched: fewer bytes, same-box A/B 5.83 vs 5.90 ms - off)
     lazy_residual_grad = os.environ.get("SP_LAZY_RES", "1") != "0"      # (env: development knob)
     fold_in_consumer_rows = 50    # partial rows (one per phase and M tile) up to which the BatchNorm pass folds them itself (sp_bn_fold_*): above, a stand-alone

@@ -222,6 +222,8 @@ def test_gradient_buckets_tile_the_flat_buffer_in_reverse_parameter_order():
         assert a["lo"] == b["hi"]
     assert sorted(n for b in shim.buckets for n in b["names"]) == sorted(names)
     assert "3.bias" in shim.buckets[0]["names"] and "0.weight" in shim.buckets[-1]["names"]
+    # the net's first three parameters (the stem: conv weight + BatchNorm pair, whose gradients exist last) have a bucket of their own
+    assert shim.buckets[-1]["names"] == {"0.weight", "0.bias", "1.weight"} and shim.buckets[-1]["lo"] == 0
     for b in shim.buckets:
         for n in b["names"]:
             o, k = shim.flat.offsets[n]
@@ -334,10 +336,11 @@ def test_bench_dry_launch_eight_ranks_over_gloo():
     assert d["dry_launch"] and d["n_ranks"] == 8 and d["ranks_seen"] == list(range(8)) and d["reductions_ok"]
     assert d["config"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"                 # the explicit default, recorded
     # the world-8 train step's exchange plan, built on every rank without a GPU: 4 gradient buckets of >= 32 MiB cut at parameter
-    # boundaries (40.0 / 34.0 / 32.6 / 23.1 MiB = the 136 MB of fp32 gradients, ddp...:91-93; the round-3 text said "5": it counted a
-    # 25 MB-style cut) and 52 + 52 SyncBatchNorm messages (ddp...:89-90; what PoseTrainer.collective_count reaches on the GPU)
+    # boundaries (40.0 / 34.0 / 32.6 / 23.0 MiB = the 136 MB of fp32 gradients, ddp...:91-93) + since round 5 the stem's own bucket (conv1.weight,
+    # bn1.weight, bn1.bias: 0.04 MiB - its gradients exist last, so layer1's bucket no longer waits for them) and 52 + 52 SyncBatchNorm
+    # messages (ddp...:89-90; what PoseTrainer.collective_count reaches on the GPU)
     plan = d["train_step_plan"]
-    assert plan["gradient_buckets"] == 4 and plan["sync_bn_messages_per_step"] == 104 and plan["batchnorm_layers"] == 56
+    assert plan["gradient_buckets"] == 5 and plan["bucket_mbytes"][-1] < 0.1 and plan["sync_bn_messages_per_step"] == 104 and plan["batchnorm_layers"] == 56
     assert plan["same_on_every_rank"] and abs(sum(plan["bucket_mbytes"]) - 4 * plan["gradient_floats"] / (1 << 20)) < 0.5
     assert plan["communicators"] == 1
     n_dev = torch.cuda.device_count()
