@@ -498,7 +498,8 @@ int plan_job(const sp_wgrad_job& j, Plan* pl) {
     // A layer with more units than CUs (the stem: 393,216 pixels -> 384 units of 50 us) is the step's TAIL when its gradient is the last to
     // exist - 1.5 rounds of workgroups take the time of 2.  Its splits are rounded so that the units fill whole rounds of 256 (round 5: the
     // stem's 512 units of 37 us finish in 2 x 37 instead of 2 x 50 us).  Still a function of the layer alone: bits do not depend on the group.
-    {
+    static const bool fill_rounds = getenv("SP_WGRAD_FILL_ROUNDS") && atoi(getenv("SP_WGRAD_FILL_ROUNDS"));   // (env: development knob, off: A/B below)
+    if (fill_rounds) {
         const long long tiles = (long long)pl->tiles_g * pl->tiles_a, units = tiles * splits;
         if (units > 256) {
             const long long rounds = (units + 128) / 256;
