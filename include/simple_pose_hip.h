@@ -310,6 +310,14 @@ int sp_bn_train_stats_nhwc(const void* z, int bf16, int64_t rows, int c, float e
 int sp_conv2d_bn_stats_rows(const sp_conv_desc* desc, int* partial_rows);
 int sp_conv2d_fwd_bn_stats(const sp_conv_desc* desc, const void* x, const void* w_packed, void* y, float* stats_sum,
                            float* stats_sumsq, int stats_rows_capacity, void* stream);
+/* sp_conv2d_fwd_bn_stats of a bf16 1x1 stride-1 convolution (c_in <= 512) whose input is relu(BatchNorm(z_in)) of the previous layer
+ * (`Bottleneck.forward`: out = relu(bn2(conv2(.))); out = conv3(out), nets/pose_resnet_dconv.py:118-122): the map is applied while z_in is staged
+ * (in_mean / in_invstd: that layer's batch statistics, in_gamma / in_beta its affine pair), and the launch also writes the activation `y_in`
+ * [same layout as z_in] and, when not null, its ReLU bit mask (one byte per 8 channels) - what the backward pass and the weight gradient read.
+ * Replaces sp_bn_apply_nhwc(relu = 1) + sp_conv2d_fwd_bn_stats with the same bits (ABI 33). */
+int sp_conv2d_fwd_bn_stats_abn(const sp_conv_desc* desc, const void* z_in, const float* in_mean, const float* in_invstd, const float* in_gamma,
+                               const float* in_beta, void* y_in, void* relu_mask_in, const void* w_packed, void* y, float* stats_sum,
+                               float* stats_sumsq, int stats_rows_capacity, void* stream);
 int sp_bn_train_stats_from_conv(const float* stats_sum, const float* stats_sumsq, int partial_rows, int stride, int64_t rows, int c,
                                 float eps, float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
                                 void* stream);

@@ -120,6 +120,7 @@ SYMBOLS = {
     "sp_warp_affine_u8c3": (c_int, [_P, c_int, c_int, _P, c_int, _P, c_int, c_int, _P]),
     "sp_conv2d_bn_stats_rows": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_int)]),
     "sp_conv2d_fwd_bn_stats": (c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, c_int, _P]),
+    "sp_conv2d_fwd_bn_stats_abn": (c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "sp_bn_train_stats_from_conv": (c_int, [_P, _P, c_int, c_int, c_int64, c_int, c_float, c_float, _P, _P, _P, _P, _P]),
     "sp_conv2d_dgrad_bn_bwd_stats": (c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "sp_conv2d_dgrad_bn_bwd_stats2": (c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),

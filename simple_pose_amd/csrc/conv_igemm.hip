@@ -105,6 +105,15 @@ struct ConvArgs {
     // panel of the tile is [tile_n][taps * c_in_g] (zeros where a panel spans several groups), and the A gather adds the tile's channel offset.
     // 0: dense.
     int c_in_g;
+    // ABN instantiation (round 5; train-mode forward of a Bottleneck's conv3): the A operand is relu(bn(z)) of the PREVIOUS BatchNorm, formed in
+    // the staging pass from z (what `x` points to) and that layer's batch statistics; the N-tile-0 workgroups also store the activation (and
+    // its ReLU bit mask) the backward pass and the weight gradient read - the stand-alone BatchNorm + ReLU pass over that tensor disappears
+    const float* abn_mean;
+    const float* abn_invstd;
+    const float* abn_gamma;
+    const float* abn_beta;
+    void* abn_y;                 // NHWC bf16, layout of x
+    unsigned char* abn_mask;     // one byte per 8 channels of abn_y (null: no mask)
 };
 
 constexpr int BK = 32;  // floats per K tile (8 chunks of 16 B)
@@ -113,8 +122,16 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * BK + ((chu
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int BM, int BN, int WR, int WC, bool UNIFORM_TAP, bool BF16, bool OUT16, bool STATS = false, bool DEEP = false, bool BSTATS = false>
-__global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm_kernel(const ConvArgs p) {
+// (the BatchNorm element map of train.hip's bn_fwd_elem, operation by operation with contraction off: the ABN staging pass must give the bits
+// of the stand-alone pass it replaces)
+__device__ __forceinline__ float abn_elem(float v, float mu, float is, float g, float b) {
+#pragma clang fp contract(off)
+    return (v - mu) * is * g + b;
+}
+
+template <int BM, int BN, int WR, int WC, bool UNIFORM_TAP, bool BF16, bool OUT16, bool STATS, bool DEEP, bool BSTATS, bool ABN>
+__device__ __forceinline__ void conv_igemm_body(const ConvArgs& p) {
+    static_assert(!ABN || (UNIFORM_TAP && BF16 && OUT16 && STATS && !DEEP && !BSTATS), "ABN: the bf16 train-mode forward of a 1x1 conv");
     constexpr int ES = BF16 ? 2 : 4;     // element size of activations / weights
     constexpr int EPC = 16 / ES;         // elements per 16-byte chunk
     constexpr int BKE = 128 / ES;        // elements per K tile (one 128-byte LDS row)
@@ -200,6 +217,11 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
         }
         reinterpret_cast<int4*>(rowtab)[tid] = e;
     }
+    float* const abn_tab = reinterpret_cast<float*>(rowtab + BM * 4) + 3 * WR * BN;    // [c_in][4]: mean, invstd, gamma, beta (ABN only)
+    if constexpr (ABN) {
+        for (int c = tid; c < p.c_in; c += 256)
+            *reinterpret_cast<f32x4*>(abn_tab + 4 * c) = f32x4{p.abn_mean[c], p.abn_invstd[c], p.abn_gamma[c], p.abn_beta[c]};
+    }
     __syncthreads();
 
     // ---- staging assignment: thread -> (row = tid/8 + 32 i, chunk = tid%8) ----
@@ -277,10 +299,37 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
         constexpr int S = decltype(s_tag)::value;
         sb[S][i] = __builtin_amdgcn_raw_buffer_load_b128(wr_, b_voff + (unsigned)(32 * i * k_pad * ES), b_soff0 + (unsigned)(t_k0 * ES), 0);
     };
+    const __amdgpu_buffer_rsrc_t abn_yr = __builtin_amdgcn_make_buffer_rsrc(ABN ? p.abn_y : p.y, (short)0, ABN ? p.x_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t abn_mr = __builtin_amdgcn_make_buffer_rsrc((ABN && p.abn_mask) ? (void*)p.abn_mask : p.y, (short)0,
+                                                                            (ABN && p.abn_mask) ? (p.x_bytes >> 4) : 0, 0x00020000);
     auto store_piece = [&](int buf, int o, auto s_tag) {  // o in [0, A_CH + B_CH)
         constexpr int S = decltype(s_tag)::value;
-        if (o < A_CH) *reinterpret_cast<u32x4*>(As + buf * BM * BK + swz(srow + 32 * o, kc)) = sa[S][o];
-        else *reinterpret_cast<u32x4*>(Bs + buf * BN * BK + swz(srow + 32 * (o - A_CH), kc)) = sb[S][o - A_CH];
+        if (o < A_CH) {
+            u32x4 piece = sa[S][o];
+            if constexpr (ABN) {
+                // (1x1, stride 1, no padding: one tap, K tile t_k0 = channels t_k0 .. t_k0 + 63 of the pixel; a_mask bit 0 = row < M)
+                const bool valid = (a_mask[o] & 1u) != 0;
+                const bf16x8 zin = __builtin_bit_cast(bf16x8, piece);
+                const float* tb = abn_tab + 4 * (t_k0 + kc * 8);
+                bf16x8 yo;
+                unsigned bits = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const f32x4 q = *reinterpret_cast<const f32x4*>(tb + 4 * e);
+                    float v = abn_elem((float)zin[e], q[0], q[1], q[2], q[3]);
+                    bits |= (v > 0.f ? 1u : 0u) << e;
+                    v = v > 0.f ? v : 0.f;
+                    yo[e] = (__bf16)(valid ? v : 0.f);
+                }
+                piece = __builtin_bit_cast(u32x4, yo);
+                if (tn == 0) {                     // every A element is staged by exactly one N-tile-0 workgroup: it writes y (and the mask)
+                    const unsigned off = valid ? (unsigned)(a_off0[o] + t_k0 * 2) : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(piece, abn_yr, off, 0, 0);
+                    if (p.abn_mask) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)bits, abn_mr, valid ? (off >> 4) : OOB, 0, 0);
+                }
+            }
+            *reinterpret_cast<u32x4*>(As + buf * BM * BK + swz(srow + 32 * o, kc)) = piece;
+        } else *reinterpret_cast<u32x4*>(Bs + buf * BN * BK + swz(srow + 32 * (o - A_CH), kc)) = sb[S][o - A_CH];
     };
 
     f32x16 acc[TM][TN];
@@ -825,6 +874,17 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm
 #endif
 }
 
+template <int BM, int BN, int WR, int WC, bool UNIFORM_TAP, bool BF16, bool OUT16, bool STATS = false, bool DEEP = false, bool BSTATS = false>
+__global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm_kernel(const ConvArgs p) {
+    conv_igemm_body<BM, BN, WR, WC, UNIFORM_TAP, BF16, OUT16, STATS, DEEP, BSTATS, false>(p);
+}
+
+// the same body with the ABN staging pass (a kernel of its own name: the instantiation names of conv_igemm_kernel stay what the profiles key on)
+template <int BM, int BN, int WR, int WC>
+__global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm_abn_kernel(const ConvArgs p) {
+    conv_igemm_body<BM, BN, WR, WC, true, true, true, true, false, false, true>(p);
+}
+
 template <int BM, int BN, int WR, int WC, bool BF16, bool OUT16, bool STATS, bool DEEP = false, bool BSTATS = false>
 int launch_t(const ConvArgs& a, int phases, bool uniform, hipStream_t stream) {
     if constexpr (!DEEP && BF16) {
@@ -881,7 +941,35 @@ int launch_t(const ConvArgs& a, int phases, bool uniform, hipStream_t stream) {
 }
 
 template <int BM, int BN, int WR, int WC>
+int launch_abn(const ConvArgs& a, hipStream_t stream) {
+    if (sp_name_query_active()) {
+        sp_name_query_set("conv_igemm_abn_kernel<%d, %d, %d, %d>", BM, BN, WR, WC);
+        return SP_OK;
+    }
+    ConvArgs p = a;
+    p.tiles_m = (a.M + BM - 1) / BM;
+    p.tiles_n = a.n_pad / BN;
+    const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float) + (size_t)BM * 4 * sizeof(int) + (size_t)3 * WR * BN * sizeof(float) +
+                       (size_t)a.c_in * 4 * sizeof(float);                                   // + the [c_in][4] BatchNorm table
+    static bool opted[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!opted[dev]) {
+        const size_t lds_max = (size_t)2 * (BM + BN) * BK * sizeof(float) + (size_t)BM * 4 * sizeof(int) + (size_t)3 * WR * BN * sizeof(float) + 512 * 16;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_abn_kernel<BM, BN, WR, WC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_max) != hipSuccess) {
+            sp_set_error("conv_igemm_abn: hipFuncSetAttribute(max dynamic LDS = %zu) failed on device %d", lds_max, dev);
+            return SP_ELAUNCH;
+        }
+        opted[dev] = true;
+    }
+    hipLaunchKernelGGL((conv_igemm_abn_kernel<BM, BN, WR, WC>), dim3(p.tiles_m * p.tiles_n, 1, 1), dim3(256, 1, 1), lds, stream, p);
+    return sp_check_launch("conv_igemm_abn_kernel");
+}
+
+template <int BM, int BN, int WR, int WC>
 int launch(const ConvArgs& a, int phases, bool uniform, hipStream_t stream) {
+    if (a.abn_mean) return launch_abn<BM, BN, WR, WC>(a, stream);
     if (a.bz) {                                        // dgrad launch that also reduces the BN backward sums of the tensor it writes
         if ((a.flags & SP_CONV_BF16) && !(a.flags & SP_CONV_OUT_F32)) return launch_t<BM, BN, WR, WC, true, true, false, false, true>(a, phases, uniform, stream);
         if (a.flags & SP_CONV_BF16) return launch_t<BM, BN, WR, WC, true, false, false, false, true>(a, phases, uniform, stream);
@@ -912,10 +1000,11 @@ struct BnBwdSrc { const void* y; const void* z; const float* mean; const float* 
                   const void* res_mask = nullptr; };
 
 struct PhaseSet { const sp_conv_desc* descs; const void* const* w; int n; };
+struct AbnSrc { const float* mean; const float* invstd; const float* gamma; const float* beta; void* y; unsigned char* mask; };
 
 static int conv_fwd_impl(const sp_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift,
                          const void* residual, void* y, float* stats_s, float* stats_q, int stats_rows_capacity, void* stream,
-                         const BnBwdSrc* bsrc = nullptr, const PhaseSet* phs = nullptr) {
+                         const BnBwdSrc* bsrc = nullptr, const PhaseSet* phs = nullptr, const AbnSrc* abn = nullptr) {
     SP_REQUIRE(d && x && w_packed && y, "sp_conv2d_fwd: null pointer");
     SP_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->grid_h > 0 && d->grid_w > 0 && d->c_out > 0,
                "sp_conv2d_fwd: non-positive dimension");
@@ -988,6 +1077,15 @@ static int conv_fwd_impl(const sp_conv_desc* d, const void* x, const void* w_pac
     a.bz2 = bsrc ? bsrc->z2 : nullptr; a.bmean2 = bsrc ? bsrc->mean2 : nullptr; a.binvstd2 = bsrc ? bsrc->invstd2 : nullptr; a.stats_q2 = bsrc ? bsrc->q2 : nullptr;
     a.bz_bytes = (int)(out_elems * es);
     a.c_in_g = d->c_in_group > 0 ? d->c_in_group : 0;
+    a.abn_mean = nullptr; a.abn_invstd = a.abn_gamma = a.abn_beta = nullptr; a.abn_y = nullptr; a.abn_mask = nullptr;
+    if (abn) {
+        SP_REQUIRE(abn->mean && abn->invstd && abn->gamma && abn->beta && abn->y, "sp_conv2d_fwd_bn_stats_abn: null pointer");
+        SP_REQUIRE(bf16 && out16 && stats_s && !bsrc && !phs && uniform && d->taps_h == 1 && d->taps_w == 1 && d->stride == 1 && d->stride_x <= 1 && d->dy0 == 0 &&
+                       d->dx0 == 0 && d->in_h == d->grid_h && d->in_w == d->grid_w && d->phases_y == 1 && d->phases_x == 1 && d->c_in <= 512 && d->c_in_group == 0 &&
+                       d->kernel == SP_CONV_KERNEL_IGEMM && d->k_pad / 64 < 12,
+                   "sp_conv2d_fwd_bn_stats_abn: needs a bf16 1x1 stride-1 convolution with c_in <= 512 (< 12 K tiles) on the implicit-GEMM kernel");
+        a.abn_mean = abn->mean; a.abn_invstd = abn->invstd; a.abn_gamma = abn->gamma; a.abn_beta = abn->beta; a.abn_y = abn->y; a.abn_mask = abn->mask;
+    }
     a.ph_n = 0;
     int phases = d->phases_y * d->phases_x;
     if (phs) {                                         // every descriptor was validated on its own by the caller; here: what they must share
@@ -1093,6 +1191,17 @@ extern "C" int sp_conv2d_fwd_bn_stats(const sp_conv_desc* d, const void* x, cons
                                       float* stats_sumsq, int stats_rows_capacity, void* stream) {
     SP_REQUIRE(stats_sum && stats_sumsq, "sp_conv2d_fwd_bn_stats: null statistics pointer");
     return conv_fwd_impl(d, x, w_packed, nullptr, nullptr, nullptr, y, stats_sum, stats_sumsq, stats_rows_capacity, stream);
+}
+
+// sp_conv2d_fwd_bn_stats whose input is z of the PREVIOUS conv: relu(BatchNorm(z)) with that layer's batch statistics is formed while the A
+// operand is staged, and written out (activation + ReLU bit mask) by the N-tile-0 workgroups - the stand-alone pass disappears.  Same bits as
+// sp_bn_apply_nhwc (relu, mask) followed by sp_conv2d_fwd_bn_stats.
+extern "C" int sp_conv2d_fwd_bn_stats_abn(const sp_conv_desc* d, const void* z_in, const float* in_mean, const float* in_invstd, const float* in_gamma,
+                                          const float* in_beta, void* y_in, void* relu_mask_in, const void* w_packed, void* y, float* stats_sum,
+                                          float* stats_sumsq, int stats_rows_capacity, void* stream) {
+    SP_REQUIRE(stats_sum && stats_sumsq, "sp_conv2d_fwd_bn_stats_abn: null statistics pointer");
+    const AbnSrc abn = {in_mean, in_invstd, in_gamma, in_beta, y_in, reinterpret_cast<unsigned char*>(relu_mask_in)};
+    return conv_fwd_impl(d, z_in, w_packed, nullptr, nullptr, nullptr, y, stats_sum, stats_sumsq, stats_rows_capacity, stream, nullptr, nullptr, &abn);
 }
 
 extern "C" int sp_conv2d_dgrad_bn_bwd_stats(const sp_conv_desc* d, const void* dz, const void* w_packed, const void* accumulate, void* dx,
