@@ -143,13 +143,19 @@ class StepTape:
         """The conv launch of a conv + BatchNorm pair; with `fuse_bn_stats` its epilogue also leaves the per-channel partial sums."""
         layer = self.L[cname]
         xa.consumers += 1
-        if self.tr.fuse_bn_stats:
+        if xa.pending_apply is not None:
+            # the input's BatchNorm + ReLU pass was deferred to this launch (conv_bn(defer_apply=True)): it forms the activation while it stages its A
+            # operand and writes xa.data / xa.mask for the backward pass and the weight gradient
+            zin, mean, invstd, gamma, beta = xa.pending_apply
+            xa.pending_apply = None
+            z, part, prow = layer.forward_bn_stats_abn(zin, self.B, mean, invstd, gamma, beta, xa.data, xa.mask)
+        elif self.tr.fuse_bn_stats:
             z, part, prow = layer.forward_bn_stats(xa.data, self.B)
         else:
             z, part, prow = layer.forward(xa.data, self.B), None, 0
         return dict(layer=layer, z=z, part=part, prow=prow, rows=z.shape[0] * z.shape[1] * z.shape[2], C=z.shape[3])
 
-    def batch_stats(self, pends: List[dict], bnames: List[str]) -> None:
+    def batch_stats(self, pends: List[dict], bnames: List[str], standalone: bool = False) -> None:
         """Batch mean / invstd (+ running statistics) of the BatchNorm layers behind the pending convs.  SyncBatchNorm: every
         layer folds its fp64 (sum, sum of squares) into a slice of ONE buffer and the group shares ONE all-reduce (the conv1 /
         downsample pair of a stage's first bottleneck); no second pass over z either way when the conv left partial sums."""
@@ -160,7 +166,7 @@ class StepTape:
         if not self.sync:
             for pd, bn in zip(pends, bnames):
                 rm, rv = run(bn)
-                if pd["part"] is not None and pd["prow"] <= tr.fold_in_consumer_rows:
+                if pd["part"] is not None and pd["prow"] <= tr.fold_in_consumer_rows and not standalone:
                     pd["fold_in_apply"] = True      # few partial rows: the consuming sp_bn_fold_apply_nhwc folds them in its prologue
                     continue
                 if pd["part"] is not None:
@@ -191,13 +197,17 @@ class StepTape:
                                                     rm, rv, stream), bn)
 
     def conv_bn(self, xa, cname: str, bname: str, relu: bool, res=None, pend: Optional[dict] = None,
-                shortcut: bool = True, before_apply: Optional[Callable[[], None]] = None):
-        """conv -> train-mode BatchNorm (-> + res) (-> ReLU): forward launches, the resulting Act, and the backward closure on the tape."""
+                shortcut: bool = True, before_apply: Optional[Callable[[], None]] = None, defer_apply_to: Optional[str] = None):
+        """conv -> train-mode BatchNorm (-> + res) (-> ReLU): forward launches, the resulting Act, and the backward closure on the tape.
+        `defer_apply_to`: name of the ONE conv that consumes the result next - when that is a 1x1 convolution the kernels can feed from z
+        (ConvT.abn_ok), the BatchNorm + ReLU pass is not launched: the consumer forms the activation in its staging pass and writes it."""
         from .train import Act
         tr, lib, bf, W, sync, B, dev = self.tr, self.lib, self.bf, self.W, self.sync, self.B, self.dev
+        defer = (defer_apply_to is not None and tr.apply_in_consumer and relu and res is None and not sync and tr.fuse_bn_stats and pend is None
+                 and before_apply is None and self.L[defer_apply_to].abn_ok(B) and self.L[defer_apply_to].ci == self.L[cname].O)
         if pend is None:
             pend = self.conv_stats(xa, cname)
-            self.batch_stats([pend], [bname])
+            self.batch_stats([pend], [bname], standalone=defer)     # (deferred: the statistics come from the stand-alone fold, whatever the row count)
         if before_apply is not None:
             before_apply()                   # (the residual comes from the branch stream: join before the pass that reads it)
         stream = self.stream
@@ -209,7 +219,9 @@ class StepTape:
         # bf16 gradients: the pass also leaves the ReLU mask as one bit per element; the BatchNorm backward pass and the dgrad epilogue
         # that reduces its sums then read that byte instead of 16 bytes of y
         mask = tr._take((rows * C // 8,), torch.uint8, dev) if (relu and self.use_mask and not pend.get("from_sums") and C % 8 == 0) else None
-        if pend.get("fold_in_apply"):
+        if defer:
+            pass                                 # y / mask are written by the consumer's launch (conv_stats sees pending_apply)
+        elif pend.get("fold_in_apply"):
             part = pend["part"]
             _lib.check(lib.sp_bn_fold_apply_nhwc(P(z), bf, P(part[0]), P(part[1]), pend["prow"], part.shape[2], rows, BN_EPS, BN_MOMENTUM, P(gamma),
                                                  P(beta), P(res.data) if res else None, P(y), rows, C, int(relu), P(mean), P(invstd),
@@ -224,6 +236,8 @@ class StepTape:
                                             int(relu), P(mask), stream), bname)
         ya = Act(y, z.shape[1], z.shape[2], C)
         ya.mask = mask
+        if defer:
+            ya.pending_apply = (z, mean, invstd, gamma, beta)
         if res is not None:
             res.consumers += 1
         if relu:
@@ -626,7 +640,7 @@ def build_resnet_bottleneck(t: StepTape, a):
             if bi > 0 and len(L[p + ".conv1"].d_dgrad) == 1 and L[p + ".conv1"].dgrad_full_cover and (p + ".se.fc.0") not in L:
                 a.lazy_ok = True                   # identity block: consumers = conv1 and the residual add
             u = t.conv_bn(a, p + ".conv1", p + ".bn1", True, pend=p1)
-            u = t.conv_bn(u, p + ".conv2", p + ".bn2", True)
+            u = t.conv_bn(u, p + ".conv2", p + ".bn2", True, defer_apply_to=p + ".conv3")     # bn2 + ReLU inside conv3's staging pass where it can be
             if join_fwd is not None:
                 t.tape.append(ds_bwd_on_branch)
             else:

@@ -151,6 +151,8 @@ class Act:
     mask: Optional[torch.Tensor] = None    # bf16 training: the ReLU bit mask of this BatchNorm+ReLU output (uint8, one byte per 8 channels)
     grad_event: Optional[object] = None    # backward: .grad's first share was written on the branch stream; whoever touches .grad next waits
     deferred: list = field(default_factory=list)   # ... and then runs these (the branch's weight-gradient jobs, queued on the main stream)
+    pending_apply: Optional[tuple] = None  # forward: .data (and .mask) are NOT written yet - the one consumer, a 1x1 conv, forms relu(bn(z)) in its staging pass
+                                           # and writes them (sp_conv2d_fwd_bn_stats_abn): (z, mean, invstd, gamma, beta)
 
 
 @dataclass
@@ -384,6 +386,26 @@ class ConvT:
         done = self._timed("forward")
         _lib.check(lib.sp_conv2d_fwd_bn_stats(d, P(x), P(self.w_fwd), P(out), P(part[0]), P(part[1]), rows, _lib.current_stream()),
                    self.name)
+        done()
+        return out, part, rows
+
+    def abn_ok(self, B: int) -> bool:
+        """Can this layer's forward take relu(BatchNorm(z)) of the previous layer in its staging pass (sp_conv2d_fwd_bn_stats_abn)?  A bf16 1x1
+        stride-1 convolution with at most 512 input channels (< 12 K tiles) on the implicit-GEMM kernel."""
+        d = self.d_fwd
+        return (self.bf16 and self.kind == "conv" and (self.kh, self.kw) == (1, 1) and self.stride == 1 and self.pad == 0 and d.c_in <= 512
+                and d.c_in % 64 == 0 and d.k_pad // 64 < 12 and d.kernel == _lib.SP_CONV_KERNEL_IGEMM and not self.out_nchw)
+
+    def forward_bn_stats_abn(self, z_in: torch.Tensor, B: int, mean, invstd, gamma, beta, y_in: torch.Tensor, mask_in: Optional[torch.Tensor]):
+        """forward_bn_stats with x = relu(BatchNorm(z_in)) formed in the kernel's staging pass; also writes x (`y_in`) and its ReLU bit mask."""
+        lib, d = _lib.lib(), self.d_fwd
+        d.batch = B
+        rows = self._stats_rows(d, B, self.name)
+        part = self._new((2, rows, d.n_pad), torch.float32, z_in.device)
+        out = self._new((B, d.out_h, d.out_w, d.out_c), self._wdt, z_in.device)
+        done = self._timed("forward")
+        _lib.check(lib.sp_conv2d_fwd_bn_stats_abn(d, P(z_in), P(mean), P(invstd), P(gamma), P(beta), P(y_in), P(mask_in), P(self.w_fwd), P(out),
+                                                  P(part[0]), P(part[1]), rows, _lib.current_stream()), self.name)
         done()
         return out, part, rows
 
@@ -1349,6 +1371,10 @@ class PoseTrainer:
     _in_branch = False
     overlap_shortcut = True
     relu_bit_masks = os.environ.get("SP_RELU_MASK", "1") != "0"        # (env: development knob)
+    # bn2 + ReLU inside conv3's staging pass (tape.conv_bn defer_apply_to; sp_conv2d_fwd_bn_stats_abn): built and bit-identical in round 5, and
+    # measured SLOWER in the step (same-box A/B x4: 5.80-5.84 ms against 5.75-5.78 - the map is re-applied once per N tile of the consumer and sits
+    # in the MFMA waves' issue stream; the 16 launches it removes cost less).  Off; SP_ABN=1 switches it on.
+    apply_in_consumer = os.environ.get("SP_ABN", "0") == "1"
     stem_bucket_params = int(os.environ.get("SP_STEM_BUCKET", "3"))      # (env: development knob; 0 = the stem shares layer1's bucket, rounds 1-4)
     repack_tiled = os.environ.get("SP_REPACK_TILED", "0") == "1"       # (walk 3 of sp_permute4_batched: fewer bytes, same-box A/B 5.83 vs 5.90 ms - off)
     lazy_residual_grad = os.environ.get("SP_LAZY_RES", "1") != "0"      # (env: development knob)

@@ -771,6 +771,79 @@ def test_shortcut_branch_stream_changes_no_bits(dtype, monkeypatch):
             assert torch.equal(fn(True), ref), fn.__name__
 
 
+@pytest.mark.parametrize("grad_dtype,head", [("bf16", "dconv"), ("fp32", "dconv"), ("bf16", "duc")])
+def test_batchnorm_relu_inside_the_consumer_conv_changes_no_bits(grad_dtype, head, monkeypatch):
+    """Round 5: bn2 + ReLU of a Bottleneck is formed in conv3's staging pass (sp_conv2d_fwd_bn_stats_abn; `PoseTrainer.apply_in_consumer`),
+    which also writes the activation and its ReLU bit mask for the backward pass - 16 launches less on the forward chain.  Same element map,
+    same roundings: three bf16 steps give the same parameters, moments and BatchNorm buffers bit for bit as the stand-alone passes."""
+    x, t, w = _batch(4, 128, 96, 17)
+    xd, td, wd = (torch.from_numpy(a).to(DEV) for a in (x, t, w))
+
+    def steps(on):
+        monkeypatch.setattr(PoseTrainer, "apply_in_consumer", on)
+        m, _ = _model(17, head)
+        tr = PoseTrainer(m, in_h=128, in_w=96, lr=1e-3, dtype="bf16", grad_dtype=grad_dtype)
+        losses = [tr.step(xd, td, wd).item() for _ in range(3)]
+        torch.cuda.synchronize()
+        bufs = torch.cat([b.detach().reshape(-1).double() for b in m.buffers()])
+        return losses, tr.flat.data.clone(), tr.exp_avg.clone(), bufs
+
+    ref = steps(False)
+    got = steps(True)
+    assert got[0] == ref[0]
+    for a, b in zip(got[1:], ref[1:]):
+        assert torch.equal(a, b)
+
+
+def test_abn_conv_launch_equals_the_pass_plus_the_plain_launch():
+    """sp_conv2d_fwd_bn_stats_abn alone: on z of 64 / 256 / 512 channels (1, 4, 8 K tiles), M not a multiple of the tile, with and without the
+    mask: y, mask, the conv output and both partial-sum arrays equal sp_bn_apply_nhwc(relu) + sp_conv2d_fwd_bn_stats bit for bit, on every tile."""
+    from simple_pose_amd import _lib
+    from simple_pose_amd.train import ConvT
+    lib, st = _lib.lib(), _lib.current_stream()
+    P = _lib.ptr
+    g = torch.Generator().manual_seed(5)
+
+    class _Tr:                       # the little of a trainer a ConvT needs
+        bf16, g16, kernel_events = True, True, None
+        grad_dtype = torch.bfloat16
+    for Cin, Cout, B, H, W in ((64, 256, 3, 9, 7), (256, 1024, 2, 5, 6), (512, 2048, 3, 4, 3), (128, 512, 5, 8, 6)):
+        wt = (torch.randn(Cout, Cin, 1, 1, generator=g) * (2.0 / Cin) ** 0.5).to(DEV)
+        flat_stub = type("F", (), {})()
+        tr = _Tr()
+        tr.flat = flat_stub
+        layer = ConvT(tr, "c", "conv", wt, H, W)
+        # pack the forward copy by hand (PackJob 0 = the forward pack)
+        j = layer.pack_jobs[0]
+        import ctypes
+        d4 = (ctypes.c_int32 * 4)(*j.dims); s4 = (ctypes.c_int64 * 4)(*j.strides); v4 = (ctypes.c_int32 * 4)(*j.valid)
+        _lib.check(lib.sp_permute4_f32(P(wt.reshape(-1)), P(j.dst), 1, d4, s4, v4, j.base, j.dst_off, st), "pack")
+        rows = B * H * W
+        z = (torch.randn(B, H, W, Cin, generator=g) * 1.2 + 0.1).bfloat16().to(DEV)
+        mean, invstd = torch.randn(Cin, generator=g).mul(0.2).to(DEV), (0.5 + torch.rand(Cin, generator=g)).to(DEV)
+        gamma, beta = (0.75 + 0.5 * torch.rand(Cin, generator=g)).to(DEV), (0.2 * torch.randn(Cin, generator=g)).to(DEV)
+        for with_mask in (True, False):
+            y_ref = torch.empty_like(z)
+            m_ref = torch.empty(rows * Cin // 8, dtype=torch.uint8, device=DEV) if with_mask else None
+            _lib.check(lib.sp_bn_apply_nhwc(P(z), 1, P(mean), P(invstd), P(gamma), P(beta), None, P(y_ref), rows, Cin, 1, P(m_ref), st), "apply")
+            for tile in ((128, 128), (64, 128), (128, 64), (64, 64), (256, 64), (128, 32)):
+                if layer.d_fwd.n_pad % tile[1]:
+                    continue
+                layer.d_fwd.tile_m, layer.d_fwd.tile_n = tile
+                layer._rows_cache.clear()
+                o_ref, p_ref, r_ref = layer.forward_bn_stats(y_ref, B)
+                y = torch.full_like(z, float("nan"))
+                m = torch.full((rows * Cin // 8,), 0xA5, dtype=torch.uint8, device=DEV) if with_mask else None
+                o, p, r = layer.forward_bn_stats_abn(z, B, mean, invstd, gamma, beta, y, m)
+                torch.cuda.synchronize()
+                assert r == r_ref
+                assert torch.equal(y.view(torch.int16), y_ref.view(torch.int16)), (Cin, tile)
+                if with_mask:
+                    assert torch.equal(m, m_ref), (Cin, tile)
+                assert torch.equal(o.view(torch.int16), o_ref.view(torch.int16)), (Cin, tile)
+                assert torch.equal(p, p_ref), (Cin, tile)
+
+
 def test_lazy_residual_gradient_changes_no_bits():
     """bf16 gradients: bn3's backward pass of an identity Bottleneck does not write the residual share g = dy * mask; conv1's dgrad forms it
     from (dy, ReLU bit mask) in its epilogue (sp_conv2d_dgrad_bn_bwd_stats_macc).  g is dy or zero, so three steps end on the same bits."""
