@@ -6,7 +6,7 @@ processors/ddp_pose_resnet_solver.py:36,89-93):
   * "sp_comm"            RCCL called directly on the step's own streams (csrc/comm.hip, two private communicators): one host call per
                          message, nothing between the message and its consumer but the stream's order;
   * "torch.distributed"  the process group's collectives (one communicator on RCCL's own stream, five stream / event calls per message
-                         from Python: with SyncBatchNorm on the step is host-bound, DESIGN.md section 6).
+                         from Python: with SyncBatchNorm on the step is host-bound, DESIGN.md section 7).
 
 The native path is the design, but it has never met a second rank on this pool's 1-GPU boxes.  So nobody has to trust it: when a peer
 exists (world >= 2 over an nccl group) `select()` runs the comparison that `tests/test_gpu_train.py::test_two_rank_rccl_*` runs - a few
