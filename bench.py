@@ -30,8 +30,8 @@ BF16_MATRIX_PEAK_TFLOPS = 2500.0  # dense (MI355X_MICROARCH.md); the bf16 path i
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50, help="timed steps (SURVEY 8d: >= 50)")
+    ap.add_argument("--warmup", type=int, default=10, help="untimed warm-up steps (SURVEY 8d: >= 10)")
     ap.add_argument("--batch", type=int, default=128, help="images per GPU per step")
     ap.add_argument("--arch", default="dconv", choices=["dconv", "duc", "hrnet_w32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -84,6 +84,13 @@ def parse():
                     help="default run (N = 1, infer, dconv f32 bs=128) only: skip the other BASELINE configs that are otherwise timed after the "
                          "headline with the same --steps / --warmup and appended as `other_configs` (DUC bf16 bs=128, HRNet-W32 bf16 bs=128, the "
                          "32-image bf16 train step)")
+    ap.add_argument("--self-check-only", action="store_true",
+                    help="rank job (N > 1): run the collective-path self-check (comm_select.self_check_rank: two small train steps through the native "
+                         "RCCL path and through torch.distributed, compared bit for bit), every rank prints the agreed verdict as one JSON line; a "
+                         "rank that cannot complete it exits 13.  Started by the supervisor (launch.run_job) under a deadline, never inside a training process")
+    ap.add_argument("--no-extra-jobs", action="store_true",
+                    help="N > 1, the driver's command (infer, dconv f32 bs=128): skip the two extra N-rank jobs that otherwise follow the headline "
+                         "job - the collective self-check and the bf16 32-image-per-GPU train step (BASELINE config 4), appended as `other_configs`")
     ap.add_argument("--by-kernel", action="store_true", help="keep the per-instantiation table (`roofline.by_kernel`) in the JSON line")
     ap.add_argument("--native-comm", action="store_true", help="train mode, N > 1: the step's collectives through our own RCCL communicators on the "
                     "step's streams (sp_comm_*) instead of torch.distributed; opt-in until it has run on a multi-GPU box")
@@ -114,8 +121,9 @@ def dry_rank(args) -> int:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     n_dev = torch.cuda.device_count()                         # (counting devices does not initialise HIP)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        init_group("gloo", rank, world)
+    if args.self_check_only or args.mode == "train":
+        return dry_extra_job(args, rank, world)
     if os.environ.get("SP_BENCH_DRY_FAIL_RANK") == str(rank):    # test hook: a rank that dies after the rendezvous
         os._exit(3)
     device = local_rank % n_dev if n_dev else None
@@ -163,6 +171,42 @@ def dry_rank(args) -> int:
                           "visible_devices": n_dev, "rank_to_device": devs, "one_device_per_rank": one_per_device,
                           "reductions_ok": ok, "config": {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "unset")}}))
     return 0 if ok else 1
+
+
+def dry_extra_job(args, rank: int, world: int) -> int:
+    """The two extra N-rank jobs of the driver's command, without a GPU (gloo): the SAME decision code with the comparison's local verdict
+    injected - SP_BENCH_TEST_SELF_CHECK = pass | fail | raise | hang (rank 1 is the odd one out; unset: the real answer over gloo, "not
+    nccl") - and a train job that only agrees on the flag it was handed and reports the path it would take."""
+    import torch.distributed as dist
+
+    from simple_pose_amd import comm_select
+    hook = os.environ.get("SP_BENCH_TEST_SELF_CHECK", "")
+    odd = rank == min(1, world - 1)
+    if args.self_check_only:
+        def check():
+            if hook == "hang" and odd:
+                time.sleep(3600.0)                             # code that has never met a peer fails by hanging
+            if hook == "raise" and odd:
+                raise RuntimeError("sp_comm_create failed (test hook)")
+            return (not (hook == "fail" and odd)), f"rank {rank}: injected verdict ({hook or 'none'})"
+        try:
+            out = comm_select.decide(None, "nccl" if hook else "gloo", bool(hook), world, self_check=check,
+                                     agree=lambda v: comm_select._agree_min(v, None))
+        except comm_select.SelfCheckError as e:
+            print(f"bench.py dry self-check: rank {rank} could not complete the comparison ({e}) - exit 13, no vote", file=sys.stderr, flush=True)
+            os._exit(13)
+        emit({"self_check_job": True, "dry_launch": True, "rank": rank, "world": world, "decision": out})
+    else:
+        mine = os.environ.get("SP_NATIVE_COMM") == "1"
+        native = comm_select._agree_min(mine, None) if world > 1 else mine
+        if rank == 0:
+            emit({"dry_launch": True, "job": "train", "n_gpus": world, "native_flag_agreed": native, "dtype": args.dtype, "steps": args.steps, "warmup": args.warmup,
+                  "collective_path": "sp_comm (RCCL on the step's streams)" if native else "torch.distributed",
+                  "collective_self_check": handed_in_decision(), "config": {"global_batch": args.batch * world}})
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
 
 
 def cpu_baseline(arch: str):
@@ -214,80 +258,167 @@ def cpu_baseline(arch: str):
                       f"best of thread counts <= {threads} on {os.cpu_count()} logical CPUs"}
 
 
-def launch_ranks(args) -> int:
-    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: this process is only a launcher.  It has
-    touched neither torch nor the GPU (a process that has initialised HIP must never be replaced or forked into ranks); it starts
-    N fresh interpreters of this same file, one per GPU, with the env:// rendezvous variables the reference's DDP solver reads
-    (processors/ddp_pose_resnet_solver.py:36,85-93: rank doubles as the device index), forwards rank 0's single JSON line and
-    returns non-zero if any rank fails."""
-    import socket
-    import subprocess
+TRAIN_JOB_CONFIG = "ResNet50-DConv 256x192 bf16 train step (fwd+bwd+Adam), batch sharded 32 images per GPU over {n} ranks (BASELINE config 4: bs=256 on 8 GPUs)"
 
-    with socket.socket() as s:                      # a free rendezvous port on the loopback interface
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+
+def wants_extra_jobs(args) -> bool:
+    """N > 1 and the command the driver runs (the headline config, nothing overridden): the supervisor then also runs the collective
+    self-check job and the N-rank train-step job, so that the first multi-GPU run measures BASELINE config 4 and proves (or safely
+    rejects) the RCCL path."""
+    return (args.gpus > 1 and args.mode == "infer" and args.arch == "dconv" and args.dtype == "f32" and args.batch == 128 and not args.graph and
+            not args.no_extra_jobs and not args.no_other_configs and not args.self_check_only)
+
+
+def _deadline(name: str, default: float) -> float:
+    return float(os.environ.get(f"SP_BENCH_{name}_DEADLINE_S", default))
+
+
+def supervise(args, managed, world: int) -> int:
+    """This process is a supervisor only: it has touched neither torch nor the GPU (a process that has initialised HIP must never be
+    replaced or forked into ranks).  `managed` = the ranks whose processes it starts: all of them (`python bench.py --gpus N`, the
+    launcher) or its own one (a worker of `python -m torch.distributed.run`, which then manages the ONE child of its rank: the N
+    supervisors meet through files in a shared directory, simple_pose_amd/launch.py).  Every job = fresh interpreters of this same file
+    with the env:// variables the reference's DDP solver reads (processors/ddp_pose_resnet_solver.py:36,85-93: rank doubles as the device
+    index), a hard wall-clock deadline, and a kill of exactly the PIDs started here.  Jobs, in order:
+
+      main         the command as given (the N inference replicas; or the train step when --mode train was asked for);
+      self_check   N > 1 train steps only: comm_select's two-path comparison as a job of its own - a hang or a dead rank there costs the
+                   deadline, not the run, and means torch.distributed for the train job;
+      train        (the driver's command only) the bf16 32-image-per-GPU train step with the decision handed in, appended to the main
+                   job's line as `other_configs`.
+
+    Rank 0's supervisor prints the ONE JSON line; the exit code is the main job's."""
+    from simple_pose_amd import launch
+
+    per_rank = len(managed) < world
+    me = managed[0] if per_rank else 0
     base = dict(os.environ)
-    base.update({"WORLD_SIZE": str(args.gpus), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": base.get("MASTER_PORT", str(port)),
-                 "LOCAL_WORLD_SIZE": str(args.gpus), "SP_BENCH_CHILD": "1"})
+    base.update({"MASTER_ADDR": base.get("MASTER_ADDR", "127.0.0.1") if per_rank else "127.0.0.1", "LOCAL_WORLD_SIZE": str(world)})
     apply_ipc_mode(args, base)
-    base.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
-    procs = []
-    for r in range(args.gpus):
-        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
-    rc = 0
-    out0 = ""
-    try:
-        # rank 0's stdout is small (one line); drain it while polling every child so that one dead rank ends the job
-        import selectors
-        sel = selectors.DefaultSelector()
-        sel.register(procs[0].stdout, selectors.EVENT_READ)
-        open0 = True
-        while True:
-            if open0:
-                for _ in sel.select(timeout=0.5):
-                    chunk = procs[0].stdout.readline()
-                    if chunk == "":
-                        open0 = False
-                        sel.unregister(procs[0].stdout)
-                    else:
-                        out0 += chunk
-            else:
-                time.sleep(0.2)
-            codes = [p.poll() for p in procs]
-            bad = [c for c in codes if c not in (None, 0)]
-            if bad:
-                rc = bad[0]
-                break
-            if all(c == 0 for c in codes):
-                break
-    finally:
-        if rc != 0:
-            # a rank died: the others usually follow within moments for the same reason (no GPU, a failed rendezvous) - let them say
-            # so themselves before anything is terminated, so that every rank's message reaches stderr
-            t_end = time.time() + 5.0
-            while time.time() < t_end and any(p.poll() is None for p in procs):
-                time.sleep(0.1)
-        for p in procs:                              # exact PIDs of the children this launcher started
-            if p.poll() is None:
-                p.terminate()
-        for p in procs:
-            try:
-                p.wait(timeout=20)
-            except Exception:
-                p.kill()
-    if procs[0].stdout and not procs[0].stdout.closed:
-        out0 += procs[0].stdout.read() or ""
-    lines = [ln for ln in out0.splitlines() if ln.lstrip().startswith("{")]
-    for ln in out0.splitlines():
-        if ln not in lines:
-            print(ln, file=sys.stderr)
-    if rc == 0 and len(lines) != 1:
-        print(f"bench.py launcher: expected ONE JSON line from rank 0, got {len(lines)}", file=sys.stderr)
+    base.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // world)))
+    share_dir = None
+    if per_rank:
+        tag = "_".join(str(base.get(k, "x")) for k in ("MASTER_PORT", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT"))
+        share_dir = os.path.join(os.environ.get("SP_BENCH_SHARE_ROOT", "/tmp"), f"sp_bench_{os.getppid()}_{tag}")
+        os.makedirs(share_dir, exist_ok=True)
+    this = [sys.executable, os.path.abspath(__file__)]
+
+    def job_env(name: str, extra=None) -> dict:
+        e = dict(base)
+        if per_rank:
+            if name != "main":           # torchrun's store belongs to ITS job (the main one, run exactly as torchrun meant it): the others meet in a FileStore
+                e["SP_BENCH_INIT_METHOD"] = "file://" + os.path.join(share_dir, f"{name}.store")
+                e.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+        else:
+            e["MASTER_PORT"] = str(launch.free_port())
+            e.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+        e.update(extra or {})
+        return e
+
+    def run(name, argv, deadline, extra=None):
+        return launch.run_job(name, this + argv, managed, world, job_env(name, extra), deadline, share_dir=share_dir, capture_rank=me)
+
+    def agreed(check_job):
+        """The self-check job's outcome as the decision every supervisor arrives at."""
+        if not per_rank:
+            return launch.collective_decision(check_job)
+        launch.publish(share_dir, "decision", me, launch.collective_decision(check_job))
+        return launch.collective_decision(check_job, launch.gather(share_dir, "decision", world, wait_s=60.0))
+
+    common = (["--dist-backend", args.dist_backend, "--hsa-ipc-legacy", args.hsa_ipc_legacy] + (["--dry-launch"] if args.dry_launch else []) +
+              (["--no-sync-bn"] if args.no_sync_bn else []) + ["--bucket-mb", str(args.bucket_mb)])
+    check_argv = ["--gpus", str(world), "--self-check-only", "--mode", "train", "--dtype", "bf16", "--batch", "32"] + common
+    auto_route = not (args.torch_collectives or args.native_comm or os.environ.get("SP_NATIVE_COMM") in ("0", "1"))
+
+    main_extra = {}
+    if args.mode == "train" and auto_route and not args.self_check_only and not args.dry_launch:
+        # a train job asked for by hand: prove (or reject) the native path first, in a job of its own, then hand the verdict in
+        dec = agreed(run("self_check", check_argv, _deadline("CHECK", 300.0)))
+        main_extra = {"SP_NATIVE_COMM": "1" if dec["native"] else "0", "SP_COLLECTIVE_DECISION": json.dumps(dec)}
+    job = run("main", sys.argv[1:], _deadline("MAIN", 1800.0), main_extra)
+    line = launch.last_json(job)
+    rc = 0 if job["status"] == "ok" else (job["rc"] or 1)
+    if job["status"] != "ok":
+        print(f"bench.py supervisor: the main job {job['status']}: {job['detail']}", file=sys.stderr)
+    elif me == 0 and (line is None or len(job["lines"]) != 1):
+        print(f"bench.py supervisor: expected ONE JSON line from rank 0, got {len(job['lines'])}", file=sys.stderr)
         rc = 1
-    if lines:
-        print(lines[-1], flush=True)
+    if rc == 0 and wants_extra_jobs(args):
+        dec = agreed(run("self_check", check_argv, _deadline("CHECK", 300.0)))
+        train_argv = ["--gpus", str(world), "--mode", "train", "--dtype", "bf16", "--batch", "32", "--steps", str(args.steps), "--warmup", str(args.warmup),
+                      "--no-cpu-baseline", "--no-other-configs"] + common
+        tjob = run("train", train_argv, _deadline("TRAIN", 420.0),
+                   {"SP_NATIVE_COMM": "1" if dec["native"] else "0", "SP_COLLECTIVE_DECISION": json.dumps(dec)})
+        rec = {"config": TRAIN_JOB_CONFIG.format(n=world), "n_gpus": world, "command": "python3 bench.py " + " ".join(train_argv),
+               "job": {"status": tjob["status"], "wall_s": tjob["wall_s"]}, "collective_self_check": dec}
+        tl = launch.last_json(tjob)
+        if tjob["status"] == "ok" and tl is not None:
+            for k in ("value", "unit", "ms_per_step", "dtype", "steps", "warmup", "step_split_ms", "collective_path", "collectives_per_step",
+                      "host_enqueue_ms_per_step", "network_frac_of_matrix_peak", "rccl_census", "dry_launch", "native_flag_agreed"):
+                if k in tl:
+                    rec[k] = tl[k]
+            rec["global_batch"] = (tl.get("config") or {}).get("global_batch")
+            rec["rccl"] = (tl.get("config") or {}).get("rccl")
+            rec["roofline_frac"] = (tl.get("roofline") or {}).get("frac")
+        else:
+            rec["error"] = f"train job {tjob['status']}: {tjob['detail'] or 'no JSON line from rank 0'}"
+        if line is not None:
+            line["other_configs"] = [rec]                      # LAST key of the one line
+    if me == 0 and line is not None:
+        print(json.dumps(line), flush=True)
+    if per_rank:
+        launch.publish(share_dir, "done", me, {"rc": rc})
+        if me == 0:                                            # rank 0 tidies up once every supervisor has said it is done (bounded wait)
+            launch.gather(share_dir, "done", world, wait_s=30.0)
+            import shutil
+            shutil.rmtree(share_dir, ignore_errors=True)
+    return rc
+
+
+def init_group(backend: str, rank: int, world: int, dev_index=None) -> None:
+    """The job's process group: env:// on 127.0.0.1 (RANK / WORLD_SIZE / MASTER_* as the reference's solver reads them), or the init method
+    the supervisor handed in (SP_BENCH_INIT_METHOD: a FileStore for the extra jobs under torchrun, whose own store belongs to its job)."""
+    import torch
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    kw = {"init_method": os.environ["SP_BENCH_INIT_METHOD"]} if os.environ.get("SP_BENCH_INIT_METHOD") else {}
+    if backend == "nccl":
+        kw["device_id"] = torch.device("cuda", dev_index)
+    dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+
+
+def handed_in_decision():
+    """The self-check job's verdict as the supervisor handed it to this rank (SP_COLLECTIVE_DECISION), or None."""
+    try:
+        return json.loads(os.environ["SP_COLLECTIVE_DECISION"])
+    except (KeyError, ValueError):
+        return None
+
+
+def self_check_rank_job(args, rank: int, world: int, dev_index: int) -> int:
+    """One rank of `bench.py --gpus N --self-check-only` on the GPU: the model of the train job on this rank's device, then
+    comm_select.self_check_rank (which exits 13 itself when the comparison cannot complete)."""
+    import torch
+    import torch.distributed as dist
+
+    from simple_pose_amd import _lib, comm_select, synth
+    from simple_pose_amd.nets import pose_resnet_dconv
+
+    if world < 2:
+        raise SystemExit("--self-check-only is a rank job of an N > 1 run")
+    _lib.lib()
+    torch.cuda.set_device(dev_index)
+    init_group(args.dist_backend, rank, world, dev_index)
+    dev = torch.device("cuda", dev_index)
+    model = pose_resnet_dconv.resnet50(pretrained=False, num_classes=17)
+    layout = [(k, tuple(v.shape), str(v.dtype)) for k, v in model.state_dict().items()]
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.conditioned_state_dict(layout, seed=0).items()}, strict=True)
+    model = model.to(dev).train()
+    rc = comm_select.self_check_rank(model, "bf16" if args.dtype == "bf16" else "fp32", not args.no_sync_bn, emit=emit)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dist.destroy_process_group()
     return rc
 
 
@@ -313,8 +444,13 @@ def emit(obj) -> None:
 
 def main():
     args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(launch_ranks(args))        # before torch is imported or the GPU is touched
+    if args.gpus > 1 and os.environ.get("SP_BENCH_CHILD") != "1":     # before torch is imported or the GPU is touched
+        if "WORLD_SIZE" not in os.environ:
+            raise SystemExit(supervise(args, list(range(args.gpus)), args.gpus))       # `python bench.py --gpus N`: the launcher of all N ranks
+        if wants_extra_jobs(args) and int(os.environ["WORLD_SIZE"]) == args.gpus:
+            # a worker of `python -m torch.distributed.run` given the driver's command: it becomes the supervisor of its own rank, so that
+            # the self-check and the train-step job run here too, each with a deadline (any other command runs in this process, as given)
+            raise SystemExit(supervise(args, [int(os.environ.get("RANK", "0"))], args.gpus))
     claim_stdout()
     ipc_mode = apply_ipc_mode(args, os.environ)         # before the first HIP call (default 0: dmabuf IPC, the only mode this pool's driver has)
     if args.dry_launch:
@@ -339,18 +475,16 @@ def main():
         raise SystemExit(f"--gpus {world} on a node with {n_dev} GPU(s): RCCL needs one device per rank "
                          "(--dist-backend gloo shares devices, for exercising the N > 1 path only)")
     dev_index = local_rank % n_dev
+    if args.self_check_only:
+        raise SystemExit(self_check_rank_job(args, rank, world, dev_index))
     if world == 1 and args.preflight_rccl:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(29000 + os.getpid() % 2000))
         torch.cuda.set_device(dev_index)
         dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", dev_index))
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(dev_index)
-        if args.dist_backend == "nccl":
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        init_group(args.dist_backend, rank, world, dev_index)
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
     red_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")   # where the measurement's scalar reductions live
@@ -390,10 +524,12 @@ def main():
         emit(line)
     if abandoned:
         # the measurement is complete and printed; the diagnostic that hung is named in the line (`rccl_census`, `config.rccl.error`) and on
-        # stderr.  SP_CENSUS_STRICT=1 turns it into a failing exit code (4) for callers that want the census to gate the run.
+        # stderr.  At N > 1 that is a failing exit code (4): a job whose ranks could not be counted must not read as a success
+        # (SP_CENSUS_STRICT=0 turns that off; =1 turns it on for the 1-rank preflight group too).
         print(f"bench.py rank {rank}: RCCL communicator census abandoned after 120 s (line printed; see config.rccl.error)", file=sys.stderr)
         sys.stderr.flush()
-        os._exit(4 if os.environ.get("SP_CENSUS_STRICT", "0") == "1" else 0)
+        strict = os.environ.get("SP_CENSUS_STRICT", "1" if world > 1 else "0") == "1"
+        os._exit(4 if strict else 0)
     if world > 1:
         dist.destroy_process_group()
 
@@ -680,7 +816,8 @@ def run_once(args, ctx):
                 "host_enqueue_ms_per_step": round(host_enqueue_ms, 3), "sync_bn_latency_us_emulated": args.sync_bn_latency_us,
                 "step_as_hip_graph": bool(args.graph), "rccl_preflight_one_rank": bool(args.preflight_rccl and world == 1),
                 "collective_path": "torch.distributed" if (args.torch_collectives or trainer._comm is None and world > 1) else ("sp_comm (RCCL on the step's streams)" if trainer._comm is not None else "none"),
-                "collective_self_check": {k: coll[k] for k in ("path", "reason", "self_check")},
+                # N > 1: the verdict of the supervised self-check job when one was handed in (what decided), else this process's own decision
+                "collective_self_check": handed_in_decision() or {k: coll[k] for k in ("path", "reason", "self_check")},
                 "collectives_per_step": {"gradient_buckets": len(trainer.buckets) if world > 1 else 0, "sync_bn": trainer.collective_count}}
         else:
             peak = FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else BF16_MATRIX_PEAK_TFLOPS

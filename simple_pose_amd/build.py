@@ -43,22 +43,30 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    objs = []
+    objs, todo = [], []
     last_build.update(reused=0)
     for src in sources():
         obj = os.path.join(LIB_DIR, os.path.basename(src)[:-4] + ".o")
         if force or not os.path.isfile(obj) or os.path.getmtime(obj) < max(
                 [os.path.getmtime(src)] + [os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, "*.h")) +
                                            glob.glob(os.path.join(ROOT, "include", "*.h"))]):
-            cmd = [HIPCC, "-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-c",
-                   "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, src, "-o", obj]
-            if verbose:
-                print(" ".join(cmd), file=sys.stderr)
-            subprocess.run(cmd, check=True)
-            last_build["compiled"] += 1
+            todo.append([HIPCC, "-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-c",
+                         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, src, "-o", obj])
         else:
             last_build["reused"] += 1
         objs.append(obj)
+
+    def compile_one(cmd):
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+
+    if todo:                                   # independent translation units: a few hipcc processes side by side (SP_BUILD_JOBS, default 4)
+        from concurrent.futures import ThreadPoolExecutor
+        jobs = max(1, min(int(os.environ.get("SP_BUILD_JOBS", "4")), len(todo)))
+        with ThreadPoolExecutor(jobs) as pool:
+            list(pool.map(compile_one, todo))
+        last_build["compiled"] += len(todo)
     cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

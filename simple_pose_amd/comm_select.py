@@ -8,12 +8,21 @@ processors/ddp_pose_resnet_solver.py:36,89-93):
   * "torch.distributed"  the process group's collectives (one communicator on RCCL's own stream, five stream / event calls per message
                          from Python: with SyncBatchNorm on the step is host-bound).
 
-The native path is the design, but it has never met a second rank on this pool's 1-GPU boxes.  So nobody has to trust it: when a peer
-exists (world >= 2 over an nccl group) `select()` runs the comparison that `tests/test_gpu_train.py::test_two_rank_rccl_*` runs - a few
-small steps through BOTH paths from identical state, parameters / BatchNorm buffers compared bit for bit on every rank, the verdict agreed
-over the group - and takes the native path only if it reproduced torch.distributed exactly.  Anything else falls back, with the reason
-logged and carried in bench.py's line (`collective_self_check`).  The decision logic is pure (no GPU): `decide()`; covered over gloo with
-two ranks in tests/test_multi_rank_cpu.py.
+The native path is the design, but it has never met a second rank on this pool's 1-GPU boxes.  So nobody has to trust it: the comparison
+that `tests/test_gpu_train.py::test_two_rank_rccl_*` runs - a few small steps through BOTH paths from identical state, parameters / Adam
+moments / BatchNorm buffers compared bit for bit on every rank, the verdict agreed over the group - decides, and the native path is taken
+only if it reproduced torch.distributed exactly.
+
+Where the comparison runs (round 6): in a JOB OF ITS OWN - N fresh rank processes under a supervisor that has not touched the GPU
+(`simple_pose_amd.launch.run_job`, from `bench.py --gpus N` or `python -m simple_pose_amd.comm_select --gpus N`) with a hard deadline.  Code
+that has never met a peer fails by hanging, and a rank that raises while its peers are inside a collective cannot vote: so a rank that
+cannot complete the comparison EXITS NON-ZERO (`SelfCheckError`; it never joins an agreement from an except path), the supervisor ends
+the other ranks, and a job that died or outlived its deadline means torch.distributed, with the reason carried in bench.py's line
+(`collective_self_check`).  The job's verdict reaches the real job as SP_NATIVE_COMM=0|1; `select()` only honours it after the ranks
+agreed on it (MIN).  Without that variable a plain `select()` inside a rank takes torch.distributed: nothing unproven, and nothing
+without a deadline, runs inside a training process (SP_SELF_CHECK_INPROCESS=1 restores the in-process check for debugging).
+The decision logic is pure (no GPU): `decide()` and `launch.collective_decision()`; covered over gloo in tests/test_multi_rank_cpu.py
+and tests/test_host_logic.py.
 """
 from __future__ import annotations
 
@@ -21,6 +30,11 @@ import copy
 import os
 import sys
 from typing import Callable, Optional, Tuple
+
+
+class SelfCheckError(RuntimeError):
+    """This rank could not complete the two-path comparison.  Peers may be inside a collective at this moment, so the rank must not vote:
+    it leaves (non-zero exit in the self-check job) and the supervisor ends the job."""
 
 
 def _agree_min(ok: bool, group) -> bool:
@@ -41,6 +55,9 @@ def decide(requested: Optional[bool], backend: str, rccl_available: bool, world:
     requested   True: the caller insists on the native path (raises when it cannot exist); False: torch.distributed; None: automatic.
     backend     the process group's backend name ("nccl" is RCCL on ROCm); rccl_available: `sp_comm_available()`.
     self_check  () -> (this rank's verdict, detail): runs the two-path comparison; only called on the automatic route when a peer exists.
+                It returns only after this rank's collectives have completed; if it raises, the exception propagates as SelfCheckError
+                and NO agreement is attempted (peers may be mid-step: an all-reduce issued from the except path would pair with their
+                gradient bucket or hang) - the caller is a rank of the supervised self-check job and exits non-zero.
     agree       (local verdict) -> global verdict (every rank must pass; default: all-reduce MIN over the default group).
     Every rank must call this with the same arguments at the same point (the self-check and the agreement are collectives)."""
     if world <= 1:
@@ -59,8 +76,10 @@ def decide(requested: Optional[bool], backend: str, rccl_available: bool, world:
         return {"path": "torch.distributed", "native": False, "reason": "no self-check available: the native path is taken only when proven", "self_check": "not run"}
     try:
         ok, detail = self_check()
-    except Exception as e:                                   # a rank that cannot even run the comparison votes no; the others follow
-        ok, detail = False, f"{type(e).__name__}: {e}"[:300]
+    except SelfCheckError:
+        raise
+    except Exception as e:
+        raise SelfCheckError(f"{type(e).__name__}: {e}"[:300]) from e
     all_ok = (agree or (lambda v: _agree_min(v, None)))(bool(ok))
     if all_ok:
         return {"path": "sp_comm", "native": True, "reason": "start-up self-check passed on every rank", "self_check": f"passed: {detail}"}
@@ -87,8 +106,11 @@ def two_path_self_check(model, group, in_h: int, in_w: int, dtype: str, sync_bn:
         if in_h > 256 or in_w > 192:
             raise ValueError("self-check inputs are crops of the 256x192 synthetic images")
         x = x[:, :, :in_h, :in_w].contiguous()
-    joints = torch.from_numpy(synth.joints_batch(images, 17, seed=4200 + rank)).to(dev)
+    n_joints = int(model.final_layer.out_channels)           # (DDPProcessor builds the net with model_cfg["num_joints"])
+    joints = torch.from_numpy(synth.joints_batch(images, n_joints, seed=4200 + rank)).to(dev)
     targets, mask = RefineSimpleTransform.get_heat_map(joints, 2.0, (in_w // 4, in_h // 4))
+    if tuple(targets.shape) != (images, n_joints, in_h // 4, in_w // 4) or tuple(mask.shape) != (images, n_joints):
+        raise ValueError(f"self-check targets {tuple(targets.shape)} / mask {tuple(mask.shape)} do not match {images} x {n_joints} joints")
     kw = dict(trainer_kwargs or {})
     results = []
     for native in (True, False):
@@ -124,8 +146,13 @@ def two_path_self_check(model, group, in_h: int, in_w: int, dtype: str, sync_bn:
 
 
 def select(model, group=None, in_h: int = 256, in_w: int = 192, dtype: str = "fp32", sync_bn: bool = True, requested: Optional[bool] = None,
-           log=None) -> dict:
-    """Decide for this job (collective call: every rank).  `requested` None also honours SP_NATIVE_COMM=1 / =0 in the environment."""
+           log=None, run_self_check: Optional[bool] = None) -> dict:
+    """Decide for this job (collective call: every rank, at the same point, before the first step).
+
+    requested None is the automatic route.  It honours SP_NATIVE_COMM=0|1 - the verdict of the supervised self-check JOB - after the ranks
+    agreed on it (all-reduce MIN: a rank whose supervisor saw a different outcome must not open communicators the others do not).
+    The two-path comparison itself runs here only when `run_self_check` is True (the rank entry of the self-check job, `self_check_rank`)
+    or SP_SELF_CHECK_INPROCESS=1: it has no deadline of its own."""
     import torch.distributed as dist
 
     from . import _lib
@@ -133,12 +160,83 @@ def select(model, group=None, in_h: int = 256, in_w: int = 192, dtype: str = "fp
     if not (dist.is_available() and dist.is_initialized()):
         return decide(requested, "none", False, 1)
     world = dist.get_world_size(group)
-    if requested is None and os.environ.get("SP_NATIVE_COMM") in ("0", "1"):
-        requested = os.environ["SP_NATIVE_COMM"] == "1"
     backend = dist.get_backend(group)
+    from_env = None
+    if requested is None and world > 1 and os.environ.get("SP_NATIVE_COMM") in ("0", "1"):
+        mine = os.environ["SP_NATIVE_COMM"] == "1"
+        requested = _agree_min(mine, group)
+        from_env = ("SP_NATIVE_COMM=1 on every rank" if requested else
+                    ("SP_NATIVE_COMM=0" if not mine else "SP_NATIVE_COMM=1 here but 0 on another rank"))
+        if requested and not (backend == "nccl" and _lib.lib().sp_comm_available()):
+            requested, from_env = False, f"SP_NATIVE_COMM=1 but the native path cannot exist here (backend {backend!r})"
+    if run_self_check is None:
+        run_self_check = os.environ.get("SP_SELF_CHECK_INPROCESS", "0") == "1"
+    check = (lambda: two_path_self_check(model, group, in_h, in_w, dtype, sync_bn)) if run_self_check else None
     out = decide(requested, backend, bool(_lib.lib().sp_comm_available()) if backend == "nccl" else False, world,
-                 self_check=lambda: two_path_self_check(model, group, in_h, in_w, dtype, sync_bn),
-                 agree=lambda v: _agree_min(v, group))
+                 self_check=check, agree=lambda v: _agree_min(v, group))
+    if from_env is not None:
+        out["reason"] = f"{from_env} (the self-check job's verdict, agreed over the group)"
+    elif check is None and out["reason"].startswith("no self-check available"):
+        out["reason"] = ("not proven for this job: the two-path self-check runs as a supervised job of its own (bench.py --gpus N, or "
+                         "python -m simple_pose_amd.comm_select --gpus N) and hands its verdict over as SP_NATIVE_COMM")
     if dist.get_rank(group) == 0:
         print(f"[simple_pose_amd] collectives: {out['path']} ({out['reason']}; self-check {out['self_check']})", file=log or sys.stderr, flush=True)
     return out
+
+
+# ------------------------------------------------------------------------------------------------ the self-check as a job of its own
+def self_check_rank(model, dtype: str = "bf16", sync_bn: bool = True, in_h: int = 256, in_w: int = 192, emit=None) -> int:
+    """One rank of the self-check job (process group already initialised, `model` on this rank's device): run the comparison, agree, and
+    have EVERY rank write the verdict as one JSON line (`emit`, default stdout) - each supervisor reads its own rank's line.
+    A rank that cannot complete the comparison does not return: it reports on stderr and leaves with exit code 13, so that the
+    supervisor ends the job (`launch.run_job`: status "died")."""
+    import json
+    import traceback
+
+    import torch.distributed as dist
+
+    rank = dist.get_rank()
+    try:
+        out = select(model, None, in_h, in_w, dtype, sync_bn, requested=None, run_self_check=True)
+    except BaseException:
+        traceback.print_exc()
+        print(f"[simple_pose_amd] self-check: rank {rank} could not complete the comparison - leaving (exit 13), no vote", file=sys.stderr, flush=True)
+        sys.stderr.flush()
+        os._exit(13)
+    line = {"self_check_job": True, "rank": rank, "world": dist.get_world_size(), "decision": out}
+    if emit is None:
+        print(json.dumps(line), flush=True)
+    else:
+        emit(line)
+    return 0
+
+
+def run_self_check_job(n_ranks: int, argv: Optional[list] = None, deadline_s: float = 300.0, env: Optional[dict] = None) -> dict:
+    """From a process that has NOT touched the GPU: start the self-check job (`n_ranks` fresh interpreters of bench.py --self-check-only,
+    or `argv`), bounded by `deadline_s`, and turn its outcome into the decision (`launch.collective_decision`)."""
+    from . import launch
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    argv = argv or [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n_ranks), "--self-check-only", "--mode", "train", "--dtype", "bf16",
+                    "--batch", "32"]
+    e = dict(env if env is not None else os.environ)
+    e.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(launch.free_port())})
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("SP_NATIVE_COMM", "TORCHELASTIC_USE_AGENT_STORE"):
+        e.pop(k, None)
+    job = launch.run_job("self_check", argv, list(range(n_ranks)), n_ranks, e, deadline_s)
+    return launch.collective_decision(job)
+
+
+if __name__ == "__main__":
+    import argparse
+    import json
+
+    ap = argparse.ArgumentParser(description="Run the collective-path self-check as a supervised N-rank job and print its verdict "
+                                             "(export SP_NATIVE_COMM accordingly before starting the training job).")
+    ap.add_argument("--gpus", type=int, required=True)
+    ap.add_argument("--deadline", type=float, default=300.0)
+    a = ap.parse_args()
+    d = run_self_check_job(a.gpus, deadline_s=a.deadline)
+    print(json.dumps(d))
+    print(f"export SP_NATIVE_COMM={1 if d['native'] else 0}", file=sys.stderr)

@@ -1053,55 +1053,61 @@ struct PackJobDev {
 //      row of its own - 2.3-3.5x the compulsory sectors (the repack moved 680 MB per step for 408 MB of compulsory bytes).  Here a tile of
 //      32 i3 values x tile0 i0 values is read as 32 contiguous runs of tile0 * s[0] floats (the (i0, taps) blocks of one i3 are adjacent
 //      in the source), parked in LDS with an odd row pitch, and written with i3 fastest: 64 / 128-byte runs both ways.
+// Walk 3 lives in a kernel of its own (round 6): its 40 KB tile buffer would otherwise be reserved by EVERY repack launch - 3 workgroups
+// per CU instead of 8 for the bandwidth-bound walks 0-2 that the default repack uses.  Jobs of other walks in a tiled launch, and walk-3
+// jobs in a plain launch (treated as walk 1: the same gather-copy), stay correct.
+template <bool TILED>
 __global__ void permute4_batched_kernel(const float* __restrict__ src, const PackJobDev* __restrict__ jobs) {
     const PackJobDev pm = jobs[blockIdx.y];
     auto put = [&](long long i, float v) __attribute__((always_inline)) {
         if (pm.dst_bf16) reinterpret_cast<__bf16*>(pm.dst_ptr)[i] = (__bf16)v;
         else reinterpret_cast<float*>(pm.dst_ptr)[i] = v;
     };
-    if (pm.pad == 3) {
-        constexpr int T3 = 32, BUF = 10240;
-        __shared__ float buf[BUF];
-        __shared__ int tap_src[32], tap_dst[32];           // per destination tap: offset inside the source block (-1: zero fill), (i1 * d2 + i2) * d3
-        const int span = (int)pm.s[0], T0 = pm.tile0, run = T0 * span, pitch = run | 1;     // (host: 32 * (T0 * span | 1) <= BUF)
-        const int taps = pm.d[1] * pm.d[2];                 // (host: <= 32)
-        if (threadIdx.x < taps) {
-            const int i1 = threadIdx.x / pm.d[2], i2 = threadIdx.x - i1 * pm.d[2];
-            tap_src[threadIdx.x] = (i1 < pm.lim[1] && i2 < pm.lim[2]) ? (int)(i1 * pm.s[1] + i2 * pm.s[2]) - pm.tap0 : -1;
-            tap_dst[threadIdx.x] = (i1 * pm.d[2] + i2) * pm.d[3];
-        }
-        const int t0n = (pm.d[0] + T0 - 1) / T0, t3n = (pm.d[3] + T3 - 1) / T3;
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-        const int r3s = threadIdx.x & (T3 - 1), sub = threadIdx.x >> 5, nsub = blockDim.x >> 5;
-        for (int tl = blockIdx.x; tl < t0n * t3n; tl += gridDim.x) {
-            const int a0 = (tl % t0n) * T0, a3 = (tl / t0n) * T3;
-            // load: wave w takes rows w, w + 4, ...; a row is one contiguous run of the source (no per-element index arithmetic)
-            const int kmax = max(0, min(T0, pm.lim[0] - a0)) * span;      // floats of the run that belong to valid i0
-            for (int r3 = wave; r3 < T3; r3 += nw) {
-                const bool row_ok = a3 + r3 < pm.lim[3];
-                const float* row = src + pm.base + pm.tap0 + (long long)a0 * pm.s[0] + (long long)(a3 + r3) * pm.s[3];
-                for (int k = lane; k < run; k += 64) buf[r3 * pitch + k] = (row_ok && k < kmax) ? row[k] : 0.f;
-            }
-            __syncthreads();
-            // store: thread = (i3 lane, one of 8 (i0, tap) walkers); (cl, tp) advance without divisions
-            const int i3 = a3 + r3s;
-            int cl = 0, tp = sub;
-            while (tp >= taps) { tp -= taps; ++cl; }
-            for (; cl < T0; ) {
-                const int i0 = a0 + cl;
-                if (i0 < pm.d[0] && i3 < pm.d[3]) {
-                    const int so = tap_src[tp];
-                    const float v = (so >= 0 && i0 < pm.lim[0] && i3 < pm.lim[3]) ? buf[r3s * pitch + cl * span + so] : 0.f;
-                    put((long long)i0 * taps * pm.d[3] + tap_dst[tp] + i3, v);
-                }
-                tp += nsub;
-                while (tp >= taps) { tp -= taps; ++cl; }
-            }
-            __syncthreads();
-        }
+    if constexpr (TILED) {
+      if (pm.pad == 3) {
+          constexpr int T3 = 32, BUF = 10240;
+          __shared__ float buf[BUF];
+          __shared__ int tap_src[32], tap_dst[32];           // per destination tap: offset inside the source block (-1: zero fill), (i1 * d2 + i2) * d3
+          const int span = (int)pm.s[0], T0 = pm.tile0, run = T0 * span, pitch = run | 1;     // (host: 32 * (T0 * span | 1) <= BUF)
+          const int taps = pm.d[1] * pm.d[2];                 // (host: <= 32)
+          if (threadIdx.x < taps) {
+              const int i1 = threadIdx.x / pm.d[2], i2 = threadIdx.x - i1 * pm.d[2];
+              tap_src[threadIdx.x] = (i1 < pm.lim[1] && i2 < pm.lim[2]) ? (int)(i1 * pm.s[1] + i2 * pm.s[2]) - pm.tap0 : -1;
+              tap_dst[threadIdx.x] = (i1 * pm.d[2] + i2) * pm.d[3];
+          }
+          const int t0n = (pm.d[0] + T0 - 1) / T0, t3n = (pm.d[3] + T3 - 1) / T3;
+          const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+          const int r3s = threadIdx.x & (T3 - 1), sub = threadIdx.x >> 5, nsub = blockDim.x >> 5;
+          for (int tl = blockIdx.x; tl < t0n * t3n; tl += gridDim.x) {
+              const int a0 = (tl % t0n) * T0, a3 = (tl / t0n) * T3;
+              // load: wave w takes rows w, w + 4, ...; a row is one contiguous run of the source (no per-element index arithmetic)
+              const int kmax = max(0, min(T0, pm.lim[0] - a0)) * span;      // floats of the run that belong to valid i0
+              for (int r3 = wave; r3 < T3; r3 += nw) {
+                  const bool row_ok = a3 + r3 < pm.lim[3];
+                  const float* row = src + pm.base + pm.tap0 + (long long)a0 * pm.s[0] + (long long)(a3 + r3) * pm.s[3];
+                  for (int k = lane; k < run; k += 64) buf[r3 * pitch + k] = (row_ok && k < kmax) ? row[k] : 0.f;
+              }
+              __syncthreads();
+              // store: thread = (i3 lane, one of 8 (i0, tap) walkers); (cl, tp) advance without divisions
+              const int i3 = a3 + r3s;
+              int cl = 0, tp = sub;
+              while (tp >= taps) { tp -= taps; ++cl; }
+              for (; cl < T0; ) {
+                  const int i0 = a0 + cl;
+                  if (i0 < pm.d[0] && i3 < pm.d[3]) {
+                      const int so = tap_src[tp];
+                      const float v = (so >= 0 && i0 < pm.lim[0] && i3 < pm.lim[3]) ? buf[r3s * pitch + cl * span + so] : 0.f;
+                      put((long long)i0 * taps * pm.d[3] + tap_dst[tp] + i3, v);
+                  }
+                  tp += nsub;
+                  while (tp >= taps) { tp -= taps; ++cl; }
+              }
+              __syncthreads();
+          }
         return;
+      }
     }
-    if (pm.pad == 1) {
+    if (pm.pad == 1 || pm.pad == 3) {
         const long long pairs = (long long)pm.d[0] * pm.d[3];
         const int taps = pm.d[1] * pm.d[2];
         for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < pairs; t += (long long)gridDim.x * blockDim.x) {
@@ -1157,9 +1163,16 @@ __global__ void permute4_batched_kernel(const float* __restrict__ src, const Pac
 
 extern "C" int sp_permute4_batched(const float* src, const void* jobs_device, int n_jobs, int blocks_per_job, void* stream) {
     SP_REQUIRE(src && jobs_device && n_jobs > 0 && n_jobs <= 65535 && blocks_per_job > 0, "sp_permute4_batched: bad argument");
-    hipLaunchKernelGGL(permute4_batched_kernel, dim3(blocks_per_job, n_jobs), dim3(256), 0, (hipStream_t)stream, src,
+    hipLaunchKernelGGL(permute4_batched_kernel<false>, dim3(blocks_per_job, n_jobs), dim3(256), 0, (hipStream_t)stream, src,
                        reinterpret_cast<const PackJobDev*>(jobs_device));
     return sp_check_launch("permute4_batched_kernel");
+}
+
+extern "C" int sp_permute4_batched_tiled(const float* src, const void* jobs_device, int n_jobs, int blocks_per_job, void* stream) {
+    SP_REQUIRE(src && jobs_device && n_jobs > 0 && n_jobs <= 65535 && blocks_per_job > 0, "sp_permute4_batched_tiled: bad argument");
+    hipLaunchKernelGGL(permute4_batched_kernel<true>, dim3(blocks_per_job, n_jobs), dim3(256), 0, (hipStream_t)stream, src,
+                       reinterpret_cast<const PackJobDev*>(jobs_device));
+    return sp_check_launch("permute4_batched_kernel<tiled>");
 }
 
 extern "C" int sp_bn_train_stats_nhwc(const void* z, int bf16, int64_t rows, int c, float eps, float momentum, float* mean, float* invstd,

@@ -1008,14 +1008,16 @@ class PoseTrainer:
                     # filters packed transposed go through LDS tiles, the rest (sources contiguous along the last index) in destination order
                     walk = 1 if j.dims[1] * j.dims[2] > 1 else (2 if abs(j.strides[0]) == 1 and abs(j.strides[3]) > 1 else 0)
                     tap0 = tile0 = 0
-                    if walk == 1 and self.repack_tiled and 0 < j.strides[0] < abs(j.strides[3]) and j.strides[0] * 32 + 1 <= 320 and j.dims[1] * j.dims[2] <= 32:
+                    if walk == 1 and self.repack_tiled and 0 < j.strides[0] < abs(j.strides[3]) and 32 * (j.strides[0] | 1) <= 10240 and j.dims[1] * j.dims[2] <= 32:
                         # the fastest destination index is the source's slowest (dgrad packs of k > 1 convs, a transposed conv's phase packs):
-                        # tiles through LDS, coalesced both ways (sp_permute4_batched walk 3).  `j.base` is the tap offset inside an
-                        # (i0, i3) pair's block of strides[0] source floats.
+                        # tiles through LDS, coalesced both ways (sp_permute4_batched_tiled walk 3).  `j.base` is the tap offset inside an
+                        # (i0, i3) pair's block of strides[0] source floats (9 for a 3x3 filter, 16 for a transposed conv's 4x4: the gate
+                        # above admits any block of which at least ONE i0 row per i3 fits the 40 KB tile; tile0 = how many do).
                         walk, tap0 = 3, -int(j.base)
                         tile0 = 32
                         while 32 * ((tile0 * j.strides[0]) | 1) > 10240:
                             tile0 //= 2
+                        assert tile0 >= 1
                     rows.append(((n0,) + tuple(j.dims[1:]), j.strides, (max(0, min(n0, j.valid[0] - r0)),) + tuple(j.valid[1:]),
                                  o + j.base + r0 * j.strides[0], j.dst.data_ptr() + (j.dst_off + r0 * inner) * es, n0 * inner,
                                  int(j.dst.dtype == torch.bfloat16), walk, tap0, tile0))
@@ -1027,6 +1029,7 @@ class PoseTrainer:
             assert rec.itemsize == 104, rec.itemsize
             self._pack_table = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(self.flat.data.device)
             self._pack_n = len(rows)
+            self._pack_tiled = any(r[7] == 3 for r in rows)    # walk 3 needs the launch that owns the 40 KB LDS tile (sp_permute4_batched_tiled)
             # rows are in parameter order: the rows that read from a gradient bucket's slice of the flat buffer are one range
             self._pack_rows_of_bucket = []
             src_off = [int(r[3]) for r in rows]
@@ -1039,8 +1042,8 @@ class PoseTrainer:
             self._packed_version = self._param_version()
         if hi > lo:
             tab = _lib.c_void_p(self._pack_table.data_ptr() + 104 * lo)
-            _lib.check(_lib.lib().sp_permute4_batched(P(self.flat.data), tab, hi - lo, 8, stream if stream is not None else _lib.current_stream()),
-                       "repack")
+            launch = _lib.lib().sp_permute4_batched_tiled if self._pack_tiled else _lib.lib().sp_permute4_batched
+            _lib.check(launch(P(self.flat.data), tab, hi - lo, 8, stream if stream is not None else _lib.current_stream()), "repack")
 
     # ---- per-layer tile choice -----------------------------------------------------------------------------------------------
     def autotune(self, batch: int, reps: int = 5, rounds: int = 3) -> Dict[str, tuple]:

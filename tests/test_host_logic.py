@@ -345,8 +345,79 @@ def test_bench_dry_launch_eight_ranks_over_gloo():
     assert plan["communicators"] == 1
     n_dev = torch.cuda.device_count()
     assert d["one_device_per_rank"] == (n_dev >= 8)
+    assert "other_configs" not in d                              # (not the driver's command: --batch 32; the three-job flow is the next test)
     r = subprocess.run(cmd + ["--hsa-ipc-legacy", "1"], env=dict(env, SP_BENCH_DRY_FAIL_RANK="5"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 3 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def _dry_three_jobs(n, hook, torchrun=False, deadline="25"):
+    import json
+    import subprocess
+    import sys
+    import time
+
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "SP_BENCH_DRY_FAIL_RANK", "SP_NATIVE_COMM", "SP_BENCH_CHILD"):
+        env.pop(k, None)
+    env.update(SP_BENCH_TEST_SELF_CHECK=hook, SP_BENCH_CHECK_DEADLINE_S=deadline)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--dry-launch", "--steps", "3", "--warmup", "1"]
+    if torchrun:
+        from simple_pose_amd.launch import free_port
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port())] + tail
+    else:
+        cmd = [sys.executable] + tail
+    t0 = time.time()
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    wall = time.time() - t0
+    assert r.returncode == 0, r.stderr[-3000:]                 # the headline's exit code: whatever became of the extra jobs
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["dry_launch"] and d["n_ranks"] == n and d["reductions_ok"]
+    assert list(d)[-1] == "other_configs" and len(d["other_configs"]) == 1
+    return d["other_configs"][0], wall
+
+
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_dry_launch_runs_the_three_jobs_with_deadlines(n):
+    """The driver's command at N > 1 (`bench.py --gpus N`, nothing overridden), over gloo without a GPU: the supervisor - which touches neither
+    torch nor a GPU - runs three N-rank jobs in order, each under a hard deadline: the inference replicas (the headline line), the collective
+    self-check, and the bf16 train step (BASELINE config 4's batch-sharded step; reference: processors/ddp_pose_resnet_solver.py:36,85-93,110-133)
+    with the self-check's verdict handed in, appended to the line as `other_configs`.  The self-check's local verdict is injected:
+      pass  -> every rank agrees, the train job takes the native path;
+      hang  -> rank 1 never returns (what code that has never met a peer does): the job costs its deadline, its ranks are killed, the train
+               job runs over torch.distributed and the line says why - exit code 0, well inside the dry run's time limit;
+      raise -> rank 1 cannot complete the comparison: it exits 13 without voting, the supervisor ends the others (round-5 advisor finding)."""
+    oc, _ = _dry_three_jobs(n, "pass")
+    assert oc["n_gpus"] == n and oc["job"]["status"] == "ok" and oc["global_batch"] == 32 * n and oc["dtype"] == "bf16"
+    assert oc["collective_self_check"]["native"] and oc["collective_self_check"]["job"]["status"] == "ok"
+    assert oc["native_flag_agreed"] is True and "sp_comm" in oc["collective_path"]
+    oc, wall = _dry_three_jobs(n, "hang", deadline="20")
+    chk = oc["collective_self_check"]
+    assert chk["job"]["status"] == "timeout" and "hung" in chk["reason"] and "20 s deadline" in chk["reason"] and not chk["native"]
+    assert oc["job"]["status"] == "ok" and oc["collective_path"] == "torch.distributed" and oc["native_flag_agreed"] is False
+    assert wall < 150.0
+    if n == 2:
+        oc, _ = _dry_three_jobs(n, "raise")
+        chk = oc["collective_self_check"]
+        assert chk["job"]["status"] == "died" and "rank 1" in chk["reason"] and "13" in chk["reason"] and oc["collective_path"] == "torch.distributed"
+        oc, _ = _dry_three_jobs(n, "fail")                     # a completed comparison that found a difference on one rank: agreed "no"
+        assert oc["collective_self_check"]["job"]["status"] == "ok" and not oc["collective_self_check"]["native"]
+        assert "bit for bit" in oc["collective_self_check"]["reason"] and oc["collective_path"] == "torch.distributed"
+
+
+def test_bench_under_torchrun_each_worker_supervises_its_own_rank():
+    """The driver starts N > 1 as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`: every worker then supervises the ONE child
+    of its rank; the supervisors meet through a shared directory (exit codes, the agreed decision) and the extra jobs rendezvous in a
+    FileStore there (torchrun's store belongs to the main job).  Same three jobs, same outcomes, one line from rank 0."""
+    oc, _ = _dry_three_jobs(2, "pass", torchrun=True)
+    assert oc["job"]["status"] == "ok" and oc["collective_self_check"]["native"] and "sp_comm" in oc["collective_path"]
+    oc, _ = _dry_three_jobs(2, "raise", torchrun=True)
+    chk = oc["collective_self_check"]
+    assert chk["job"]["status"] == "died" and not chk["native"] and oc["collective_path"] == "torch.distributed" and oc["job"]["status"] == "ok"
+    oc, wall = _dry_three_jobs(2, "hang", torchrun=True, deadline="15")
+    assert oc["collective_self_check"]["job"]["status"] == "timeout" and oc["collective_path"] == "torch.distributed" and wall < 120.0
 
 
 def test_conv_kernel_name_query_matches_dispatch():
@@ -371,6 +442,13 @@ def test_conv_kernel_name_query_matches_dispatch():
     assert _lib.lib().sp_conv2d_ring_ok(d) == 0
     d.kernel = _lib.SP_CONV_KERNEL_RING
     assert _lib.lib().sp_conv2d_ring_ok(d) == 1
+    d.tile_m, d.tile_n, d.kernel = 192, 128, _lib.SP_CONV_KERNEL_RING_LW4    # four MFMA waves (2 x 2 of 96x64) + four loader waves (round 6)
+    assert _lib.lib().sp_conv2d_ring_ok(d) == 1
+    assert _lib.conv_kernel_name(d, False) == "conv_ring_kernel<192, 128, 2, 2, 3, false, 4>"
+    d.tile_m = 96                                                           # a tile eight waves cannot cut: 1 x 4 waves of 96x32
+    assert _lib.lib().sp_conv2d_ring_ok(d) == 1 and _lib.conv_kernel_name(d, True) == "conv_ring_kernel<96, 128, 1, 4, 4, true, 4>"
+    d.kernel = _lib.SP_CONV_KERNEL_RING_LW
+    assert _lib.lib().sp_conv2d_ring_ok(d) == 0                             # (no 96-row tile with eight MFMA waves)
     d.flags = _lib.SP_CONV_RELU
     d.tile_m, d.tile_n, d.kernel = 64, 128, _lib.SP_CONV_KERNEL_IGEMM
     d.c_in, d.k_pad = 256, 2304

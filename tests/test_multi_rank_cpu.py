@@ -105,8 +105,67 @@ def test_collective_path_decision_table():
     assert ok["path"] == "sp_comm" and ok["native"] and ok["self_check"].startswith("passed: 2 steps")
     bad = decide(None, "nccl", True, 2, self_check=lambda: (False, "parameters differ"), agree=lambda v: v)
     assert bad["path"] == "torch.distributed" and "parameters differ" in bad["self_check"]
-    boom = decide(None, "nccl", True, 2, self_check=lambda: 1 / 0, agree=lambda v: v)
-    assert boom["path"] == "torch.distributed" and "ZeroDivisionError" in boom["self_check"]
+    # a rank that cannot complete the comparison must NOT vote (its peers may be inside a collective: round-5 advisor finding): the
+    # exception leaves as SelfCheckError and the agreement is never reached from the except path
+    from simple_pose_amd.comm_select import SelfCheckError
+    votes = []
+    with pytest.raises(SelfCheckError, match="ZeroDivisionError"):
+        decide(None, "nccl", True, 2, self_check=lambda: 1 / 0, agree=lambda v: votes.append(v) or v)
+    assert votes == []
+
+
+def test_self_check_job_outcome_decides_the_train_jobs_path():
+    """simple_pose_amd.launch.collective_decision: the supervised self-check JOB's outcome as the decision (pure).  Native only when the job
+    ended in time with exit code 0 everywhere and its agreed verdict says so; a hang or a dead rank means torch.distributed, with the reason."""
+    import json
+    from simple_pose_amd.launch import collective_decision
+
+    yes = {"self_check_job": True, "rank": 0, "decision": {"path": "sp_comm", "native": True, "reason": "start-up self-check passed on every rank", "self_check": "passed: x"}}
+    no = {"self_check_job": True, "rank": 0, "decision": {"path": "torch.distributed", "native": False, "reason": "did not reproduce", "self_check": "failed"}}
+    job = lambda status, rec=None, detail="": {"name": "self_check", "status": status, "rc": 0 if status == "ok" else 1, "lines": [json.dumps(rec)] if rec else [],
+                                              "detail": detail, "wall_s": 1.0}
+    assert collective_decision(None)["path"] == "torch.distributed"
+    d = collective_decision(job("ok", yes))
+    assert d["native"] and d["path"] == "sp_comm" and d["job"] == {"status": "ok", "wall_s": 1.0}
+    assert not collective_decision(job("ok", no))["native"]
+    d = collective_decision(job("timeout", None, "no end within the 300 s deadline"))
+    assert d["path"] == "torch.distributed" and "hung" in d["reason"] and "300 s" in d["reason"]
+    d = collective_decision(job("died", yes, "rank 3 exited with code 13"))           # a verdict line from a job that then died counts for nothing
+    assert d["path"] == "torch.distributed" and "rank 3" in d["reason"]
+    assert collective_decision(job("ok"))["path"] == "torch.distributed"               # ended, but said nothing
+    # per-rank supervisors (torchrun): native only if EVERY supervisor's view says so, and every supervisor reported
+    v_yes, v_no = dict(yes["decision"]), dict(no["decision"])
+    assert collective_decision(job("ok", yes), [v_yes, v_yes])["native"]
+    d = collective_decision(job("ok", yes), [v_yes, v_no])
+    assert not d["native"] and d["reason"] == "did not reproduce"
+    d = collective_decision(job("ok", yes), [v_yes, None])
+    assert not d["native"] and "ranks [1]" in d["reason"]
+
+
+def test_supervised_job_deadline_and_dead_rank():
+    """simple_pose_amd.launch.run_job with stand-in rank programs: a job that outlives its deadline is ended (exactly the PIDs started here)
+    and reported as "timeout"; a rank that exits non-zero ends the job as "died"; a clean job hands back rank 0's JSON lines."""
+    import sys
+    import time
+    from simple_pose_amd.launch import last_json, run_job
+
+    env = dict(os.environ)
+    prog = ("import os, sys, time, json\n"
+            "r = int(os.environ['RANK'])\n"
+            "mode = sys.argv[1]\n"
+            "if mode == 'hang' and r == 1: time.sleep(600)\n"
+            "if mode == 'die' and r == 1: sys.exit(7)\n"
+            "if mode == 'die': time.sleep(600)\n"
+            "print('not json')\n"
+            "print(json.dumps({'rank': r, 'world': int(os.environ['WORLD_SIZE']), 'child': os.environ['SP_BENCH_CHILD']}))\n")
+    ok = run_job("t_ok", [sys.executable, "-c", prog, "ok"], [0, 1, 2], 3, env, 60.0)
+    assert ok["status"] == "ok" and ok["rc"] == 0 and last_json(ok) == {"rank": 0, "world": 3, "child": "1"} and len(ok["lines"]) == 1
+    t0 = time.time()
+    hung = run_job("t_hang", [sys.executable, "-c", prog, "hang"], [0, 1, 2], 3, env, 3.0)
+    assert hung["status"] == "timeout" and "[1]" in hung["detail"] and time.time() - t0 < 30.0
+    t0 = time.time()
+    dead = run_job("t_die", [sys.executable, "-c", prog, "die"], [0, 1, 2], 3, env, 60.0, grace_s=0.5)
+    assert dead["status"] == "died" and dead["rc"] == 7 and "rank 1" in dead["detail"] and time.time() - t0 < 30.0
 
 
 def _decide_worker(rank, world, port, out):
@@ -121,12 +180,9 @@ def _decide_worker(rank, world, port, out):
         a = decide(None, "nccl", True, world, self_check=lambda: (True, f"rank {rank} ok"), agree=agree)
         # (b) rank 1 alone sees a mismatch -> BOTH ranks fall back, each saying why
         b = decide(None, "nccl", True, world, self_check=lambda: (rank != 1, "exp_avg differ" if rank == 1 else "ok"), agree=agree)
-        # (c) rank 0's comparison raises -> both fall back (the raising rank still takes part in the agreement)
-        def chk():
-            if rank == 0:
-                raise RuntimeError("sp_comm_create failed")
-            return True, "ok"
-        c = decide(None, "nccl", True, world, self_check=chk, agree=agree)
+        # (c) a comparison that RAISES is not an in-process case any more: the raising rank leaves without voting and the supervisor ends
+        #     the job (tests/test_host_logic.py::test_bench_dry_launch_runs_the_three_jobs_with_deadlines, hook "raise")
+        c = None
         # (d) the real group's backend: gloo -> torch.distributed without running anything
         d = decide(None, dist.get_backend(), False, world, self_check=lambda: (True, "never"), agree=agree)
         out[rank] = (a, b, c, d)
@@ -144,7 +200,5 @@ def test_collective_path_self_check_is_agreed_over_the_group():
         a, b, c, d = res[rank]
         assert a["path"] == "sp_comm" and a["native"]
         assert b["path"] == "torch.distributed" and not b["native"]
-        assert c["path"] == "torch.distributed"
         assert d["path"] == "torch.distributed" and d["self_check"] == "not run"
     assert "exp_avg differ" in res[1][1]["self_check"] and "another rank" in res[0][1]["self_check"]
-    assert "sp_comm_create failed" in res[0][2]["self_check"] and "another rank" in res[1][2]["self_check"]
