@@ -17,6 +17,7 @@ is committed - never reference source.  Fixture inventory
   g12_resnext.npz          resnext50_32x4d-dconv, resnext101_32x8d-duc (grouped 3x3, groups = 32; same content as g11)
   g10_fwd_wide.npz   8 / 8 / 4 / 4 distinct images through DConv / DUC / HRNet-W32 / DConv+SE (sub-sampled maps, per-joint sums, key points)
   g6_train_step.npz  one reference training step (B=2): loss, gradient slices, BN running stats, params after Adam
+  g6b_train_step_b8.npz  one reference training step at B=8: loss, the gradient NORM and two sketches of every parameter, slices as in g6
   g5_encode.npz      encoders (Refine + Basic) incl. out-of-range / trunc-toward-zero / vis=0 cases
 """
 from __future__ import annotations
@@ -31,6 +32,7 @@ sys.dont_write_bytecode = True
 
 from oracle import ref_import  # noqa: E402
 from simple_pose_amd import synth  # noqa: E402
+from oracle.train_oracle import gradient_sketch_vector  # noqa: E402
 
 GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 SEED = 0
@@ -181,6 +183,52 @@ def gen_train(ns):
     out["buf/bn1.num_batches_tracked"] = bufs["bn1.num_batches_tracked"].numpy().copy()
     np.savez_compressed(os.path.join(GOLD, "g6_train_step.npz"), **out)
     print("g6_train_step.npz loss", out["loss"], "gradnorm conv1", out["gradnorm/conv1.weight"])
+
+
+def gen_train_b8(ns):
+    """g6b_train_step_b8.npz (round 6): ONE training step of the real reference (ddp...:94,110-119) at B = 8, 256x192 - four times G6's samples
+    per BatchNorm channel - pinned through quantities the reference's own fp32 arithmetic holds to 1e-3: the fp64 NORM of every parameter's
+    gradient (its own 1-thread / 8-thread / fp64 evaluations agree to <= 1.1e-3, median 5e-5; the max over a gradient SLICE moves by 2e-2),
+    two sketches <grad, r> per parameter (<= 8.4e-3 of the norm), next to G6's slices, running statistics and parameters after Adam."""
+    torch.set_num_threads(8)
+    B = 8
+    net = ns.dconv.resnet50(pretrained=False, num_classes=17)
+    synth.load_conditioned(net, SEED)
+    net.train()
+    x = torch.from_numpy(synth.input_images(B, SEED))
+    joints = synth.joints_batch(B, 17, seed=43)
+    enc = ns.transforms.RefineSimpleTransform.get_heat_map
+    tw = [enc(joints[b], 2.0, (48, 64)) for b in range(B)]
+    targets = torch.from_numpy(np.stack([t for t, _ in tw]))
+    mask = torch.from_numpy(np.stack([w for _, w in tw]))
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    crit = torch.nn.MSELoss()
+    opt.zero_grad()
+    pred = net(x)
+    loss = 0.5 * crit(pred.mul(mask[[..., None, None]]), targets.mul(mask[[..., None, None]]))
+    loss.backward()
+    out = {"loss": np.float32(loss.item()), "joints": joints, "batch": B, "seed": SEED, "heat_train_sub": pred.detach().numpy()[:, :, ::4, ::4].copy()}
+    named = dict(net.named_parameters())
+    keys = list(named)
+    out["keys"] = np.array(keys)
+    out["gradnorm"] = np.array([named[k].grad.double().norm().item() for k in keys], dtype=np.float64)
+    out["sketch"] = np.array([[float((named[k].grad.double().numpy() * gradient_sketch_vector(k, i, named[k].shape)).sum()) for i in range(2)]
+                              for k in keys], dtype=np.float64)
+    picks = {"conv1.weight": (slice(0, 2),), "layer1.0.conv1.weight": (slice(0, 4),), "layer2.0.conv2.weight": (slice(0, 2), slice(0, 8)),
+             "layer2.0.downsample.0.weight": (slice(0, 2), slice(0, 16)), "layer4.2.conv3.weight": (slice(0, 2), slice(0, 8)),
+             "deconv_layers.0.weight": (slice(0, 2), slice(0, 2)), "deconv_layers.6.weight": (slice(0, 2), slice(0, 4)),
+             "final_layer.weight": (slice(None),), "final_layer.bias": (slice(None),), "bn1.weight": (slice(None),), "bn1.bias": (slice(None),),
+             "layer1.0.bn3.weight": (slice(0, 32),), "layer3.2.bn2.bias": (slice(0, 32),), "deconv_layers.4.weight": (slice(0, 32),)}
+    for k, sl in picks.items():
+        out["grad/" + k] = named[k].grad[sl].numpy().copy()
+    opt.step()
+    for k, sl in picks.items():
+        out["param/" + k] = named[k].detach()[sl].numpy().copy()
+    bufs = dict(net.named_buffers())
+    for k in ("bn1.running_mean", "bn1.running_var", "layer3.5.bn3.running_var", "deconv_layers.7.running_mean"):
+        out["buf/" + k] = bufs[k].numpy().copy()
+    np.savez_compressed(os.path.join(GOLD, "g6b_train_step_b8.npz"), **out)
+    print("g6b_train_step_b8.npz loss", out["loss"], "gradnorm conv1", out["gradnorm"][0], "params", len(keys))
 
 
 def edge_maps():
@@ -477,6 +525,9 @@ def main():
     if "--only-resnext" in sys.argv:
         gen_resnext(ns)
         return
+    if "--only-train-b8" in sys.argv:      # (round 6 addition)
+        gen_train_b8(ns)
+        return
     hm = gen_forward(ns)  # returns the DUC maps last; reload dconv maps for the decoder set
     net_maps = np.load(os.path.join(GOLD, "g1_dconv_fwd.npz"))["heat_maps"]
     gen_decode(ns, net_maps)
@@ -485,6 +536,7 @@ def main():
     gen_se(ns)
     gen_next(ns)
     gen_train(ns)
+    gen_train_b8(ns)
     gen_nms(ns)
     gen_crop(ns)
     gen_forward_wide(ns)

@@ -51,3 +51,13 @@ def adam_step(params: Dict[str, torch.Tensor], grads: Dict[str, torch.Tensor], s
         v.mul_(b2).addcmul_(g, g, value=1 - b2)
         denom = (v.sqrt() / (bc2 ** 0.5)).add_(eps)
         p.addcdiv_(m, denom, value=-(lr / bc1))
+
+
+def gradient_sketch_vector(key: str, i: int, shape):
+    """The fixed pseudo-random vector (uniform in [-1, 1), keyed by parameter name) that golden G6b's gradient sketches are taken against
+    (oracle/gen_golden.py::gen_train_b8): <grad, r> sums over every element, so fp32 summation noise averages out where the max over a
+    gradient slice picks its worst element."""
+    import numpy as np
+
+    from simple_pose_amd import synth
+    return synth.tensor_uniform(7, f"sketch{i}/{key}", tuple(shape), -1.0, 1.0).astype(np.float64)

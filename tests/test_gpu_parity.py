@@ -1505,7 +1505,7 @@ def test_ring_kernel_matches_igemm_on_ragged_shapes():
         (3, 256, 7, 5, 256, 4, 2, 1, False, "deconv"),
         (70, 512, 8, 6, 256, 4, 2, 1, False, "deconv"),      # 4 phases x 3,360 rows
     ]
-    ran = ran_lw = 0
+    ran = ran_lw = ran_lw4 = 0
     for ci, (B, Cin, H, W, Cout, k, s, p, with_res, kind) in enumerate(cases):
         tag = f"ring{ci}"
         wshape = (Cin, Cout, 4, 4) if kind == "deconv" else (Cout, Cin, k, k)
@@ -1553,6 +1553,7 @@ def test_ring_kernel_matches_igemm_on_ragged_shapes():
         ring = [c for c, _, _ in results if c[2] == _lib.SP_CONV_KERNEL_RING]
         ran += len(ring)
         ran_lw += len([c for c, _, _ in results if c[2] == _lib.SP_CONV_KERNEL_RING_LW])      # the same ring fed by four loader waves (round 5)
+        ran_lw4 += len([c for c, _, _ in results if c[2] == _lib.SP_CONV_KERNEL_RING_LW4])    # ... with four MFMA waves, one per SIMD (round 6)
         for cand, bits, _ in results[1:]:
             assert torch.equal(bits, results[0][1]), (tag, cand, int((bits != results[0][1]).sum()))
         got = results[0][2].permute(0, 3, 1, 2).double()
@@ -1561,6 +1562,7 @@ def test_ring_kernel_matches_igemm_on_ragged_shapes():
         assert err < 6e-3, (tag, err)
     assert ran >= 20, ran                                      # the ring kernel really took part
     assert ran_lw >= 15, ran_lw                                # ... and so did its loader-wave variant
+    assert ran_lw4 >= 20, ran_lw4                              # ... and the four-MFMA-wave tiles (96-row tiles included)
     print(f"ring-vs-igemm: {ran} ring launches + {ran_lw} loader-wave ring launches bit-identical to the implicit GEMM")
 
 
@@ -1935,6 +1937,41 @@ def test_bench_self_launches_two_ranks(mode):
             assert ("sp_comm" in line["collective_path"]) == (chk["path"] == "sp_comm")
             assert "rccl" in line["config"]
         assert "allreduce_wait" in line["step_split_ms"] and line["collectives_per_step"]["gradient_buckets"] >= 1
+
+
+def test_bench_two_ranks_driver_command_runs_the_three_jobs():
+    """The driver's own command at N = 2 (`bench.py --gpus 2 --steps K --warmup W`, headline config untouched) on the GPU: the supervisor runs
+    the inference replicas, the collective self-check and the bf16 32-image-per-GPU train step as three N-rank jobs with deadlines, and the
+    ONE line carries the train step as `other_configs` with the path its collectives took and why (round-5 verdict, next 1).  On a 1-GPU
+    box the ranks share the device over gloo (self-check verdict: not nccl -> torch.distributed); with two GPUs it is RCCL and the
+    comparison really runs."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "SP_NATIVE_COMM", "SP_BENCH_CHILD")}
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--dist-backend", backend, "--no-kernel-events"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 256 and line["dtype"] == "f32" and line["value"] > 0
+    assert list(line)[-1] == "other_configs" and len(line["other_configs"]) == 1
+    oc = line["other_configs"][0]
+    assert "error" not in oc, oc
+    assert oc["job"]["status"] == "ok" and oc["n_gpus"] == 2 and oc["global_batch"] == 64 and oc["dtype"] == "bf16" and oc["value"] > 0
+    assert abs(oc["value"] - 64 / (oc["ms_per_step"] * 1e-3)) / oc["value"] < 0.02
+    chk = oc["collective_self_check"]
+    assert chk["job"]["status"] == "ok"
+    if backend == "gloo":
+        assert oc["collective_path"] == "torch.distributed" and "gloo" in chk["reason"] and chk["self_check"] == "not run"
+    else:
+        assert chk["self_check"] != "not run" and ("sp_comm" in oc["collective_path"]) == chk["native"] and oc["rccl"] is not None
+    assert "allreduce_wait" in oc["step_split_ms"] and oc["collectives_per_step"]["gradient_buckets"] >= 1
 
 
 def test_bench_micro_mode_prints_one_json_line_on_stdout():

@@ -134,6 +134,41 @@ def test_train_step_oracle_matches_reference(golden):
     assert int(sd["bn1.num_batches_tracked"]) == int(g["buf/bn1.num_batches_tracked"]) == 1
 
 
+def test_train_step_oracle_matches_reference_at_batch_8(golden):
+    """G6b (round 6): one step of the real reference at B = 8, 256x192, pinned by quantities its own fp32 arithmetic holds to 1e-3 - the fp64
+    norm and two sketches <grad, r> of EVERY parameter's gradient (oracle/gen_golden.py::gen_train_b8) - next to G6's slices.  The oracle
+    (same torch ops, same thread count) reproduces them to rounding."""
+    from oracle import train_oracle
+    from oracle.train_oracle import gradient_sketch_vector
+    g = golden("g6b_train_step_b8.npz")
+    B = int(g["batch"])
+    shapes = nets_oracle.state_dict_shapes_resnet50("dconv")
+    sd = {k: torch.from_numpy(v) for k, v in synth.conditioned_state_dict(shapes, int(g["seed"])).items()}
+    x = torch.from_numpy(synth.input_images(B, int(g["seed"])))
+    t, w = pose_oracle.encode_refine(g["joints"], 2.0, (48, 64))
+    torch.set_num_threads(8)
+    loss, grads, heat = train_oracle.forward_backward(sd, x, torch.from_numpy(t), torch.from_numpy(w))
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    assert np.abs(heat.numpy()[:, :, ::4, ::4] - g["heat_train_sub"]).max() <= 1e-4 * np.abs(g["heat_train_sub"]).max()
+    keys = [str(k) for k in g["keys"]]
+    assert keys == list(grads) and len(keys) == 170
+    worst_n = worst_s = 0.0
+    for i, k in enumerate(keys):
+        gd = grads[k].double()
+        n = float(g["gradnorm"][i])
+        worst_n = max(worst_n, abs(float(gd.norm()) - n) / n)
+        for j in range(2):
+            sk = float((gd.numpy() * gradient_sketch_vector(k, j, gd.shape)).sum())
+            worst_s = max(worst_s, abs(sk - float(g["sketch"][i, j])) / n)
+    # measured here: 0 (8 threads, the generator's count) ... 1.1e-3 / 8.4e-3 (1 thread): the reference's own summation-order spread
+    assert worst_n <= 2e-3 and worst_s <= 1.5e-2, (worst_n, worst_s)
+    for k in [k[5:] for k in g.files if k.startswith("grad/")]:
+        ref = g["grad/" + k]
+        got = grads[k].numpy()[tuple(slice(0, s) for s in ref.shape)]
+        scale = float(g["gradnorm"][keys.index(k)]) / np.sqrt(grads[k].numel())
+        assert np.abs(got - ref).max() <= 6e-2 * scale + 1e-12, k      # (a slice's max moves by 2-5e-2 with the thread count: tests/measure_reference_spread.py)
+
+
 def test_se_variant_oracle_and_key_layout_match_reference(golden):
     g = golden("g1s_dconv_se_fwd.npz")
     shapes = nets_oracle.state_dict_shapes_resnet50("dconv", se=True)
