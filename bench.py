@@ -540,6 +540,9 @@ OTHER_CONFIGS = [
     {"config": "HRNet-W32 256x192 bs=128 bf16 forward+decode", "argv": ["--arch", "hrnet_w32", "--dtype", "bf16"]},
     {"config": "ResNet50-DConv 256x192 bs=32/GPU bf16 train step (fwd+bwd+Adam), 1-GPU shard of the bs=256 DDP config",
      "argv": ["--mode", "train", "--dtype", "bf16", "--batch", "32"]},
+    # the reference's SHIPPED arithmetic for that step (configs/ddp_fast_pose.yaml: `amp: False`, processors/ddp_pose_resnet_solver.py:110-133)
+    {"config": "ResNet50-DConv 256x192 bs=32/GPU fp32 train step (fwd+bwd+Adam), the reference's shipped arithmetic (amp: False)",
+     "argv": ["--mode", "train", "--dtype", "f32", "--batch", "32"]},
 ]
 
 

@@ -27,7 +27,7 @@ extern "C" {
 #define SP_EINVAL (-1)   /* bad argument / unsupported shape (message in sp_last_error) */
 #define SP_ELAUNCH (-2)  /* HIP launch or runtime failure */
 
-#define SP_ABI_VERSION 33
+#define SP_ABI_VERSION 34
 
 /* epilogue / layout flags of sp_conv_desc.flags */
 #define SP_CONV_RELU 0x1u          /* y = max(y, 0) after scale/shift (+ residual) */
@@ -85,6 +85,9 @@ typedef struct sp_conv_desc {
 #define SP_CONV_KERNEL_RING_LW 3 /* the same ring with four extra "loader" waves per workgroup (one per SIMD) that issue every LDS-DMA piece; the eight
                                   MFMA waves only read fragments and multiply (round 5; same bits as 0 / 1); tiles 256x128 128x256 256x64 128x128
                                   192x128; needs sp_conv2d_ring_ok(desc) == 1 with desc.kernel set to this id */
+#define SP_CONV_KERNEL_RING_LW4 4 /* (ABI 34) the loader-wave ring with FOUR MFMA waves, one per SIMD, instead of eight: the same workgroup tile as four wave
+                                  * tiles of twice the area (fewer LDS fragment bytes per MFMA), and the 96-row tiles eight waves cannot cut; tiles
+                                  * 192x128, 128x128, 96x128, 256x128, 128x256, 96x256, 64x128; same bits */
 #define SP_CONV_KERNEL_PW 2    /* fp32 1x1 stride-1 NHWC layers with c_in 64 / 128 and c_out % 256 == 0 (bottleneck conv3, projection shortcut):
                                   one persistent workgroup per CU streams 64-row tiles, weights in registers (sp_conv2d_pw_ok); tile_m / tile_n unused */
 
@@ -493,8 +496,11 @@ int sp_permute4_f32(const float* src, void* dst, int dst_bf16, const int32_t* ds
  * are one contiguous run, 2 a 2-D transpose (dims 1 and 2 of extent 1, source contiguous along i0) in 32x32 tiles through LDS,
  * 3 multi-tap filters whose fastest destination index is the source's slowest (stride[0] = floats per (i0, i3) block < |stride[3]|): tiles of
  * 32 i3 x tile0 i0 values through LDS, coalesced both ways; the record then ends in two more int32: tap0 (offset <= 0 from `base` to the
- * block's first tap) and tile0 (32 * (tile0 * stride[0] | 1) <= 10240).  Record size: 104 bytes (ABI 33; 96 before). */
+ * block's first tap) and tile0 (32 * (tile0 * stride[0] | 1) <= 10240).  Record size: 104 bytes (ABI 33; 96 before).
+ * Walk 3 needs a 40 KB LDS tile: it exists only in sp_permute4_batched_tiled (ABI 34: same arguments, same results; a launch of its own so
+ * that the default repack keeps 8 workgroups per CU); sp_permute4_batched visits a walk-3 job as walk 1. */
 int sp_permute4_batched(const float* src, const void* jobs_device, int n_jobs, int blocks_per_job, void* stream);
+int sp_permute4_batched_tiled(const float* src, const void* jobs_device, int n_jobs, int blocks_per_job, void* stream);
 
 /* measurement aid: occupies `stream` for `us` microseconds (one idle wave on the 100 MHz constant clock) - bench.py's stand-in for the
  * latency of a SyncBatchNorm message (ddp...:89-90) on a box with a single GPU */

@@ -21,8 +21,9 @@ SP_CONV_BF16 = 0x8
 SP_CONV_OUT_F32 = 0x10
 SP_CONV_BN_Y_MASK = 0x20
 CONV_TILES = ((128, 128), (64, 128), (128, 64), (64, 64), (256, 64), (128, 32))
-ABI_VERSION = 33
-SP_CONV_KERNEL_IGEMM, SP_CONV_KERNEL_RING, SP_CONV_KERNEL_PW, SP_CONV_KERNEL_RING_LW = 0, 1, 2, 3
+ABI_VERSION = 34
+SP_CONV_KERNEL_IGEMM, SP_CONV_KERNEL_RING, SP_CONV_KERNEL_PW, SP_CONV_KERNEL_RING_LW, SP_CONV_KERNEL_RING_LW4 = 0, 1, 2, 3, 4
+RING_LW4_TILES = ((192, 128), (128, 128), (96, 128), (256, 128), (128, 256), (96, 256), (64, 128))   # kernel = SP_CONV_KERNEL_RING_LW4 (four MFMA waves + four loader waves)
 RING_LW_TILES = ((256, 128), (128, 256), (256, 64), (128, 128), (192, 128))   # kernel = SP_CONV_KERNEL_RING_LW (bf16; the ring with loader waves)
 RING_TILES = ((256, 256), (256, 128), (128, 256), (256, 64), (128, 128), (192, 128), (192, 256))   # kernel = SP_CONV_KERNEL_RING (bf16)
 
@@ -109,6 +110,7 @@ SYMBOLS = {
     "sp_stream_delay_us": (c_int, [c_double, _P]),
     "sp_permute4_f32": (c_int, [_P, _P, c_int, ctypes.POINTER(c_int32), ctypes.POINTER(c_int64), ctypes.POINTER(c_int32), c_int64, c_int64, _P]),
     "sp_permute4_batched": (c_int, [_P, _P, c_int, c_int, _P]),
+    "sp_permute4_batched_tiled": (c_int, [_P, _P, c_int, c_int, _P]),
     "sp_pose_score": (c_int, [_P, c_int, c_int, _P, _P]),
     "sp_pose_rescore": (c_int, [_P, _P, c_int, c_int, c_double, _P, _P, _P]),
     "sp_oks_nms": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_double, c_double, _P, _P, _P]),

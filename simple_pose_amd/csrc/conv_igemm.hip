@@ -1109,13 +1109,13 @@ static int conv_fwd_impl(const sp_conv_desc* d, const void* x, const void* w_pac
     }
     hipStream_t s = (hipStream_t)stream;
 
-    SP_REQUIRE(d->kernel == SP_CONV_KERNEL_IGEMM || d->kernel == SP_CONV_KERNEL_RING || d->kernel == SP_CONV_KERNEL_PW || d->kernel == SP_CONV_KERNEL_RING_LW,
+    SP_REQUIRE(d->kernel == SP_CONV_KERNEL_IGEMM || d->kernel == SP_CONV_KERNEL_RING || d->kernel == SP_CONV_KERNEL_PW || d->kernel == SP_CONV_KERNEL_RING_LW || d->kernel == SP_CONV_KERNEL_RING_LW4,
                "sp_conv2d_fwd: unknown kernel id %d", d->kernel);
     if (d->kernel == SP_CONV_KERNEL_PW) {
         SP_REQUIRE(!stats_s && !bsrc, "sp_conv2d_fwd: the streaming 1x1 kernel has no statistics epilogue");
         return sp_conv_pw_launch(d, x, w_packed, scale, shift, residual, y, stream);
     }
-    if (d->kernel == SP_CONV_KERNEL_RING || d->kernel == SP_CONV_KERNEL_RING_LW) {
+    if (d->kernel == SP_CONV_KERNEL_RING || d->kernel == SP_CONV_KERNEL_RING_LW || d->kernel == SP_CONV_KERNEL_RING_LW4) {
         SP_REQUIRE(!stats_s && !bsrc, "sp_conv2d_fwd: the LDS-DMA ring kernel has no statistics epilogue");
         return sp_conv_ring_launch(d, x, w_packed, scale, shift, residual, y, stream);
     }

@@ -97,21 +97,28 @@ __device__ __forceinline__ void dma16(unsigned lds_addr, unsigned voff, u32x4 rs
 // does nothing else) - on the 192x128 tile 5 pieces per 12 MFMAs, i.e. more issue time than matrix time, in the very waves whose MFMA chain
 // it interrupts.  The ring, the counted vmcnt + one barrier per K tile, the fragment reads and the MFMA chain per output are unchanged, so
 // the bits are too (`test_ring_kernel_matches_igemm_on_ragged_shapes` covers both).
+//
+// MFMA waves (round 6): WR x WC = 8 (two per SIMD, rounds 2-5) or, with loader waves only, 4 (ONE per SIMD; kernel = SP_CONV_KERNEL_RING_LW4):
+// the same workgroup tile cut into four wave tiles of twice the area - 192x128 as 2 x 2 waves of 96x64 reads 5 fragments per 6 MFMAs where
+// eight 96x32 waves read 4 per 3 (LDS fragment bytes per K tile 128 -> 80 KB) - and tiles eight waves cannot cut (96 rows as 1 x 4 waves of
+// 96x32: 256 tiles where 128-row tiles give 192).  Same slot image, same K order, same MFMA chain per output: same bits.
 template <int BM, int BN, int WR, int WC, int NS, bool HAS_RES, int NLW>
-__global__ __launch_bounds__(512 + 64 * NLW, NLW ? 3 : 2) void conv_ring_kernel(const RingArgs p) {
-    static_assert(WR * WC == 8, "8 MFMA waves per workgroup");
+__global__ __launch_bounds__(64 * (WR * WC + NLW), (WR * WC + NLW) / 4) void conv_ring_kernel(const RingArgs p) {
+    constexpr int NMW = WR * WC;                       // MFMA waves
+    static_assert(NMW == 8 || (NMW == 4 && NLW == 4), "8 MFMA waves, or 4 next to the 4 loader waves");
     static_assert(NLW == 0 || NLW == 4, "loader waves: none or one per SIMD");
+    static_assert(BM <= 64 * NMW, "the row table of a tile is written by the MFMA waves' threads");
     constexpr int WM = BM / WR, WN = BN / WC;          // wave tile
     constexpr int TM = WM / 32, TN = WN / 32;          // 32x32 MFMA tiles per wave
-    static_assert(TM >= 1 && TN >= 1 && BM % 64 == 0 && BN % 64 == 0, "tile shape");
-    constexpr int NIW = NLW ? NLW : 8;                 // waves that issue the LDS-DMA pieces
+    static_assert(TM >= 1 && TN >= 1 && BM % 32 == 0 && BN % 64 == 0 && WM % 32 == 0 && WN % 32 == 0, "tile shape");
+    constexpr int NIW = NLW ? NLW : NMW;               // waves that issue the LDS-DMA pieces
     static_assert((BM / 8) % NIW == 0 && (BN / 8) % NIW == 0, "whole pieces per issuing wave");
     constexpr int LA = BM / 8 / NIW, LB = BN / 8 / NIW, L = LA + LB;   // 1-KiB DMA pieces per issuing wave per K tile (8 rows of 128 B each)
     constexpr int SB = (BM + BN) * 128;                // bytes of one ring slot: A rows, then B rows
     constexpr int D = NS - 1;                          // K tiles in flight ahead of the one being multiplied
     constexpr int NM = 4 * TM * TN;                    // MFMAs per wave per K tile
     constexpr int TRS = WN + 4;                        // floats per row of the epilogue's transpose scratch (padded)
-    static_assert(8 * 16 * TRS * 4 <= SB, "epilogue scratch must fit in one ring slot");
+    static_assert(NMW * 16 * TRS * 4 <= SB, "epilogue scratch must fit in one ring slot");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const ring = smem;                                   // [NS][BM + BN][128 B]
@@ -122,8 +129,8 @@ __global__ __launch_bounds__(512 + 64 * NLW, NLW ? 3 : 2) void conv_ring_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WC, wc = wave % WC;
     const int fr = lane & 31, fh = lane >> 5;
-    const bool loader_wave = NLW > 0 && wave >= 8;      // (wave-uniform)
-    const int iw = NLW ? (wave >= 8 ? wave - 8 : 0) : wave;   // index among the issuing waves
+    const bool loader_wave = NLW > 0 && wave >= NMW;    // (wave-uniform)
+    const int iw = NLW ? (wave >= NMW ? wave - NMW : 0) : wave;   // index among the issuing waves
 #ifdef SP_RING_DIAG
     unsigned long long dg_wait = 0, dg_bar = 0, dg_mma = 0, dg_epi = 0, dg_tiles = 0;
     SP_RSTAMP(dg_entry)
@@ -516,7 +523,7 @@ int device_cus() {                       // CUs of the current device (cached pe
 template <int BM, int BN, int WR, int WC, int NS, bool HAS_RES, int NLW>
 int launch_ring_t(const RingArgs& a, hipStream_t stream) {
     if (sp_name_query_active()) {
-        sp_name_query_set("conv_ring_kernel<%d, %d, %d, %d, %d, %s, %d>", BM, BN, WR, WC, NS, HAS_RES ? "true" : "false", NLW);
+        sp_name_query_set("conv_ring_kernel<%d, %d, %d, %d, %d, %s, %d>", BM, BN, WR, WC, NS, HAS_RES ? "true" : "false", NLW);   // (as rocprofv3 prints it)
         return SP_OK;
     }
     RingArgs p = a;
@@ -533,7 +540,7 @@ int launch_ring_t(const RingArgs& a, hipStream_t stream) {
         sp_set_error("conv_ring: hipFuncSetAttribute(max dynamic LDS = %zu) failed: %s", lds, hipGetErrorString(e));
         return SP_ELAUNCH;
     }
-    hipLaunchKernelGGL((conv_ring_kernel<BM, BN, WR, WC, NS, HAS_RES, NLW>), dim3(grid, 1, 1), dim3(512 + 64 * NLW, 1, 1), lds, stream, p);
+    hipLaunchKernelGGL((conv_ring_kernel<BM, BN, WR, WC, NS, HAS_RES, NLW>), dim3(grid, 1, 1), dim3(64 * (WR * WC + NLW), 1, 1), lds, stream, p);
     return sp_check_launch("conv_ring_kernel");
 }
 
@@ -551,7 +558,15 @@ constexpr RingTile kRingTiles[] = {{256, 256, 2}, {256, 128, 3}, {128, 256, 3}, 
 // budget - the 256x256 tile (221 VGPRs) and the 192x256 tile (179) stay on the 8-wave kernel
 constexpr RingTile kRingTilesLW[] = {{256, 128, 3}, {128, 256, 3}, {256, 64, 3}, {128, 128, 4}, {192, 128, 3}};
 
+// four MFMA waves (one per SIMD) + four loader waves (kernel = SP_CONV_KERNEL_RING_LW4, round 6): eight waves per workgroup, 256 VGPRs each
+constexpr RingTile kRingTilesLW4[] = {{192, 128, 3}, {128, 128, 4}, {96, 128, 4}, {256, 128, 3}, {128, 256, 3}, {96, 256, 3}, {64, 128, 5}};
+
 const RingTile* find_tile(int bm, int bn, int kernel = SP_CONV_KERNEL_RING) {
+    if (kernel == SP_CONV_KERNEL_RING_LW4) {
+        for (const RingTile& t : kRingTilesLW4)
+            if (t.bm == bm && t.bn == bn) return &t;
+        return nullptr;
+    }
     if (kernel == SP_CONV_KERNEL_RING_LW) {
         for (const RingTile& t : kRingTilesLW)
             if (t.bm == bm && t.bn == bn) return &t;
@@ -588,7 +603,7 @@ int sp_conv_ring_launch(const sp_conv_desc* d, const void* x, const void* w_pack
                         const void* residual, void* y, void* stream) {
     SP_REQUIRE(sp_conv2d_ring_ok(d), "sp_conv2d_fwd: descriptor / tile %dx%d not supported by the LDS-DMA ring kernel (bf16 NHWC in and out, "
                "c_in %% 64 == 0, k_pad / 64 >= ring depth, tile_n | n_pad; tiles 256x256 256x128 128x256 256x64 128x128 192x128 192x256; loader-wave "
-               "variant: all but 256x256 and 192x256)", d->tile_m, d->tile_n);
+               "variant: all but 256x256 and 192x256; four-MFMA-wave variant: 192x128 128x128 96x128 256x128 128x256 96x256 64x128)", d->tile_m, d->tile_n);
     const long long M = (long long)d->batch * d->grid_h * d->grid_w;
     const long long in_elems = (long long)d->batch * d->in_h * d->in_w * d->c_in;
     const long long out_elems = (long long)d->batch * d->out_h * d->out_w * d->out_c;
@@ -612,6 +627,17 @@ int sp_conv_ring_launch(const sp_conv_desc* d, const void* x, const void* w_pack
     a.x_bytes = (int)(in_elems * 2); a.w_bytes = (int)(w_elems * 2); a.y_bytes = (int)(out_elems * 2);
     hipStream_t s = (hipStream_t)stream;
     const int bm = d->tile_m, bn = d->tile_n;
+    if (d->kernel == SP_CONV_KERNEL_RING_LW4) {
+        if (bm == 192 && bn == 128) return launch_ring<192, 128, 2, 2, 3, 4>(a, s);     // 96x64 per wave
+        if (bm == 128 && bn == 128) return launch_ring<128, 128, 2, 2, 4, 4>(a, s);     // 64x64
+        if (bm == 96 && bn == 128) return launch_ring<96, 128, 1, 4, 4, 4>(a, s);       // 96x32
+        if (bm == 256 && bn == 128) return launch_ring<256, 128, 2, 2, 3, 4>(a, s);     // 128x64
+        if (bm == 128 && bn == 256) return launch_ring<128, 256, 2, 2, 3, 4>(a, s);     // 64x128
+        if (bm == 96 && bn == 256) return launch_ring<96, 256, 1, 4, 3, 4>(a, s);       // 96x64
+        if (bm == 64 && bn == 128) return launch_ring<64, 128, 1, 4, 5, 4>(a, s);       // 64x32
+        sp_set_error("sp_conv2d_fwd: four-wave ring tile %dx%d not instantiated", bm, bn);
+        return SP_EINVAL;
+    }
     if (d->kernel == SP_CONV_KERNEL_RING_LW) {
         if (bm == 256 && bn == 128) return launch_ring<256, 128, 4, 2, 3, 4>(a, s);
         if (bm == 128 && bn == 256) return launch_ring<128, 256, 2, 4, 3, 4>(a, s);

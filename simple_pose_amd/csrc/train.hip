@@ -1163,8 +1163,13 @@ __global__ void permute4_batched_kernel(const float* __restrict__ src, const Pac
 
 extern "C" int sp_permute4_batched(const float* src, const void* jobs_device, int n_jobs, int blocks_per_job, void* stream) {
     SP_REQUIRE(src && jobs_device && n_jobs > 0 && n_jobs <= 65535 && blocks_per_job > 0, "sp_permute4_batched: bad argument");
+#ifdef SP_REPACK_AB_DIAG   // DIAGNOSTIC BUILD ONLY (same-box A/B of round 5's launch, whose every repack reserved walk 3's 40 KB tile; never the shipped library)
+    hipLaunchKernelGGL(permute4_batched_kernel<true>, dim3(blocks_per_job, n_jobs), dim3(256), 0, (hipStream_t)stream, src,
+                       reinterpret_cast<const PackJobDev*>(jobs_device));
+#else
     hipLaunchKernelGGL(permute4_batched_kernel<false>, dim3(blocks_per_job, n_jobs), dim3(256), 0, (hipStream_t)stream, src,
                        reinterpret_cast<const PackJobDev*>(jobs_device));
+#endif
     return sp_check_launch("permute4_batched_kernel");
 }
 

@@ -384,6 +384,10 @@ class Program:
                 d.tile_m, d.tile_n, d.kernel = bm, bn, _lib.SP_CONV_KERNEL_RING_LW
                 if lib.sp_conv2d_ring_ok(d):
                     out.append((bm, bn, _lib.SP_CONV_KERNEL_RING_LW))
+            for bm, bn in _lib.RING_LW4_TILES:
+                d.tile_m, d.tile_n, d.kernel = bm, bn, _lib.SP_CONV_KERNEL_RING_LW4
+                if lib.sp_conv2d_ring_ok(d):
+                    out.append((bm, bn, _lib.SP_CONV_KERNEL_RING_LW4))
         d.tile_m, d.tile_n, d.kernel = keep
         if lib.sp_conv2d_pw_ok(d):
             out.append((64, 256, _lib.SP_CONV_KERNEL_PW))
@@ -576,6 +580,12 @@ class Program:
         for op in self.ops:
             if op.kind == "conv" and op.name in tiles:
                 t = [int(v) for v in tiles[op.name]]
+                if op.desc.c_in_group:
+                    # grouped conv: the N tile IS the weight panel and only the implicit GEMM reads block-diagonal panels.  Tables are
+                    # keyed by layer name and resnet50 / resnext50 share names: an entry of another backbone must not reach this launch
+                    if t[0] > 0 and t[1] == op.desc.c_in_group and (len(t) < 3 or t[2] == _lib.SP_CONV_KERNEL_IGEMM):
+                        op.desc.tile_m = t[0]
+                    continue
                 op.direct = t[0] < 0
                 if not op.direct:
                     op.desc.tile_m, op.desc.tile_n = t[0], t[1]

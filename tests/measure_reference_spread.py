@@ -8,7 +8,7 @@ reproduces the golden exactly: 0.0000 on every slice.)
 `python tests/measure_reference_spread.py 8` (round 6): the same three evaluations of golden G6b's step (B = 8, 256x192), on the quantities G6b
 pins: over all 170 parameters the fp64 NORM of a gradient moves by <= 1.0e-3 (8 threads) / 1.1e-3 (1 thread) from fp64, median 5e-5; a sketch
 <grad, r> by <= 6.5e-3 / 8.4e-3 of the norm; the relative L2 of a whole gradient by <= 6.7e-3; the max over a slice still by 2-6e-2 of the rms
-(B = 8 does not calm the per-element noise - sums over the tensor do).  Hence G6B_NORM_BAR = 5e-3 and G6B_SKETCH_BAR = 2.5e-2 in test_gpu_train.py."""
+(B = 8 does not calm the per-element noise - sums over the tensor do).  Hence G6B_NORM_BAR = 3.5e-3 (3x the HIP step's 1.17e-3) and G6B_SKETCH_BAR = 2.5e-2 in test_gpu_train.py."""
 # how far apart are two fp32 CPU evaluations (1 vs 8 threads, oneDNN summation order) and fp64 on G6's gradient-slice metric?
 import numpy as np, torch, sys
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))

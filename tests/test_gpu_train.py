@@ -297,8 +297,10 @@ def test_train_step_vs_reference_golden(golden, measured):
 # G6b (round 6): the bars the reference's OWN arithmetic allows at B = 8 (its 1-thread / 8-thread / fp64 evaluations of this very step, /tmp-free:
 # `python tests/measure_reference_spread.py 8`): gradient norm of any parameter <= 1.1e-3 (median 5e-5), a sketch <= 8.4e-3 of the norm, relative
 # L2 of a whole gradient <= 6.7e-3, the max over a slice 2-6e-2 of the rms.  A 1 % error in a dgrad epilogue moves every upstream norm by 1 %.
-G6B_NORM_BAR = 5e-3
+# Measured on the MI355X (round 6, `measured`): norm 1.17e-3, sketch 8.8e-3, slices <= 1.95e-2 (conv1.weight): every bar <= 3x its measurement.
+G6B_NORM_BAR = 3.5e-3
 G6B_SKETCH_BAR = 2.5e-2
+G6B_SLICE_BAR = 5e-2
 
 
 def test_train_step_vs_reference_golden_batch_8(golden, measured):
@@ -342,8 +344,8 @@ def test_train_step_vs_reference_golden_batch_8(golden, measured):
         ref = g[key]
         got = named[k].grad.cpu().numpy()[tuple(slice(0, s) for s in ref.shape)]
         scale = float(g["gradnorm"][keys.index(k)]) / np.sqrt(named[k].numel())
-        measured(f"g6b/grad_slice_err_over_scale/{k}", np.abs(got - ref).max() / scale, 8e-2)
-        assert np.abs(got - ref).max() <= 8e-2 * scale + 1e-12, k
+        measured(f"g6b/grad_slice_err_over_scale/{k}", np.abs(got - ref).max() / scale, G6B_SLICE_BAR)
+        assert np.abs(got - ref).max() <= G6B_SLICE_BAR * scale + 1e-12, k
     bufs = dict(model.named_buffers())
     for k in ("bn1.running_mean", "bn1.running_var", "layer3.5.bn3.running_var", "deconv_layers.7.running_mean"):
         assert np.abs(bufs[k].cpu().numpy() - g["buf/" + k]).max() <= 1e-4 * max(1.0, np.abs(g["buf/" + k]).max()), k
