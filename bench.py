@@ -34,6 +34,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10, help="untimed warm-up steps (SURVEY 8d: >= 10)")
     ap.add_argument("--batch", type=int, default=128, help="images per GPU per step")
     ap.add_argument("--arch", default="dconv", choices=["dconv", "duc", "hrnet_w32"])
+    ap.add_argument("--backbone", default="resnet50",
+                    help="dconv / duc only: another factory of the reference's nets.pose_resnet_* (resnet18 ... resnet152, wide_resnet50_2, resnext50_32x4d, "
+                         "resnext101_32x8d; nets/pose_resnet_dconv.py:282-368).  Not a BASELINE config: no tracked tile table (tuned on this GPU, untimed setup), "
+                         "no cpu_baseline; the line's metric names the backbone")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL over xGMI, default); gloo only to exercise the N > 1 code path on a single-GPU box")
@@ -62,8 +66,8 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (roofline object)")
     ap.add_argument("--fuse-bottlenecks", action="store_true", help="(default since round 3; kept so that older command lines still parse)")
     ap.add_argument("--pipeline-decode", action="store_true", help="infer mode: decode of step i on its own stream while the forward of step i + 1 runs "
-                    "(engine.PipelinedForward; same results).  Default for hrnet_w32 (+4 %: its forward ends in low-occupancy launches); "
-                    "measured -2 % on the ResNets in bf16, neutral in fp32")
+                    "(engine.PipelinedForward; same results).  Default for hrnet_w32 (+4 %%: its forward ends in low-occupancy launches); "
+                    "measured -2 %% on the ResNets in bf16, neutral in fp32")
     ap.add_argument("--interleave", type=int, default=None, help="infer mode: consecutive steps on this many independent streams, each with its own "
                     "activation pool (engine.InterleavedForward; same results).  Default 2 for the ResNets (two batches in flight fill the launch "
                     "boundaries and partial last rounds of each other's kernels: +2.7 %% fp32, +10 %% bf16), 3 for hrnet_w32 with every forward on "
@@ -265,8 +269,8 @@ def wants_extra_jobs(args) -> bool:
     """N > 1 and the command the driver runs (the headline config, nothing overridden): the supervisor then also runs the collective
     self-check job and the N-rank train-step job, so that the first multi-GPU run measures BASELINE config 4 and proves (or safely
     rejects) the RCCL path."""
-    return (args.gpus > 1 and args.mode == "infer" and args.arch == "dconv" and args.dtype == "f32" and args.batch == 128 and not args.graph and
-            not args.no_extra_jobs and not args.no_other_configs and not args.self_check_only)
+    return (args.gpus > 1 and args.mode == "infer" and args.arch == "dconv" and args.backbone == "resnet50" and args.dtype == "f32" and args.batch == 128 and
+            not args.graph and not args.no_extra_jobs and not args.no_other_configs and not args.self_check_only)
 
 
 def _deadline(name: str, default: float) -> float:
@@ -550,7 +554,7 @@ def is_default_command(args) -> bool:
     """The command the driver runs: N = 1, the headline config, nothing overridden."""
     return (args.gpus == 1 and os.environ.get("WORLD_SIZE", "1") == "1" and args.mode == "infer" and args.arch == "dconv" and args.dtype == "f32" and
             args.batch == 128 and not args.graph and args.tiles is None and not args.retune and args.interleave is None and
-            not args.no_other_configs and not args.dry_launch)
+            not args.no_other_configs and not args.dry_launch and args.backbone == "resnet50")
 
 
 def measure_other_configs(args):
@@ -601,7 +605,9 @@ def run_once(args, ctx):
         sd = synth.conditioned_state_dict(hrnet_state_dict_shapes(model.cfg, 17), seed=0)
     else:
         mod = {"dconv": pose_resnet_dconv, "duc": pose_resnet_duc}[args.arch]
-        model = mod.resnet50(pretrained=False, num_classes=17)
+        if not hasattr(mod, args.backbone):
+            raise SystemExit(f"--backbone {args.backbone}: no such factory in nets.pose_resnet_{args.arch}")
+        model = getattr(mod, args.backbone)(pretrained=False, num_classes=17)
         # names / shapes / dtypes come from the model itself (its state_dict layout is the reference's, tests/test_host_logic.py)
         layout = [(k, tuple(v.shape), str(v.dtype)) for k, v in model.state_dict().items()]
         sd = synth.conditioned_state_dict(layout, seed=0)
@@ -642,7 +648,7 @@ def run_once(args, ctx):
         # committed rocprofv3 summaries were taken with: no tuner launches in a profiled run, same launches on every rank and box);
         # --retune / a missing table: timed on rank 0 at this batch and shared
         tiles_src = "built-in heuristic"
-        tpath = args.tiles or (None if (args.retune or args.arch != "dconv") else tracked_tiles("train", args.dtype))   # the tracked tables are ResNet50-DConv's
+        tpath = args.tiles or (None if (args.retune or args.arch != "dconv" or args.backbone != "resnet50") else tracked_tiles("train", args.dtype))   # the tracked tables are ResNet50-DConv's
         if not args.no_train_autotune:
             if tpath and os.path.isfile(tpath) and B == 32:
                 with open(tpath) as fh:
@@ -679,7 +685,7 @@ def run_once(args, ctx):
         # untimed setup: pin the fastest workgroup tile per layer shape (or reuse a saved table: profiling runs do, so that
         # the trial launches of the tuner stay out of the per-kernel statistics)
         tiles_src = "autotuned on this GPU (untimed setup)"
-        pinned = tracked_tiles(args.arch, args.dtype) if (args.tiles is None and not args.retune and B == 128) else None
+        pinned = tracked_tiles(args.arch, args.dtype) if (args.tiles is None and not args.retune and B == 128 and args.backbone == "resnet50") else None
         if args.tiles and os.path.isfile(args.tiles):
             with open(args.tiles) as fh:
                 prog.set_tiles(json.load(fh), B)
@@ -801,9 +807,11 @@ def run_once(args, ctx):
                                       layers_out=args.layers_out)
     if rank == 0:
         name = ARCH_NAMES[args.arch]
+        if args.backbone != "resnet50" and args.arch in ("dconv", "duc"):
+            name = name.replace("ResNet50", args.backbone)
         if args.mode == "train":
             # train step ~ 3 x forward (fwd + dgrad + wgrad) = 32.56 GFLOP / image (HRNet: from the trainer's own layer table)
-            gflop = 3 * ({"dconv": 10.8528, "duc": 11.7517}.get(args.arch) or sum(L.flops for L in trainer.layers.values()) / 1e9)
+            gflop = 3 * (({"dconv": 10.8528, "duc": 11.7517}.get(args.arch) if args.backbone == "resnet50" else None) or sum(L.flops for L in trainer.layers.values()) / 1e9)
             line = {
                 "metric": f"images/sec train step (fwd+bwd+Adam), {name} 256x192 bs={B}/GPU", "value": round(value, 1), "unit": "images/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -843,7 +851,7 @@ def run_once(args, ctx):
                 "roofline": roofline,
                 "one_batch_in_flight": one_in_flight,
                 "host_enqueue_ms_per_step": round(host_enqueue_ms, 3),
-                "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args.arch),   # rank 0 at N = 1 only
+                "cpu_baseline": None if (args.no_cpu_baseline or world > 1 or args.backbone != "resnet50") else cpu_baseline(args.arch),   # rank 0 at N = 1 only
             }
     else:
         line = None

@@ -562,6 +562,20 @@ int sp_pack_conv_weights(const float* w, int c_out, int c_in, int kh, int kw, in
  * within the panel); row n belongs to panel n / panel and holds its group's weights at the group's channels inside the panel, zeros elsewhere).
  * `panel` = sp_conv_desc.c_in_group = tile_n of the launch: a multiple of c_in / g and of the K tile (32 fp32 / 64 bf16 elements). */
 int sp_pack_conv_weights_grouped(const float* w, int c_out, int groups, int kh, int kw, int panel, void* dst, int dst_bf16, void* stream);
+/* (ABI 34) the same block-diagonal panels for the TRAIN step of that grouped conv (loss.backward() through nets/pose_resnet_dconv.py:101): a tap subset
+ * (ky, kx) = (ky0 + ky_step * ty, kx0 + kx_step * tx), ty < taps_h, tx < taps_w, of the kh x kw filter (taps outside it are zero) - the forward
+ * (0, 1, 0, 1), the flipped taps of the stride-1 input gradient (kh-1, -1, kw-1, -1), one output phase of the stride-2 input gradient (ky0, 2, kx0, 2) -
+ * and, with `transpose`, rows = the layer's INPUT channels: the input gradient is a grouped conv of dz with Wd[c][o_local][tap] = W[o][c_local][tap].
+ * dst: [c][taps_h * taps_w * panel]. */
+int sp_pack_conv_weights_grouped_taps(const float* w, int c, int groups, int kh, int kw, int transpose, int taps_h, int taps_w, int ky0, int ky_step,
+                                      int kx0, int kx_step, int panel, void* dst, int dst_bf16, void* stream);
+/* (ABI 34) weight gradient of that grouped conv (c_out == c_in = c, `groups` groups): dw[o][cl][ky][kx] (fp32, the nn.Conv2d weight layout, WRITTEN) =
+ * sum over (b, oy, ox) of dz[b, oy, ox, o] * x[b, oy*stride - pad + ky, ox*stride - pad + kx, group(o) * (c / groups) + cl]; x and dz NHWC, fp32 or
+ * (bf16 = 1) bf16.  A streaming reduction (1 / groups of the dense layer's FLOPs): partial sums per row chunk in `workspace`, folded in a fixed
+ * order in fp64 (no atomics).  c / groups must divide 256, kh * kw <= 9. */
+int sp_conv2d_wgrad_grouped_workspace(int batch, int out_h, int c, int groups, int kh, int kw, int64_t* bytes);
+int sp_conv2d_wgrad_grouped(const void* x, const void* dz, int bf16, int batch, int in_h, int in_w, int out_h, int out_w, int c, int groups, int kh,
+                            int kw, int stride, int pad, float* dw, void* workspace, int64_t workspace_bytes, void* stream);
 int sp_pack_deconv_k4s2p1(const float* w, int c_in, int c_out, int n_pad, void* dst, int dst_bf16, void* stream);
 /* eval-mode nn.BatchNorm2d as the conv epilogue's (scale, shift): scale = weight / sqrt(running_var + eps),
  * shift = bias - running_mean * scale (each operation rounded on its own, as the torch expressions); weight / bias NULL = 1 / 0;

@@ -153,6 +153,9 @@ SYMBOLS = {
     "sp_conv_packed_dims": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "sp_pack_conv_weights": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),
     "sp_pack_conv_weights_grouped": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),
+    "sp_pack_conv_weights_grouped_taps": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),
+    "sp_conv2d_wgrad_grouped_workspace": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int64)]),
+    "sp_conv2d_wgrad_grouped": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int64, _P]),
     "sp_pack_deconv_k4s2p1": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P]),
     "sp_fold_bn": (c_int, [_P, _P, _P, _P, c_int, c_float, c_int, _P, _P, _P]),
 }

@@ -7,9 +7,11 @@
 // y out; layer1 and layer2 already sit on the HBM roofline conv by conv (profiles/r02_dconv_bf16_floors.md), so only fewer bytes move them.
 //
 // One persistent 8-wave workgroup per CU, 16x8-pixel output tiles (the 3x3 stage is the round-2 64-channel direct kernel's):
-//   A  t1 = relu(bn1(x . W1^T)) on the 18x10-pixel halo (192-row GEMM, K = 256): A fragments straight from the NHWC rows of x (a lane's
-//      8 channels are 16 contiguous bytes), W1's fragments from L2; t1 -> LDS as bf16 (zero outside the image: the 3x3's padding
-//      applies to t1);
+//   A  t1 = relu(bn1(x . W1^T)) on the 18x10-pixel halo (192-row GEMM, K = 256).  x is loaded as whole 128-byte pieces of a pixel row (a
+//      wave-instruction = 8 pixels x 8 chunks: eight cache lines - round 6; the MFMA fragment gather it replaces, 32 pixels x 32 bytes per
+//      instruction, cost ~110-140 cycles of address coalescing per load, 78 loads per tile) and turned into fragments through a small
+//      per-wave LDS slot (ds_write_b128 + ds_read_b128 on the ring kernel's swizzled [32 rows][128 B] image); W1's fragments from LDS;
+//      t1 -> LDS as bf16 (zero outside the image: the 3x3's padding applies to t1);
 //   B  t2 = relu(bn2(conv3x3(t1))) from the LDS halo tile, W2 resident in LDS in fragment order (72 KiB); t2 -> the wave's LDS slice;
 //   C  y = relu(bn3(t2 . W3^T) + x): K = 64, N = 256 (8 column blocks, 128 accumulator registers); W3's fragments come from L2 (32 KB,
 //      requested during stage B), the residual from the centre pixels of x; 16-byte stores through the per-wave transpose scratch.
@@ -48,10 +50,10 @@ constexpr int NHALO = BH_H * BH_W;
 constexpr int CM = 64, CIO = 256;                  // mid / in-out channels
 constexpr int PIXM = CM * 2;                       // 128 B per t1 pixel = 8 chunks of 16 B
 constexpr int W2B = 9 * 4 * 2 * 2 * 32 * 16;       // [tap][k step][column block][k half][column] 16-B fragments = 73,728 B
-constexpr int W1B = 16 * 2 * 2 * 32 * 16;          // [k step][column block][k half][column]                     = 32,768 B
 constexpr int T1B = NHALO * PIXM;                  // 23,040 B: t1 on the halo
 constexpr int T2B = 128 * PIXM;                    // 16,384 B: t2 of the tile, bf16 [128 pixels][64 channels]
-constexpr int TRB = 32 * 32 * 4;                   // per wave: fp32 transpose slab of one 32x32 accumulator (4 KB)
+constexpr int W1B = 16 * 2 * 2 * 32 * 16;          // [k step][column block][k half][column]                     = 32,768 B
+constexpr int TRB = 32 * 32 * 4;                   // per wave: fp32 transpose slab of one 32x32 accumulator (4 KB) = one x staging slot [32 pixels][128 B]
 constexpr int LDSB = W2B + W1B + T1B + T2B + 4 * TRB;   // 162,304 B of the CU's 163,840
 constexpr unsigned OOB = 0x80000000u;
 
@@ -74,11 +76,13 @@ __device__ __forceinline__ int t1off(int hy, int hx, int c) {
 // Four waves, one per SIMD (512 registers each), the three stages one after the other per tile.  What the measured versions taught
 // (tools/diag_bneck.py, cycles per tile of a wave; MFMA work is 4,900):
 //   * W1 / W3 fragments and the residual fetched from L2 inside each tile: every round trip exposed, 40,000 cycles per tile (228 us);
+//   * (round 6) x fetched as MFMA fragments (32 pixels x 32 bytes per wave-instruction): ~110-140 cycles of address coalescing per load,
+//     78 of them per tile = a third of the tile's 30,600 cycles.  Now whole 128-byte pieces + an LDS transposition (this file's header);
 //   * eight waves in two roles (stage A one tile ahead | stages B, C): the 256-register cap spilled the 3x3 loop's addresses to scratch
 //     (a scratch load per MFMA pair: 25,000 cycles for 72 MFMAs) and the roles fought for one SIMD's issue slots (236-245 us);
 //   * the t1 store with a division by 10 per accumulator register: 10,400 cycles of vector instructions.
 // Hence: W1 and W2 resident in LDS in fragment order, W3's 8 fragments of a wave's 64 output channels and nothing else per tile from
-// L2; x requested 6 k steps ahead AND the next tile's first 6 k steps requested before stage C of the current one; halo coordinates
+// L2; x requested 6 units (24 KiB per wave) ahead AND the next tile's first 6 units requested before stage C of the current one; halo coordinates
 // of the t1 store folded to compile-time constants; stage C split by output channels (wave w: channels 64w..64w+63 of all 128 pixels,
 // from the shared t2 tile), the residual of a 32-pixel block requested one block ahead.
 __global__ __launch_bounds__(256, 1) void bottleneck_c64_kernel(const BneckArgs p) {
@@ -90,6 +94,9 @@ __global__ __launch_bounds__(256, 1) void bottleneck_c64_kernel(const BneckArgs 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* const tr = reinterpret_cast<float*>(smemb + W2B + W1B + T1B + T2B + wave * TRB);
+    // this wave's x staging slot is its transpose slab: ONE slot is enough - a unit's fragments are read into registers right after its
+    // pieces are written, and the LDS executes a wave's operations in order, so the next unit's writes cannot overtake those reads
+    unsigned char* const xslot = reinterpret_cast<unsigned char*>(tr);
     const int fr = lane & 31, fh = lane >> 5;
     const int ntiles = p.tiles_x * p.tiles_y * p.batch;
     const int G = gridDim.x;
@@ -141,52 +148,80 @@ __global__ __launch_bounds__(256, 1) void bottleneck_c64_kernel(const BneckArgs 
     const unsigned char* const w2frag = Ws2 + (fh * 32 + fr) * 16;
     const int py = 4 * wave + (fr >> 3), px = fr & 7;        // stage B: output pixel of this lane's A row inside the tile
 
-    constexpr int PFA = 10, NKA = 16;                        // stage A: k steps of 16 channels, x requested PFA steps ahead
-    u32x4 fa[PFA + 1][3];
-    unsigned abase[3];
+    // stage A: the 192 halo rows x 256 channels of x as 12 UNITS (k group q = 4 k steps = 128 bytes of a pixel, row block j): a unit is four
+    // 1-KiB loads (8 pixels x 128 B each), requested PFU units ahead; consumed through an LDS slot as four A fragments
+    constexpr int NUNIT = 12, PFU = 6, NRING = PFU + 1;
+    u32x4 fa[NRING][4];
+    unsigned abase[3][4];
     int cy0 = 0, cx0 = 0, cb = 0;                            // tile whose x is in flight: origin and image
+    const int lp = lane >> 3, lc = lane & 7;                 // load role: pixel lp of the piece, 16-byte chunk lc of its 128 bytes
     auto tile_origin = [&](int tile) __attribute__((always_inline)) {
         int t = tile;
         const int tx = t % p.tiles_x; t /= p.tiles_x;
         const int ty = t % p.tiles_y;
         cb = t / p.tiles_y; cy0 = ty * BT_H; cx0 = tx * BT_W;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int P = (mb0 + 2 * j) * 32 + fr;
-            const int hy = P / BH_W, hx = P - hy * BH_W;
-            const int iy = cy0 - 1 + hy, ix = cx0 - 1 + hx;
-            const bool ok = P < NHALO && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            abase[j] = ok ? (unsigned)((((cb * p.H + iy) * p.W + ix) * CIO + fh * 8) * 2) : OOB;
-        }
-    };
-    auto reqA = [&](int ks) __attribute__((always_inline)) {
+        for (int j = 0; j < 3; ++j)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) fa[ks % (PFA + 1)][j] = __builtin_amdgcn_raw_buffer_load_b128(xr, abase[j] + (unsigned)(ks * 32), 0, 0);
+            for (int i = 0; i < 4; ++i) {
+                const int P = (mb0 + 2 * j) * 32 + 8 * i + lp;
+                const int hy = (P * 6554) >> 16, hx = P - hy * BH_W;          // P / 10 for P < 192
+                const int iy = cy0 - 1 + hy, ix = cx0 - 1 + hx;
+                const bool ok = P < NHALO && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                abase[j][i] = ok ? (unsigned)((((cb * p.H + iy) * p.W + ix) * CIO + lc * 8) * 2) : OOB;
+            }
     };
+    auto reqU = [&](int u) __attribute__((always_inline)) {     // unit u = (k group u / 3, row block u % 3)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[u % NRING][i] = __builtin_amdgcn_raw_buffer_load_b128(xr, abase[u % 3][i] + (unsigned)((u / 3) * 128), 0, 0);
+    };
+    // staging slot image: [32 pixels][128 B], chunk c of pixel r at position c ^ ((r >> 1) & 7) (conv_ring.hip's row image: conflict-free
+    // ds_read_b128 fragment beats); a lane writes chunk lc of pixel 8 i + lp and reads, for k step ks, chunk 2 ks + fh of pixel fr
+    int wofs[4], rofs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 8 * i + lp;
+        wofs[i] = r * 128 + ((lc ^ ((r >> 1) & 7)) << 4);
+        rofs[i] = fr * 128 + (((2 * i + fh) ^ ((fr >> 1) & 7)) << 4);
+    }
     if ((int)blockIdx.x < ntiles) {
         tile_origin(blockIdx.x);
 #pragma unroll
-        for (int ks = 0; ks < PFA; ++ks) reqA(ks);
+        for (int u = 0; u < PFU; ++u) reqU(u);
     }
     __syncthreads();                                         // filters are in LDS
 
     for (int tile = blockIdx.x; tile < ntiles; tile += G) {
         const int y0 = cy0, x0 = cx0, b = cb;
         // =================== stage A: t1 = relu(bn1(x . W1^T)) on the halo ===================
-        f32x16 a0, a1, a2;
+        f32x16 aacc[3];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; a2[r] = 0.f; }
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) aacc[j][r] = 0.f;
         SP_BSTAMP(ta0)
+        u32x4 fcur[4], fnext[4];
+        auto stage_unit = [&](int u, u32x4 (&dst)[4]) __attribute__((always_inline)) {   // registers -> the slot -> the unit's four A fragments
+            unsigned char* const sl = xslot;
 #pragma unroll
-        for (int ks = 0; ks < NKA; ++ks) {
-            if (ks + PFA < NKA) reqA(ks + PFA);
-            const u32x4 bbq = *reinterpret_cast<const u32x4*>(w1frag + ks * 2048);
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(sl + wofs[i]) = fa[u % NRING][i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dst[i] = *reinterpret_cast<const u32x4*>(sl + rofs[i]);
+        };
+        stage_unit(0, fcur);
+#pragma unroll
+        for (int u = 0; u < NUNIT; ++u) {
+            if (u + PFU < NUNIT) reqU(u + PFU);
+            if (u + 1 < NUNIT) stage_unit(u + 1, fnext);         // the next unit's fragments land under this unit's MFMAs
             __builtin_amdgcn_sched_barrier(0);
-            const bf16x8 bb = __builtin_bit_cast(bf16x8, bbq);
-            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[ks % (PFA + 1)][0]), bb, a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[ks % (PFA + 1)][1]), bb, a1, 0, 0, 0);
-            a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[ks % (PFA + 1)][2]), bb, a2, 0, 0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const u32x4 bbq = *reinterpret_cast<const u32x4*>(w1frag + ((u / 3) * 4 + ks) * 2048);
+                aacc[u % 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fcur[ks]), __builtin_bit_cast(bf16x8, bbq), aacc[u % 3], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fcur[i] = fnext[i];
         }
         SP_BSTAMP(ta1)
         SP_BACC(0, ta0, ta1)
@@ -219,9 +254,9 @@ __global__ __launch_bounds__(256, 1) void bottleneck_c64_kernel(const BneckArgs 
                     if (P < NHALO) *reinterpret_cast<u32x4*>(T1 + t1off(hy, hx, nbA * 4 + chunk)) = __builtin_bit_cast(u32x4, o8);
                 }
             };
-            put(a0, mb0);
-            put(a1, mb0 + 2);
-            put(a2, mb0 + 4);
+            put(aacc[0], mb0);
+            put(aacc[1], mb0 + 2);
+            put(aacc[2], mb0 + 4);
         }
         SP_BSTAMP(ta2)
         SP_BACC(1, ta1, ta2)
@@ -290,11 +325,11 @@ __global__ __launch_bounds__(256, 1) void bottleneck_c64_kernel(const BneckArgs 
         SP_BSTAMP(tc0)
         SP_BACC(2, tb2, tc0)
 
-        // the next tile's x: its first PFA k steps fly during stage C
+        // the next tile's x: its first PFU units fly during stage C
         if (tile + G < ntiles) {
             tile_origin(tile + G);
 #pragma unroll
-            for (int ks = 0; ks < PFA; ++ks) reqA(ks);
+            for (int u = 0; u < PFU; ++u) reqU(u);
         }
 
         SP_BSTAMP(tc0b)

@@ -150,6 +150,47 @@ extern "C" int sp_pack_conv_weights_grouped(const float* w, int c_out, int group
     return sp_check_launch("pack_conv_grouped_kernel");
 }
 
+// The same block-diagonal panels for the TRAIN step of a grouped conv (round 6): a tap subset (ky, kx) = (ky0 + ky_step * ty, kx0 + kx_step * tx) of
+// the kh x kw filter - the forward (0, 1, 0, 1), the flipped taps of the stride-1 input gradient (kh-1, -1, kw-1, -1), one output phase of the
+// stride-2 input gradient (ky0, 2, kx0, 2) - and, with `transpose`, rows = the layer's INPUT channels (the input gradient is a grouped conv of dz
+// with Wd[c][o_local][tap] = W[o][c_local][tap]): row n's panel covers channels [(n / panel) * panel, +panel) of the K operand; element (n, t, j) is
+// W[o][cl][ky][kx] with (o, c) = (n, P*panel + j) [forward] or (P*panel + j, n) [transpose] when o and c share a group, cl = c % cpg; else 0.
+template <bool BF16OUT>
+__global__ void pack_conv_grouped_taps_kernel(const float* __restrict__ w, void* __restrict__ dst, int C, int cpg, int kh, int kw, int transpose, int th,
+                                              int tw, int ky0, int ky_step, int kx0, int kx_step, int panel) {
+    const int K = th * tw * panel;
+    const long long total = (long long)C * K;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / K), k = (int)(i - (long long)n * K);
+        const int t = k / panel, j = k - t * panel;
+        const int ty = t / tw, tx = t - ty * tw;
+        const int ky = ky0 + ky_step * ty, kx = kx0 + kx_step * tx;
+        const int m = (n / panel) * panel + j;
+        const int o = transpose ? m : n, c = transpose ? n : m;
+        float v = 0.f;
+        if (o / cpg == c / cpg && (unsigned)ky < (unsigned)kh && (unsigned)kx < (unsigned)kw) v = w[(((long long)o * cpg + (c % cpg)) * kh + ky) * kw + kx];
+        if constexpr (BF16OUT) reinterpret_cast<__bf16*>(dst)[i] = (__bf16)v;
+        else reinterpret_cast<float*>(dst)[i] = v;
+    }
+}
+
+extern "C" int sp_pack_conv_weights_grouped_taps(const float* w, int c, int groups, int kh, int kw, int transpose, int taps_h, int taps_w, int ky0,
+                                                 int ky_step, int kx0, int kx_step, int panel, void* dst, int dst_bf16, void* stream) {
+    SP_REQUIRE(w && dst, "sp_pack_conv_weights_grouped_taps: null pointer");
+    SP_REQUIRE(c > 0 && groups > 0 && c % groups == 0 && kh > 0 && kw > 0 && taps_h > 0 && taps_w > 0, "sp_pack_conv_weights_grouped_taps: bad shape");
+    const int cpg = c / groups;
+    SP_REQUIRE(panel > 0 && panel % cpg == 0 && c % panel == 0 && panel % (dst_bf16 ? 64 : 32) == 0,
+               "sp_pack_conv_weights_grouped_taps: panel=%d must be a multiple of the group size %d and of the K tile, and divide c=%d", panel, cpg, c);
+    const long long total = (long long)c * taps_h * taps_w * panel;
+    if (dst_bf16)
+        hipLaunchKernelGGL(pack_conv_grouped_taps_kernel<true>, dim3(grid_of(total)), dim3(256), 0, (hipStream_t)stream, w, dst, c, cpg, kh, kw, transpose ? 1 : 0,
+                           taps_h, taps_w, ky0, ky_step, kx0, kx_step, panel);
+    else
+        hipLaunchKernelGGL(pack_conv_grouped_taps_kernel<false>, dim3(grid_of(total)), dim3(256), 0, (hipStream_t)stream, w, dst, c, cpg, kh, kw, transpose ? 1 : 0,
+                           taps_h, taps_w, ky0, ky_step, kx0, kx_step, panel);
+    return sp_check_launch("pack_conv_grouped_taps_kernel");
+}
+
 extern "C" int sp_pack_deconv_k4s2p1(const float* w, int c_in, int c_out, int n_pad, void* dst, int dst_bf16, void* stream) {
     SP_REQUIRE(w && dst, "sp_pack_deconv_k4s2p1: null pointer");
     SP_REQUIRE(c_in > 0 && c_out > 0 && c_in % (dst_bf16 ? 16 : 8) == 0, "sp_pack_deconv_k4s2p1: 4*c_in must be a whole number of K tiles");

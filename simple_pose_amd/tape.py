@@ -133,6 +133,11 @@ class StepTape:
         # one fold launch): a layer alone has too few dW tiles to fill 256 CUs without cutting its pixels into hundreds of partial
         # slabs.  The group goes out when a gradient bucket completes, when `wgrad_group_gflop` of work is queued, or at the end.
         tr = self.tr
+        if layer.groups > 1:
+            # a grouped layer's dW is a streaming reduction of its own (sp_conv2d_wgrad_grouped), not a tile of the batched MFMA launch: it
+            # goes out here, on the chain's stream, and writes its slice of the flat gradient buffer
+            layer.wgrad_grouped(xin, dzt, self.B)
+            return
         tr._wg_queue.append((layer, xin, dzt))
         tr._wg_queued_flops += layer.flops * self.B
         if tr._wg_queued_flops >= tr._group_gflop * 1e9 or len(tr._wg_queue) >= 64:     # (64 jobs: the batched call's limit)
@@ -149,7 +154,7 @@ class StepTape:
             zin, mean, invstd, gamma, beta = xa.pending_apply
             xa.pending_apply = None
             z, part, prow = layer.forward_bn_stats_abn(zin, self.B, mean, invstd, gamma, beta, xa.data, xa.mask)
-        elif self.tr.fuse_bn_stats:
+        elif self.tr.fuse_bn_stats and layer.groups == 1:
             z, part, prow = layer.forward_bn_stats(xa.data, self.B)
         else:
             z, part, prow = layer.forward(xa.data, self.B), None, 0
@@ -386,7 +391,8 @@ class StepTape:
             # the last consumer to contribute sees the complete dy of xa in its epilogue: BN backward sums for free.  (Block outputs:
             # the residual share lands first, conv1 of the next block - a full-cover 1x1 - accumulates last.)
             last = xa.contrib == xa.consumers - 1
-            fuse = tr.fuse_bn_bwd and xa.bn is not None and last and (xa.grad is None or layer.dgrad_full_cover)
+            fuse = (tr.fuse_bn_bwd and xa.bn is not None and last and (xa.grad is None or layer.dgrad_full_cover)
+                    and layer.groups == 1)              # (a grouped launch has no BSTATS epilogue: that BatchNorm reduces its own sums)
             if xa.lazy_g is not None:
                 assert fuse and xa.grad is None, "a lazy residual share needs the BSTATS dgrad of conv1 as the last contributor"
                 xa.grad = layer.dgrad(dz, B, None, bn_src=xa, acc_masked=xa.lazy_g)

@@ -171,8 +171,10 @@ class ConvT:
 
     def __init__(self, tr: "PoseTrainer", name: str, kind: str, weight: torch.Tensor, h: int, w: int, stride: int = 1, pad: int = 0,
                  c_in_buf: Optional[int] = None, bias_name: Optional[str] = None, out_nchw: bool = False, need_dgrad: bool = True,
-                 taps_w: Optional[int] = None):
+                 taps_w: Optional[int] = None, groups: int = 1):
         self.tr, self.name, self.kind, self.wname = tr, name, kind, name + ".weight"
+        self.groups = groups
+        self.gpacks: List[tuple] = []                   # grouped layers: (transpose, taps_h, taps_w, ky0, ky_step, kx0, kx_step, dst) of sp_pack_conv_weights_grouped_taps
         self._rows_cache: Dict[tuple, int] = {}
         self.stride, self.pad, self.h, self.w = stride, pad, h, w
         self.bias_name, self.out_nchw, self.need_dgrad = bias_name, out_nchw, need_dgrad
@@ -183,7 +185,9 @@ class ConvT:
         kmul = 64 if self.bf16 else 32                 # K tile = 128 bytes
         fbf = SP_CONV_BF16 if self.bf16 else 0
         self._wdt, self._kmul, self._fbf = wdt, kmul, fbf
-        if kind == "conv":
+        if kind == "conv" and groups > 1:
+            self._init_grouped(weight, h, w, stride, pad, need_dgrad)
+        elif kind == "conv":
             O, I, kh, kw = weight.shape
             self.O, self.I, self.kh, self.kw = O, I, kh, kw
             ci = c_in_buf or I                                     # stem: 3 -> NHWC4
@@ -261,6 +265,89 @@ class ConvT:
             self.wg = dict(n_valid=I, c_valid=O, kw_valid=4, s_n=O * 16, s_c=16)
         else:
             raise ValueError(kind)
+
+    def _init_grouped(self, weight, h, w, stride, pad, need_dgrad) -> None:
+        """nn.Conv2d(groups = g) with c_out == c_in (the 3x3 of the resnext* Bottlenecks, nets/pose_resnet_dconv.py:97-101): forward and input
+        gradient are grouped launches of the implicit GEMM (sp_conv_desc.c_in_group: an N tile of `panel` channels reads only its own groups'
+        channels; block-diagonal panels from sp_pack_conv_weights_grouped_taps), the weight gradient a streaming reduction of its own
+        (sp_conv2d_wgrad_grouped).  No statistics epilogues: the BatchNorm passes around it take their sums from the tensors."""
+        C, cpg, kh, kw = weight.shape
+        dev, wdt, fbf = weight.device, self._wdt, self._fbf
+        if C % self.groups or C // self.groups != cpg or kh * kw > 9 or 256 % cpg:
+            raise NotImplementedError(f"{self.name}: grouped convolutions are lowered for c_out == c_in with a group width dividing 256 and at most 9 taps "
+                                      f"(weight {tuple(weight.shape)}, groups {self.groups})")
+        panel = 64
+        while panel % cpg:
+            panel *= 2
+        if C % panel or panel > 128:
+            raise NotImplementedError(f"{self.name}: no panel width for {self.groups} groups of {cpg} channels in {C}")
+        self.O, self.I, self.kh, self.kw, self.ci, self.tw, self.panel = C, cpg, kh, kw, C, kw, panel
+        self.oh, self.ow = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+        self.c_out_buf = C
+        self.flops = 2 * self.oh * self.ow * C * cpg * kh * kw
+        self.one_launch_phases = False                   # (sp_conv2d_dgrad_phases has no grouped form: one launch per output phase)
+
+        def desc(in_h, in_w, gh, gw, th, tw, st, dy0, dys, dx0, dxs, oh, ow, oym=1, oya=0, oxm=1, oxa=0, out_f32=False):
+            d = ConvDesc()
+            d.batch, d.in_h, d.in_w, d.c_in = 1, in_h, in_w, C
+            d.grid_h, d.grid_w, d.c_out, d.n_pad = gh, gw, C, C
+            d.taps_h, d.taps_w, d.k_pad, d.stride = th, tw, th * tw * panel, st
+            d.dy0, d.dy_step, d.dx0, d.dx_step = dy0, dys, dx0, dxs
+            d.out_h, d.out_w, d.out_c = oh, ow, C
+            d.oy_mul, d.oy_add, d.ox_mul, d.ox_add = oym, oya, oxm, oxa
+            d.phases_y = d.phases_x = 1
+            d.flags = fbf | (SP_CONV_OUT_F32 if out_f32 else 0)
+            d.c_in_group, d.tile_m, d.tile_n = panel, 128, panel
+            return d
+
+        self.w_fwd = torch.zeros((C, kh * kw * panel), dtype=wdt, device=dev)
+        self.gpacks.append((0, kh, kw, 0, 1, 0, 1, self.w_fwd))
+        self.d_fwd = desc(h, w, self.oh, self.ow, kh, kw, stride, -pad, 1, -pad, 1, self.oh, self.ow)
+        self.d_wgrad = self.d_fwd
+        self.w_dgrad, self.d_dgrad = [], []
+        self.dgrad_full_cover = True
+        if not need_dgrad:
+            return
+        g32 = self.bf16 and not self.tr.g16                 # activation gradients: fp32 unless grad_dtype is bf16
+        if stride == 1:
+            wd = torch.zeros((C, kh * kw * panel), dtype=wdt, device=dev)
+            self.gpacks.append((1, kh, kw, kh - 1, -1, kw - 1, -1, wd))          # Wd[c][(ty, tx, o)] = W[o][c][kh-1-ty][kw-1-tx]
+            pp = kh - 1 - pad
+            self.w_dgrad.append(wd)
+            self.d_dgrad.append(desc(self.oh, self.ow, h, w, kh, kw, 1, -pp, 1, -pp, 1, h, w, out_f32=g32))
+        else:
+            assert stride == 2 and h % 2 == 0 and w % 2 == 0
+            for py in range(2):                             # one launch per output phase (ConvT._build_conv_dgrad's decomposition)
+                for px in range(2):
+                    ky0, kx0 = (py + pad) % 2, (px + pad) % 2
+                    th, tw = len(range(ky0, kh, 2)), len(range(kx0, kw, 2))
+                    if th == 0 or tw == 0:
+                        self.dgrad_full_cover = False
+                        continue
+                    wd = torch.zeros((C, th * tw * panel), dtype=wdt, device=dev)
+                    self.gpacks.append((1, th, tw, ky0, 2, kx0, 2, wd))
+                    self.w_dgrad.append(wd)
+                    self.d_dgrad.append(desc(self.oh, self.ow, h // 2, w // 2, th, tw, 1, (py + pad - ky0) // 2, -1, (px + pad - kx0) // 2, -1, h, w,
+                                             2, py, 2, px, out_f32=g32))
+
+    def pack_grouped(self, stream) -> None:
+        """Regenerate this grouped layer's block-diagonal panels (forward + input-gradient phases) from the flat parameter buffer."""
+        lib, w = _lib.lib(), self.tr.flat.view(self.wname)
+        for tr_, th, tw, ky0, kys, kx0, kxs, dst in self.gpacks:
+            _lib.check(lib.sp_pack_conv_weights_grouped_taps(P(w), self.O, self.groups, self.kh, self.kw, tr_, th, tw, ky0, kys, kx0, kxs, self.panel, P(dst),
+                                                             int(self.bf16), stream), self.name + ".pack")
+
+    def wgrad_grouped(self, x: torch.Tensor, dz: torch.Tensor, B: int, stream=None) -> None:
+        """dW of a grouped layer, written into the flat gradient buffer (sp_conv2d_wgrad_grouped: partial sums per row chunk, fixed-order fold)."""
+        lib, tr = _lib.lib(), self.tr
+        need = ctypes.c_int64(0)
+        _lib.check(lib.sp_conv2d_wgrad_grouped_workspace(B, self.oh, self.O, self.groups, self.kh, self.kw, ctypes.byref(need)), self.name + ".wgrad")
+        ws = self._new(((need.value + 3) // 4,), torch.float32, x.device)
+        done = self._timed("wgrad")
+        _lib.check(lib.sp_conv2d_wgrad_grouped(P(x), P(dz), int(self.bf16), B, self.h, self.w, self.oh, self.ow, self.O, self.groups, self.kh, self.kw,
+                                               self.stride, self.pad, P(tr.flat.view(self.wname, grad=True)), P(ws), ws.numel() * 4,
+                                               stream if stream is not None else _lib.current_stream()), self.name + ".wgrad")
+        done()
 
     def _pad_rows(self, rows: int, row_elems: int) -> int:
         """Smallest number of tap rows >= `rows` whose elements fill whole K tiles."""
@@ -607,8 +694,6 @@ class PoseTrainer:
                                       "read fp32 gradients)")
         self.g16 = grad_dtype == "bf16"
         self.grad_dtype = torch.bfloat16 if self.g16 else torch.float32
-        if getattr(model, "GROUPS", 1) != 1:
-            raise NotImplementedError("PoseTrainer: the grouped resnext* nets run the eval-mode forward only (their grouped 3x3 has no dgrad / wgrad lowering)")
         if getattr(model, "BLOCK", "bottleneck") not in ("bottleneck", "basic"):
             raise NotImplementedError(f"PoseTrainer lowers the Bottleneck / BasicBlock ResNets and HRNet, not block type {model.BLOCK!r}")
         self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
@@ -649,6 +734,7 @@ class PoseTrainer:
         self.in_h, self.in_w = in_h, in_w
         self.layers: Dict[str, ConvT] = {}
         self._build(in_h, in_w)
+        self._grouped_layers = [L for L in self.layers.values() if L.groups > 1]
         if self.world > 1 and broadcast_init:
             dist.broadcast(self.flat.data, src=dist.get_global_rank(self.pg, 0) if self.pg is not None else 0, group=self.pg)
             for b in self.buffers.values():
@@ -765,7 +851,7 @@ class PoseTrainer:
                 elif self.world > 1 or self.force_collectives:
                     dist.all_reduce(self.flat.grad[b["lo"]:b["hi"]], op=dist.ReduceOp.SUM, group=self.pg)
                 self._adam(slice(b["lo"], b["hi"]), 1.0 / self.world, _lib.c_void_p(opt.cuda_stream))
-                self.repack(self._pack_rows_of_bucket[i], _lib.c_void_p(opt.cuda_stream))
+                self.repack(self._pack_rows_of_bucket[i], _lib.c_void_p(opt.cuda_stream), bucket=i)
             ev[1].record(opt)
             self._works[i] = ev[1]
 
@@ -966,7 +1052,7 @@ class PoseTrainer:
                     inpl = planes
                     continue
                 self._conv(p + ".conv1", h, w)
-                self._conv(p + ".conv2", h, w, stride=s, pad=1)
+                self._conv(p + ".conv2", h, w, stride=s, pad=1, groups=getattr(self.model, "GROUPS", 1))      # (resnext*: groups = 32, :97-101)
                 self._conv(p + ".conv3", h // s, w // s)
                 if bi == 0:
                     self._conv(p + ".downsample.0", h, w, stride=s)
@@ -988,7 +1074,7 @@ class PoseTrainer:
             self._conv("final_layer", h, w, pad=1, bias_name="final_layer.bias", out_nchw=True)
         self.heat_hw = (h, w)
 
-    def repack(self, rows_range=None, stream=None):
+    def repack(self, rows_range=None, stream=None, bucket: Optional[int] = None):
         """Regenerate every packed weight copy from the (just updated) flat parameter buffer: one launch over a device-side
         job table (141 pack jobs for ResNet50-DConv, cut into ~1,200 equal-sized slabs so that the grid is balanced)."""
         if getattr(self, "_pack_table", None) is None:
@@ -1044,6 +1130,10 @@ class PoseTrainer:
             tab = _lib.c_void_p(self._pack_table.data_ptr() + 104 * lo)
             launch = _lib.lib().sp_permute4_batched_tiled if self._pack_tiled else _lib.lib().sp_permute4_batched
             _lib.check(launch(P(self.flat.data), tab, hi - lo, 8, stream if stream is not None else _lib.current_stream()), "repack")
+        # grouped layers (resnext*): their block-diagonal panels are not an affine gather - one small launch per packed copy
+        for layer in self._grouped_layers:
+            if bucket is None or self._bucket_of[layer.wname] == bucket:
+                layer.pack_grouped(stream if stream is not None else _lib.current_stream())
 
     # ---- per-layer tile choice -----------------------------------------------------------------------------------------------
     def autotune(self, batch: int, reps: int = 5, rounds: int = 3) -> Dict[str, tuple]:
@@ -1115,13 +1205,18 @@ class PoseTrainer:
     def set_tiles(self, table: Dict[str, list], batch: int) -> None:
         """Pin a tile table (`get_tiles` / `autotune` of another run or rank).  The BatchNorm partial sums are grouped per tile row block,
         so ranks (and runs) that must agree to the last bit share ONE table: `autotune_shared` tunes on rank 0 and broadcasts it."""
+        def pin(d, t):
+            tm, tn = (int(v) for v in t)
+            if d.c_in_group and tn != d.c_in_group:
+                return                                   # a grouped launch's N tile IS its weight panel: an entry of another backbone (same layer names) is not for it
+            d.tile_m, d.tile_n = tm, tn
         for name, layer in self.layers.items():
             if name in table:
-                layer.d_fwd.tile_m, layer.d_fwd.tile_n = (int(v) for v in table[name])
+                pin(layer.d_fwd, table[name])
             if layer.need_dgrad:
                 for i, d in enumerate(layer.d_dgrad):
                     if f"{name}.dgrad{i}" in table:
-                        d.tile_m, d.tile_n = (int(v) for v in table[f"{name}.dgrad{i}"])
+                        pin(d, table[f"{name}.dgrad{i}"])
         self.tuned_for_batch = batch
 
     def autotune_shared(self, batch: int) -> Dict[str, list]:

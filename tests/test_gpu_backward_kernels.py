@@ -17,7 +17,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-from simple_pose_amd import _lib  # noqa: E402
+from simple_pose_amd import _lib, synth  # noqa: E402
 from simple_pose_amd.train import ConvT, FlatParams  # noqa: E402
 
 DEV = "cuda:0"
@@ -723,3 +723,60 @@ def test_pixel_unshuffle_bf16_is_the_fp32_permutation():
     assert torch.equal(a, b.float())
     ref = torch.nn.functional.pixel_unshuffle(dy.float().permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
     assert torch.equal(a, ref.contiguous())
+
+
+# ---------------------------------------------------------------------------------------------- grouped convolutions (resnext*, round 6)
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("C,groups,stride,B,H,W", [(128, 32, 1, 3, 12, 10), (256, 32, 2, 2, 16, 12), (512, 32, 1, 2, 9, 7), (1024, 32, 2, 2, 8, 6),
+                                                   (2048, 32, 1, 1, 5, 4)])
+def test_grouped_conv_forward_dgrad_wgrad_against_float64(C, groups, stride, B, H, W, dtype):
+    """nn.Conv2d(C, C, 3, stride, padding=1, groups=32) (nets/pose_resnet_dconv.py:97-101) through ConvT's grouped lowering, one layer alone:
+    forward (sp_conv2d_fwd with sp_conv_desc.c_in_group on panels from sp_pack_conv_weights_grouped_taps), input gradient (the same launch on
+    transposed / flipped panels; stride 2: one launch per output phase) and weight gradient (sp_conv2d_wgrad_grouped: partial sums per row chunk,
+    fixed-order fp64 fold) against torch's float64 grouped convolution on the same (bf16-rounded) operands; group widths 4 ... 64."""
+    import types
+    from simple_pose_amd.train import ConvT, FlatParams
+    bf = dtype == "bf16"
+    adt = torch.bfloat16 if bf else torch.float32
+    cpg = C // groups
+    conv = torch.nn.Conv2d(C, C, 3, stride=stride, padding=1, groups=groups, bias=False)
+    wn = synth.tensor_normal(3, f"gconv{C}/w", (C, cpg, 3, 3), std=(2.0 / (cpg * 9)) ** 0.5)
+    conv.weight.data.copy_(torch.from_numpy(wn).to(adt).float())
+    holder = torch.nn.Module()
+    holder.add_module("g", conv)
+    holder = holder.to(DEV)
+    flat = FlatParams(holder)
+    tr = types.SimpleNamespace(bf16=bf, g16=bf, grad_dtype=adt, flat=flat, kernel_events=None)
+    layer = ConvT(tr, "g", "conv", holder.g.weight.detach(), H, W, stride=stride, pad=1, groups=groups)
+    assert layer.d_fwd.c_in_group == 64 and len(layer.d_dgrad) == (1 if stride == 1 else 4)
+    layer.pack_grouped(_lib.current_stream())
+    x = torch.from_numpy(synth.tensor_normal(3, f"gconv{C}/x", (B, C, H, W))).to(adt)
+    OH, OW = layer.oh, layer.ow
+    dz = torch.from_numpy(synth.tensor_normal(3, f"gconv{C}/dz", (B, C, OH, OW))).to(adt)
+    xd = x.double().requires_grad_(True)
+    wd = torch.from_numpy(wn).to(adt).double().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(xd, wd, stride=stride, padding=1, groups=groups)
+    ref.backward(dz.double())
+    xg = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    dzg = dz.permute(0, 2, 3, 1).contiguous().to(DEV)
+    z = layer.forward(xg, B)
+    dx = layer.dgrad(dzg, B, None)
+    layer.wgrad_grouped(xg, dzg, B)
+    torch.cuda.synchronize()
+    tol = 2e-2 if bf else 2e-5                       # (bf16: outputs are rounded to bf16; the weight gradient is fp32 either way)
+    got = z.float().cpu().permute(0, 3, 1, 2).double()
+    assert float((got - ref.detach()).abs().max() / ref.detach().abs().max()) < tol
+    gdx = dx.float().cpu().permute(0, 3, 1, 2).double()
+    assert float((gdx - xd.grad).abs().max() / xd.grad.abs().max()) < tol
+    gdw = flat.view("g.weight", grad=True).cpu().double().view(C, cpg, 3, 3)
+    assert float((gdw - wd.grad).abs().max() / wd.grad.abs().max()) < 2e-5
+    # accumulate form of the input gradient (a second consumer's share already in place), and bit-reproducibility of the weight gradient
+    acc0 = torch.from_numpy(synth.tensor_normal(3, f"gconv{C}/acc", (B, H, W, C))).to(adt).to(DEV)
+    dx2 = layer.dgrad(dzg, B, acc0.clone())
+    torch.cuda.synchronize()
+    want = (acc0.float().cpu().double() + xd.grad.permute(0, 2, 3, 1)).abs().max()
+    assert float((dx2.float().cpu().double() - (acc0.float().cpu().double() + xd.grad.permute(0, 2, 3, 1))).abs().max() / want) < tol
+    first = flat.view("g.weight", grad=True).clone()
+    layer.wgrad_grouped(xg, dzg, B)
+    torch.cuda.synchronize()
+    assert torch.equal(first, flat.view("g.weight", grad=True))

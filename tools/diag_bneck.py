@@ -34,7 +34,8 @@ def main():
     a = ap.parse_args()
     if a.build:
         return build()
-    diag = os.path.isfile(LIB)
+    # SIMPLE_POSE_HIP_LIB already set (another build of the library, e.g. a same-box A/B): time that one, no stamps
+    diag = os.path.isfile(LIB) and os.environ.get("SIMPLE_POSE_HIP_LIB", LIB) == LIB
     if diag:
         os.environ["SIMPLE_POSE_HIP_LIB"] = LIB
     import numpy as np
@@ -64,7 +65,7 @@ def main():
     for _ in range(10):
         b.p._launch(lib, op, bufs, B, st)
     e1.record(); e1.synchronize()
-    print(f"bottleneck_c64 bs={B}: {1e3 * e0.elapsed_time(e1) / 10:.1f} us per launch ({'diag build' if diag else 'shipped build'})")
+    print(f"bottleneck_c64 bs={B}: {1e3 * e0.elapsed_time(e1) / 10:.1f} us per launch ({'diag build' if diag else os.path.basename(os.environ.get('SIMPLE_POSE_HIP_LIB', 'shipped build'))})")
     if diag:
         fn = ctypes.CDLL(LIB).sp_bneck_debug_read
         n = 256 * 8 * 8
