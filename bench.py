@@ -967,6 +967,8 @@ def _variant_name(op):
         return "basic_block_c32_kernel"
     if op.kind == "bneck64":
         return "bottleneck_c64_kernel"
+    if op.kind == "dual1x1":
+        return "dual_pw_bf16_kernel"
     if op.kind == "htrans":
         return "hrnet_transition1_kernel"
     if op.kind == "hstem":
@@ -1041,7 +1043,7 @@ def kernel_roofline(prog, x, steps: int, layers_out=None, peak=FP32_MATRIX_PEAK_
     bufs = dict(prog._alloc(B, x.device))
     bufs["input"] = x
     bufs[prog.out_name] = torch.empty((B,) + tuple(prog.out_shape), dtype=torch.float32, device=x.device)
-    FLOP_KINDS = ("conv", "bb32", "bneck64", "stem7", "hstem", "htrans")
+    FLOP_KINDS = ("conv", "bb32", "bneck64", "dual1x1", "stem7", "hstem", "htrans")
     conv_ops = [op for op in prog.ops if op.kind in FLOP_KINDS]            # every launch that carries algorithmic FLOPs
     ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in conv_ops]
           for _ in range(steps)]

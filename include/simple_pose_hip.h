@@ -125,6 +125,15 @@ int sp_basic_block_c32_ok(const sp_conv_desc* desc);
 int sp_basic_block_c32(const sp_conv_desc* desc, const void* x, const void* w1_packed, const float* scale1, const float* shift1,
                        const void* w2_packed, const float* scale2, const float* shift2, void* y, void* stream);
 
+/* (ABI 34) The tail of a stage-opening Bottleneck with 64 mid channels as ONE launch (bf16 NHWC, stride 1: layer1.0 of the ResNet pose nets and of HRNet):
+ *     y = relu( bn3(conv1x1_{64->256}(a_main)) + bn_d(conv1x1_{64->256}(a_short)) )          nets/pose_resnet_dconv.py:99-103,120-131
+ * a_main = the block's 3x3 output, a_short = the block input ([rows][64] each), weights packed by sp_pack_conv_weights ([256][64]), the folded
+ * BatchNorms as (scale, shift).  Replaces the projection shortcut's launch + conv3's launch (the 256-channel shortcut tensor is neither written nor
+ * read: 703 -> 301 MB at bs=128) with the same bits: the shortcut value is rounded to bf16 where the two-launch program stores it. */
+int sp_dual_pw_bf16_ok(int64_t rows, int c_main, int c_short, int c_out);
+int sp_dual_pw_bf16(const void* a_main, const void* w_main_packed, const float* scale_main, const float* shift_main, const void* a_short,
+                    const void* w_short_packed, const float* scale_short, const float* shift_short, void* y, int64_t rows, int c_main, int c_short,
+                    int c_out, int relu, void* stream);
 /* One ResNet Bottleneck (nets/pose_resnet_dconv.py:112-133) with an identity shortcut, stride 1, 256 -> 64 -> 64 -> 256 channels, in ONE
  * launch, bf16: y = relu(bn3(conv1x1(relu(bn2(conv3x3(relu(bn1(conv1x1(x)))))))) + x).  `desc` describes the block's 3x3 convolution
  * (sp_bottleneck_c64_ok(desc) == 1: what sp_conv3x3_direct_ok accepts at 64 channels); w1 [>=64][256], w2 [>=64][576], w3 [256][64]

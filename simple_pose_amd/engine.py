@@ -14,6 +14,7 @@ Reference behaviour being lowered (file:line relative to liangheming/simple_pose
 from __future__ import annotations
 
 import ctypes
+import os
 
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
@@ -247,6 +248,10 @@ class Program:
             w1, s1, h1, w3, s3, h3 = op.args
             _lib.check(lib.sp_bottleneck_c64(op.desc, P(bufs[op.src]), P(w1), P(s1), P(h1), P(op.w), P(op.scale), P(op.shift), P(w3), P(s3), P(h3),
                                              P(bufs[op.dst]), stream), op.name)
+        elif op.kind == "dual1x1":
+            w_s, s_s, h_s, rows_per_image, relu = op.args
+            _lib.check(lib.sp_dual_pw_bf16(P(bufs[op.src]), P(op.w), P(op.scale), P(op.shift), P(bufs[op.res]), P(w_s), P(s_s), P(h_s), P(bufs[op.dst]),
+                                           B * rows_per_image, 64, 64, 256, relu, stream), op.name)
         elif op.kind == "stem7":
             h, w, k_pad, unfused = op.args
             src = bufs[op.src]
@@ -772,6 +777,9 @@ class ProgramBuilder:
         # bf16: whole identity-shortcut Bottlenecks with 64 mid channels (ResNet-50 layer1.1 / layer1.2) as one launch
         # (sp_bottleneck_c64: same bits, x read once and y written once)
         self.fuse_bottlenecks = False
+        # bf16: conv3 + the projection shortcut of a stage-opening Bottleneck with 64 mid channels (layer1.0 of the ResNets and of HRNet) as one
+        # launch (sp_dual_pw_bf16: same bits, the 256-channel shortcut tensor is neither written nor read: 703 -> 301 MB at bs=128)
+        self.fuse_tail = os.environ.get("SP_FUSE_TAIL", "1") != "0"       # (env: development knob for same-box A/Bs)
         # the ResNet stem (conv1 7x7 s2 + bn1 + relu + maxpool) as one launch on the fp32 NCHW image (sp_stem7_pool: same bits, the
         # 128 x 96 x 64 map between conv and pooling never reaches HBM, K is not padded to a GEMM tile)
         self.fuse_stem = True
@@ -972,6 +980,22 @@ class ProgramBuilder:
                      flops=2 * h * w * (256 * 64 + 64 * 64 * 9 + 64 * 256)))
         return dst
 
+    def dual_pointwise_tail(self, main: str, w3, s3, h3, short: str, wd, sd_, hd, name: str) -> Optional[str]:
+        """conv3 + the projection shortcut of a stage-opening Bottleneck with 64 mid channels as one launch (sp_dual_pw_bf16): y = relu(bn3(conv3(main))
+        + bn_d(conv_d(short))); None when the shapes do not qualify or the fusion is off."""
+        h, w, c = self.p.shapes[main]
+        hs, ws_, cs = self.p.shapes[short]
+        if not (self.bf16 and self.fuse_tail and (h, w) == (hs, ws_) and c == 64 and cs == 64 and tuple(w3.shape) == (256, 64, 1, 1)
+                and tuple(wd.shape) == (256, 64, 1, 1) and _lib.lib().sp_dual_pw_bf16_ok(h * w, 64, 64, 256)):
+            return None
+        p3, pd = self.packer.conv(w3, bf16=True)[0], self.packer.conv(wd, bf16=True)[0]
+        if tuple(p3.shape) != (256, 64) or tuple(pd.shape) != (256, 64):
+            return None
+        dst = self._fresh(name)
+        self.p.shapes[dst] = (h, w, 256)
+        self._add(Op("dual1x1", main, dst, res=short, w=p3, scale=s3, shift=h3, args=(pd, sd_, hd, h * w, 1), name=name, flops=2 * h * w * 2 * 64 * 256))
+        return dst
+
     def deconv_k4s2p1(self, src: str, weight: torch.Tensor, *, scale=None, shift=None, relu: bool = False,
                       name: str = "deconv") -> str:
         h, w, c = self.p.shapes[src]
@@ -1061,6 +1085,13 @@ def _bottleneck(b: ProgramBuilder, sd, x: str, p: str, stride: int) -> str:
     w2 = sd[p + ".conv2.weight"]
     t = b.conv(t, w2, stride=stride, pad=1, scale=s2, shift=h2, relu=True, name=p + ".conv2", groups=w2.shape[0] // w2.shape[1])   # (resnext*: groups = 32)
     idn = x
+    if (p + ".downsample.0.weight") in sd and stride == 1 and (p + ".se.fc.0.weight") not in sd and w2.shape[0] == w2.shape[1]:
+        # layer1.0 (64 mid channels): conv3 + the projection shortcut as one launch - the 256-channel shortcut tensor is never written (same bits)
+        sdn, hdn = _bn(b, sd, p + ".downsample.1")
+        s3, h3 = _bn(b, sd, p + ".bn3")
+        y = b.dual_pointwise_tail(t, sd[p + ".conv3.weight"], s3, h3, x, sd[p + ".downsample.0.weight"], sdn, hdn, name=p + ".conv3+downsample")
+        if y is not None:
+            return y
     if (p + ".downsample.0.weight") in sd:
         sdn, hdn = _bn(b, sd, p + ".downsample.1")
         # (stays on the main path's stream: giving the shortcut its own stream measured -1 % fp32 / -4 % bf16 at bs=128 - these
@@ -1084,6 +1115,13 @@ def _res_basic_block(b: ProgramBuilder, sd, x: str, p: str, stride: int) -> str:
     s1, h1 = _bn(b, sd, p + ".bn1")
     t = b.conv(x, sd[p + ".conv1.weight"], stride=stride, pad=1, scale=s1, shift=h1, relu=True, name=p + ".conv1")
     idn = x
+    if (p + ".downsample.0.weight") in sd and stride == 1 and (p + ".se.fc.0.weight") not in sd and w2.shape[0] == w2.shape[1]:
+        # layer1.0 (64 mid channels): conv3 + the projection shortcut as one launch - the 256-channel shortcut tensor is never written (same bits)
+        sdn, hdn = _bn(b, sd, p + ".downsample.1")
+        s3, h3 = _bn(b, sd, p + ".bn3")
+        y = b.dual_pointwise_tail(t, sd[p + ".conv3.weight"], s3, h3, x, sd[p + ".downsample.0.weight"], sdn, hdn, name=p + ".conv3+downsample")
+        if y is not None:
+            return y
     if (p + ".downsample.0.weight") in sd:
         sdn, hdn = _bn(b, sd, p + ".downsample.1")
         idn = b.conv(x, sd[p + ".downsample.0.weight"], stride=stride, scale=sdn, shift=hdn, name=p + ".downsample")
@@ -1103,6 +1141,7 @@ def resnet_program(sd: Dict[str, torch.Tensor], head: str, in_h: int = 256, in_w
     `fuse_bottlenecks`: bf16 identity-shortcut Bottlenecks with 64 mid channels as one launch each (sp_bottleneck_c64; same bits)."""
     b = ProgramBuilder(in_h, in_w, dtype, packer)
     b.fuse_bottlenecks = fuse_bottlenecks
+    b.fuse_tail = fuse_bottlenecks and b.fuse_tail      # (one switch for the Bottleneck fusions of the ResNet programs: the per-conv program is the bitwise reference)
     b.fuse_stem = fuse_stem
     s, h = _bn(b, sd, "bn1")
     x = b.stem_pool("input", sd["conv1.weight"], s, h, name="conv1")
@@ -1218,13 +1257,15 @@ def _fuse_transition1(b: "ProgramBuilder") -> None:
 
 
 def hrnet_program(sd: Dict[str, torch.Tensor], cfg: dict, in_h: int = 256, in_w: int = 192, dtype: str = "fp32", packer=None,
-                  fuse_blocks: bool = False, fuse_stem: bool = True, fuse_terms: bool = True, fuse_transition: bool = True) -> Program:
+                  fuse_blocks: bool = False, fuse_stem: bool = True, fuse_terms: bool = True, fuse_transition: bool = True, fuse_tail: bool = True) -> Program:
     """Lower a reference-layout HRNet state_dict into a Program (PoseHighResolutionNet.forward, pose_hrnet.py:419-454).
     `fuse_blocks`: bf16 32-channel BasicBlocks as one launch each (sp_basic_block_c32; same bits as the two conv launches; opt-in,
     see ProgramBuilder.fuse_blocks)."""
     extra = cfg["MODEL"]["EXTRA"]
     b = ProgramBuilder(in_h, in_w, dtype, packer)
     b.fuse_blocks = fuse_blocks
+    b.fuse_tail = fuse_tail and b.fuse_tail
+    b.fuse_bottlenecks = os.environ.get("SP_HRNET_BNECK", "0") == "1"     # (env: development knob - layer1.1-1.3 through sp_bottleneck_c64; measured neutral in round 4)
     b.fuse_terms = fuse_terms
     b.fuse_transition = fuse_transition
     b.fuse_stem = fuse_stem

@@ -612,9 +612,10 @@ def test_deeper_resnet_factories_vs_oracle(measured, factory, head):
 
 @pytest.mark.parametrize("head,B,H,W", [("dconv", 3, 256, 192), ("duc", 2, 128, 96), ("dconv", 1, 96, 160)])
 def test_fused_bottlenecks_equal_the_per_conv_program_bitwise(head, B, H, W):
-    """model.fuse_bottlenecks (default on): layer1.1 / layer1.2 (identity shortcut, 256 -> 64 -> 64 -> 256) as ONE launch each (sp_bottleneck_c64) give
+    """model.fuse_bottlenecks (default on): layer1.1 / layer1.2 (identity shortcut, 256 -> 64 -> 64 -> 256) as ONE launch each (sp_bottleneck_c64) and
+    - round 6 - layer1.0's conv3 + projection shortcut as one launch (sp_dual_pw_bf16: the 256-channel shortcut tensor is never written) give
     the heat maps of the conv-by-conv bf16 program bit for bit - same accumulation chains, intermediates rounded to bf16 at the same
-    places; incl. sizes whose 16x8 tiles are ragged (96x160 input: 24x40 maps)."""
+    places; incl. sizes whose 16x8 tiles are ragged (96x160 input: 24x40 maps) and row counts that are no multiple of the 128-pixel tile."""
     m = {"dconv": pose_resnet_dconv, "duc": pose_resnet_duc}[head].resnet50(pretrained=False, num_classes=17)
     sd = synth.conditioned_state_dict(nets_oracle.state_dict_shapes_resnet50(head), 6)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
@@ -630,8 +631,48 @@ def test_fused_bottlenecks_equal_the_per_conv_program_bitwise(head, B, H, W):
         m.fuse_bottlenecks = True                  # (the default)
         got = m(x)
         prog = m.hip_program(x)
-    assert sum(op.kind == "bneck64" for op in prog.ops) == 2 and len(prog.ops) == n_ref - 4
+    assert sum(op.kind == "bneck64" for op in prog.ops) == 2 and sum(op.kind == "dual1x1" for op in prog.ops) == 1 and len(prog.ops) == n_ref - 5
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("rows,relu", [(128 * 7, True), (1000, True), (77, False), (128 * 300 + 5, True)])
+def test_dual_pointwise_tail_equals_the_two_launches_bitwise(rows, relu):
+    """sp_dual_pw_bf16 alone: y = [relu](bn3(t . W3^T) + bn_d(x . Wd^T)) (nets/pose_resnet_dconv.py:99-103,120-131) against the two launches it
+    replaces - the shortcut's 1x1 conv (bf16 store) and conv3 with that tensor as its residual - bit for bit, on row counts below, at and far
+    above one 128-pixel tile (several tiles per workgroup, a ragged last tile), and against float64 on the same bf16 operands."""
+    lib = _lib.lib()
+    t = torch.from_numpy(synth.tensor_normal(9, "dual/t", (rows, 64))).bfloat16()
+    x = torch.from_numpy(synth.tensor_normal(9, "dual/x", (rows, 64))).bfloat16()
+    w3 = torch.from_numpy(synth.tensor_normal(9, "dual/w3", (256, 64, 1, 1), std=0.2)).bfloat16().float()
+    wd = torch.from_numpy(synth.tensor_normal(9, "dual/wd", (256, 64, 1, 1), std=0.2)).bfloat16().float()
+    s3, h3, sd_, hd = (torch.from_numpy(synth.tensor_uniform(9, "dual/" + n, (256,), lo, hi)).float().to(DEV)
+                       for n, lo, hi in (("s3", 0.5, 1.5), ("h3", -0.3, 0.3), ("sd", 0.5, 1.5), ("hd", -0.3, 0.3)))
+    b = engine.ProgramBuilder(1, rows, dtype="bf16")                     # a [1 x rows] "image" of 64 channels
+    b.p.shapes["t"] = (1, rows, 64)
+    b.p.shapes["x"] = (1, rows, 64)
+    b.fuse_tail = False
+    r = b.conv("x", wd.to(DEV), scale=sd_, shift=hd, name="ds")
+    y2 = b.conv("t", w3.to(DEV), scale=s3, shift=h3, relu=relu, res=r, name="c3")
+    ops = {o.name: o for o in b.p.ops}
+    tg, xg = t.to(DEV).view(1, 1, rows, 64), x.to(DEV).view(1, 1, rows, 64)
+    rbuf = torch.empty((1, 1, rows, 256), dtype=torch.bfloat16, device=DEV)
+    two = torch.full((1, 1, rows, 256), float("nan"), dtype=torch.bfloat16, device=DEV)
+    for o, src, res, dst in ((ops["ds"], xg, None, rbuf), (ops["c3"], tg, rbuf, two)):
+        o.desc.batch = 1
+        _lib.check(lib.sp_conv2d_fwd(o.desc, _lib.ptr(src), _lib.ptr(o.w), _lib.ptr(o.scale), _lib.ptr(o.shift), _lib.ptr(res), _lib.ptr(dst),
+                                     _lib.current_stream()), o.name)
+    one = torch.full((1, 1, rows, 256), float("nan"), dtype=torch.bfloat16, device=DEV)
+    assert lib.sp_dual_pw_bf16_ok(rows, 64, 64, 256) == 1
+    _lib.check(lib.sp_dual_pw_bf16(_lib.ptr(tg), _lib.ptr(ops["c3"].w), _lib.ptr(s3), _lib.ptr(h3), _lib.ptr(xg), _lib.ptr(ops["ds"].w), _lib.ptr(sd_), _lib.ptr(hd),
+                                   _lib.ptr(one), rows, 64, 64, 256, int(relu), _lib.current_stream()), "dual")
+    torch.cuda.synchronize()
+    assert not torch.isnan(one.float()).any()
+    assert torch.equal(one.view(torch.int16), two.view(torch.int16)), int((one.view(torch.int16) != two.view(torch.int16)).sum())
+    rd = (x.double() @ wd.double().view(256, 64).T) * sd_.cpu().double() + hd.cpu().double()
+    ref = (t.double() @ w3.double().view(256, 64).T) * s3.cpu().double() + h3.cpu().double() + rd.bfloat16().double()
+    if relu:
+        ref = torch.relu(ref)
+    assert float((one.float().cpu().double().view(rows, 256) - ref).abs().max() / ref.abs().max()) < 8e-3
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
