@@ -348,10 +348,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_tile_kernel(const DirectAr
 bool sp_tile128_ok(const sp_conv_desc* d);               // conv_tile128.hip: the 128-channel tile kernel behind the same entry point
 int sp_tile128_launch(const sp_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift, const void* residual,
                       void* y, void* stream);
+bool sp_head128_ok(const sp_conv_desc* d);               // conv_head128.hip: 128 -> J <= 32 channels, fp32 NCHW out (the DUC head's last layer)
+int sp_head128_launch(const sp_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift, const void* residual,
+                      void* y, void* stream);
 
 static bool direct_ok(const sp_conv_desc* d) {
     if (d && d->c_in_group > 0) return false;            // grouped convolutions run on the implicit GEMM only
-    if (d && d->c_in == 128) return sp_tile128_ok(d);
+    if (d && d->c_in == 128) return sp_tile128_ok(d) || sp_head128_ok(d);
     if (!d || (d->c_in != 32 && d->c_in != 64)) return false;
     const int c = d->c_in, kp = c == 32 ? 320 : 576;          // k_pad: 9 taps x c, rounded to whole 64-element K tiles
     return (d->flags & SP_CONV_BF16) && !(d->flags & (SP_CONV_OUT_NCHW | SP_CONV_PIXEL_SHUFFLE | SP_CONV_OUT_F32)) &&
@@ -366,8 +369,10 @@ extern "C" int sp_conv3x3_direct_ok(const sp_conv_desc* d) { return direct_ok(d)
 extern "C" int sp_conv3x3_direct(const sp_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift,
                                  const void* residual, void* y, void* stream) {
     SP_REQUIRE(d && x && w_packed && y, "sp_conv3x3_direct: null pointer");
-    SP_REQUIRE(direct_ok(d), "sp_conv3x3_direct: needs a bf16 3x3 stride-1 pad-1 convolution with 32 -> 32, 64 -> 64 or 128 -> 128 channels (NHWC bf16 out)");
+    SP_REQUIRE(direct_ok(d), "sp_conv3x3_direct: needs a bf16 3x3 stride-1 pad-1 convolution with 32 -> 32, 64 -> 64 or 128 -> 128 channels (NHWC bf16 out), or "
+               "128 -> at most 32 channels with fp32 NCHW output");
     SP_REQUIRE(d->batch > 0, "sp_conv3x3_direct: bad batch");
+    if (d->c_in == 128 && sp_head128_ok(d)) return sp_head128_launch(d, x, w_packed, scale, shift, residual, y, stream);
     if (d->c_in == 128) return sp_tile128_launch(d, x, w_packed, scale, shift, residual, y, stream);
     const long long elems = (long long)d->batch * d->in_h * d->in_w * d->c_in;
     SP_REQUIRE(elems < (1ll << 29), "sp_conv3x3_direct: tensor too large");

@@ -1161,11 +1161,15 @@ extern "C" int sp_conv2d_fwd(const sp_conv_desc* d, const void* x, const void* w
 extern "C" int sp_conv2d_kernel_name(const sp_conv_desc* d, int has_residual, int variant, char* buf, int cap) {
     SP_REQUIRE(d && buf && cap > 0, "sp_conv2d_kernel_name: null pointer");
     SP_REQUIRE(variant >= 0 && variant <= 3, "sp_conv2d_kernel_name: variant %d", variant);
-    if (variant == 3) {
-        snprintf(buf, (size_t)cap, "conv3x3_c%d_tile_kernel", d->c_in);
+    void* const dummy = reinterpret_cast<void*>(16);        // never dereferenced: the launch functions return before launching
+    if (variant == 3) {                                     // asked of the direct kernels' own dispatch (c32 / c64 / c128 tile kernels, the 128 -> J head kernel)
+        sp_name_query_begin();
+        const int rc3 = sp_conv3x3_direct(d, dummy, dummy, nullptr, nullptr, has_residual ? dummy : nullptr, dummy, nullptr);
+        const char* name3 = sp_name_query_end();
+        if (rc3 != SP_OK) return rc3;
+        snprintf(buf, (size_t)cap, "%s", name3);
         return SP_OK;
     }
-    void* const dummy = reinterpret_cast<void*>(16);        // never dereferenced: the launch functions return before launching
     float* const fdummy = reinterpret_cast<float*>(16);
     const BnBwdSrc src = {dummy, dummy, fdummy, fdummy, nullptr, nullptr, nullptr, nullptr};
     sp_name_query_begin();

@@ -1881,6 +1881,36 @@ def test_direct_3x3_kernels_are_bit_identical_to_the_implicit_gemm(B, H, W, res_
     assert lib.sp_conv3x3_direct_ok(d) == 0 and lib.sp_conv3x3_direct(d, P(x), P(op.w), None, None, None, P(y1), st) != 0
 
 
+@pytest.mark.parametrize("B,H,W,J,relu", [(128, 64, 48, 17, False), (3, 20, 17, 17, False), (2, 16, 12, 32, True), (5, 33, 47, 5, False), (1, 7, 5, 17, False)])
+def test_head_3x3_kernel_is_bit_identical_to_the_implicit_gemm(B, H, W, J, relu):
+    """The DUC head's last layer, nn.Conv2d(128, J, 3, padding=1) + bias with the fp32 NCHW heat-map store (nets/pose_resnet_duc.py:172-177), through
+    conv3x3_c128_head_kernel (round 6: halo tile in LDS, the whole filter resident, 16-byte NCHW stores straight from the accumulator) against
+    sp_conv2d_fwd bit for bit: the BASELINE shape, ragged tiles and widths that are no multiple of 4, every J <= 32."""
+    lib, P = _lib.lib(), _lib.ptr
+    w = torch.from_numpy(synth.tensor_normal(1, f"hd/w{J}", (J, 128, 3, 3), std=(2.0 / (9 * 128)) ** 0.5))
+    bias = torch.from_numpy(synth.tensor_normal(1, f"hd/b{J}", (J,), std=0.3)).to(DEV)
+    b = engine.ProgramBuilder(H, W, dtype="bf16")
+    b.p.shapes["input"] = (H, W, 128)
+    b.conv("input", w.to(DEV), pad=1, shift=bias, relu=relu, out_nchw=True, name="final_layer")
+    op = b.p.ops[-1]
+    d = op.desc
+    d.batch = B
+    assert op.direct and lib.sp_conv3x3_direct_ok(d) == 1 and _lib.conv_kernel_name(d, False, 3) == "conv3x3_c128_head_kernel"
+    x = torch.from_numpy(synth.tensor_normal(2, "hd/x", (B, H, W, 128))).to(DEV).bfloat16()
+    y0 = torch.full((B, J, H, W), float("nan"), dtype=torch.float32, device=DEV)
+    y1 = y0.clone()
+    st = _lib.current_stream()
+    _lib.check(lib.sp_conv2d_fwd(d, P(x), P(op.w), None, P(bias), None, P(y0), st))
+    _lib.check(lib.sp_conv3x3_direct(d, P(x), P(op.w), None, P(bias), None, P(y1), st))
+    torch.cuda.synchronize()
+    assert torch.isfinite(y1).all() and torch.equal(y0.view(torch.int32), y1.view(torch.int32)), int((y0 != y1).sum())
+    ref = torch.nn.functional.conv2d(x.float().cpu().permute(0, 3, 1, 2).double(), w.bfloat16().double(), bias.cpu().double(), padding=1)
+    if relu:
+        ref = torch.relu(ref)
+    assert float((y1.cpu().double() - ref).abs().max() / ref.abs().max()) < 1e-5
+    assert lib.sp_conv3x3_direct(d, P(x), P(op.w), None, P(bias), P(y0), P(y1), st) != 0        # no residual form
+
+
 @pytest.mark.parametrize("B,H,W", [(2, 20, 17), (3, 8, 16), (1, 7, 5), (5, 33, 47), (128, 64, 48), (37, 9, 40)])
 def test_fused_basic_block_c32_is_bit_identical_to_its_two_convs(B, H, W):
     """sp_basic_block_c32 (HRNet BasicBlock of the 32-channel branch in one launch: conv1 on the halo'd tile, t kept in LDS as bf16,
