@@ -968,7 +968,7 @@ def _variant_name(op):
     if op.kind == "bneck64":
         return "bottleneck_c64_kernel"
     if op.kind == "dual1x1":
-        return "dual_pw_bf16_kernel"
+        return "dual_pw_bf16_kernel" if op.w.element_size() == 2 else "conv_pw_dual_kernel<64>"
     if op.kind == "htrans":
         return "hrnet_transition1_kernel"
     if op.kind == "hstem":

@@ -130,7 +130,12 @@ int sp_basic_block_c32(const sp_conv_desc* desc, const void* x, const void* w1_p
  * a_main = the block's 3x3 output, a_short = the block input ([rows][64] each), weights packed by sp_pack_conv_weights ([256][64]), the folded
  * BatchNorms as (scale, shift).  Replaces the projection shortcut's launch + conv3's launch (the 256-channel shortcut tensor is neither written nor
  * read: 703 -> 301 MB at bs=128) with the same bits: the shortcut value is rounded to bf16 where the two-launch program stores it. */
+/* sp_dual_pw_f32: the fp32 twin (csrc/conv_pw.hip; c_out a multiple of 256): 1,406 -> 602 MB at bs=128, the same bits as the two fp32 launches. */
 int sp_dual_pw_bf16_ok(int64_t rows, int c_main, int c_short, int c_out);
+int sp_dual_pw_f32_ok(int64_t rows, int c_main, int c_short, int c_out);
+int sp_dual_pw_f32(const float* a_main, const float* w_main_packed, const float* scale_main, const float* shift_main, const float* a_short,
+                   const float* w_short_packed, const float* scale_short, const float* shift_short, float* y, int64_t rows, int c_main, int c_short,
+                   int c_out, int relu, void* stream);
 int sp_dual_pw_bf16(const void* a_main, const void* w_main_packed, const float* scale_main, const float* shift_main, const void* a_short,
                     const void* w_short_packed, const float* scale_short, const float* shift_short, void* y, int64_t rows, int c_main, int c_short,
                     int c_out, int relu, void* stream);

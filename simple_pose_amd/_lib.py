@@ -140,6 +140,8 @@ SYMBOLS = {
     "sp_basic_block_c32_ok": (c_int, [ctypes.POINTER(ConvDesc)]),
     "sp_basic_block_c32": (c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sp_dual_pw_bf16_ok": (c_int, [c_int64, c_int, c_int, c_int]),
+    "sp_dual_pw_f32_ok": (c_int, [c_int64, c_int, c_int, c_int]),
+    "sp_dual_pw_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, _P]),
     "sp_dual_pw_bf16": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, _P]),
     "sp_bottleneck_c64_ok": (c_int, [ctypes.POINTER(ConvDesc)]),
     "sp_conv2d_pw_ok": (c_int, [ctypes.POINTER(ConvDesc)]),

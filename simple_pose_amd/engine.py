@@ -250,7 +250,8 @@ class Program:
                                              P(bufs[op.dst]), stream), op.name)
         elif op.kind == "dual1x1":
             w_s, s_s, h_s, rows_per_image, relu = op.args
-            _lib.check(lib.sp_dual_pw_bf16(P(bufs[op.src]), P(op.w), P(op.scale), P(op.shift), P(bufs[op.res]), P(w_s), P(s_s), P(h_s), P(bufs[op.dst]),
+            fn = lib.sp_dual_pw_bf16 if op.w.element_size() == 2 else lib.sp_dual_pw_f32
+            _lib.check(fn(P(bufs[op.src]), P(op.w), P(op.scale), P(op.shift), P(bufs[op.res]), P(w_s), P(s_s), P(h_s), P(bufs[op.dst]),
                                            B * rows_per_image, 64, 64, 256, relu, stream), op.name)
         elif op.kind == "stem7":
             h, w, k_pad, unfused = op.args
@@ -981,14 +982,15 @@ class ProgramBuilder:
         return dst
 
     def dual_pointwise_tail(self, main: str, w3, s3, h3, short: str, wd, sd_, hd, name: str) -> Optional[str]:
-        """conv3 + the projection shortcut of a stage-opening Bottleneck with 64 mid channels as one launch (sp_dual_pw_bf16): y = relu(bn3(conv3(main))
-        + bn_d(conv_d(short))); None when the shapes do not qualify or the fusion is off."""
+        """conv3 + the projection shortcut of a stage-opening Bottleneck with 64 mid channels as one launch (sp_dual_pw_bf16 / sp_dual_pw_f32): y =
+        relu(bn3(conv3(main)) + bn_d(conv_d(short))); None when the shapes do not qualify or the fusion is off."""
         h, w, c = self.p.shapes[main]
         hs, ws_, cs = self.p.shapes[short]
-        if not (self.bf16 and self.fuse_tail and (h, w) == (hs, ws_) and c == 64 and cs == 64 and tuple(w3.shape) == (256, 64, 1, 1)
-                and tuple(wd.shape) == (256, 64, 1, 1) and _lib.lib().sp_dual_pw_bf16_ok(h * w, 64, 64, 256)):
+        ok = _lib.lib().sp_dual_pw_bf16_ok if self.bf16 else _lib.lib().sp_dual_pw_f32_ok
+        if not (self.fuse_tail and (h, w) == (hs, ws_) and c == 64 and cs == 64 and tuple(w3.shape) == (256, 64, 1, 1)
+                and tuple(wd.shape) == (256, 64, 1, 1) and ok(h * w, 64, 64, 256)):
             return None
-        p3, pd = self.packer.conv(w3, bf16=True)[0], self.packer.conv(wd, bf16=True)[0]
+        p3, pd = self.packer.conv(w3, bf16=self.bf16)[0], self.packer.conv(wd, bf16=self.bf16)[0]
         if tuple(p3.shape) != (256, 64) or tuple(pd.shape) != (256, 64):
             return None
         dst = self._fresh(name)

@@ -635,6 +635,45 @@ def test_fused_bottlenecks_equal_the_per_conv_program_bitwise(head, B, H, W):
     assert torch.equal(got, ref)
 
 
+@pytest.mark.parametrize("rows,relu", [(64 * 9, True), (1000, True), (50, False), (64 * 700 + 3, True)])
+def test_dual_pointwise_tail_fp32_equals_the_two_launches_bitwise(rows, relu):
+    """sp_dual_pw_f32 (csrc/conv_pw.hip: the fp32 twin, on the headline configuration's layer1.0) against the two fp32 launches it replaces, bit for bit -
+    the shortcut's tensor is an fp32 tensor there, so nothing is rounded differently - and against float64."""
+    lib = _lib.lib()
+    t = torch.from_numpy(synth.tensor_normal(9, "dual32/t", (rows, 64)))
+    x = torch.from_numpy(synth.tensor_normal(9, "dual32/x", (rows, 64)))
+    w3 = torch.from_numpy(synth.tensor_normal(9, "dual32/w3", (256, 64, 1, 1), std=0.2))
+    wd = torch.from_numpy(synth.tensor_normal(9, "dual32/wd", (256, 64, 1, 1), std=0.2))
+    s3, h3, sd_, hd = (torch.from_numpy(synth.tensor_uniform(9, "dual32/" + n, (256,), lo, hi)).float().to(DEV)
+                       for n, lo, hi in (("s3", 0.5, 1.5), ("h3", -0.3, 0.3), ("sd", 0.5, 1.5), ("hd", -0.3, 0.3)))
+    b = engine.ProgramBuilder(1, rows, dtype="fp32")
+    b.p.shapes["t"] = (1, rows, 64)
+    b.p.shapes["x"] = (1, rows, 64)
+    b.fuse_tail = False
+    r = b.conv("x", wd.to(DEV), scale=sd_, shift=hd, name="ds")
+    b.conv("t", w3.to(DEV), scale=s3, shift=h3, relu=relu, res=r, name="c3")
+    ops = {o.name: o for o in b.p.ops}
+    tg, xg = t.to(DEV).view(1, 1, rows, 64), x.to(DEV).view(1, 1, rows, 64)
+    rbuf = torch.empty((1, 1, rows, 256), dtype=torch.float32, device=DEV)
+    two = torch.full((1, 1, rows, 256), float("nan"), dtype=torch.float32, device=DEV)
+    for o, src, res, dst in ((ops["ds"], xg, None, rbuf), (ops["c3"], tg, rbuf, two)):
+        o.desc.batch = 1
+        _lib.check(lib.sp_conv2d_fwd(o.desc, _lib.ptr(src), _lib.ptr(o.w), _lib.ptr(o.scale), _lib.ptr(o.shift), _lib.ptr(res), _lib.ptr(dst),
+                                     _lib.current_stream()), o.name)
+    one = torch.full((1, 1, rows, 256), float("nan"), dtype=torch.float32, device=DEV)
+    assert lib.sp_dual_pw_f32_ok(rows, 64, 64, 256) == 1
+    _lib.check(lib.sp_dual_pw_f32(_lib.ptr(tg), _lib.ptr(ops["c3"].w), _lib.ptr(s3), _lib.ptr(h3), _lib.ptr(xg), _lib.ptr(ops["ds"].w), _lib.ptr(sd_), _lib.ptr(hd),
+                                  _lib.ptr(one), rows, 64, 64, 256, int(relu), _lib.current_stream()), "dual f32")
+    torch.cuda.synchronize()
+    assert not torch.isnan(one).any()
+    assert torch.equal(one.view(torch.int32), two.view(torch.int32)), int((one.view(torch.int32) != two.view(torch.int32)).sum())
+    ref = ((t.double() @ w3.double().view(256, 64).T) * s3.cpu().double() + h3.cpu().double() +
+           (x.double() @ wd.double().view(256, 64).T) * sd_.cpu().double() + hd.cpu().double())
+    if relu:
+        ref = torch.relu(ref)
+    assert float((one.cpu().double().view(rows, 256) - ref).abs().max() / ref.abs().max()) < 2e-6
+
+
 @pytest.mark.parametrize("rows,relu", [(128 * 7, True), (1000, True), (77, False), (128 * 300 + 5, True)])
 def test_dual_pointwise_tail_equals_the_two_launches_bitwise(rows, relu):
     """sp_dual_pw_bf16 alone: y = [relu](bn3(t . W3^T) + bn_d(x . Wd^T)) (nets/pose_resnet_dconv.py:99-103,120-131) against the two launches it
@@ -673,6 +712,27 @@ def test_dual_pointwise_tail_equals_the_two_launches_bitwise(rows, relu):
     if relu:
         ref = torch.relu(ref)
     assert float((one.float().cpu().double().view(rows, 256) - ref).abs().max() / ref.abs().max()) < 8e-3
+
+
+@pytest.mark.parametrize("head,B,H,W", [("dconv", 3, 256, 192), ("duc", 1, 96, 160)])
+def test_fp32_dual_tail_equals_the_per_conv_program_bitwise(head, B, H, W):
+    """fp32 (the headline configuration's arithmetic): layer1.0's conv3 + projection shortcut as one launch (sp_dual_pw_f32, round 6) gives the heat
+    maps of the conv-by-conv program bit for bit (`fuse_bottlenecks` switches it; the fused identity Bottlenecks exist in bf16 only)."""
+    m = {"dconv": pose_resnet_dconv, "duc": pose_resnet_duc}[head].resnet50(pretrained=False, num_classes=17)
+    sd = synth.conditioned_state_dict(nets_oracle.state_dict_shapes_resnet50(head), 6)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m = m.to(DEV).eval()
+    m.autotune = False
+    x = _cuda(synth.input_images(B, 23, h=H, w=W))
+    with torch.no_grad():
+        m.fuse_bottlenecks = False
+        ref = m(x).clone()
+        n_ref = len(m.hip_program(x).ops)
+        m.fuse_bottlenecks = True
+        got = m(x)
+        prog = m.hip_program(x)
+    assert sum(op.kind == "dual1x1" for op in prog.ops) == 1 and not any(op.kind == "bneck64" for op in prog.ops) and len(prog.ops) == n_ref - 1
+    assert torch.equal(got, ref)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
