@@ -112,6 +112,20 @@ def run_program_cpu(prog, x):
             conv_desc_cpu(d, bufs[op.src], op.w, op.scale, op.shift, bufs[op.res] if op.res else None, y, B)
             assert not torch.isnan(y).any(), f"{op.name}: launch does not cover its output"
             bufs[op.dst] = y
+        elif op.kind == "dual1x1":
+            # y = relu(bn3(t . W3^T) + bn_d(x . Wd^T)) (sp_dual_pw_bf16 / sp_dual_pw_f32): the shortcut value takes the activation dtype's rounding,
+            # as the tensor the two-launch program stores
+            w_s, s_s, h_s, rows_per_image, relu = op.args
+            t, xs = bufs[op.src].double(), bufs[op.res].double()
+            w3, wd = op.w.double()[:256, :64], w_s.double()[:256, :64]
+            one = lambda v, n: torch.ones(n, dtype=torch.float64) if v is None else v.double()
+            zero = lambda v, n: torch.zeros(n, dtype=torch.float64) if v is None else v.double()
+            r = (xs @ wd.T) * one(s_s, 256) + zero(h_s, 256)
+            r = r.float().to(act_dt).double()
+            y = (t @ w3.T) * one(op.scale, 256) + zero(op.shift, 256) + r
+            if relu:
+                y = y.clamp(min=0)
+            bufs[op.dst] = y.float().to(act_dt)
         else:
             raise ValueError(op.kind)
     return bufs[prog.out_name], bufs
