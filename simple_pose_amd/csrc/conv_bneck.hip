@@ -19,6 +19,7 @@
 // intermediates are rounded to bf16 exactly where the per-conv program stores them -> bit-identical results, which is how it is tested.
 #include "sp_common.h"
 
+#include <stdlib.h>
 #include <type_traits>
 
 #ifdef SP_BNECK_DIAG
@@ -403,6 +404,250 @@ __global__ __launch_bounds__(256, 1) void bottleneck_c64_kernel(const BneckArgs 
 #endif
 }
 
+// ---- the same block with EIGHT waves, two per SIMD (round 6) -------------------------------------------------------------------------------
+// The four-wave kernel above is bound by instruction issue and exposed latency at ONE wave per SIMD (27,400 cycles per tile for 4,900 cycles of
+// MFMA work, profiles/r06_bneck_stages.txt): every LDS round trip of the transposes, every load issue and every barrier wait stalls the SIMD
+// outright.  Same LDS image (W2, W1, t1, t2; the transpose slabs become eight HALF slabs of 16 rows), same tile, same accumulation chains
+// and roundings - so the same bits - with the work of every stage cut eight ways instead of four, so that a second wave fills the stalls:
+//   A  the six halo row blocks on waves 0 .. 5, BOTH column blocks each: an x fragment (straight from the NHWC rows, 8 k steps ahead; the next
+//      tile's first 8 before stage C) is loaded once and feeds two MFMAs - half the vector-memory instructions of a (row block, column block) split;
+//   B  8 (row tile, column block) units: one accumulator per wave, 36 MFMAs;
+//   C  wave w = output channels 32 w .. 32 w + 31 of all four 32-pixel row tiles (W3's 4 fragments in registers), residual requested
+//      during stage B.
+// 256 registers per wave are enough now: nobody holds more than two accumulators, and the x ring is 8 k steps of one row block.
+constexpr int TRH = 16 * 32 * 4;                          // per wave: fp32 transpose half-slab (16 rows x 32 columns)
+constexpr int LDSB8 = W2B + W1B + T1B + T2B + 8 * TRH;    // 162,304 B
+static_assert(LDSB8 == LDSB, "both kernels use the same LDS image");
+
+__global__ __launch_bounds__(512, 2) void bottleneck_c64_w8_kernel(const BneckArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smemb8[];
+    unsigned char* const Ws2 = smemb8;
+    unsigned char* const Ws1 = smemb8 + W2B;
+    unsigned char* const T1 = smemb8 + W2B + W1B;
+    unsigned char* const T2 = smemb8 + W2B + W1B + T1B;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* const tr = reinterpret_cast<float*>(smemb8 + W2B + W1B + T1B + T2B + wave * TRH);
+    const int fr = lane & 31, fh = lane >> 5;
+    const int ntiles = p.tiles_x * p.tiles_y * p.batch;
+    const int G = gridDim.x;
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), (short)0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, (short)0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w1r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w1), (short)0, p.w1_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w2r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w2), (short)0, p.w2_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w3r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w3), (short)0, p.w3_bytes, 0x00020000);
+
+    for (int q = tid; q < W2B / 16; q += 512) {
+        const int n = q & 31, kh = (q >> 5) & 1, nb = (q >> 6) & 1, f = q >> 7;
+        *reinterpret_cast<u32x4*>(Ws2 + q * 16) = __builtin_amdgcn_raw_buffer_load_b128(w2r, (unsigned)(((nb * 32 + n) * 576 + f * 16 + kh * 8) * 2), 0, 0);
+    }
+    for (int q = tid; q < W1B / 16; q += 512) {
+        const int n = q & 31, kh = (q >> 5) & 1, nb = (q >> 6) & 1, f = q >> 7;
+        *reinterpret_cast<u32x4*>(Ws1 + q * 16) = __builtin_amdgcn_raw_buffer_load_b128(w1r, (unsigned)(((nb * 32 + n) * 256 + f * 16 + kh * 8) * 2), 0, 0);
+    }
+    // stage C role: output channels 32 wave .. +31; W3's fragments of that column block (4 k steps) in registers for the whole launch
+    u32x4 w3reg[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) w3reg[ks] = __builtin_amdgcn_raw_buffer_load_b128(w3r, (unsigned)(((wave * 32 + fr) * CM + ks * 16 + fh * 8) * 2), 0, 0);
+    float sc3[8], sh3[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ch = wave * 32 + (lane & 3) * 8 + e;
+        sc3[e] = p.s3 ? p.s3[ch] : 1.f; sh3[e] = p.b3 ? p.b3[ch] : 0.f;
+    }
+    // stage A role: waves 0 .. 5 = halo row block `wave` x BOTH column blocks (an x fragment is loaded once and feeds two MFMAs); waves 6, 7 wait
+    const bool hasA = wave < 6;                               // (wave-uniform)
+    float sc1[2][8], sh1[2][8];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ch = nb * 32 + (lane & 3) * 8 + e;
+            sc1[nb][e] = p.s1 ? p.s1[ch] : 1.f; sh1[nb][e] = p.b1 ? p.b1[ch] : 0.f;
+        }
+    const unsigned char* const w1frag = Ws1 + (fh * 32 + fr) * 16;       // + ks * 2048 + nb * 1024
+    // stage B role: row tile mB x column block nbB
+    const int mB = wave >> 1, nbB = wave & 1;
+    const float s2v = p.s2 ? p.s2[nbB * 32 + fr] : 1.f, b2v = p.b2 ? p.b2[nbB * 32 + fr] : 0.f;
+    const unsigned char* const w2frag = Ws2 + (fh * 32 + fr) * 16 + nbB * 1024;
+    const int py = 4 * mB + (fr >> 3), px = fr & 7;
+
+    constexpr int PFA = 8, NKA = 16;
+    u32x4 fa[PFA + 1];
+    unsigned abase = OOB;
+    int cy0 = 0, cx0 = 0, cb = 0;
+    auto tile_origin = [&](int tile) __attribute__((always_inline)) {
+        int t = tile;
+        const int tx = t % p.tiles_x; t /= p.tiles_x;
+        const int ty = t % p.tiles_y;
+        cb = t / p.tiles_y; cy0 = ty * BT_H; cx0 = tx * BT_W;
+        {
+            const int P = wave * 32 + fr;
+            const int hy = (P * 6554) >> 16, hx = P - hy * BH_W;          // P / 10 for P < 256
+            const int iy = cy0 - 1 + hy, ix = cx0 - 1 + hx;
+            const bool ok = hasA && P < NHALO && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            abase = ok ? (unsigned)((((cb * p.H + iy) * p.W + ix) * CIO + fh * 8) * 2) : OOB;
+#if defined(SP_BNECK_KNOCKOUT) && SP_BNECK_KNOCKOUT == 3   // DIAGNOSTIC BUILD ONLY (tools/r06_bneck_knockout.sh): no x loads
+            abase = OOB;
+#endif
+        }
+    };
+    auto reqA = [&](int ks) __attribute__((always_inline)) {
+        if (hasA) fa[ks % (PFA + 1)] = __builtin_amdgcn_raw_buffer_load_b128(xr, abase + (unsigned)(ks * 32), 0, 0);
+    };
+    if ((int)blockIdx.x < ntiles) {
+        tile_origin(blockIdx.x);
+#pragma unroll
+        for (int ks = 0; ks < PFA; ++ks) reqA(ks);
+    }
+    __syncthreads();                                         // filters are in LDS
+    for (int tile = blockIdx.x; tile < ntiles; tile += G) {
+        const int y0 = cy0, x0 = cx0, b = cb;
+        // an opaque zero: address arithmetic that depends on it is redone per tile instead of being hoisted out of the persistent loop, where its
+        // 36 + 16 loop-invariant fragment addresses would be live across every stage (the register cap is 256 at two waves per SIMD)
+        int zt = 0;
+        asm volatile("" : "+v"(zt));
+        const int pyt = py + zt, pxt = px + zt, frt = fr + zt;
+        // =================== stage A ===================
+        f32x16 a0, a1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+        if (hasA) {
+#pragma unroll
+            for (int ks = 0; ks < NKA; ++ks) {
+                if (ks + PFA < NKA) reqA(ks + PFA);
+                const u32x4 b0q = *reinterpret_cast<const u32x4*>(w1frag + ks * 2048);
+                const u32x4 b1q = *reinterpret_cast<const u32x4*>(w1frag + ks * 2048 + 1024);
+                const bf16x8 xa = __builtin_bit_cast(bf16x8, fa[ks % (PFA + 1)]);
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, __builtin_bit_cast(bf16x8, b0q), a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, __builtin_bit_cast(bf16x8, b1q), a1, 0, 0, 0);
+            }
+            auto put = [&](const f32x16& acc, int rb, const float (&scv)[8], const float (&shv)[8], int nbA) __attribute__((always_inline)) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) tr[((q & 3) + 8 * (q >> 2) + 4 * fh) * 32 + fr] = acc[8 * h + q];
+                    const int rl = lane >> 2, chunk = lane & 3;
+                    float v[8];
+#pragma unroll
+                    for (int e4 = 0; e4 < 2; ++e4) {
+                        const f32x4 tt = *reinterpret_cast<const f32x4*>(tr + rl * 32 + chunk * 8 + 4 * e4);
+                        v[4 * e4] = tt[0]; v[4 * e4 + 1] = tt[1]; v[4 * e4 + 2] = tt[2]; v[4 * e4 + 3] = tt[3];
+                    }
+                    const int P = rb * 32 + h * 16 + rl;
+                    const int hy = (P * 6554) >> 16, hx = P - hy * BH_W;
+                    const bool in = (unsigned)(y0 - 1 + hy) < (unsigned)p.H && (unsigned)(x0 - 1 + hx) < (unsigned)p.W;
+                    bf16x8 o8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float q = v[e] * scv[e] + shv[e];
+                        q = q > 0.f ? q : 0.f;
+                        o8[e] = (__bf16)(in ? q : 0.f);
+                    }
+                    if (P < NHALO) *reinterpret_cast<u32x4*>(T1 + t1off(hy, hx, nbA * 4 + chunk)) = __builtin_bit_cast(u32x4, o8);
+                }
+            };
+            put(a0, wave, sc1[0], sh1[0], 0);
+            put(a1, wave, sc1[1], sh1[1], 1);
+        }
+        __syncthreads();                                     // t1 complete
+
+        // the residual of this wave's 32 channels for all four 32-pixel row tiles (8 loads): it flies during stage B
+        u32x4 rv[4][2];
+        auto ooff = [&](int m, int it) __attribute__((always_inline)) {
+            const int row = it * 16 + (lane >> 2);
+            const int oy = y0 + 4 * m + (row >> 3), ox = x0 + (row & 7);
+            return (oy < p.H && ox < p.W) ? (unsigned)((((b * p.H + oy) * p.W + ox) * CIO + wave * 32 + (lane & 3) * 8) * 2) : OOB;
+        };
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#if defined(SP_BNECK_KNOCKOUT) && SP_BNECK_KNOCKOUT == 2   // no residual loads
+                rv[m][it] = u32x4{0u, 0u, 0u, 0u};
+#else
+                rv[m][it] = __builtin_amdgcn_raw_buffer_load_b128(xr, ooff(m, it), 0, 0);
+#endif
+        // =================== stage B ===================
+        {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            constexpr int PF = 3, NSTEP = 36;
+            u32x4 fx[PF + 1], fb[PF + 1];
+            auto frags = [&](int st) __attribute__((always_inline)) {
+                const int tap = st >> 2, ks = st & 3;
+                fx[st % (PF + 1)] = *reinterpret_cast<const u32x4*>(T1 + t1off(pyt + tap / 3, pxt + tap % 3, ks * 2 + fh));
+                fb[st % (PF + 1)] = *reinterpret_cast<const u32x4*>(w2frag + zt + st * 2048);
+            };
+#pragma unroll
+            for (int st = 0; st < PF; ++st) frags(st);
+#pragma unroll
+            for (int st = 0; st < NSTEP; ++st) {
+                if (st + PF < NSTEP) frags(st + PF);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fx[st % (PF + 1)]), __builtin_bit_cast(bf16x8, fb[st % (PF + 1)]), acc, 0, 0, 0);
+            }
+            unsigned char* const t2w = T2 + mB * 32 * PIXM;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const int sw = (row >> 1) & 7;
+                float v0 = acc[r] * s2v + b2v;
+                v0 = v0 > 0.f ? v0 : 0.f;
+                *reinterpret_cast<__bf16*>(t2w + row * 128 + (((nbB * 4 + (fr >> 3)) ^ sw) << 4) + (fr & 7) * 2) = (__bf16)v0;
+            }
+        }
+        __syncthreads();                                     // t2 complete; every wave is done reading t1
+
+        if (tile + G < ntiles) {                             // the next tile's x: its first PFA k steps fly during stage C
+            tile_origin(tile + G);
+#pragma unroll
+            for (int ks = 0; ks < PFA; ++ks) reqA(ks);
+        }
+        // =================== stage C ===================
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            u32x4 a3[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) a3[ks] = *reinterpret_cast<const u32x4*>(T2 + (m * 32 + frt) * 128 + (((ks * 2 + fh) ^ ((frt >> 1) & 7)) << 4));
+            f32x16 c0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c0[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a3[ks]), __builtin_bit_cast(bf16x8, w3reg[ks]), c0, 0, 0, 0);
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) tr[((q & 3) + 8 * (q >> 2) + 4 * fh) * 32 + fr] = c0[8 * it + q];
+                const int rl = lane >> 2, chunk = lane & 3;
+                float v[8];
+#pragma unroll
+                for (int e4 = 0; e4 < 2; ++e4) {
+                    const f32x4 tt = *reinterpret_cast<const f32x4*>(tr + rl * 32 + chunk * 8 + 4 * e4);
+                    v[4 * e4] = tt[0]; v[4 * e4 + 1] = tt[1]; v[4 * e4 + 2] = tt[2]; v[4 * e4 + 3] = tt[3];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] * sc3[e] + sh3[e];
+                const bf16x8 r8 = __builtin_bit_cast(bf16x8, rv[m][it]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                bf16x8 o8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o8[e] = (__bf16)v[e];
+#if defined(SP_BNECK_KNOCKOUT) && SP_BNECK_KNOCKOUT == 1   // no y stores (one lane of one workgroup still stores, so that nothing is optimised away)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o8), yr, (tile == 0 && tid == 0) ? ooff(m, it) : OOB, 0, 0);
+#else
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o8), yr, ooff(m, it), 0, 0);
+#endif
+            }
+        }
+    }
+}
+
 bool bneck_ok(const sp_conv_desc* d) {
     if (d && d->c_in_group > 0) return false;
     // `d`: the block's 3x3 convolution (64 -> 64, stride 1, pad 1) on bf16 NHWC; conv1 / conv3 are 1x1 on the same grid
@@ -424,7 +669,8 @@ extern "C" int sp_bottleneck_c64(const sp_conv_desc* d, const void* x, const voi
     SP_REQUIRE(d->batch > 0 && x != y, "sp_bottleneck_c64: bad batch / y must not alias x");
     const long long elems = (long long)d->batch * d->in_h * d->in_w * CIO;
     SP_REQUIRE(elems < (1ll << 30), "sp_bottleneck_c64: tensor too large");
-    if (sp_name_query_active()) { sp_name_query_set("bottleneck_c64_kernel"); return SP_OK; }
+    static const int w8 = [] { const char* e = getenv("SP_BNECK_W8"); return e ? atoi(e) : 1; }();     // (0: the four-wave kernel, for same-box A/Bs)
+    if (sp_name_query_active()) { sp_name_query_set(w8 ? "bottleneck_c64_w8_kernel" : "bottleneck_c64_kernel"); return SP_OK; }
     BneckArgs a;
     a.x = x; a.y = y; a.w1 = w1_packed; a.w2 = w2_packed; a.w3 = w3_packed;
     a.s1 = scale1; a.b1 = shift1; a.s2 = scale2; a.b2 = shift2; a.s3 = scale3; a.b3 = shift3;
@@ -442,6 +688,12 @@ extern "C" int sp_bottleneck_c64(const sp_conv_desc* d, const void* x, const voi
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_c64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
     if (e != hipSuccess) { sp_set_error("sp_bottleneck_c64: hipFuncSetAttribute(max dynamic LDS = %d) failed: %s", LDSB, hipGetErrorString(e)); return SP_ELAUNCH; }
     const long long grid = tiles < cus ? tiles : cus;
+    if (w8) {
+        const hipError_t e8 = hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_c64_w8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB8);
+        if (e8 != hipSuccess) { sp_set_error("sp_bottleneck_c64: hipFuncSetAttribute(max dynamic LDS = %d) failed: %s", LDSB8, hipGetErrorString(e8)); return SP_ELAUNCH; }
+        hipLaunchKernelGGL(bottleneck_c64_w8_kernel, dim3((unsigned)grid), dim3(512), LDSB8, (hipStream_t)stream, a);
+        return sp_check_launch("bottleneck_c64_w8_kernel");
+    }
     hipLaunchKernelGGL(bottleneck_c64_kernel, dim3((unsigned)grid), dim3(256), LDSB, (hipStream_t)stream, a);
     return sp_check_launch("bottleneck_c64_kernel");
 }
