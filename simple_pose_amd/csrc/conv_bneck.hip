@@ -409,12 +409,12 @@ __global__ __launch_bounds__(256, 1) void bottleneck_c64_kernel(const BneckArgs 
 // MFMA work, profiles/r06_bneck_stages.txt): every LDS round trip of the transposes, every load issue and every barrier wait stalls the SIMD
 // outright.  Same LDS image (W2, W1, t1, t2; the transpose slabs become eight HALF slabs of 16 rows), same tile, same accumulation chains
 // and roundings - so the same bits - with the work of every stage cut eight ways instead of four, so that a second wave fills the stalls:
-//   A  the six halo row blocks on waves 0 .. 5, BOTH column blocks each: an x fragment (straight from the NHWC rows, 8 k steps ahead; the next
-//      tile's first 8 before stage C) is loaded once and feeds two MFMAs - half the vector-memory instructions of a (row block, column block) split;
+//   A  the six halo row blocks on waves 0 .. 5, BOTH column blocks each: an x fragment (straight from the NHWC rows; the 16 k steps of the
+//      next tile are requested between the MFMAs of stage B) is loaded once and feeds two MFMAs - half the vector-memory instructions of a (row block, column block) split;
 //   B  8 (row tile, column block) units: one accumulator per wave, 36 MFMAs;
 //   C  wave w = output channels 32 w .. 32 w + 31 of all four 32-pixel row tiles (W3's 4 fragments in registers), residual requested
 //      during stage B.
-// 256 registers per wave are enough now: nobody holds more than two accumulators, and the x ring is 8 k steps of one row block.
+// 256 registers per wave are enough now: nobody holds more than two accumulators, and the x fragments of one row block are 64 registers.
 constexpr int TRH = 16 * 32 * 4;                          // per wave: fp32 transpose half-slab (16 rows x 32 columns)
 constexpr int LDSB8 = W2B + W1B + T1B + T2B + 8 * TRH;    // 162,304 B
 static_assert(LDSB8 == LDSB, "both kernels use the same LDS image");
@@ -450,22 +450,14 @@ __global__ __launch_bounds__(512, 2) void bottleneck_c64_w8_kernel(const BneckAr
     u32x4 w3reg[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) w3reg[ks] = __builtin_amdgcn_raw_buffer_load_b128(w3r, (unsigned)(((wave * 32 + fr) * CM + ks * 16 + fh * 8) * 2), 0, 0);
-    float sc3[8], sh3[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int ch = wave * 32 + (lane & 3) * 8 + e;
-        sc3[e] = p.s3 ? p.s3[ch] : 1.f; sh3[e] = p.b3 ? p.b3[ch] : 0.f;
-    }
+    // folded BatchNorms in the ACCUMULATOR layout (this lane's channel = column fr of the block): one (scale, shift) pair per block instead of
+    // eight per lane in the store layout - the same fma per element, applied before the transposition instead of after it
+    const float sc3 = p.s3 ? p.s3[wave * 32 + fr] : 1.f, sh3 = p.b3 ? p.b3[wave * 32 + fr] : 0.f;
     // stage A role: waves 0 .. 5 = halo row block `wave` x BOTH column blocks (an x fragment is loaded once and feeds two MFMAs); waves 6, 7 wait
     const bool hasA = wave < 6;                               // (wave-uniform)
-    float sc1[2][8], sh1[2][8];
+    float sc1[2], sh1[2];
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int ch = nb * 32 + (lane & 3) * 8 + e;
-            sc1[nb][e] = p.s1 ? p.s1[ch] : 1.f; sh1[nb][e] = p.b1 ? p.b1[ch] : 0.f;
-        }
+    for (int nb = 0; nb < 2; ++nb) { sc1[nb] = p.s1 ? p.s1[nb * 32 + fr] : 1.f; sh1[nb] = p.b1 ? p.b1[nb * 32 + fr] : 0.f; }
     const unsigned char* const w1frag = Ws1 + (fh * 32 + fr) * 16;       // + ks * 2048 + nb * 1024
     // stage B role: row tile mB x column block nbB
     const int mB = wave >> 1, nbB = wave & 1;
@@ -473,8 +465,11 @@ __global__ __launch_bounds__(512, 2) void bottleneck_c64_w8_kernel(const BneckAr
     const unsigned char* const w2frag = Ws2 + (fh * 32 + fr) * 16 + nbB * 1024;
     const int py = 4 * mB + (fr >> 3), px = fr & 7;
 
-    constexpr int PFA = 8, NKA = 16;
-    u32x4 fa[PFA + 1];
+    // x of the NEXT tile: all 16 k steps are requested during stage B of the current one, one load per two MFMAs - a load costs ~100 cycles of
+    // issue, free between MFMAs and paid in full anywhere else (requested in one burst before stage C: 4 % slower; requested inside stage A: needed
+    // 0.25 us later when HBM answers in 1-2: profiles/r06_bneck8_ab.txt)
+    constexpr int NKA = 16;
+    u32x4 fa[NKA];
     unsigned abase = OOB;
     int cy0 = 0, cx0 = 0, cb = 0;
     auto tile_origin = [&](int tile) __attribute__((always_inline)) {
@@ -494,12 +489,12 @@ __global__ __launch_bounds__(512, 2) void bottleneck_c64_w8_kernel(const BneckAr
         }
     };
     auto reqA = [&](int ks) __attribute__((always_inline)) {
-        if (hasA) fa[ks % (PFA + 1)] = __builtin_amdgcn_raw_buffer_load_b128(xr, abase + (unsigned)(ks * 32), 0, 0);
+        if (hasA) fa[ks] = __builtin_amdgcn_raw_buffer_load_b128(xr, abase + (unsigned)(ks * 32), 0, 0);
     };
     if ((int)blockIdx.x < ntiles) {
         tile_origin(blockIdx.x);
 #pragma unroll
-        for (int ks = 0; ks < PFA; ++ks) reqA(ks);
+        for (int ks = 0; ks < NKA; ++ks) reqA(ks);
     }
     __syncthreads();                                         // filters are in LDS
     for (int tile = blockIdx.x; tile < ntiles; tile += G) {
@@ -513,21 +508,27 @@ __global__ __launch_bounds__(512, 2) void bottleneck_c64_w8_kernel(const BneckAr
         f32x16 a0, a1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+#if defined(SP_BNECK_KNOCKOUT) && SP_BNECK_KNOCKOUT == 6   // no stage A at all (t1 stays what it was)
+        if (false) {
+#else
         if (hasA) {
+#endif
 #pragma unroll
             for (int ks = 0; ks < NKA; ++ks) {
-                if (ks + PFA < NKA) reqA(ks + PFA);
                 const u32x4 b0q = *reinterpret_cast<const u32x4*>(w1frag + ks * 2048);
                 const u32x4 b1q = *reinterpret_cast<const u32x4*>(w1frag + ks * 2048 + 1024);
-                const bf16x8 xa = __builtin_bit_cast(bf16x8, fa[ks % (PFA + 1)]);
+                const bf16x8 xa = __builtin_bit_cast(bf16x8, fa[ks]);
                 a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, __builtin_bit_cast(bf16x8, b0q), a0, 0, 0, 0);
                 a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, __builtin_bit_cast(bf16x8, b1q), a1, 0, 0, 0);
             }
-            auto put = [&](const f32x16& acc, int rb, const float (&scv)[8], const float (&shv)[8], int nbA) __attribute__((always_inline)) {
+            auto put = [&](const f32x16& acc, int rb, float scv, float shv, int nbA) __attribute__((always_inline)) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) tr[((q & 3) + 8 * (q >> 2) + 4 * fh) * 32 + fr] = acc[8 * h + q];
+                    for (int q = 0; q < 8; ++q) {
+                        float t = acc[8 * h + q] * scv + shv;
+                        tr[((q & 3) + 8 * (q >> 2) + 4 * fh) * 32 + fr] = t > 0.f ? t : 0.f;
+                    }
                     const int rl = lane >> 2, chunk = lane & 3;
                     float v[8];
 #pragma unroll
@@ -540,11 +541,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_c64_w8_kernel(const BneckAr
                     const bool in = (unsigned)(y0 - 1 + hy) < (unsigned)p.H && (unsigned)(x0 - 1 + hx) < (unsigned)p.W;
                     bf16x8 o8;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        float q = v[e] * scv[e] + shv[e];
-                        q = q > 0.f ? q : 0.f;
-                        o8[e] = (__bf16)(in ? q : 0.f);
-                    }
+                    for (int e = 0; e < 8; ++e) o8[e] = (__bf16)(in ? v[e] : 0.f);
                     if (P < NHALO) *reinterpret_cast<u32x4*>(T1 + t1off(hy, hx, nbA * 4 + chunk)) = __builtin_bit_cast(u32x4, o8);
                 }
             };
@@ -570,6 +567,8 @@ __global__ __launch_bounds__(512, 2) void bottleneck_c64_w8_kernel(const BneckAr
                 rv[m][it] = __builtin_amdgcn_raw_buffer_load_b128(xr, ooff(m, it), 0, 0);
 #endif
         // =================== stage B ===================
+        const bool more = tile + G < ntiles;
+        if (more) tile_origin(tile + G);                      // (y0 / x0 / b of THIS tile were copied above)
         {
             f32x16 acc;
 #pragma unroll
@@ -586,6 +585,10 @@ __global__ __launch_bounds__(512, 2) void bottleneck_c64_w8_kernel(const BneckAr
 #pragma unroll
             for (int st = 0; st < NSTEP; ++st) {
                 if (st + PF < NSTEP) frags(st + PF);
+                if (more && (st & 1) == 0 && st / 2 < NKA) reqA(st / 2);
+#if defined(SP_BNECK_KNOCKOUT) && SP_BNECK_KNOCKOUT == 4   // stage B: one MFMA in four (the fragment reads stay)
+                if ((st & 3) == 0)
+#endif
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fx[st % (PF + 1)]), __builtin_bit_cast(bf16x8, fb[st % (PF + 1)]), acc, 0, 0, 0);
             }
             unsigned char* const t2w = T2 + mB * 32 * PIXM;
@@ -600,11 +603,6 @@ __global__ __launch_bounds__(512, 2) void bottleneck_c64_w8_kernel(const BneckAr
         }
         __syncthreads();                                     // t2 complete; every wave is done reading t1
 
-        if (tile + G < ntiles) {                             // the next tile's x: its first PFA k steps fly during stage C
-            tile_origin(tile + G);
-#pragma unroll
-            for (int ks = 0; ks < PFA; ++ks) reqA(ks);
-        }
         // =================== stage C ===================
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -619,17 +617,20 @@ __global__ __launch_bounds__(512, 2) void bottleneck_c64_w8_kernel(const BneckAr
                 c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a3[ks]), __builtin_bit_cast(bf16x8, w3reg[ks]), c0, 0, 0, 0);
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) tr[((q & 3) + 8 * (q >> 2) + 4 * fh) * 32 + fr] = c0[8 * it + q];
                 const int rl = lane >> 2, chunk = lane & 3;
                 float v[8];
+#if defined(SP_BNECK_KNOCKOUT) && SP_BNECK_KNOCKOUT == 5   // stage C: no LDS transposition (wrong values in the right places)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = c0[8 * it + e];
+#else
+#pragma unroll
+                for (int q = 0; q < 8; ++q) tr[((q & 3) + 8 * (q >> 2) + 4 * fh) * 32 + fr] = c0[8 * it + q] * sc3 + sh3;
 #pragma unroll
                 for (int e4 = 0; e4 < 2; ++e4) {
                     const f32x4 tt = *reinterpret_cast<const f32x4*>(tr + rl * 32 + chunk * 8 + 4 * e4);
                     v[4 * e4] = tt[0]; v[4 * e4 + 1] = tt[1]; v[4 * e4 + 2] = tt[2]; v[4 * e4 + 3] = tt[3];
                 }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = v[e] * sc3[e] + sh3[e];
+#endif
                 const bf16x8 r8 = __builtin_bit_cast(bf16x8, rv[m][it]);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
