@@ -1259,7 +1259,8 @@ def _fuse_transition1(b: "ProgramBuilder") -> None:
 
 
 def hrnet_program(sd: Dict[str, torch.Tensor], cfg: dict, in_h: int = 256, in_w: int = 192, dtype: str = "fp32", packer=None,
-                  fuse_blocks: bool = False, fuse_stem: bool = True, fuse_terms: bool = True, fuse_transition: bool = True, fuse_tail: bool = True) -> Program:
+                  fuse_blocks: bool = False, fuse_stem: bool = True, fuse_terms: bool = True, fuse_transition: bool = True, fuse_tail: bool = True,
+                  fuse_bottlenecks: bool = True) -> Program:
     """Lower a reference-layout HRNet state_dict into a Program (PoseHighResolutionNet.forward, pose_hrnet.py:419-454).
     `fuse_blocks`: bf16 32-channel BasicBlocks as one launch each (sp_basic_block_c32; same bits as the two conv launches; opt-in,
     see ProgramBuilder.fuse_blocks)."""
@@ -1267,7 +1268,9 @@ def hrnet_program(sd: Dict[str, torch.Tensor], cfg: dict, in_h: int = 256, in_w:
     b = ProgramBuilder(in_h, in_w, dtype, packer)
     b.fuse_blocks = fuse_blocks
     b.fuse_tail = fuse_tail and b.fuse_tail
-    b.fuse_bottlenecks = os.environ.get("SP_HRNET_BNECK", "0") == "1"     # (env: development knob - layer1.1-1.3 through sp_bottleneck_c64; measured neutral in round 4)
+    # layer1.1-1.3 (identity Bottlenecks 256 -> 64 -> 64 -> 256) through sp_bottleneck_c64: neutral with the 171 / 168 us kernels of rounds 4-6, +2.3 % with
+    # the eight-wave kernel (146 us against ~190 for the three launches; profiles/r06_summary.md)
+    b.fuse_bottlenecks = fuse_bottlenecks and os.environ.get("SP_HRNET_BNECK", "1") != "0"
     b.fuse_terms = fuse_terms
     b.fuse_transition = fuse_transition
     b.fuse_stem = fuse_stem

@@ -115,17 +115,18 @@ class PoseHighResolutionNet(ParamTree):
     fuse_terms = True      # the identity / upsampled terms of a fuse output in one launch (sp_upsample_add_n_nhwc); fp32: same bits as the chain
     fuse_transition = True # bf16: transition1's two 3x3 convs on layer1's output as one launch (sp_hrnet_transition1); agrees with the two launches to fp32 summation order
     fuse_tail = True       # bf16: layer1.0's conv3 + projection shortcut as one launch (sp_dual_pw_bf16); same bits
+    fuse_bottlenecks = True  # bf16: layer1.1-1.3 as one launch each (sp_bottleneck_c64, eight-wave kernel); same bits, +2.3 % (round 6)
     fuse_blocks = False    # True: bf16 32-channel BasicBlocks as one launch each (sp_basic_block_c32); same bits, measured no faster
 
     def hip_program(self, x: torch.Tensor) -> engine.Program:
         sd = self.state_dict(keep_vars=True)
-        key = (tuple(x.shape[2:]), str(x.device), self.compute_dtype, self.fuse_blocks, self.fuse_stem, self.fuse_terms, self.fuse_transition, self.fuse_tail) + tuple((v.data_ptr(), v._version) for v in sd.values())
+        key = (tuple(x.shape[2:]), str(x.device), self.compute_dtype, self.fuse_blocks, self.fuse_stem, self.fuse_terms, self.fuse_transition, self.fuse_tail, self.fuse_bottlenecks) + tuple((v.data_ptr(), v._version) for v in sd.values())
         if self._program is None or key != self._program_key:
             for k, v in sd.items():
                 if v.device != x.device:
                     raise HipLibraryError(f"parameter {k} is on {v.device} but the input is on {x.device}; call .to(device)")
             self._program = engine.hrnet_program({k: v.detach() for k, v in sd.items()}, self.cfg, x.shape[2], x.shape[3],
-                                                  dtype=self.compute_dtype, fuse_blocks=self.fuse_blocks, fuse_stem=self.fuse_stem, fuse_terms=self.fuse_terms, fuse_transition=self.fuse_transition, fuse_tail=self.fuse_tail)
+                                                  dtype=self.compute_dtype, fuse_blocks=self.fuse_blocks, fuse_stem=self.fuse_stem, fuse_terms=self.fuse_terms, fuse_transition=self.fuse_transition, fuse_tail=self.fuse_tail, fuse_bottlenecks=self.fuse_bottlenecks)
             self._program_key = key
         return self._program
 

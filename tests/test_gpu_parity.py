@@ -2031,6 +2031,31 @@ def test_hrnet_with_fused_basic_blocks_equals_the_per_conv_program_bitwise(golde
     assert torch.equal(plain, fused)
 
 
+def test_hrnet_fused_layer1_equals_the_per_conv_program_bitwise(golden):
+    """HRNet-W32 bf16: layer1.0's conv3 + projection shortcut as one launch (`fuse_tail`, sp_dual_pw_bf16) and layer1.1-1.3 as one launch each
+    (`fuse_bottlenecks`, sp_bottleneck_c64's eight-wave kernel; round 6 defaults) give the heat maps of the conv-by-conv program bit for bit."""
+    import os
+    from simple_pose_amd.nets.pose_hrnet import get_pose_net, hrnet_state_dict_shapes
+    g = golden("g3_hrnet_w32_fwd.npz")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    m = get_pose_net(os.path.join(root, "simple_pose_amd", "nets", "hrnet_w32.yaml"), pretrained=None, joint_num=17)
+    sd = synth.conditioned_state_dict(hrnet_state_dict_shapes(m.cfg, 17), int(g["seed"]))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m = m.to(DEV).eval()
+    m.compute_dtype = "bf16"
+    x = _cuda(synth.input_images(3, 7))
+    with torch.no_grad():
+        m.fuse_tail = m.fuse_bottlenecks = False
+        plain = m(x).clone()
+        kinds = [op.kind for op in m.hip_program(x).ops]
+        assert "dual1x1" not in kinds and "bneck64" not in kinds
+        m.fuse_tail = m.fuse_bottlenecks = True
+        fused = m(x)
+        kinds = [op.kind for op in m.hip_program(x).ops]
+    assert kinds.count("dual1x1") == 1 and kinds.count("bneck64") == 3
+    assert torch.equal(plain, fused)
+
+
 # ---------------------------------------------------------------------------------------------- bench.py --gpus N as the driver invokes it
 @pytest.mark.parametrize("mode", ["infer", "train"])
 def test_bench_self_launches_two_ranks(mode):
