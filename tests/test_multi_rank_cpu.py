@@ -202,3 +202,37 @@ def test_collective_path_self_check_is_agreed_over_the_group():
         assert b["path"] == "torch.distributed" and not b["native"]
         assert d["path"] == "torch.distributed" and d["self_check"] == "not run"
     assert "exp_avg differ" in res[1][1]["self_check"] and "another rank" in res[0][1]["self_check"]
+
+
+def _env_flag_worker(rank, world, port, out):
+    """comm_select.select() with the self-check job's verdict handed in as SP_NATIVE_COMM: honoured only after the ranks agreed on it (MIN)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from simple_pose_amd import comm_select
+        res = []
+        for flags in (("1", "0"), ("0", "0"), ("1", "1")):
+            os.environ["SP_NATIVE_COMM"] = flags[rank]
+            res.append(comm_select.select(None, None, requested=None))
+        os.environ.pop("SP_NATIVE_COMM", None)
+        res.append(comm_select.select(None, None, requested=None))          # no verdict handed in: nothing unproven runs inside a training process
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_handed_in_verdict_is_agreed_before_it_is_honoured():
+    """Round 6: the supervised self-check job hands its verdict to the train job as SP_NATIVE_COMM.  A rank whose supervisor saw a different outcome must not
+    open communicators the others do not: select() all-reduces the flag (MIN) first.  Over gloo the native path cannot exist at all, and says so."""
+    world, port = 2, _free_port()
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_env_flag_worker, args=(world, port, out), nprocs=world, join=True)
+        res = dict(out)
+    for rank in range(world):
+        mixed, zeros, ones, none = res[rank]
+        assert mixed["path"] == "torch.distributed" and not mixed["native"]
+        assert ("another rank" in mixed["reason"]) == (rank == 0) and ("SP_NATIVE_COMM=0" in mixed["reason"]) == (rank == 1)
+        assert zeros["path"] == "torch.distributed" and "SP_NATIVE_COMM=0" in zeros["reason"]
+        assert ones["path"] == "torch.distributed" and "cannot exist here" in ones["reason"] and "gloo" in ones["reason"]
+        assert none["path"] == "torch.distributed" and none["self_check"] == "not run"
