@@ -397,9 +397,10 @@ def test_bench_dry_launch_runs_the_three_jobs_with_deadlines(n):
     assert oc["n_gpus"] == n and oc["job"]["status"] == "ok" and oc["global_batch"] == 32 * n and oc["dtype"] == "bf16"
     assert oc["collective_self_check"]["native"] and oc["collective_self_check"]["job"]["status"] == "ok"
     assert oc["native_flag_agreed"] is True and "sp_comm" in oc["collective_path"]
-    oc, wall = _dry_three_jobs(n, "hang", deadline="20")
+    dl = "10" if n == 2 else "15"
+    oc, wall = _dry_three_jobs(n, "hang", deadline=dl)
     chk = oc["collective_self_check"]
-    assert chk["job"]["status"] == "timeout" and "hung" in chk["reason"] and "20 s deadline" in chk["reason"] and not chk["native"]
+    assert chk["job"]["status"] == "timeout" and "hung" in chk["reason"] and f"{dl} s deadline" in chk["reason"] and not chk["native"]
     assert oc["job"]["status"] == "ok" and oc["collective_path"] == "torch.distributed" and oc["native_flag_agreed"] is False
     assert wall < 150.0
     if n == 2:
@@ -420,7 +421,7 @@ def test_bench_under_torchrun_each_worker_supervises_its_own_rank():
     oc, _ = _dry_three_jobs(2, "raise", torchrun=True)
     chk = oc["collective_self_check"]
     assert chk["job"]["status"] == "died" and not chk["native"] and oc["collective_path"] == "torch.distributed" and oc["job"]["status"] == "ok"
-    oc, wall = _dry_three_jobs(2, "hang", torchrun=True, deadline="15")
+    oc, wall = _dry_three_jobs(2, "hang", torchrun=True, deadline="10")
     assert oc["collective_self_check"]["job"]["status"] == "timeout" and oc["collective_path"] == "torch.distributed" and wall < 120.0
 
 
