@@ -294,6 +294,7 @@ def supervise(args, managed, world: int) -> int:
     Rank 0's supervisor prints the ONE JSON line; the exit code is the main job's."""
     from simple_pose_amd import launch
 
+    launch.install_signal_handlers()                 # told to stop (torchrun after a failed worker, a driver's timeout): the rank processes go first
     per_rank = len(managed) < world
     me = managed[0] if per_rank else 0
     base = dict(os.environ)
@@ -305,6 +306,8 @@ def supervise(args, managed, world: int) -> int:
         tag = "_".join(str(base.get(k, "x")) for k in ("MASTER_PORT", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT"))
         share_dir = os.path.join(os.environ.get("SP_BENCH_SHARE_ROOT", "/tmp"), f"sp_bench_{os.getppid()}_{tag}")
         os.makedirs(share_dir, exist_ok=True)
+        if me == 0:
+            launch._CLEANUP_DIRS.append(share_dir)
     this = [sys.executable, os.path.abspath(__file__)]
 
     def job_env(name: str, extra=None) -> dict:

@@ -50,6 +50,28 @@ def _read(path: str) -> Optional[str]:
         return None
 
 
+_ACTIVE: List[subprocess.Popen] = []          # children of the job that is running now (for the signal handler)
+_CLEANUP_DIRS: List[str] = []
+
+
+def install_signal_handlers() -> None:
+    """A supervisor that is told to stop (torchrun ends its workers with SIGTERM when another worker failed; a driver's timeout does the same) must not
+    leave its rank processes behind - on a GPU they would sit in a collective forever: SIGTERM / SIGINT end exactly the children started here, then exit."""
+    import shutil
+    import signal
+
+    def handler(signum, _frame):
+        stop(list(_ACTIVE), wait_s=5.0)
+        for d in _CLEANUP_DIRS:
+            shutil.rmtree(d, ignore_errors=True)
+        os._exit(128 + signum)
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        try:
+            signal.signal(sig, handler)
+        except (ValueError, OSError):          # (not the main thread)
+            pass
+
+
 def stop(procs: Sequence[subprocess.Popen], wait_s: float = 10.0) -> None:
     """End exactly the children in `procs` (SIGTERM, then SIGKILL for whatever ignores it)."""
     for p in procs:
@@ -79,6 +101,7 @@ def run_job(name: str, argv: List[str], ranks: Sequence[int], world: int, env: D
     for r in ranks:
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), SP_BENCH_CHILD="1")
         procs[r] = subprocess.Popen(argv, env=e, stdout=subprocess.PIPE if r == capture_rank else sys.stderr, stderr=sys.stderr)
+        _ACTIVE.append(procs[r])
     out = b""
     sel = selectors.DefaultSelector()
     cap = procs.get(capture_rank)
@@ -142,6 +165,9 @@ def run_job(name: str, argv: List[str], ranks: Sequence[int], world: int, env: D
             while time.time() < t_end and any(p.poll() is None for p in procs.values()):
                 time.sleep(0.1)
         stop(list(procs.values()))
+        for p in procs.values():
+            if p in _ACTIVE:
+                _ACTIVE.remove(p)
         drain()
         if cap is not None:
             try:

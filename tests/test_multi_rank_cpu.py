@@ -236,3 +236,33 @@ def test_handed_in_verdict_is_agreed_before_it_is_honoured():
         assert zeros["path"] == "torch.distributed" and "SP_NATIVE_COMM=0" in zeros["reason"]
         assert ones["path"] == "torch.distributed" and "cannot exist here" in ones["reason"] and "gloo" in ones["reason"]
         assert none["path"] == "torch.distributed" and none["self_check"] == "not run"
+
+
+def test_supervisor_told_to_stop_takes_its_rank_processes_with_it(tmp_path):
+    """torchrun ends its workers with SIGTERM when another worker failed (and a driver's timeout does the same): a supervisor
+    (launch.install_signal_handlers) then ends exactly the rank processes it started before it leaves - on a GPU they would otherwise sit in a
+    collective forever."""
+    import signal
+    import subprocess
+    import sys
+    import time
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = f"import time, os; open(r'{tmp_path}/child_' + os.environ['RANK'], 'w').write(str(os.getpid())); time.sleep(600)"
+    code = (f"import sys, os; sys.path.insert(0, {root!r})\n"
+            "from simple_pose_amd import launch\n"
+            "launch.install_signal_handlers()\n"
+            "print(os.getpid(), flush=True)\n"
+            f"launch.run_job('t', [sys.executable, '-c', {child!r}], [0, 1], 2, dict(os.environ), 600.0)\n")
+    p = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, text=True)
+    sup = int(p.stdout.readline())
+    t_end = time.time() + 30
+    while time.time() < t_end and not all(os.path.exists(tmp_path / f"child_{r}") and (tmp_path / f"child_{r}").read_text() for r in (0, 1)):
+        time.sleep(0.1)
+    kids = [int((tmp_path / f"child_{r}").read_text()) for r in (0, 1)]
+    os.kill(sup, signal.SIGTERM)
+    assert p.wait(timeout=30) == 128 + signal.SIGTERM
+    time.sleep(0.5)
+    for k in kids:
+        with pytest.raises(ProcessLookupError):
+            os.kill(k, 0)
