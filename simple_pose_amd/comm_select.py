@@ -216,6 +216,7 @@ def run_self_check_job(n_ranks: int, argv: Optional[list] = None, deadline_s: fl
     or `argv`), bounded by `deadline_s`, and turn its outcome into the decision (`launch.collective_decision`)."""
     from . import launch
 
+    launch.install_signal_handlers()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     argv = argv or [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n_ranks), "--self-check-only", "--mode", "train", "--dtype", "bf16",
                     "--batch", "32"]
