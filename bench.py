@@ -967,9 +967,9 @@ def _variant_name(op):
     (sp_conv2d_kernel_name), so it cannot drift from what is launched."""
     from simple_pose_amd import _lib
     if op.kind == "bb32":
-        return "basic_block_c32_kernel"
+        return _lib.conv_kernel_name(op.desc, False, 4)
     if op.kind == "bneck64":
-        return "bottleneck_c64_kernel"
+        return _lib.conv_kernel_name(op.desc, False, 5)
     if op.kind == "dual1x1":
         return "dual_pw_bf16_kernel" if op.w.element_size() == 2 else "conv_pw_dual_kernel<64>"
     if op.kind == "htrans":

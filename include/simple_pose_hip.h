@@ -190,7 +190,8 @@ int sp_conv2d_ring_ok(const sp_conv_desc* desc);
 
 /* Name of the kernel instantiation a launch of `desc` resolves to, as rocprofv3's kernel trace reports it (without the
  * "void (anonymous namespace)::" prefix and the argument list).  variant 0 = sp_conv2d_fwd, 1 = sp_conv2d_fwd_bn_stats,
- * 2 = sp_conv2d_dgrad_bn_bwd_stats, 3 = sp_conv3x3_direct.  Produced by the launch dispatch itself (nothing is launched), so
+ * 2 = sp_conv2d_dgrad_bn_bwd_stats, 3 = sp_conv3x3_direct, 4 = sp_basic_block_c32, 5 = sp_bottleneck_c64 (`desc` = the block's 3x3
+ * convolution).  Produced by the launch dispatch itself (nothing is launched), so
  * profiles and bench.py's roofline line key on exactly what ran. */
 int sp_conv2d_kernel_name(const sp_conv_desc* desc, int has_residual, int variant, char* buf, int cap);
 

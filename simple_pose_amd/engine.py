@@ -771,9 +771,9 @@ class ProgramBuilder:
         if dtype not in ("fp32", "bf16"):
             raise ValueError(dtype)
         self.packer = packer or HipPacker()         # parameters -> kernel layouts (device kernels behind the C ABI)
-        # bf16: whole 32-channel BasicBlocks as one launch (sp_basic_block_c32: same bits, 2.5x less HBM traffic).  Opt-in: measured at
-        # bs=128 it ties with the two direct-conv launches it replaces (40 vs 2 x 20 us per block) - both are bound by the per-tile chain
-        # of dependent steps at two waves per SIMD, not by bytes (profiles/r02_pmc_hrnet_blocks.md) - and the network step is not faster
+        # bf16: whole 32-channel BasicBlocks as one launch (sp_basic_block_c32: same bits, 2.5x less HBM traffic).  The round-2 four-wave kernel
+        # tied with the two direct-conv launches it replaces (40 vs 2 x 20 us per block at bs=128, profiles/r02_pmc_hrnet_blocks.md); round 6's
+        # eight-wave strip kernel takes 25.8 us against 2 x 16.5: hrnet_program turns this on, a bare builder leaves it to the caller
         self.fuse_blocks = False
         # bf16: whole identity-shortcut Bottlenecks with 64 mid channels (ResNet-50 layer1.1 / layer1.2) as one launch
         # (sp_bottleneck_c64: same bits, x read once and y written once)
@@ -1259,14 +1259,14 @@ def _fuse_transition1(b: "ProgramBuilder") -> None:
 
 
 def hrnet_program(sd: Dict[str, torch.Tensor], cfg: dict, in_h: int = 256, in_w: int = 192, dtype: str = "fp32", packer=None,
-                  fuse_blocks: bool = False, fuse_stem: bool = True, fuse_terms: bool = True, fuse_transition: bool = True, fuse_tail: bool = True,
+                  fuse_blocks: bool = True, fuse_stem: bool = True, fuse_terms: bool = True, fuse_transition: bool = True, fuse_tail: bool = True,
                   fuse_bottlenecks: bool = True) -> Program:
     """Lower a reference-layout HRNet state_dict into a Program (PoseHighResolutionNet.forward, pose_hrnet.py:419-454).
-    `fuse_blocks`: bf16 32-channel BasicBlocks as one launch each (sp_basic_block_c32; same bits as the two conv launches; opt-in,
-    see ProgramBuilder.fuse_blocks)."""
+    `fuse_blocks`: bf16 32-channel BasicBlocks as one launch each (sp_basic_block_c32; same bits as the two conv launches; default since
+    round 6's eight-wave strip kernel: 25.8 against 2 x 16.5 us per block at bs=128, HRNet-W32 +6.5 %)."""
     extra = cfg["MODEL"]["EXTRA"]
     b = ProgramBuilder(in_h, in_w, dtype, packer)
-    b.fuse_blocks = fuse_blocks
+    b.fuse_blocks = {"1": True, "0": False}.get(os.environ.get("SP_HRNET_BLOCKS", ""), fuse_blocks)     # (env: development knob for same-box A/Bs)
     b.fuse_tail = fuse_tail and b.fuse_tail
     # layer1.1-1.3 (identity Bottlenecks 256 -> 64 -> 64 -> 256) through sp_bottleneck_c64: neutral with the 171 / 168 us kernels of rounds 4-6, +2.3 % with
     # the eight-wave kernel (146 us against ~190 for the three launches; profiles/r06_summary.md)

@@ -116,7 +116,7 @@ class PoseHighResolutionNet(ParamTree):
     fuse_transition = True # bf16: transition1's two 3x3 convs on layer1's output as one launch (sp_hrnet_transition1); agrees with the two launches to fp32 summation order
     fuse_tail = True       # bf16: layer1.0's conv3 + projection shortcut as one launch (sp_dual_pw_bf16); same bits
     fuse_bottlenecks = True  # bf16: layer1.1-1.3 as one launch each (sp_bottleneck_c64, eight-wave kernel); same bits, +2.3 % (round 6)
-    fuse_blocks = False    # True: bf16 32-channel BasicBlocks as one launch each (sp_basic_block_c32); same bits, measured no faster
+    fuse_blocks = True     # bf16: the 32 BasicBlocks of the 32-channel branch as one launch each (sp_basic_block_c32, eight-wave strip kernel); same bits, +6.5 % (round 6)
 
     def hip_program(self, x: torch.Tensor) -> engine.Program:
         sd = self.state_dict(keep_vars=True)

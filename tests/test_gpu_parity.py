@@ -1971,7 +1971,8 @@ def test_head_3x3_kernel_is_bit_identical_to_the_implicit_gemm(B, H, W, J, relu)
     assert lib.sp_conv3x3_direct(d, P(x), P(op.w), None, P(bias), P(y0), P(y1), st) != 0        # no residual form
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 20, 17), (3, 8, 16), (1, 7, 5), (5, 33, 47), (128, 64, 48), (37, 9, 40)])
+@pytest.mark.parametrize("B,H,W", [(2, 20, 17), (3, 8, 16), (1, 7, 5), (5, 33, 47), (128, 64, 48), (37, 9, 40), (2, 96, 72), (3, 17, 49), (1, 8, 48),
+                                   (300, 16, 48), (1, 1, 1), (2, 23, 100)])
 def test_fused_basic_block_c32_is_bit_identical_to_its_two_convs(B, H, W):
     """sp_basic_block_c32 (HRNet BasicBlock of the 32-channel branch in one launch: conv1 on the halo'd tile, t kept in LDS as bf16,
     zero outside the image, residual from the input halo) against the two conv launches it replaces - bit for bit on ragged tiles and
@@ -2010,8 +2011,8 @@ def test_fused_basic_block_c32_is_bit_identical_to_its_two_convs(B, H, W):
 
 
 def test_hrnet_with_fused_basic_blocks_equals_the_per_conv_program_bitwise(golden):
-    """HRNet-W32 bf16 end to end with `fuse_blocks` (32 BasicBlocks of the high-resolution branch as one launch each): same heat maps,
-    bit for bit, as the default one-launch-per-conv program."""
+    """HRNet-W32 bf16 end to end with `fuse_blocks` (32 BasicBlocks of the high-resolution branch as one launch each; the default since round 6's
+    eight-wave strip kernel): same heat maps, bit for bit, as the one-launch-per-conv program."""
     import os
     from simple_pose_amd.nets.pose_hrnet import get_pose_net, hrnet_state_dict_shapes
     g = golden("g3_hrnet_w32_fwd.npz")
@@ -2023,6 +2024,8 @@ def test_hrnet_with_fused_basic_blocks_equals_the_per_conv_program_bitwise(golde
     m.compute_dtype = "bf16"
     x = _cuda(synth.input_images(3, 7))
     with torch.no_grad():
+        assert m.fuse_blocks                      # (round 6 default)
+        m.fuse_blocks = False
         plain = m(x).clone()
         assert sum(op.kind == "bb32" for op in m.hip_program(x).ops) == 0
         m.fuse_blocks = True
