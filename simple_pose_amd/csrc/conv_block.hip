@@ -564,6 +564,7 @@ __global__ __launch_bounds__(512) void basic_block_c32_w8_kernel(const BlockArgs
     }
 #endif
 }
+
 }  // namespace s48
 
 bool block_ok(const sp_conv_desc* d) {

@@ -99,7 +99,7 @@ def main():
     same = torch.equal(outs[True].view(torch.int16), outs[False].view(torch.int16))
     mb = B * H * W * 32 * 2 / 1e6
     print(f"BasicBlock c32 bs={B} {H}x{W}: fused {res[True]:.1f} us ({2 * mb / res[True] / 1e6 * 1e6 / 1e6:.2f} TB/s of {2 * mb:.0f} MB), two convs {res[False]:.1f} us, "
-          f"bit-identical: {same} (SP_BB32_W8={os.environ.get('SP_BB32_W8', '1')})")
+          f"bit-identical: {same} (SP_BB32_W8={os.environ.get('SP_BB32_W8', 'default')})")
 
 
 if __name__ == "__main__":
