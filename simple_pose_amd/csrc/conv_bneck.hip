@@ -438,6 +438,21 @@ __global__ __launch_bounds__(512, 2) void bottleneck_c64_w8_kernel(const BneckAr
     const __amdgpu_buffer_rsrc_t w2r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w2), (short)0, p.w2_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w3r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w3), (short)0, p.w3_bytes, 0x00020000);
 
+    // the filters -> LDS in fragment order (piece q = f*128 + nb*64 + kh*32 + n holds W[nb*32 + n][f*16 + kh*8 .. + 8]).  Read in MEMORY order - consecutive
+    // lanes take consecutive 16-byte pieces of a row - and scattered on the LDS side: read in fragment order every wave-instruction gathered 16 bytes from
+    // each of 32 rows, the same 104 KB for all 512 workgroups (conv_block.hip's strip kernel lost 6 us of prologue to that pattern)
+#ifndef SP_BNECK_GATHER_W
+    for (int pi = tid; pi < W2B / 16; pi += 512) {
+        const int r = pi / 72, c = pi - r * 72;                 // row (output channel), 16-byte column of the 1,152-byte row
+        const int q = (c >> 1) * 128 + (r >> 5) * 64 + (c & 1) * 32 + (r & 31);
+        *reinterpret_cast<u32x4*>(Ws2 + q * 16) = __builtin_amdgcn_raw_buffer_load_b128(w2r, (unsigned)(pi * 16), 0, 0);
+    }
+    for (int pi = tid; pi < W1B / 16; pi += 512) {
+        const int r = pi >> 5, c = pi & 31;                     // 512-byte rows
+        const int q = (c >> 1) * 128 + (r >> 5) * 64 + (c & 1) * 32 + (r & 31);
+        *reinterpret_cast<u32x4*>(Ws1 + q * 16) = __builtin_amdgcn_raw_buffer_load_b128(w1r, (unsigned)(pi * 16), 0, 0);
+    }
+#else                                                           // (the round-6 A/B: tools/r06_bneck_wload.sh)
     for (int q = tid; q < W2B / 16; q += 512) {
         const int n = q & 31, kh = (q >> 5) & 1, nb = (q >> 6) & 1, f = q >> 7;
         *reinterpret_cast<u32x4*>(Ws2 + q * 16) = __builtin_amdgcn_raw_buffer_load_b128(w2r, (unsigned)(((nb * 32 + n) * 576 + f * 16 + kh * 8) * 2), 0, 0);
@@ -446,6 +461,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_c64_w8_kernel(const BneckAr
         const int n = q & 31, kh = (q >> 5) & 1, nb = (q >> 6) & 1, f = q >> 7;
         *reinterpret_cast<u32x4*>(Ws1 + q * 16) = __builtin_amdgcn_raw_buffer_load_b128(w1r, (unsigned)(((nb * 32 + n) * 256 + f * 16 + kh * 8) * 2), 0, 0);
     }
+#endif
     // stage C role: output channels 32 wave .. +31; W3's fragments of that column block (4 k steps) in registers for the whole launch
     u32x4 w3reg[4];
 #pragma unroll

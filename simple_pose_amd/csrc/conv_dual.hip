@@ -75,11 +75,15 @@ __global__ __launch_bounds__(512, 2) void dual_pw_bf16_kernel(const DualArgs p) 
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, (short)0, p.y_bytes, 0x00020000);
 
     // ---- both weight matrices -> LDS in fragment order, once per workgroup: fragment (ks, nb, kh, n) = W[nb*32 + n][ks*16 + kh*8 .. +8] ----
+    // (read in MEMORY order - consecutive lanes take consecutive 16-byte pieces of the 128-byte rows - and scattered on the LDS side; reading in fragment
+    //  order gathered 16 bytes from each of 32 rows per wave-instruction: conv_bneck.hip's A/B of the same change, profiles/r06_bneck8_ab.txt)
+    static_assert(DP_K == 64, "eight 16-byte pieces per row");
     for (int q = tid; q < 2 * DP_WB / 16; q += 512) {
-        const int g = q / (DP_WB / 16), r = q - g * (DP_WB / 16);
-        const int n = r & 31, kh = (r >> 5) & 1, nb = (r >> 6) & 7, ks = r >> 9;
-        const unsigned off = (unsigned)(((nb * 32 + n) * DP_K + ks * 16 + kh * 8) * 2);
-        *reinterpret_cast<u32x4*>(Wl + q * 16) = g ? __builtin_amdgcn_raw_buffer_load_b128(wr1, off, 0, 0) : __builtin_amdgcn_raw_buffer_load_b128(wr0, off, 0, 0);
+        const int g = q / (DP_WB / 16), pi = q - g * (DP_WB / 16);
+        const int row = pi >> 3, c = pi & 7;                     // output channel, 16-byte column
+        const int r = (c >> 1) * 512 + (row >> 5) * 64 + (c & 1) * 32 + (row & 31);
+        const unsigned off = (unsigned)(pi * 16);
+        *reinterpret_cast<u32x4*>(Wl + (g * (DP_WB / 16) + r) * 16) = g ? __builtin_amdgcn_raw_buffer_load_b128(wr1, off, 0, 0) : __builtin_amdgcn_raw_buffer_load_b128(wr0, off, 0, 0);
     }
 
     // ---- A tiles by LDS-DMA: a tile's two images are 32 pieces of 1 KiB (8 pixels x 128 B); wave w issues pieces w and w + 8 of both ----
