@@ -968,6 +968,8 @@ def _variant_name(op):
     from simple_pose_amd import _lib
     if op.kind == "bb32":
         return _lib.conv_kernel_name(op.desc, False, 4)
+    if op.kind == "bb64":
+        return _lib.conv_kernel_name(op.desc, False, 6)
     if op.kind == "bneck64":
         return _lib.conv_kernel_name(op.desc, False, 5)
     if op.kind == "dual1x1":
@@ -1046,7 +1048,7 @@ def kernel_roofline(prog, x, steps: int, layers_out=None, peak=FP32_MATRIX_PEAK_
     bufs = dict(prog._alloc(B, x.device))
     bufs["input"] = x
     bufs[prog.out_name] = torch.empty((B,) + tuple(prog.out_shape), dtype=torch.float32, device=x.device)
-    FLOP_KINDS = ("conv", "bb32", "bneck64", "dual1x1", "stem7", "hstem", "htrans")
+    FLOP_KINDS = ("conv", "bb32", "bb64", "bneck64", "dual1x1", "stem7", "hstem", "htrans")
     conv_ops = [op for op in prog.ops if op.kind in FLOP_KINDS]            # every launch that carries algorithmic FLOPs
     ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in conv_ops]
           for _ in range(steps)]

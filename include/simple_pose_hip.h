@@ -27,7 +27,7 @@ extern "C" {
 #define SP_EINVAL (-1)   /* bad argument / unsupported shape (message in sp_last_error) */
 #define SP_ELAUNCH (-2)  /* HIP launch or runtime failure */
 
-#define SP_ABI_VERSION 34
+#define SP_ABI_VERSION 35
 
 /* epilogue / layout flags of sp_conv_desc.flags */
 #define SP_CONV_RELU 0x1u          /* y = max(y, 0) after scale/shift (+ residual) */
@@ -125,6 +125,14 @@ int sp_basic_block_c32_ok(const sp_conv_desc* desc);
 int sp_basic_block_c32(const sp_conv_desc* desc, const void* x, const void* w1_packed, const float* scale1, const float* shift1,
                        const void* w2_packed, const float* scale2, const float* shift2, void* y, void* stream);
 
+/* (ABI 35) The same block on a 64-channel branch (HRNet's 32 x 24 maps): both 64 x 576 filters stay in registers because the eight waves take roles - four
+ * run conv1 of strip j while four run conv2 of strip j - 1 (4 x 24-pixel strips, one barrier per strip; csrc/conv_block64.hip).  Same arguments and
+ * contract as sp_basic_block_c32 (`desc` = either convolution, sp_basic_block_c64_ok(desc) == 1: what sp_conv3x3_direct_ok accepts at 64 channels);
+ * bit-identical to the two launches. */
+int sp_basic_block_c64_ok(const sp_conv_desc* desc);
+int sp_basic_block_c64(const sp_conv_desc* desc, const void* x, const void* w1_packed, const float* scale1, const float* shift1,
+                       const void* w2_packed, const float* scale2, const float* shift2, void* y, void* stream);
+
 /* (ABI 34) The tail of a stage-opening Bottleneck with 64 mid channels as ONE launch (bf16 NHWC, stride 1: layer1.0 of the ResNet pose nets and of HRNet):
  *     y = relu( bn3(conv1x1_{64->256}(a_main)) + bn_d(conv1x1_{64->256}(a_short)) )          nets/pose_resnet_dconv.py:99-103,120-131
  * a_main = the block's 3x3 output, a_short = the block input ([rows][64] each), weights packed by sp_pack_conv_weights ([256][64]), the folded
@@ -190,8 +198,8 @@ int sp_conv2d_ring_ok(const sp_conv_desc* desc);
 
 /* Name of the kernel instantiation a launch of `desc` resolves to, as rocprofv3's kernel trace reports it (without the
  * "void (anonymous namespace)::" prefix and the argument list).  variant 0 = sp_conv2d_fwd, 1 = sp_conv2d_fwd_bn_stats,
- * 2 = sp_conv2d_dgrad_bn_bwd_stats, 3 = sp_conv3x3_direct, 4 = sp_basic_block_c32, 5 = sp_bottleneck_c64 (`desc` = the block's 3x3
- * convolution).  Produced by the launch dispatch itself (nothing is launched), so
+ * 2 = sp_conv2d_dgrad_bn_bwd_stats, 3 = sp_conv3x3_direct, 4 = sp_basic_block_c32, 5 = sp_bottleneck_c64, 6 = sp_basic_block_c64 (`desc` = the
+ * block's 3x3 convolution).  Produced by the launch dispatch itself (nothing is launched), so
  * profiles and bench.py's roofline line key on exactly what ran. */
 int sp_conv2d_kernel_name(const sp_conv_desc* desc, int has_residual, int variant, char* buf, int cap);
 

@@ -21,7 +21,7 @@ SP_CONV_BF16 = 0x8
 SP_CONV_OUT_F32 = 0x10
 SP_CONV_BN_Y_MASK = 0x20
 CONV_TILES = ((128, 128), (64, 128), (128, 64), (64, 64), (256, 64), (128, 32))
-ABI_VERSION = 34
+ABI_VERSION = 35
 SP_CONV_KERNEL_IGEMM, SP_CONV_KERNEL_RING, SP_CONV_KERNEL_PW, SP_CONV_KERNEL_RING_LW, SP_CONV_KERNEL_RING_LW4 = 0, 1, 2, 3, 4
 RING_LW4_TILES = ((192, 128), (128, 128), (96, 128), (256, 128), (128, 256), (96, 256), (64, 128))   # kernel = SP_CONV_KERNEL_RING_LW4 (four MFMA waves + four loader waves)
 RING_LW_TILES = ((256, 128), (128, 256), (256, 64), (128, 128), (192, 128))   # kernel = SP_CONV_KERNEL_RING_LW (bf16; the ring with loader waves)
@@ -139,6 +139,8 @@ SYMBOLS = {
     "sp_conv3x3_direct": (c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
     "sp_basic_block_c32_ok": (c_int, [ctypes.POINTER(ConvDesc)]),
     "sp_basic_block_c32": (c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "sp_basic_block_c64_ok": (c_int, [ctypes.POINTER(ConvDesc)]),
+    "sp_basic_block_c64": (c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sp_dual_pw_bf16_ok": (c_int, [c_int64, c_int, c_int, c_int]),
     "sp_dual_pw_f32_ok": (c_int, [c_int64, c_int, c_int, c_int]),
     "sp_dual_pw_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, _P]),

@@ -1157,16 +1157,17 @@ extern "C" int sp_conv2d_fwd(const sp_conv_desc* d, const void* x, const void* w
 
 // Name of the kernel instantiation a launch of `d` resolves to (what rocprofv3's kernel trace calls it, minus the
 // "void (anonymous namespace)::" / "(...Args)" decoration).  variant: 0 = sp_conv2d_fwd, 1 = sp_conv2d_fwd_bn_stats, 2 =
-// sp_conv2d_dgrad_bn_bwd_stats, 3 = sp_conv3x3_direct, 4 = sp_basic_block_c32, 5 = sp_bottleneck_c64 (`d` = the block's 3x3 convolution).  Nothing is
+// sp_conv2d_dgrad_bn_bwd_stats, 3 = sp_conv3x3_direct, 4 = sp_basic_block_c32, 5 = sp_bottleneck_c64, 6 = sp_basic_block_c64 (`d` = the block's 3x3 convolution).  Nothing is
 // launched; `d` is validated exactly as a launch would.
 extern "C" int sp_conv2d_kernel_name(const sp_conv_desc* d, int has_residual, int variant, char* buf, int cap) {
     SP_REQUIRE(d && buf && cap > 0, "sp_conv2d_kernel_name: null pointer");
-    SP_REQUIRE(variant >= 0 && variant <= 5, "sp_conv2d_kernel_name: variant %d", variant);
+    SP_REQUIRE(variant >= 0 && variant <= 6, "sp_conv2d_kernel_name: variant %d", variant);
     void* const dummy = reinterpret_cast<void*>(16);        // never dereferenced: the launch functions return before launching
     if (variant >= 4) {                                     // the fused blocks' own dispatch (which of their kernels SP_BB32_W8 / SP_BNECK_W8 select)
         void* const dummy2 = reinterpret_cast<void*>(32);   // (x and y must differ)
         sp_name_query_begin();
         const int rcb = variant == 4 ? sp_basic_block_c32(d, dummy, dummy, nullptr, nullptr, dummy, nullptr, nullptr, dummy2, nullptr)
+                      : variant == 6 ? sp_basic_block_c64(d, dummy, dummy, nullptr, nullptr, dummy, nullptr, nullptr, dummy2, nullptr)
                                      : sp_bottleneck_c64(d, dummy, dummy, nullptr, nullptr, dummy, nullptr, nullptr, dummy, nullptr, nullptr, dummy2, nullptr);
         const char* nameb = sp_name_query_end();
         if (rcb != SP_OK) return rcb;

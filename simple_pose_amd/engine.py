@@ -107,7 +107,7 @@ class HipPacker:
 # ------------------------------------------------------------------------------------------------
 @dataclass
 class Op:
-    kind: str                    # "conv" | "bb32" (fused BasicBlock) | "bneck64" (fused Bottleneck) | "stem7" / "hstem" (fused ResNet / HRNet stem) | "htrans" (HRNet transition1) | "maxpool" | ...
+    kind: str                    # "conv" | "bb32" / "bb64" (fused BasicBlock, 32 / 64 channels) | "bneck64" (fused Bottleneck) | "stem7" / "hstem" (fused ResNet / HRNet stem) | "htrans" (HRNet transition1) | "maxpool" | ...
     src: str
     dst: str
     res: Optional[str] = None
@@ -238,10 +238,10 @@ class Program:
             fn = lib.sp_conv3x3_direct if op.direct else lib.sp_conv2d_fwd
             _lib.check(fn(op.desc, P(bufs[op.src]), P(op.w), P(op.scale), P(op.shift),
                           P(bufs[op.res]) if op.res else None, P(bufs[op.dst]), stream), op.name)
-        elif op.kind == "bb32":
+        elif op.kind in ("bb32", "bb64"):
             op.desc.batch = B
             w2, scale2, shift2 = op.args
-            _lib.check(lib.sp_basic_block_c32(op.desc, P(bufs[op.src]), P(op.w), P(op.scale), P(op.shift), P(w2), P(scale2), P(shift2),
+            _lib.check((lib.sp_basic_block_c32 if op.kind == "bb32" else lib.sp_basic_block_c64)(op.desc, P(bufs[op.src]), P(op.w), P(op.scale), P(op.shift), P(w2), P(scale2), P(shift2),
                                               P(bufs[op.dst]), stream), op.name)
         elif op.kind == "bneck64":
             op.desc.batch = B
@@ -775,6 +775,9 @@ class ProgramBuilder:
         # tied with the two direct-conv launches it replaces (40 vs 2 x 20 us per block at bs=128, profiles/r02_pmc_hrnet_blocks.md); round 6's
         # eight-wave strip kernel takes 25.8 us against 2 x 16.5: hrnet_program turns this on, a bare builder leaves it to the caller
         self.fuse_blocks = False
+        # ... and the 64-channel BasicBlocks (sp_basic_block_c64: conv1 waves / conv2 waves pipelined over 4-row strips).  Opt-in: bit-identical and 13.9 us
+        # against 27.4 for the two launches at bs=32, but at bs=128 it ties with them alone (27.8 / 26.1 us) and costs HRNet-W32 0-4 % (profiles/r06_bb64_ab.txt)
+        self.fuse_blocks64 = False
         # bf16: whole identity-shortcut Bottlenecks with 64 mid channels (ResNet-50 layer1.1 / layer1.2) as one launch
         # (sp_bottleneck_c64: same bits, x read once and y written once)
         self.fuse_bottlenecks = False
@@ -929,28 +932,31 @@ class ProgramBuilder:
         return dst
 
     def basic_block_c32(self, src: str, w1: torch.Tensor, scale1, shift1, w2: torch.Tensor, scale2, shift2, name: str) -> Optional[str]:
-        """HRNet BasicBlock on a 32-channel bf16 activation as one launch (sp_basic_block_c32); None when the shapes do not qualify."""
+        """HRNet BasicBlock on a 32- or 64-channel bf16 activation as one launch (sp_basic_block_c32 / sp_basic_block_c64); None when the shapes do
+        not qualify."""
         h, w, c = self.p.shapes[src]
-        if not (self.bf16 and self.fuse_blocks and c == 32 and tuple(w1.shape) == (32, 32, 3, 3) and tuple(w2.shape) == (32, 32, 3, 3)):
+        if not (self.bf16 and self.fuse_blocks and c in (32, 64) and tuple(w1.shape) == (c, c, 3, 3) and tuple(w2.shape) == (c, c, 3, 3)):
+            return None
+        if c == 64 and not self.fuse_blocks64:
             return None
         p1, th, tw, ci, k_pad = self.packer.conv(w1, bf16=True)
         p2 = self.packer.conv(w2, bf16=True)[0]
         d = ConvDesc()
         d.batch, d.in_h, d.in_w, d.c_in = 1, h, w, ci
-        d.grid_h, d.grid_w, d.c_out, d.n_pad = h, w, 32, p1.shape[0]
+        d.grid_h, d.grid_w, d.c_out, d.n_pad = h, w, c, p1.shape[0]
         d.taps_h, d.taps_w, d.k_pad, d.stride = th, tw, k_pad, 1
         d.dy0, d.dy_step, d.dx0, d.dx_step = -1, 1, -1, 1
         d.phases_y = d.phases_x = 1
-        d.out_h, d.out_w, d.out_c = h, w, 32
+        d.out_h, d.out_w, d.out_c = h, w, c
         d.oy_mul = d.ox_mul = 1
         d.oy_add = d.ox_add = 0
         d.flags = SP_CONV_RELU | SP_CONV_BF16
-        if not _lib.lib().sp_basic_block_c32_ok(d):
+        if not (_lib.lib().sp_basic_block_c32_ok(d) if c == 32 else _lib.lib().sp_basic_block_c64_ok(d)):
             return None
         dst = self._fresh(name)
-        self.p.shapes[dst] = (h, w, 32)
-        self._add(Op("bb32", src, dst, desc=d, w=p1, scale=scale1, shift=shift1, args=(p2, scale2, shift2), name=name,
-                     flops=2 * (2 * h * w * 32 * 32 * 9)))
+        self.p.shapes[dst] = (h, w, c)
+        self._add(Op("bb32" if c == 32 else "bb64", src, dst, desc=d, w=p1, scale=scale1, shift=shift1, args=(p2, scale2, shift2), name=name,
+                     flops=2 * (2 * h * w * c * c * 9)))
         return dst
 
     def bottleneck_c64(self, src: str, w1, s1, h1, w2, s2, h2, w3, s3, h3, name: str) -> Optional[str]:
@@ -1259,7 +1265,7 @@ def _fuse_transition1(b: "ProgramBuilder") -> None:
 
 
 def hrnet_program(sd: Dict[str, torch.Tensor], cfg: dict, in_h: int = 256, in_w: int = 192, dtype: str = "fp32", packer=None,
-                  fuse_blocks: bool = True, fuse_stem: bool = True, fuse_terms: bool = True, fuse_transition: bool = True, fuse_tail: bool = True,
+                  fuse_blocks: bool = True, fuse_blocks64: bool = False, fuse_stem: bool = True, fuse_terms: bool = True, fuse_transition: bool = True, fuse_tail: bool = True,
                   fuse_bottlenecks: bool = True) -> Program:
     """Lower a reference-layout HRNet state_dict into a Program (PoseHighResolutionNet.forward, pose_hrnet.py:419-454).
     `fuse_blocks`: bf16 32-channel BasicBlocks as one launch each (sp_basic_block_c32; same bits as the two conv launches; default since
@@ -1267,6 +1273,7 @@ def hrnet_program(sd: Dict[str, torch.Tensor], cfg: dict, in_h: int = 256, in_w:
     extra = cfg["MODEL"]["EXTRA"]
     b = ProgramBuilder(in_h, in_w, dtype, packer)
     b.fuse_blocks = {"1": True, "0": False}.get(os.environ.get("SP_HRNET_BLOCKS", ""), fuse_blocks)     # (env: development knob for same-box A/Bs)
+    b.fuse_blocks64 = {"1": True, "0": False}.get(os.environ.get("SP_HRNET_BLOCKS64", ""), fuse_blocks64)
     b.fuse_tail = fuse_tail and b.fuse_tail
     # layer1.1-1.3 (identity Bottlenecks 256 -> 64 -> 64 -> 256) through sp_bottleneck_c64: neutral with the 171 / 168 us kernels of rounds 4-6, +2.3 % with
     # the eight-wave kernel (146 us against ~190 for the three launches; profiles/r06_summary.md)

@@ -118,15 +118,17 @@ class PoseHighResolutionNet(ParamTree):
     fuse_bottlenecks = True  # bf16: layer1.1-1.3 as one launch each (sp_bottleneck_c64, eight-wave kernel); same bits, +2.3 % (round 6)
     fuse_blocks = True     # bf16: the 32 BasicBlocks of the 32-channel branch as one launch each (sp_basic_block_c32, eight-wave strip kernel); same bits, +6.5 % (round 6)
 
+    fuse_blocks64 = False  # True: the 64-channel branch's BasicBlocks too (sp_basic_block_c64); same bits, pays at small batch only (profiles/r06_bb64_ab.txt)
+
     def hip_program(self, x: torch.Tensor) -> engine.Program:
         sd = self.state_dict(keep_vars=True)
-        key = (tuple(x.shape[2:]), str(x.device), self.compute_dtype, self.fuse_blocks, self.fuse_stem, self.fuse_terms, self.fuse_transition, self.fuse_tail, self.fuse_bottlenecks) + tuple((v.data_ptr(), v._version) for v in sd.values())
+        key = (tuple(x.shape[2:]), str(x.device), self.compute_dtype, self.fuse_blocks, self.fuse_blocks64, self.fuse_stem, self.fuse_terms, self.fuse_transition, self.fuse_tail, self.fuse_bottlenecks) + tuple((v.data_ptr(), v._version) for v in sd.values())
         if self._program is None or key != self._program_key:
             for k, v in sd.items():
                 if v.device != x.device:
                     raise HipLibraryError(f"parameter {k} is on {v.device} but the input is on {x.device}; call .to(device)")
             self._program = engine.hrnet_program({k: v.detach() for k, v in sd.items()}, self.cfg, x.shape[2], x.shape[3],
-                                                  dtype=self.compute_dtype, fuse_blocks=self.fuse_blocks, fuse_stem=self.fuse_stem, fuse_terms=self.fuse_terms, fuse_transition=self.fuse_transition, fuse_tail=self.fuse_tail, fuse_bottlenecks=self.fuse_bottlenecks)
+                                                  dtype=self.compute_dtype, fuse_blocks=self.fuse_blocks, fuse_blocks64=self.fuse_blocks64, fuse_stem=self.fuse_stem, fuse_terms=self.fuse_terms, fuse_transition=self.fuse_transition, fuse_tail=self.fuse_tail, fuse_bottlenecks=self.fuse_bottlenecks)
             self._program_key = key
         return self._program
 

@@ -1971,35 +1971,38 @@ def test_head_3x3_kernel_is_bit_identical_to_the_implicit_gemm(B, H, W, J, relu)
     assert lib.sp_conv3x3_direct(d, P(x), P(op.w), None, P(bias), P(y0), P(y1), st) != 0        # no residual form
 
 
+@pytest.mark.parametrize("C", [32, 64])
 @pytest.mark.parametrize("B,H,W", [(2, 20, 17), (3, 8, 16), (1, 7, 5), (5, 33, 47), (128, 64, 48), (37, 9, 40), (2, 96, 72), (3, 17, 49), (1, 8, 48),
-                                   (300, 16, 48), (1, 1, 1), (2, 23, 100)])
-def test_fused_basic_block_c32_is_bit_identical_to_its_two_convs(B, H, W):
-    """sp_basic_block_c32 (HRNet BasicBlock of the 32-channel branch in one launch: conv1 on the halo'd tile, t kept in LDS as bf16,
-    zero outside the image, residual from the input halo) against the two conv launches it replaces - bit for bit on ragged tiles and
-    image borders - and against the fp64 block on the same bf16 operands."""
+                                   (300, 16, 48), (1, 1, 1), (2, 23, 100), (128, 32, 24), (64, 48, 36), (3, 5, 25), (7, 4, 24)])
+def test_fused_basic_block_c32_is_bit_identical_to_its_two_convs(B, H, W, C):
+    """sp_basic_block_c32 / sp_basic_block_c64 (HRNet BasicBlock of the 32- / 64-channel branch in one launch: conv1 on the halo'd strip, t kept in LDS
+    as bf16, zero outside the image, residual = the block input) against the two conv launches it replaces - bit for bit on ragged strips and image
+    borders - and against the fp64 block on the same bf16 operands."""
+    if C == 64 and B * H * W > 128 * 64 * 48 // 2:
+        pytest.skip("the 64-channel cases stop at the size of HRNet's 32 x 24 maps at bs=128 (x4)")
     lib, P = _lib.lib(), _lib.ptr
-    w1, w2 = (torch.from_numpy(synth.tensor_normal(3, f"bb/w{i}", (32, 32, 3, 3), std=(2.0 / 288) ** 0.5)).bfloat16().float() for i in (1, 2))
-    s1, s2 = (torch.from_numpy(synth.tensor_uniform(3, f"bb/s{i}", (32,), 0.5, 1.5)) for i in (1, 2))
-    h1, h2 = (torch.from_numpy(synth.tensor_normal(3, f"bb/h{i}", (32,), std=0.3)) for i in (1, 2))
-    x = torch.from_numpy(synth.tensor_normal(3, "bb/x", (B, 32, H, W))).bfloat16()
+    w1, w2 = (torch.from_numpy(synth.tensor_normal(3, f"bb/w{i}", (C, C, 3, 3), std=(2.0 / (9 * C)) ** 0.5)).bfloat16().float() for i in (1, 2))
+    s1, s2 = (torch.from_numpy(synth.tensor_uniform(3, f"bb/s{i}", (C,), 0.5, 1.5)) for i in (1, 2))
+    h1, h2 = (torch.from_numpy(synth.tensor_normal(3, f"bb/h{i}", (C,), std=0.3)) for i in (1, 2))
+    x = torch.from_numpy(synth.tensor_normal(3, "bb/x", (B, C, H, W))).bfloat16()
     outs = []
     for fuse in (True, False):
         b = engine.ProgramBuilder(H, W, dtype="bf16")
-        b.fuse_blocks = fuse
-        b.p.shapes["input"] = (H, W, 32)
+        b.fuse_blocks = b.fuse_blocks64 = fuse
+        b.p.shapes["input"] = (H, W, C)
         y = b.basic_block_c32("input", w1.to(DEV), s1.to(DEV), h1.to(DEV), w2.to(DEV), s2.to(DEV), h2.to(DEV), name="blk")
         if not fuse:
             assert y is None
             t = b.conv("input", w1.to(DEV), pad=1, scale=s1.to(DEV), shift=h1.to(DEV), relu=True, name="c1")
             y = b.conv(t, w2.to(DEV), pad=1, scale=s2.to(DEV), shift=h2.to(DEV), relu=True, res="input", name="c2")
-        assert [o.kind for o in b.p.ops] == (["bb32"] if fuse else ["conv", "conv"])
+        assert [o.kind for o in b.p.ops] == ([f"bb{C}"] if fuse else ["conv", "conv"])
         bufs = dict(b.p._alloc(B, torch.device(DEV)))
         bufs["input"] = x.permute(0, 2, 3, 1).contiguous().to(DEV)
         bufs[y].fill_(float("nan"))
         for op in b.p.ops:
             b.p._launch(lib, op, bufs, B, _lib.current_stream())
         torch.cuda.synchronize()
-        outs.append(bufs[y].clone().view(B, H, W, 32))
+        outs.append(bufs[y].clone().view(B, H, W, C))
     assert torch.isfinite(outs[0].float()).all()
     assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), int((outs[0] != outs[1]).sum())
     xd = x.double()
@@ -2011,8 +2014,8 @@ def test_fused_basic_block_c32_is_bit_identical_to_its_two_convs(B, H, W):
 
 
 def test_hrnet_with_fused_basic_blocks_equals_the_per_conv_program_bitwise(golden):
-    """HRNet-W32 bf16 end to end with `fuse_blocks` (32 BasicBlocks of the high-resolution branch as one launch each; the default since round 6's
-    eight-wave strip kernel): same heat maps, bit for bit, as the one-launch-per-conv program."""
+    """HRNet-W32 bf16 end to end with `fuse_blocks` (the 32 + 32 BasicBlocks of the 32- and 64-channel branches as one launch each; the default since
+    round 6's strip kernels): same heat maps, bit for bit, as the one-launch-per-conv program."""
     import os
     from simple_pose_amd.nets.pose_hrnet import get_pose_net, hrnet_state_dict_shapes
     g = golden("g3_hrnet_w32_fwd.npz")
@@ -2027,10 +2030,16 @@ def test_hrnet_with_fused_basic_blocks_equals_the_per_conv_program_bitwise(golde
         assert m.fuse_blocks                      # (round 6 default)
         m.fuse_blocks = False
         plain = m(x).clone()
-        assert sum(op.kind == "bb32" for op in m.hip_program(x).ops) == 0
+        assert sum(op.kind in ("bb32", "bb64") for op in m.hip_program(x).ops) == 0
         m.fuse_blocks = True
         fused = m(x)
-        assert sum(op.kind == "bb32" for op in m.hip_program(x).ops) == 32
+        kinds = [op.kind for op in m.hip_program(x).ops]
+        assert kinds.count("bb32") == 32 and kinds.count("bb64") == 0
+        m.fuse_blocks64 = True                    # (opt-in: the 64-channel branch's blocks too)
+        fused64 = m(x)
+        kinds = [op.kind for op in m.hip_program(x).ops]
+        assert kinds.count("bb32") == 32 and kinds.count("bb64") == 32
+        assert torch.equal(plain, fused64)
     assert torch.equal(plain, fused)
 
 

@@ -458,8 +458,8 @@ def test_conv_kernel_name_query_matches_dispatch():
     d.tile_m, d.tile_n, d.kernel = 64, 128, _lib.SP_CONV_KERNEL_IGEMM
     d.c_in, d.k_pad = 256, 2304
     assert _lib.conv_kernel_name(d, False).startswith("conv_igemm_kernel<64, 128, 2, 2, true, false, false")
-    # the fused blocks name the kernel their own dispatch selects (variant 4 = sp_basic_block_c32, 5 = sp_bottleneck_c64; `d` = the block's 3x3 conv)
-    for variant, c, k_pad, name in ((4, 32, 320, "basic_block_c32_w8_kernel"), (5, 64, 576, "bottleneck_c64_w8_kernel")):
+    # the fused blocks name the kernel their own dispatch selects (variant 4 = sp_basic_block_c32, 5 = sp_bottleneck_c64, 6 = sp_basic_block_c64; `d` = the block's 3x3 conv)
+    for variant, c, k_pad, name in ((4, 32, 320, "basic_block_c32_w8_kernel"), (5, 64, 576, "bottleneck_c64_w8_kernel"), (6, 64, 576, "basic_block_c64_kernel")):
         d = _lib.ConvDesc()
         d.batch, d.in_h, d.in_w, d.c_in = 2, 64, 48, c
         d.grid_h, d.grid_w, d.c_out, d.n_pad = 64, 48, c, 64
@@ -469,7 +469,7 @@ def test_conv_kernel_name_query_matches_dispatch():
         d.oy_mul = d.ox_mul = 1
         d.phases_y = d.phases_x = 1
         d.flags = _lib.SP_CONV_BF16 | _lib.SP_CONV_RELU
-        ok = _lib.lib().sp_basic_block_c32_ok(d) if variant == 4 else _lib.lib().sp_bottleneck_c64_ok(d)
+        ok = {4: _lib.lib().sp_basic_block_c32_ok, 5: _lib.lib().sp_bottleneck_c64_ok, 6: _lib.lib().sp_basic_block_c64_ok}[variant](d)
         assert ok == 1 and _lib.conv_kernel_name(d, False, variant) == name
 
 

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--h", type=int, default=64)
     ap.add_argument("--w", type=int, default=48)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--channels", type=int, default=32, help="32 (sp_basic_block_c32) or 64 (sp_basic_block_c64; HRNet's map is --h 32 --w 24)")
     ap.add_argument("--build", action="store_true", help="here: the SP_BB32_DIAG build of the library (simple_pose_amd/lib/libsimple_pose_hip_bb32diag.so)")
     ap.add_argument("--variant", default="", help="suffix of the diag library's name (with --defs: another build of the kernel, for same-box A/Bs)")
     ap.add_argument("--defs", default="", help="extra compiler flags of the diag build, e.g. '-DBB_STAGGER=7'")
@@ -46,14 +47,15 @@ def main():
     g = torch.Generator(device="cpu").manual_seed(0)
     mk = lambda *s: (torch.randn(*s, generator=g) * 0.06).to(dev)
     sc = lambda c: ((torch.rand(c, generator=g) + 0.5).to(dev), (torch.randn(c, generator=g) * 0.1).to(dev))
-    w1, w2, (s1, h1), (s2, h2) = mk(32, 32, 3, 3), mk(32, 32, 3, 3), sc(32), sc(32)
-    x = torch.randn(B, H, W, 32, device=dev).bfloat16()
+    CH = a.channels
+    w1, w2, (s1, h1), (s2, h2) = mk(CH, CH, 3, 3), mk(CH, CH, 3, 3), sc(CH), sc(CH)
+    x = torch.randn(B, H, W, CH, device=dev).bfloat16()
     res = {}
     outs = {}
     for fuse in (True, False):
         b = engine.ProgramBuilder(H, W, dtype="bf16")
-        b.fuse_blocks = fuse
-        b.p.shapes["input"] = (H, W, 32)
+        b.fuse_blocks = b.fuse_blocks64 = fuse
+        b.p.shapes["input"] = (H, W, CH)
         y = b.basic_block_c32("input", w1, s1, h1, w2, s2, h2, name="blk")
         if not fuse:
             t = b.conv("input", w1, pad=1, scale=s1, shift=h1, relu=True, name="c1")
@@ -78,7 +80,7 @@ def main():
         import numpy as np
         b = engine.ProgramBuilder(H, W, dtype="bf16")
         b.fuse_blocks = True
-        b.p.shapes["input"] = (H, W, 32)
+        b.p.shapes["input"] = (H, W, CH)
         y = b.basic_block_c32("input", w1, s1, h1, w2, s2, h2, name="blk")
         bufs = dict(b.p._alloc(B, torch.device(dev)))
         bufs["input"] = x
@@ -97,8 +99,8 @@ def main():
         life, rt = d[:, :, 8].mean(), d[:, :, 9].mean()
         print(f"  s_memtime ticks per us: {life / (rt / 100.0):.1f}; lifetime {rt / 100.0:.2f} us")
     same = torch.equal(outs[True].view(torch.int16), outs[False].view(torch.int16))
-    mb = B * H * W * 32 * 2 / 1e6
-    print(f"BasicBlock c32 bs={B} {H}x{W}: fused {res[True]:.1f} us ({2 * mb / res[True] / 1e6 * 1e6 / 1e6:.2f} TB/s of {2 * mb:.0f} MB), two convs {res[False]:.1f} us, "
+    mb = B * H * W * CH * 2 / 1e6
+    print(f"BasicBlock c{CH} bs={B} {H}x{W}: fused {res[True]:.1f} us ({2 * mb / res[True]:.2f} TB/s of {2 * mb:.0f} MB), two convs {res[False]:.1f} us, "
           f"bit-identical: {same} (SP_BB32_W8={os.environ.get('SP_BB32_W8', 'default')})")
 
 
