@@ -74,7 +74,11 @@ def parse():
                     "ONE stream (+20 %% over one forward spread over four branch streams)")
     ap.add_argument("--multi-stream", action="store_true", help="hrnet_w32 with --interleave > 1: keep the per-branch streams inside each forward")
     ap.add_argument("--no-pipeline-decode", action="store_true", help="hrnet_w32: decode in line, on the forward's stream")
-    ap.add_argument("--fuse-blocks", action="store_true", help="hrnet_w32 bf16: 32-channel BasicBlocks as one launch each (sp_basic_block_c32; same bits)")
+    ap.add_argument("--fuse-blocks", action="store_true", help="hrnet_w32 bf16: 32-channel BasicBlocks as one launch each (sp_basic_block_c32; same bits) - the "
+                    "default since round 6; kept for old command lines")
+    ap.add_argument("--no-fuse-blocks", action="store_true", help="hrnet_w32 bf16: one launch per conv in the 32-channel branch (same-box A/Bs)")
+    ap.add_argument("--fuse-blocks64", action="store_true", help="hrnet_w32 bf16: the 64-channel BasicBlocks as one launch each too (sp_basic_block_c64; same bits; "
+                    "pays at small batch, profiles/r06_bb64_ab.txt)")
     ap.add_argument("--no-fuse-stem", action="store_true", help="infer mode: run the stem launch by launch (layout change, conv(s), pooling) instead of "
                     "as one launch (sp_stem7_pool for the ResNets, sp_hrnet_stem for HRNet in bf16; same bits)")
     ap.add_argument("--no-fuse-bottlenecks", action="store_true",
@@ -618,8 +622,13 @@ def run_once(args, ctx):
     model = model.to(dev).eval()
     if args.no_fuse_stem:
         model.fuse_stem = False
-    if args.fuse_blocks and args.arch == "hrnet_w32":
-        model.fuse_blocks = True
+    if args.arch == "hrnet_w32":
+        if args.fuse_blocks:
+            model.fuse_blocks = True
+        if args.no_fuse_blocks:
+            model.fuse_blocks = False
+        if args.fuse_blocks64:
+            model.fuse_blocks64 = True
     if args.dtype == "bf16" and args.mode == "infer":
         model.compute_dtype = "bf16"
         if args.arch in ("dconv", "duc"):
