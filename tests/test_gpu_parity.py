@@ -2166,3 +2166,20 @@ def test_bench_micro_mode_prints_one_json_line_on_stdout():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["metric"].startswith("HBM-bound kernels") and d["rows"] > 10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("knob,selector", [("SP_BB32_W8", "test_fused_basic_block_c32_is_bit_identical_to_its_two_convs and 5-33-47-32"),
+                                           ("SP_BNECK_W8", "test_fused_bottlenecks_equal_the_per_conv_program_bitwise and duc")])
+def test_kernels_kept_for_same_box_ab_still_match(knob, selector):
+    """The round-2 four-wave BasicBlock kernel (SP_BB32_W8=0) and the four-wave fused bottleneck (SP_BNECK_W8=0) stay in the library for same-box A/Bs
+    (profiles/r06_bb32_ab.txt, r06_bneck8_ab.txt): the knobs are read once per process, so a fresh interpreter runs one parity case of each on them."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **{knob: "0"})
+    selector += " and not test_kernels_kept_for_same_box_ab"           # (this test's own id contains the selector: never select it in the child)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k", selector],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
