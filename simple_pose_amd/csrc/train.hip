@@ -178,10 +178,16 @@ __global__ void pair_sum_final_kernel(const double* __restrict__ part, int nblk,
 // BatchNorm passes below and the body of the stand-alone fold kernels, so the two ways of running a layer agree bit for bit.
 // Result: threads tid < 64 hold (sum0, sum1) of channel c0 + tid; returns whether that channel exists.
 constexpr int SLAB = 64, FOLD_THREADS = 1024;
-__device__ __forceinline__ bool fold_slab64(const float* __restrict__ ps, const float* __restrict__ pq, int nrows, int stride, int C, int c0,
-                                            double& s0, double& s1) {
-    __shared__ double sh[16][SLAB][2];                  // [wave][channel][stat]: 16 KB
-    const int tid = threadIdx.x, q = tid & 15, rl = tid >> 4, wave = tid >> 6;
+// QUADS channel quads x 64 row lanes: QUADS = 16 is the 64-channel slab of 1,024 threads (the fused passes below), QUADS = 4 a 16-channel slab of 256
+// threads (the stand-alone folds: a layer1 / stem fold is 0.4-1.5 MB of partial rows, and ONE workgroup per 64 channels read them at one CU's
+// 50-60 GB/s - 29 / 65 us for the stem's pair; four times the workgroups, the SAME sums: a channel's rows are added in the same order by the same
+// tree whatever QUADS is - row lane rl takes rows rl, rl + 64, ..., groups of four row lanes combine as (t0 + t1) + (t2 + t3), the sixteen groups in order)
+template <int QUADS>
+__device__ __forceinline__ bool fold_slab(const float* __restrict__ ps, const float* __restrict__ pq, int nrows, int stride, int C, int c0,
+                                          double& s0, double& s1) {
+    constexpr int SL = 4 * QUADS;
+    __shared__ double sh[16][SL][2];                    // [group of four row lanes][channel][stat]: 16 KB at QUADS = 16
+    const int tid = threadIdx.x, q = tid % QUADS, rl = tid / QUADS, wave = rl >> 2;
     const int c = c0 + 4 * q;
     double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0}, b0[4] = {0, 0, 0, 0}, b1[4] = {0, 0, 0, 0};
     if (c < C) {
@@ -213,13 +219,13 @@ __device__ __forceinline__ bool fold_slab64(const float* __restrict__ ps, const 
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         double t0 = a0[e] + b0[e], t1 = a1[e] + b1[e];
-        t0 += __shfl_xor(t0, 16, SP_WAVE); t1 += __shfl_xor(t1, 16, SP_WAVE);     // row lanes 4w+0/1 and 4w+2/3
-        t0 += __shfl_xor(t0, 32, SP_WAVE); t1 += __shfl_xor(t1, 32, SP_WAVE);
-        if ((tid & 63) < 16) { sh[wave][4 * q + e][0] = t0; sh[wave][4 * q + e][1] = t1; }
+        t0 += __shfl_xor(t0, QUADS, SP_WAVE); t1 += __shfl_xor(t1, QUADS, SP_WAVE);     // row lanes 4w+0/1 and 4w+2/3
+        t0 += __shfl_xor(t0, 2 * QUADS, SP_WAVE); t1 += __shfl_xor(t1, 2 * QUADS, SP_WAVE);
+        if ((rl & 3) == 0) { sh[wave][4 * q + e][0] = t0; sh[wave][4 * q + e][1] = t1; }
     }
     __syncthreads();
     bool have = false;
-    if (tid < SLAB) {
+    if (tid < SL) {
         s0 = 0; s1 = 0;
 #pragma unroll
         for (int w = 0; w < 16; ++w) { s0 += sh[w][tid][0]; s1 += sh[w][tid][1]; }
@@ -228,6 +234,12 @@ __device__ __forceinline__ bool fold_slab64(const float* __restrict__ ps, const 
     __syncthreads();                                    // (the slab's LDS may be folded into again: second array pair of a BSTATS2 launch)
     return have;
 }
+
+__device__ __forceinline__ bool fold_slab64(const float* __restrict__ ps, const float* __restrict__ pq, int nrows, int stride, int C, int c0,
+                                            double& s0, double& s1) {
+    return fold_slab<16>(ps, pq, nrows, stride, C, c0, s0, s1);
+}
+constexpr int SFQ = 4, SFC = 4 * SFQ, SFT = 64 * SFQ;      // the stand-alone folds: 16 channels, 256 threads per workgroup
 
 __device__ __forceinline__ void bn_finalize(double s0, double s1, double M, float eps, float momentum, int c, float& mu_f, float& is_f,
                                             float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ run_mean,
@@ -249,24 +261,24 @@ __device__ __forceinline__ void bn_finalize(double s0, double s1, double M, floa
 }
 
 // BN forward statistics from the partial sums of the STATS conv epilogue (fp32 sums of one M tile's rows each), then the same
-// finalisation as bn_stats_final_kernel.  One workgroup per 64-channel slab.
-__global__ __launch_bounds__(FOLD_THREADS) void bn_stats_from_conv_kernel(const float* __restrict__ ps, const float* __restrict__ pq, int nrows, int stride, int C,
+// finalisation as bn_stats_final_kernel.  One workgroup per 16-channel slab.
+__global__ __launch_bounds__(SFT) void bn_stats_from_conv_kernel(const float* __restrict__ ps, const float* __restrict__ pq, int nrows, int stride, int C,
                                           double M, float eps, float momentum, float* __restrict__ mean, float* __restrict__ invstd,
                                           float* __restrict__ run_mean, float* __restrict__ run_var) {
     double s0, s1;
-    const int c0 = blockIdx.x * SLAB;
-    if (!fold_slab64(ps, pq, nrows, stride, C, c0, s0, s1)) return;
+    const int c0 = blockIdx.x * SFC;
+    if (!fold_slab<SFQ>(ps, pq, nrows, stride, C, c0, s0, s1)) return;
     float mu, is;
     bn_finalize(s0, s1, M, eps, momentum, c0 + threadIdx.x, mu, is, mean, invstd, run_mean, run_var, true);
 }
 
 // SyncBatchNorm on the fused statistics: the same fold, stopped before the finalisation - this rank's (sum, sum of squares) per channel
 // in fp64, the [c][2] layout sp_bn_train_finalize consumes after the cross-rank SUM
-__global__ __launch_bounds__(FOLD_THREADS) void bn_sums_from_conv_kernel(const float* __restrict__ ps, const float* __restrict__ pq, int nrows, int stride, int C,
+__global__ __launch_bounds__(SFT) void bn_sums_from_conv_kernel(const float* __restrict__ ps, const float* __restrict__ pq, int nrows, int stride, int C,
                                          double* __restrict__ sums) {
     double s0, s1;
-    const int c0 = blockIdx.x * SLAB;
-    if (!fold_slab64(ps, pq, nrows, stride, C, c0, s0, s1)) return;
+    const int c0 = blockIdx.x * SFC;
+    if (!fold_slab<SFQ>(ps, pq, nrows, stride, C, c0, s0, s1)) return;
     sums[2 * (c0 + threadIdx.x)] = s0;
     sums[2 * (c0 + threadIdx.x) + 1] = s1;
 }
@@ -274,14 +286,14 @@ __global__ __launch_bounds__(FOLD_THREADS) void bn_sums_from_conv_kernel(const f
 // dbeta = sum g, dgamma = sum g*xhat from the partial rows a BSTATS dgrad launch (or several: one per output phase) left
 // (gridDim.y = 2: the second row of workgroups folds (ps, pq2) into (dbeta2, dgamma2) - the projection shortcut's BatchNorm, whose d beta is
 // the same sum g and whose d gamma comes from the third array of the BSTATS2 epilogue: one launch for the pair)
-__global__ __launch_bounds__(FOLD_THREADS) void bn_bwd_sums_from_conv_kernel(const float* __restrict__ ps, const float* __restrict__ pq, int nrows, int stride, int C,
+__global__ __launch_bounds__(SFT) void bn_bwd_sums_from_conv_kernel(const float* __restrict__ ps, const float* __restrict__ pq, int nrows, int stride, int C,
                                              float* __restrict__ dbeta, float* __restrict__ dgamma, float* __restrict__ dbeta_copy,
                                              float* __restrict__ dgamma_copy, const float* __restrict__ pq2 = nullptr,
                                              float* __restrict__ dbeta2 = nullptr, float* __restrict__ dgamma2 = nullptr) {
     if (blockIdx.y == 1) { pq = pq2; dbeta = dbeta2; dgamma = dgamma2; dbeta_copy = nullptr; dgamma_copy = nullptr; }
     double s0, s1;
-    const int c0 = blockIdx.x * SLAB;
-    if (!fold_slab64(ps, pq, nrows, stride, C, c0, s0, s1)) return;
+    const int c0 = blockIdx.x * SFC;
+    if (!fold_slab<SFQ>(ps, pq, nrows, stride, C, c0, s0, s1)) return;
     const int c = c0 + threadIdx.x;
     dbeta[c] = (float)s0;
     dgamma[c] = (float)s1;
@@ -1222,7 +1234,7 @@ extern "C" int sp_bn_train_stats_from_conv(const float* stats_sum, const float* 
     SP_REQUIRE(stats_sum && stats_sumsq && mean && invstd, "sp_bn_train_stats_from_conv: null pointer");
     SP_REQUIRE(partial_rows > 0 && stride >= c && c > 0 && rows > 0, "sp_bn_train_stats_from_conv: bad shape");
     SP_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "sp_bn_train_stats_from_conv: running stats come in pairs");
-    hipLaunchKernelGGL(bn_stats_from_conv_kernel, dim3((c + SLAB - 1) / SLAB), dim3(FOLD_THREADS), 0, (hipStream_t)stream, stats_sum, stats_sumsq, partial_rows, stride,
+    hipLaunchKernelGGL(bn_stats_from_conv_kernel, dim3((c + SFC - 1) / SFC), dim3(SFT), 0, (hipStream_t)stream, stats_sum, stats_sumsq, partial_rows, stride,
                        c, (double)rows, eps, momentum, mean, invstd, running_mean, running_var);
     return sp_check_launch("bn_stats_from_conv_kernel");
 }
@@ -1230,7 +1242,7 @@ extern "C" int sp_bn_train_stats_from_conv(const float* stats_sum, const float* 
 extern "C" int sp_bn_sums_from_conv(const float* stats_sum, const float* stats_sumsq, int partial_rows, int stride, int c, double* sums,
                                     void* stream) {
     SP_REQUIRE(stats_sum && stats_sumsq && sums && partial_rows > 0 && stride >= c && c > 0, "sp_bn_sums_from_conv: bad argument");
-    hipLaunchKernelGGL(bn_sums_from_conv_kernel, dim3((c + SLAB - 1) / SLAB), dim3(FOLD_THREADS), 0, (hipStream_t)stream, stats_sum, stats_sumsq, partial_rows, stride,
+    hipLaunchKernelGGL(bn_sums_from_conv_kernel, dim3((c + SFC - 1) / SFC), dim3(SFT), 0, (hipStream_t)stream, stats_sum, stats_sumsq, partial_rows, stride,
                        c, sums);
     return sp_check_launch("bn_sums_from_conv_kernel");
 }
@@ -1238,7 +1250,7 @@ extern "C" int sp_bn_sums_from_conv(const float* stats_sum, const float* stats_s
 extern "C" int sp_bn_bwd_sums_from_conv(const float* sum_g, const float* sum_g_xhat, int partial_rows, int stride, int c, float* dgamma,
                                         float* dbeta, void* stream) {
     SP_REQUIRE(sum_g && sum_g_xhat && dgamma && dbeta && partial_rows > 0 && stride >= c && c > 0, "sp_bn_bwd_sums_from_conv: bad argument");
-    hipLaunchKernelGGL(bn_bwd_sums_from_conv_kernel, dim3((c + SLAB - 1) / SLAB), dim3(FOLD_THREADS), 0, (hipStream_t)stream, sum_g, sum_g_xhat, partial_rows, stride,
+    hipLaunchKernelGGL(bn_bwd_sums_from_conv_kernel, dim3((c + SFC - 1) / SFC), dim3(SFT), 0, (hipStream_t)stream, sum_g, sum_g_xhat, partial_rows, stride,
                        c, dbeta, dgamma, nullptr, nullptr);
     return sp_check_launch("bn_bwd_sums_from_conv_kernel");
 }
@@ -1247,7 +1259,7 @@ extern "C" int sp_bn_bwd_sums_from_conv_pair(const float* sum_g, const float* su
                                              float* dgamma, float* dbeta, float* dgamma2, float* dbeta2, void* stream) {
     SP_REQUIRE(sum_g && sum_g_xhat && sum_g_xhat2 && dgamma && dbeta && dgamma2 && dbeta2 && partial_rows > 0 && stride >= c && c > 0,
                "sp_bn_bwd_sums_from_conv_pair: bad argument");
-    hipLaunchKernelGGL(bn_bwd_sums_from_conv_kernel, dim3((c + SLAB - 1) / SLAB, 2), dim3(FOLD_THREADS), 0, (hipStream_t)stream, sum_g, sum_g_xhat, partial_rows,
+    hipLaunchKernelGGL(bn_bwd_sums_from_conv_kernel, dim3((c + SFC - 1) / SFC, 2), dim3(SFT), 0, (hipStream_t)stream, sum_g, sum_g_xhat, partial_rows,
                        stride, c, dbeta, dgamma, nullptr, nullptr, sum_g_xhat2, dbeta2, dgamma2);
     return sp_check_launch("bn_bwd_sums_from_conv_kernel");
 }
@@ -1256,7 +1268,7 @@ extern "C" int sp_bn_bwd_sums_from_conv2(const float* sum_g, const float* sum_g_
                                          float* dgamma_copy, float* dbeta_copy, void* stream) {
     SP_REQUIRE(sum_g && sum_g_xhat && dgamma && dbeta && dgamma_copy && dbeta_copy && partial_rows > 0 && stride >= c && c > 0,
                "sp_bn_bwd_sums_from_conv2: bad argument");
-    hipLaunchKernelGGL(bn_bwd_sums_from_conv_kernel, dim3((c + SLAB - 1) / SLAB), dim3(FOLD_THREADS), 0, (hipStream_t)stream, sum_g, sum_g_xhat, partial_rows, stride,
+    hipLaunchKernelGGL(bn_bwd_sums_from_conv_kernel, dim3((c + SFC - 1) / SFC), dim3(SFT), 0, (hipStream_t)stream, sum_g, sum_g_xhat, partial_rows, stride,
                        c, dbeta, dgamma, dbeta_copy, dgamma_copy);
     return sp_check_launch("bn_bwd_sums_from_conv_kernel");
 }
@@ -1265,7 +1277,8 @@ extern "C" int sp_bn_bwd_sums_from_conv2(const float* sum_g, const float* sum_g_
 // prologue's fold is repeated per workgroup)
 static int fold_stripes(long long rows, int slabs, int partial_rows) {
     long long want = (512 + slabs - 1) / slabs;
-    const long long cap = (rows + 255) / 256;
+    static const long long min_rows = getenv("SP_FOLD_MIN_ROWS") ? atoll(getenv("SP_FOLD_MIN_ROWS")) : 256;          // (env: development knob)
+    const long long cap = (rows + min_rows - 1) / min_rows;
     if (want > cap) want = cap;
     // every workgroup repeats the fold: (workgroups) x (partial rows) x 512 B of L2 reads.  Bounded to ~64 MB per launch: tensors with many
     // partial rows get fewer, fatter workgroups (each thread keeps four rows of every operand in flight, so a few hundred workgroups of
